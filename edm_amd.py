@@ -1,0 +1,13 @@
+"""Import alias: the product package lives in ``electronic-dance-music_amd/`` (a
+directory name Python cannot import directly); ``import edm_amd`` loads it."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "electronic-dance-music_amd")
+_spec = importlib.util.spec_from_file_location(
+    "edm_amd", os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir]
+)
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["edm_amd"] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,129 @@
+/*
+ * edm_oracle.h -- CPU restatement of the EDM per-timestep bias hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing outside tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may include, link or call this.  The product
+ * path (electronic-dance-music_amd/csrc, include/edm_hip.h) never does.
+ *
+ * Every function restates, in plain C with a runtime dimension, the arithmetic
+ * of the reference C++ library in the same operation order (IEEE double,
+ * built with -ffp-contract=off) so that integer indices are bit-exact and
+ * doubles are identical on x86-64.  Citations are file:line relative to
+ * /root/reference.  Parity is PINNED: tests/test_oracle_vs_ref.py compares
+ * every entry point below with the real reference compiled into
+ * oracle/_ref/libedm_ref.so (same C API, prefix ref_ instead of ora_), and
+ * tests/golden/ holds outputs of that reference build.
+ */
+#ifndef EDM_ORACLE_H_
+#define EDM_ORACLE_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDM_MAXDIM 3
+
+/* ---- plain grid (lib/grid.h DimmedGrid<DIM>) -------------------------- */
+typedef struct ora_grid ora_grid;
+
+ora_grid *ora_grid_create(int dim, const double *min, const double *max,
+                          const double *spacing, const int *periodic,
+                          int b_derivatives, int b_interpolate);
+ora_grid *ora_grid_read(int dim, const char *filename, int b_interpolate);
+void ora_grid_free(ora_grid *g);
+int ora_grid_dim(const ora_grid *g);
+size_t ora_grid_size(const ora_grid *g);
+const int *ora_grid_number(const ora_grid *g);
+const double *ora_grid_dx(const ora_grid *g);
+const double *ora_grid_min(const ora_grid *g);
+const double *ora_grid_max(const ora_grid *g);
+const int *ora_grid_periodic(const ora_grid *g);
+int ora_grid_has_deriv(const ora_grid *g);
+double *ora_grid_values(ora_grid *g);
+double *ora_grid_derivs(ora_grid *g);
+void ora_grid_set_interpolation(ora_grid *g, int b);
+void ora_grid_get_index(const ora_grid *g, const double *x, size_t *out);
+size_t ora_grid_multi2one(const ora_grid *g, const size_t *idx);
+void ora_grid_one2multi(const ora_grid *g, size_t index, size_t *out);
+int ora_grid_in_grid(const ora_grid *g, const double *x);
+double ora_grid_get_value(const ora_grid *g, const double *x);
+double ora_grid_get_value_deriv(const ora_grid *g, const double *x, double *der);
+/* returns -1e300 and does nothing where the reference would abort */
+double ora_grid_add_value(ora_grid *g, const double *x, double value);
+void ora_grid_clear(ora_grid *g);
+double ora_grid_max_value(const ora_grid *g);
+double ora_grid_min_value(const ora_grid *g);
+double ora_grid_expected_bias(const ora_grid *g);
+void ora_grid_add_grid(ora_grid *g, const ora_grid *other, double scale, double offset);
+void ora_grid_write(const ora_grid *g, const char *filename);
+/* single-rank restatement of multi_write (grid.h:509-674) */
+void ora_grid_multi_write(const ora_grid *g, const char *filename,
+                          const double *box_min, const double *box_max,
+                          const int *b_periodic, int b_lammps_format);
+
+/* ---- gaussian grid (lib/gaussian_grid.h DimmedGaussGrid<DIM>) --------- */
+typedef struct ora_gauss ora_gauss;
+
+ora_gauss *ora_gauss_create(int dim, const double *min, const double *max,
+                            const double *spacing, const int *periodic,
+                            int b_interpolate, const double *sigma);
+ora_gauss *ora_gauss_read(int dim, const char *filename, const double *sigma);
+void ora_gauss_free(ora_gauss *g);
+ora_grid *ora_gauss_grid(ora_gauss *g);
+void ora_gauss_set_boundary(ora_gauss *g, const double *min, const double *max,
+                            const int *periodic);
+double ora_gauss_add_value(ora_gauss *g, const double *x, double height);
+double ora_gauss_get_value(const ora_gauss *g, const double *x);
+double ora_gauss_get_value_deriv(const ora_gauss *g, const double *x, double *der);
+void ora_gauss_remap(const ora_gauss *g, double *x);
+int ora_gauss_in_bounds(const ora_gauss *g, const double *x);
+double ora_gauss_get_volume(const ora_gauss *g);
+const double *ora_gauss_sigma(const ora_gauss *g);
+const size_t *ora_gauss_minisize(const ora_gauss *g);
+size_t ora_gauss_minisize_total(const ora_gauss *g);
+const double *ora_gauss_bc_table(const ora_gauss *g, int dim_index, int deriv);
+const double *ora_gauss_boundary_min(const ora_gauss *g);
+const double *ora_gauss_boundary_max(const ora_gauss *g);
+const int *ora_gauss_boundary_periodic(const ora_gauss *g);
+void ora_gauss_write(const ora_gauss *g, const char *filename);
+void ora_gauss_multi_write(const ora_gauss *g, const char *filename, int b_lammps_format);
+
+/* ---- bias controller (lib/edm_bias.cpp EDMBias, serial build) ---------- */
+typedef struct ora_bias ora_bias;
+
+ora_bias *ora_bias_create(const char *input_filename);
+void ora_bias_free(ora_bias *b);
+void ora_bias_setup(ora_bias *b, double temperature, double boltzmann);
+void ora_bias_subdivide(ora_bias *b, const double *sublo, const double *subhi,
+                        const double *boxlo, const double *boxhi,
+                        const int *b_periodic, const double *skin);
+/* positions/forces are row-major [n][stride] blocks (LAMMPS atom->x / f) */
+double ora_bias_update_forces(const ora_bias *b, int n, const double *positions,
+                              double *forces, int stride, int apply_mask);
+double ora_bias_update_force(const ora_bias *b, const double *position, double *force);
+void ora_bias_set_mask(ora_bias *b, const int *mask);
+void ora_bias_add_hills(ora_bias *b, int n, const double *positions, int stride,
+                        const double *runiform, int apply_mask);
+void ora_bias_pre_add_hill(ora_bias *b, int est_hill_count);
+void ora_bias_add_hill(ora_bias *b, const double *position, double runiform);
+void ora_bias_post_add_hill(ora_bias *b);
+void ora_bias_write_bias(const ora_bias *b, const char *filename);
+void ora_bias_write_lammps_table(const ora_bias *b, const char *filename);
+void ora_bias_write_histogram(const ora_bias *b);
+void ora_bias_clear_histogram(ora_bias *b);
+ora_gauss *ora_bias_gauss(ora_bias *b);
+ora_grid *ora_bias_hist(ora_bias *b);
+/* scalar state, by name: dim, b_tempering, b_targeting, global_tempering,
+ * bias_factor, boltzmann_factor, temperature, hill_prefactor, bias_per_step,
+ * hill_density, cum_bias, total_volume, expected_target, b_outofbounds,
+ * overflow_left, overflow_right, b_skip_hill_add, hills_added, steps */
+double ora_bias_get(const ora_bias *b, const char *name);
+void ora_bias_set(ora_bias *b, const char *name, double value);
+const double *ora_bias_array(const ora_bias *b, const char *name); /* bias_dx, bias_sigma, min, max */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,294 @@
+"""Pins the C restatement (oracle/edm_oracle.c) against the REAL reference
+(oracle/_ref/libedm_ref.so, compiled from /root/reference/lib by oracle/Makefile).
+
+Every comparison is bit-exact on doubles and exact on integers / file bytes:
+both run on the same host with the same libm.  Skipped where the reference
+build is unavailable.
+"""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as B
+
+from conftest import FIXTURES
+
+RNG = np.random.default_rng(20261004)
+
+
+def _geoms():
+    """(lo, hi, spacing, periodic) cases for dim 1..3, including awkward spacings."""
+    cases = [
+        ([0.0], [10.0], [1.0], [0]),
+        ([0.0], [2.8], [0.00025], [0]),
+        ([-np.pi], [np.pi], [np.pi / 100], [1]),
+        ([2.0], [10.0], [1.0], [1]),
+        ([-0.3], [3.6], [0.25], [0]),
+        ([0.0, 0.0], [10.0, 5.0], [1.0, 1.0], [1, 0]),
+        ([0.0, -3.141593], [2.5, 3.141593], [0.05, 0.2513274], [0, 1]),
+        ([-2.0, -5.0, -3.0], [125.0, 63.0, 78.0], [1.27, 1.36, 0.643], [0, 1, 1]),
+        ([-np.pi, -np.pi, 0.0], [np.pi, np.pi, 10.0], [np.pi / 20, np.pi / 20, 1.0], [1, 1, 0]),
+        ([0.0] * 3, [4.0] * 3, [0.5, 0.25, 1.0], [1, 1, 1]),
+    ]
+    return cases
+
+
+def _same_geometry(a, b):
+    assert a.dim == b.dim and a.size == b.size
+    assert np.array_equal(a.number, b.number)
+    assert np.array_equal(a.dx, b.dx)
+    assert np.array_equal(a.min, b.min)
+    assert np.array_equal(a.max, b.max)
+    assert np.array_equal(a.periodic, b.periodic)
+
+
+def _query_points(g, n):
+    lo, hi = g.min, g.max
+    span = hi - lo
+    pts = lo + (RNG.random((n, g.dim)) * 1.6 - 0.3) * span
+    # exact nodes, edges and just-inside/outside values
+    extra = [lo, hi, hi - g.dx, lo + g.dx * 3, lo - 1e-12, hi - g.dx - 1e-12]
+    return np.vstack([pts] + [np.atleast_2d(e) for e in extra])
+
+
+@pytest.mark.parametrize("case", _geoms())
+@pytest.mark.parametrize("deriv,interp", [(0, 0), (1, 0), (1, 1)])
+def test_grid_geometry_index_lookup(oracle_lib, ref_lib, case, deriv, interp):
+    lo, hi, sp, per = case
+    go = B.Grid.create(oracle_lib, lo, hi, sp, per, deriv, interp)
+    gr = B.Grid.create(ref_lib, lo, hi, sp, per, deriv, interp)
+    _same_geometry(go, gr)
+    vals = RNG.standard_normal(go.size)
+    # exercise the |f| < 1e-7 special case of the interpolation (grid.h:113-116)
+    vals[RNG.random(go.size) < 0.1] = 0.0
+    vals[RNG.random(go.size) < 0.05] *= 1e-8
+    go.values[:] = vals
+    gr.values[:] = vals
+    if deriv:
+        d = RNG.standard_normal((go.size, go.dim))
+        go.derivs[:] = d
+        gr.derivs[:] = d
+    for i in RNG.integers(0, go.size, 50):
+        assert go.one2multi(int(i)) == gr.one2multi(int(i))
+        assert go.multi2one(go.one2multi(int(i))) == int(i) == gr.multi2one(gr.one2multi(int(i)))
+    for x in _query_points(go, 400):
+        assert go.in_grid(x) == gr.in_grid(x)
+        if go.in_grid(x):
+            assert go.get_index(x) == gr.get_index(x)
+        assert go.get_value(x) == gr.get_value(x)
+        if deriv:
+            vo, do_ = go.get_value_deriv(x)
+            vr, dr = gr.get_value_deriv(x)
+            assert vo == vr and np.array_equal(do_, dr)
+    assert go.max_value() == gr.max_value() and go.min_value() == gr.min_value()
+    assert go.expected_bias() == gr.expected_bias()
+    if not interp:
+        for x in _query_points(go, 50):
+            assert go.add_value(x, 1.5) == gr.add_value(x, 1.5)
+        assert np.array_equal(go.values, gr.values)
+    go.clear()
+    gr.clear()
+    assert np.array_equal(go.values, gr.values) and not go.values.any()
+
+
+@pytest.mark.parametrize("name,dim", [("1.grid", 1), ("2.grid", 2), ("3.grid", 3)])
+def test_grid_read_write(oracle_lib, ref_lib, workdir, name, dim):
+    src = os.path.join(FIXTURES, name)
+    go = B.Grid.read(oracle_lib, dim, src, 1)
+    gr = B.Grid.read(ref_lib, dim, src, 1)
+    _same_geometry(go, gr)
+    assert go.has_deriv == gr.has_deriv == 1
+    assert np.array_equal(go.values, gr.values)
+    assert np.array_equal(go.derivs, gr.derivs)
+    go.write("o.grid")
+    gr.write("r.grid")
+    assert filecmp.cmp("o.grid", "r.grid", shallow=False)
+    # multi_write re-samples by interpolation (grid.h:604-671)
+    per = [int(p) for p in go.periodic]
+    hi = go.max - np.where(go.periodic == 1, 0.0, go.dx)
+    go.multi_write("o.mw", go.min, hi, per, 0)
+    gr.multi_write("r.mw", gr.min, hi, per, 0)
+    assert filecmp.cmp("o.mw", "r.mw", shallow=False)
+    if dim == 1:
+        go.multi_write("o.lt", [0.5], [2.0], [0], 1)
+        gr.multi_write("r.lt", [0.5], [2.0], [0], 1)
+        assert filecmp.cmp("o.lt", "r.lt", shallow=False)
+
+
+def test_grid_add_grid(oracle_lib, ref_lib):
+    src = os.path.join(FIXTURES, "2.grid")
+    oo = B.Grid.read(oracle_lib, 2, src, 1)
+    rr = B.Grid.read(ref_lib, 2, src, 1)
+    go = B.Grid.create(oracle_lib, [0.1, -3.0], [2.0, 3.0], [0.07, 0.11], [0, 0], 1, 1)
+    gr = B.Grid.create(ref_lib, [0.1, -3.0], [2.0, 3.0], [0.07, 0.11], [0, 0], 1, 1)
+    go.add_grid(oo, 1.0, 0.0)
+    gr.add_grid(rr, 1.0, 0.0)
+    go.add_grid(oo, -0.25, 0.5)
+    gr.add_grid(rr, -0.25, 0.5)
+    assert np.array_equal(go.values, gr.values) and np.array_equal(go.derivs, gr.derivs)
+
+
+GAUSS_CASES = [
+    # lo, hi, spacing, grid periodic, sigma, boundary (lo, hi, periodic) or None
+    dict(lo=[0.0], hi=[2.8], sp=[0.00025], per=[0], sg=[0.025], bnd=None),                      # C1D
+    dict(lo=[-10.0], hi=[10.0], sp=[1.0], per=[1], sg=[1.0], bnd=None),
+    dict(lo=[2.0], hi=[10.0], sp=[1.0], per=[1], sg=[1.0], bnd=None),
+    dict(lo=[2.0], hi=[4.0], sp=[1.0], per=[0], sg=[1.0], bnd=([2.0], [10.0], [1])),            # sub-grid in periodic box
+    dict(lo=[-2.0], hi=[7.0], sp=[0.1], per=[0], sg=[0.1], bnd=([0.0], [10.0], [1])),
+    dict(lo=[-100.0], hi=[100.0], sp=[1.0], per=[0], sg=[10.0], bnd=None),                      # McGDP
+    dict(lo=[-100.0], hi=[100.0], sp=[1.0], per=[1], sg=[10.0], bnd=([-50.0], [50.0], [0])),    # boundary inside grid
+    dict(lo=[0.0], hi=[10.0], sp=[0.009765625], per=[1], sg=[0.1], bnd=None),
+    dict(lo=[0.0], hi=[10.0], sp=[0.01], per=[0], sg=[0.5], bnd=([0.0], [1.0], [0])),           # notebook
+    dict(lo=[0.0, 0.0], hi=[10.0, 5.0], sp=[1.0, 1.0], per=[1, 0], sg=[0.1, 0.1], bnd=([0.0, 0.0], [10.0, 10.0], [1, 1])),
+    dict(lo=[0.0, 0.0], hi=[8.0, 8.0], sp=[0.25, 0.25], per=[1, 1], sg=[0.5, 0.4], bnd=None),
+    dict(lo=[0.0, 0.0], hi=[8.0, 6.0], sp=[0.25, 0.2], per=[1, 0], sg=[0.5, 0.4], bnd=None),   # mixed: McGDP in dim 1 only
+    dict(lo=[0.0, 0.0], hi=[8.0, 6.0], sp=[0.25, 0.2], per=[0, 0], sg=[0.5, 0.4], bnd=None),   # 2-D McGDP (non-product form)
+    dict(lo=[-10.0] * 3, hi=[10.0] * 3, sp=[0.9, 1.1, 1.4], per=[1, 1, 1], sg=[3.0] * 3, bnd=([-5.0] * 3, [5.0] * 3, [0, 0, 0])),
+    dict(lo=[0.0] * 3, hi=[4.0] * 3, sp=[0.25] * 3, per=[1, 1, 1], sg=[0.3] * 3, bnd=None),
+]
+
+
+def _make_pair(oracle_lib, ref_lib, c, interp=1):
+    pair = []
+    for lib in (oracle_lib, ref_lib):
+        g = B.Gauss.create(lib, c["lo"], c["hi"], c["sp"], c["per"], interp, c["sg"])
+        if c["bnd"] is not None:
+            g.set_boundary(*c["bnd"])
+        pair.append(g)
+    return pair
+
+
+@pytest.mark.parametrize("c", GAUSS_CASES)
+def test_gauss_setup_tables_remap(oracle_lib, ref_lib, c):
+    go, gr = _make_pair(oracle_lib, ref_lib, c)
+    _same_geometry(go.grid, gr.grid)
+    assert go.minisize == gr.minisize and go.minisize_total == gr.minisize_total
+    assert np.array_equal(go.sigma, gr.sigma)
+    assert np.array_equal(go.boundary_min, gr.boundary_min)
+    assert np.array_equal(go.boundary_max, gr.boundary_max)
+    assert np.array_equal(go.boundary_periodic, gr.boundary_periodic)
+    assert go.get_volume() == gr.get_volume()
+    for d in range(go.dim):
+        if not go.boundary_periodic[d]:
+            for deriv in (0, 1):
+                assert np.array_equal(go.bc_table(d, deriv), gr.bc_table(d, deriv))
+    lo = np.minimum(go.grid.min, go.boundary_min)
+    hi = np.maximum(go.grid.max, go.boundary_max)
+    for _ in range(300):
+        x = lo + (RNG.random(go.dim) * 3 - 1) * (hi - lo)
+        assert np.array_equal(go.remap(x), gr.remap(x))
+        assert go.in_bounds(x) == gr.in_bounds(x)
+
+
+@pytest.mark.parametrize("c", GAUSS_CASES)
+def test_gauss_add_value_and_lookup(oracle_lib, ref_lib, c):
+    go, gr = _make_pair(oracle_lib, ref_lib, c)
+    dim = go.dim
+    blo, bhi = go.boundary_min, go.boundary_max
+    nh = 40 if dim < 3 else 12
+    hills = [blo + RNG.random(dim) * (bhi - blo) for _ in range(nh)]
+    # exactly on the boundary, just outside, far outside (remapped or rejected)
+    hills += [blo.copy(), bhi.copy(), blo - 1e-9, bhi + 0.37 * (bhi - blo), blo - 1.21 * (bhi - blo)]
+    for x in hills:
+        h = float(RNG.random() * 2 - 0.5)
+        ao = go.add_value(x, h)
+        ar = gr.add_value(x, h)
+        assert ao == ar, (x, h)
+    assert np.array_equal(go.grid.values, gr.grid.values)
+    assert np.array_equal(go.grid.derivs, gr.grid.derivs)
+    lo = np.minimum(go.grid.min, blo)
+    hi = np.maximum(go.grid.max, bhi)
+    for _ in range(400):
+        x = lo + (RNG.random(dim) * 1.6 - 0.3) * (hi - lo)
+        vo, do_ = go.get_value_deriv(x)
+        vr, dr = gr.get_value_deriv(x)
+        assert vo == vr and np.array_equal(do_, dr)
+        assert go.get_value(x) == gr.get_value(x)
+
+
+def _write_cfg(path, text, hills):
+    with open(path, "w") as fh:
+        fh.write(text + "\nhills_filename %s\nhistogram_filename %s.hist\n" % (hills, hills))
+
+
+BIAS_CFGS = {
+    "c1d_limit": "tempering 0\nhill_prefactor 1.0\nbias_per_step 1.5\ndimension 1\nbox_low 0\nbox_high 2.8\nbias_spacing 0.00025\nbias_sigma 0.025",
+    "c1d_density": "tempering 0\nhill_prefactor 0.5\nhill_density 25\ndimension 1\nbox_low 0\nbox_high 2.8\nbias_spacing 0.001\nbias_sigma 0.05",
+    "c1d_temper": "tempering 1\nbias_factor 10\nglobal_tempering -1\nhill_prefactor 0.02\nbias_per_step 5.0\ndimension 1\nbox_low 0\nbox_high 2.8\nbias_spacing 0.001\nbias_sigma 0.05",
+    "c1d_gtemper": "tempering 1\nbias_factor 5\nglobal_tempering 0.2\nhill_prefactor 0.4\ndimension 1\nbox_low 0\nbox_high 2.8\nbias_spacing 0.001\nbias_sigma 0.05",
+    "c2d": "tempering 0\nhill_prefactor 0.3\nhill_density 10\nbias_per_step 0.12\ndimension 2\nbox_low 0 0\nbox_high 8 8\nbias_spacing 0.25 0.25\nbias_sigma 0.5 0.4",
+    "c3d": "tempering 0\nhill_prefactor 0.02\nhill_density 8\nbias_per_step 0.008\ndimension 3\nbox_low 0 0 0\nbox_high 4 4 4\nbias_spacing 0.25 0.25 0.25\nbias_sigma 0.3 0.3 0.3",
+}
+
+
+def _run_bias(lib, name, workdir, tag):
+    cfg = str(workdir / ("%s_%s.edm" % (name, tag)))
+    hills = str(workdir / ("HILLS_%s_%s" % (name, tag)))
+    _write_cfg(cfg, BIAS_CFGS[name], hills)
+    b = B.Bias(lib, cfg)
+    dim = int(b.get("dim"))
+    b.setup(1.0, 1.0)
+    lo, hi = b.array("min"), b.array("max")
+    per = [0] if name.startswith("c1d") else [1] * dim
+    skin = [0.3] * dim if name.startswith("c1d") else [0.0] * dim
+    b.subdivide(lo, hi, lo, hi, per, skin)
+    rng = np.random.default_rng(7)
+    out = dict(E=[], cum=[], ov=[])
+    for step in range(6):
+        n = 300
+        pos = np.zeros((n, 3))
+        pos[:, :dim] = lo + rng.random((n, dim)) * (hi - lo) * 1.05 - 0.02
+        forces = np.zeros_like(pos)
+        out["E"].append(b.update_forces(pos, forces))
+        out.setdefault("F", []).append(forces.copy())
+        ru = rng.random(n)
+        if name == "c1d_limit":
+            # explicit pre/add/post cycle with unit-ish hills crossing the limit
+            b.pre_add_hill(1)
+            for k in range(4):
+                b.add_hill(pos[k], ru[k])
+            b.post_add_hill()
+        else:
+            mask = (rng.integers(0, 4, n)).astype(np.int32)
+            b.set_mask(mask)
+            b.add_hills(pos, ru, 1 if step % 2 else -1)
+        out["cum"].append(b.get("cum_bias"))
+        out["ov"].append((b.get("overflow_left"), b.get("overflow_right"), b.get("b_skip_hill_add")))
+    out["grid"] = b.gauss.grid.values.copy()
+    out["der"] = b.gauss.grid.derivs.copy()
+    out["hist"] = b.hist.values.copy()
+    b.write_bias(str(workdir / ("BIAS_%s_%s" % (name, tag))))
+    b.write_histogram()
+    out["files"] = [hills + "_0", hills + ".hist", str(workdir / ("BIAS_%s_%s" % (name, tag)))]
+    del b
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(BIAS_CFGS))
+def test_bias_controller_sequences(oracle_lib, ref_lib, workdir, name):
+    o = _run_bias(oracle_lib, name, workdir, "o")
+    r = _run_bias(ref_lib, name, workdir, "r")
+    assert o["E"] == r["E"] and o["cum"] == r["cum"] and o["ov"] == r["ov"]
+    for a, b in zip(o["F"], r["F"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(o["grid"], r["grid"]) and np.array_equal(o["der"], r["der"])
+    assert np.array_equal(o["hist"], r["hist"])
+    for fo, fr in zip(o["files"], r["files"]):
+        assert filecmp.cmp(fo, fr, shallow=False), (fo, fr)
+    if name == "c1d_limit":
+        assert max(v[1] for v in o["ov"]) > 0  # the overflow buffer was exercised
+
+
+def test_config_reader(oracle_lib, ref_lib, workdir):
+    # the 2-D target grid the reference's read_test.edm expects next to the binary
+    B.Grid.read(ref_lib, 2, os.path.join(FIXTURES, "2.grid"), 1).write("2.grid.test")
+    vals = []
+    for lib in (oracle_lib, ref_lib):
+        b = B.Bias(lib, os.path.join(FIXTURES, "read_test.edm"))
+        vals.append([b.get(k) for k in ("dim", "b_tempering", "b_targeting", "hill_prefactor", "bias_per_step",
+                                          "hill_density", "expected_target")]
+                    + list(b.array("bias_sigma")) + list(b.array("bias_dx")))
+    assert vals[0] == vals[1]
+    assert vals[0][0] == 2 and vals[0][1] == 0 and vals[0][-4:] == [2.0, 1.0, 1.0, 1.0]
