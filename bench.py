@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- the EDM per-timestep bias hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input on every GPU:
+  (1) bias-force evaluation for W1 = 1,048,576 pair distances of a 1-D r-CV
+      (fix edm_pair, BASELINE.json configs[1]): EDMBias::update_force batched, and
+  (2) one hill step: EDMBias::add_hills semantics, hill_density 250, 2 add_hill calls
+      per pair worth of estimate, bias limiting active (bias_per_step = hill_prefactor).
+Inputs are resident in HBM before the timed region.  N > 1 is weak scaling: every rank
+(one process per GPU) owns its own W1-sized pair set of the same system, hill_density is
+a per-system quantity (divided by the rank count exactly like EDMBias::subdivide does
+under MPI) and ranks exchange over RCCL.  value = pairs evaluated by all ranks / time.
+
+Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
+  roofline     -- dominant kernel (k_pair_forces): algorithmic 16 B/eval over its HIP-event
+                  duration measured on the kernel's own stream inside the timed region
+  cpu_baseline -- the CPU oracle (or the real reference build when present) timed on a
+                  bounded sample of the same workload on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+BYTES_PER_EVAL = 16    # 8 B distance in + 8 B force out (SURVEY.md 8d, K1 r-array form)
+
+CFG = ("tempering 0\nhill_prefactor 0.5\nhill_density 250\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+       "bias_spacing 0.00025\nbias_sigma 0.025\n")
+
+
+def make_bias(mod, tmpdir, tag, rank=0):
+    cfg = os.path.join(tmpdir, "bench_%s_%d.edm" % (tag, rank))
+    with open(cfg, "w") as fh:
+        fh.write(CFG + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s_%d\n" % (tmpdir, tag, tmpdir, tag, rank))
+    return cfg
+
+
+def cpu_baseline(tmpdir, seconds=12.0):
+    """Times the CPU checker at the reference's per-call granularity on one host core."""
+    from oracle import binding as B
+    import edm_amd.workloads as W
+
+    kind, lib = "port", None
+    try:
+        lib = B.load("ref")
+        kind = "reference"
+    except Exception:  # noqa: BLE001
+        lib = B.load("oracle")
+    cfg = make_bias(None, tmpdir, "cpu")
+    b = B.Bias(lib, cfg)
+    b.setup(1.0, 1.0)
+    b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    g = b.gauss
+    for x in W.pair_distances(512, 2):
+        g.add_value([x], 1e-3)
+    n = 1 << 18
+    r = W.pair_distances(n, 1).reshape(-1, 1).copy()
+    f = np.zeros_like(r)
+    t0 = time.perf_counter()
+    evals = 0
+    while time.perf_counter() - t0 < seconds * 0.6:
+        b.update_forces(r, f)
+        evals += n
+    t_eval = time.perf_counter() - t0
+    # hill adds: GaussGrid::add_value on the C1D stencil (1131 nodes, McGDP boundary)
+    hills = W.pair_distances(200000, 5)
+    t0 = time.perf_counter()
+    done = 0
+    for x in hills:
+        g.add_value([x], 1e-6)
+        done += 1
+        if (done & 1023) == 0 and time.perf_counter() - t0 > seconds * 0.4:
+            break
+    t_hill = time.perf_counter() - t0
+    return dict(value=evals / t_eval / 1e6, unit="million bias-force evals/s", cores=1, kind=kind,
+                hill_adds_per_s=done / t_hill,
+                sample="%d update_forces passes over %d C1D pair distances (%.1f s) + %d add_value hills (%.1f s), 1 thread"
+                       % (evals // n, n, t_eval, done, t_hill))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default W1 = 1,048,576)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--w2", action="store_true", help="also capture the 38.8M-pair interpolation roofline (W2)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    import edm_amd.hip as H
+    import edm_amd.workloads as W
+
+    H.require_gpu()
+    H.check(H.lib().edm_hip_set_device(local_rank))
+    tmpdir = tempfile.mkdtemp(prefix="edm_bench_")
+    npairs = args.pairs or W.W1_PAIRS
+
+    b = H.Bias(make_bias(H, tmpdir, "gpu", rank))
+    if world > 1:
+        import torch
+
+        ident = [H.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        b.comm_init(ident[0], world, rank)
+    b.setup(1.0, 1.0)
+    b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    b.set_hill_log(False)   # the HILLS text log is host I/O outside the hot path
+    g = b.gauss
+    # bias pre-populated with 4096 hills (seed 2), identical on every rank
+    hills0 = np.zeros((4096, 1))
+    hills0[:, 0] = W.pair_distances(4096, 2)
+    g.add_values(hills0, 1e-3)
+
+    # this rank's pair set, resident in HBM
+    r = W.pair_distances(npairs, 1 + 1000 * rank)
+    u = W.uniform(3 + 1000 * rank, npairs)
+    d_r = H.DeviceArray.from_host(r)
+    d_u = H.DeviceArray.from_host(u)
+    d_f = H.DeviceArray.zeros((npairs,))
+    est = 2 * npairs  # fix_edm_pair makes up to two add_hill calls per pair (fix_edm_pair.cpp:230-237)
+
+    def step():
+        e = b.pair_forces_device(d_r, d_f, npairs)
+        b.add_hills_device(d_r, npairs, 1, d_u, -1, est)
+        return e
+
+    def barrier():
+        H.synchronize()
+        if dist is not None:
+            dist.barrier()
+            H.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    g.profile_enable(True)
+    g.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        energy = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches = g.profile_read(reset=True)
+    g.profile_enable(False)
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # component rates (not part of `value`): force evaluation alone, all-samples hill adds
+    reps = 20
+    H.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        b.pair_forces_device(d_r, d_f, npairs)
+    H.synchronize()
+    t_eval = (time.perf_counter() - t1) / reps
+    extra = {}
+    if rank == 0:
+        nh = 1 << 18
+        hx = H.DeviceArray.from_host(W.pair_distances(nh, 9))
+        tot = H.C.c_double(0)
+        H.check(H.lib().edm_hip_gauss_add_values(g.h, nh, hx.ptr, 1, None, 1e-9, None, H.C.byref(tot)))
+        H.synchronize()
+        t2 = time.perf_counter()
+        H.check(H.lib().edm_hip_gauss_add_values(g.h, nh, hx.ptr, 1, None, 1e-9, None, H.C.byref(tot)))
+        H.synchronize()
+        extra["hill_adds_per_s_all_samples"] = nh / (time.perf_counter() - t2)
+        extra["hill_adds_sample"] = "%d add_value hills in one batch, C1D stencil 1131 nodes, integrals + ordered gather" % nh
+    roof_w2 = None
+    if args.w2 and rank == 0:
+        n2 = W.W2_PAIRS
+        d_r2 = H.DeviceArray.from_host(W.pair_distances(n2, 11))
+        d_f2 = H.DeviceArray((n2,))
+        g.pair_forces_device(d_r2, d_f2, n2)
+        g.profile_enable(True)
+        g.profile_read(reset=True)
+        for _ in range(10):
+            g.pair_forces_device(d_r2, d_f2, n2)
+        ms2, l2 = g.profile_read(reset=True)
+        g.profile_enable(False)
+        a2 = BYTES_PER_EVAL * n2 / (ms2 / l2 * 1e-3) / 1e9
+        roof_w2 = dict(workload="W2: %d pair distances" % n2, bound="hbm", achieved=a2, peak=HBM_PEAK_GBS, unit="GB/s",
+                       frac=a2 / HBM_PEAK_GBS, kernel_ms=ms2 / l2, traffic=None)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        total_pairs = npairs * world
+        achieved = BYTES_PER_EVAL * npairs / (k_ms / max(k_launches, 1) * 1e-3) / 1e9
+        out = {
+            "metric": "million bias-force evals/sec (1M-pair 1D CV, force eval + hill step per step)",
+            "value": total_pairs / (elapsed / args.steps) / 1e6,
+            "unit": "million evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "W1: fix edm_pair 1-D r-CV, %d pair distances per GPU (32k-atom LJ melt ~ 1M half-list pairs), "
+                            "grid 0..2.8 spacing 0.00025 (11201 nodes) sigma 0.025 McGDP boundary, hill_density 250, "
+                            "bias_per_step = hill_prefactor, bias pre-populated with 4096 hills" % npairs,
+                "pairs_per_gpu": npairs,
+                "hill_step_every": 1,
+                "parallelism": "replicated bias grid, samples sharded, dp%d" % world,
+            },
+            "roofline": {
+                "kernel": "k_pair_forces",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_us": k_ms / max(k_launches, 1) * 1e3,
+                "launches": k_launches,
+                "bytes_per_launch": BYTES_PER_EVAL * npairs,
+            },
+            "evals_only_million_per_s": npairs / t_eval / 1e6,
+            "energy_last_step": energy,
+        }
+        out.update(extra)
+        if roof_w2:
+            out["roofline_w2"] = roof_w2
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(tmpdir)
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,772 @@
+// edm_bias.cpp -- the EDMBias controller of libedm_hip.so: configuration, hill heights,
+// bias limiting, overflow buffer, HILLS log and CV histogram bookkeeping on the
+// host; every data-parallel step (selection, integrals, limiter walk, ordered
+// gather, histogram, lookups) runs as a gfx950 kernel on the handle's stream.
+// Mirrors lib/edm_bias.cpp of the reference (citations file:line); there is no
+// CPU evaluation path for grid values anywhere in this file.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "edm_internal.h"
+
+using namespace edm;
+
+#define BIAS_CLAMP 1.0  // edm_bias.h:14
+
+struct edm_hip_bias {
+  // public data members of EDMBias (edm_bias.h:118-157)
+  int b_tempering = 0, b_targeting = 0;
+  int mpi_rank = 0, mpi_size = 0;
+  unsigned int dim = 0;
+  double global_tempering = 0, bias_factor = 0, boltzmann_factor = 0, temperature = -1.0;
+  double hill_prefactor = 0, bias_per_step = 0, hill_density = -1, cum_bias = 0, total_volume = 0;
+  double expected_target = 0;
+  int b_outofbounds = 0;
+  std::vector<double> bias_dx, bias_sigma, min, max;
+  std::vector<int> bper;
+  edm_hip_gauss *bias = nullptr;
+  edm_hip_grid *hist = nullptr;
+  edm_hip_grid *target = nullptr;
+  std::string initial_bias_file;
+  const int *d_mask = nullptr;
+  // private state (edm_bias.h:160-178)
+  double temp_hill_cum = -1, temp_hill_prefactor = -1;
+  long long est_hill_count = 0;
+  int hills_added = 0;
+  long long steps = 0;
+  std::string hist_output, hills_name;
+  FILE *hills_fp = nullptr;
+  int hill_log = 1;
+  std::vector<double> overflow;  // (dim+1) doubles per record, BIAS_BUFFER_SIZE + 1 records
+  size_t overflow_left = 0, overflow_right = 0;
+  int b_skip_hill_add = 0;
+  // staged per-sample calls (pre_add_hill / add_hill / post_add_hill)
+  std::vector<double> staged_x, staged_u;
+  bool in_cycle = false;
+  // device scratch owned by the controller
+  DevBuf<long long> sel;
+  DevBuf<long long> count;
+  DevBuf<int> sel_scratch;
+  DevBuf<double> stage_x, stage_u, stage_h, tail_w;
+  DevBuf<double> hx0;
+  // multi-GPU
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  bool split_applied = false;
+};
+
+// ---- configuration file (edm_bias.cpp:19-24, :933-979, :986-1095) ---------------
+typedef std::map<std::string, std::string> cfg_map;
+
+static bool read_pairs(const char *filename, cfg_map &out) {
+  FILE *fp = fopen(filename, "r");
+  if (!fp) return false;
+  char key[256];
+  while (fscanf(fp, "%255s", key) == 1) {
+    std::string val;
+    int c;
+    bool any = false;
+    while ((c = fgetc(fp)) != EOF) {
+      any = true;
+      if (c == '\n') break;
+      val.push_back((char)c);
+    }
+    if (!any) break;                         // getline at EOF fails: the pair is dropped
+    out.insert(std::make_pair(std::string(key), val));  // first occurrence wins
+  }
+  fclose(fp);
+  return true;
+}
+static bool cfg_double(const cfg_map &m, const char *key, double *out) {
+  cfg_map::const_iterator it = m.find(key);
+  if (it == m.end()) return false;
+  *out = atof(it->second.c_str());
+  return *out != 0.0;  // a value of exactly 0 is rejected (:937-940)
+}
+static bool cfg_int(const cfg_map &m, const char *key, int *out) {
+  cfg_map::const_iterator it = m.find(key);
+  if (it == m.end()) return false;
+  *out = atoi(it->second.c_str());
+  return true;
+}
+static bool cfg_array(const cfg_map &m, const char *key, std::vector<double> &out, int len) {
+  cfg_map::const_iterator it = m.find(key);
+  if (it == m.end()) return false;
+  const char *cur = it->second.c_str();
+  for (int i = 0; i < len; i++) {
+    char *end;
+    double t = strtod(cur, &end);
+    if (end == cur) break;
+    out[(size_t)i] = t;
+    cur = end;
+  }
+  return true;
+}
+// :1098-1111 -- strips leading blanks/tabs only
+static std::string clean_string(const std::string &in, bool append_rank, int rank) {
+  std::string r(in);
+  size_t k = r.find_first_not_of(" \t");
+  if (k != std::string::npos) r = r.substr(k);
+  if (append_rank) r += "_" + std::to_string(rank);
+  return r;
+}
+
+// Grid::expected_bias (grid.h:692-710) on the values read from the target file
+static double expected_bias_of(const std::vector<double> &v) {
+  double Z = 0, offset = 0, avg = 0;
+  for (size_t i = 0; i < v.size(); i++) offset = fmax(offset, v[i]);
+  for (size_t i = 0; i < v.size(); i++) Z += exp(-v[i] - offset);
+  for (size_t i = 0; i < v.size(); i++) avg += v[i] * exp(-v[i] - offset);
+  return avg / Z;
+}
+
+static int read_input(edm_hip_bias *b, const char *filename) {
+  cfg_map m;
+  if (!read_pairs(filename, m)) {
+    set_error(std::string("Cannot open input file ") + filename);
+    return EDM_HIP_ERR_IO;
+  }
+  if (!cfg_int(m, "tempering", &b->b_tempering)) {
+    set_error("Must specify if tempering is enabled, ex: tempering 1 or tempering 0");
+    return EDM_HIP_ERR_IO;
+  }
+  if (b->b_tempering) {
+    if (!cfg_double(m, "bias_factor", &b->bias_factor)) {
+      set_error("Could not find key bias_factor");
+      return EDM_HIP_ERR_IO;
+    }
+    cfg_double(m, "global_tempering", &b->global_tempering);
+  }
+  if (!cfg_double(m, "hill_prefactor", &b->hill_prefactor)) {
+    set_error("Could not find key hill_prefactor");
+    return EDM_HIP_ERR_IO;
+  }
+  if (!cfg_double(m, "bias_per_step", &b->bias_per_step)) b->bias_per_step = b->hill_prefactor;
+  cfg_double(m, "hill_density", &b->hill_density);
+  int tmp = 0;
+  if (!cfg_int(m, "dimension", &tmp) || tmp <= 0 || tmp > 3) {
+    set_error("Invalid dimesion");
+    return EDM_HIP_ERR_IO;
+  }
+  b->dim = (unsigned int)tmp;
+  b->bias_dx.assign(b->dim, 0);
+  b->bias_sigma.assign(b->dim, 0);
+  b->min.assign(b->dim, 0);
+  b->max.assign(b->dim, 0);
+  b->bper.assign(b->dim, 0);
+  if (!cfg_array(m, "bias_spacing", b->bias_dx, tmp) || !cfg_array(m, "bias_sigma", b->bias_sigma, tmp) ||
+      !cfg_array(m, "box_low", b->min, tmp) || !cfg_array(m, "box_high", b->max, tmp)) {
+    set_error("Could not find one of bias_spacing, bias_sigma, box_low, box_high");
+    return EDM_HIP_ERR_IO;
+  }
+  cfg_map::const_iterator it = m.find("target_filename");
+  if (it != m.end()) {
+    b->b_targeting = 1;
+    GridFile gf;
+    int rc = read_plumed(tmp, clean_string(it->second, false, 0).c_str(), 0, gf);
+    if (rc) return rc;
+    b->expected_target = expected_bias_of(gf.values);
+    // device copy for the nearest-lower lookup of add_hill (:546)
+    edm_hip_grid *t = new edm_hip_grid;
+    t->g = gf.g;
+    t->g.has_deriv = 0;
+    t->g.rec = 1;
+    t->g.interp = 0;
+    EDM_HIP_TRY(hipStreamCreate(&t->stream));
+    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&t->values), sizeof(double) * gf.values.size()));
+    EDM_HIP_TRY(hipMemcpy(t->values, gf.values.data(), sizeof(double) * gf.values.size(), hipMemcpyHostToDevice));
+    b->target = t;
+  }
+  it = m.find("initial_bias_filename");
+  if (it != m.end()) b->initial_bias_file = clean_string(it->second, false, 0);
+  it = m.find("hills_filename");
+  b->hills_name = it != m.end() ? it->second : std::string("HILLS");
+  it = m.find("histogram_filename");
+  b->hist_output = clean_string(it != m.end() ? it->second : std::string("HIST"), false, 0);
+  return EDM_HIP_OK;
+}
+
+static void open_hills(edm_hip_bias *b) {
+  if (b->hills_fp) return;
+  b->hills_fp = fopen(clean_string(b->hills_name, true, b->mpi_rank).c_str(), "w");
+}
+
+// edm_bias.cpp:586-599 (text) -- the histogram part of output_hill runs on the device
+static void log_hill(edm_hip_bias *b, const double *pos, double height, double added, char type) {
+  if (!b->hill_log || !b->hills_fp) return;
+  fprintf(b->hills_fp, "%lld %c %d ", b->steps, type, b->hills_added);
+  for (unsigned int d = 0; d < b->dim; d++) fprintf(b->hills_fp, "%.8f ", pos[d]);
+  fprintf(b->hills_fp, "%.8f %.8f %.8f\n", height, added, b->cum_bias / b->total_volume);
+}
+
+extern "C" {
+
+int edm_hip_bias_create(edm_hip_bias **out, const char *input_filename) {
+  if (!out || !input_filename) return EDM_HIP_ERR_ARG;
+  edm_hip_bias *b = new edm_hip_bias;
+  int rc = read_input(b, input_filename);  // the reference ignores the result (:68); keep the handle, report the status
+  b->overflow.assign((size_t)(EDM_HIP_BIAS_BUFFER_SIZE + 1) * (b->dim + 1), 0.0);
+  *out = b;
+  if (rc == EDM_HIP_OK) open_hills(b);
+  return rc;
+}
+
+int edm_hip_bias_destroy(edm_hip_bias *b) {
+  if (!b) return EDM_HIP_OK;
+  if (b->comm) (void)ncclCommDestroy(b->comm);
+  edm_hip_gauss_destroy(b->bias);
+  edm_hip_grid_destroy(b->hist);
+  edm_hip_grid_destroy(b->target);
+  if (b->hills_fp) fclose(b->hills_fp);
+  b->sel.release(); b->count.release(); b->sel_scratch.release();
+  b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
+  delete b;
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_setup(edm_hip_bias *b, double temperature, double boltzmann_constant) {
+  b->temperature = temperature;                       // :266
+  b->boltzmann_factor = boltzmann_constant * temperature;
+  return EDM_HIP_OK;
+}
+
+// edm_bias.cpp:98-222
+int edm_hip_bias_subdivide(edm_hip_bias *b, const double *sublo, const double *subhi, const double *boxlo,
+                           const double *boxhi, const int *b_periodic, const double *skin) {
+  if (b->bias != nullptr) return EDM_HIP_OK;          // :121-122
+  if (b->temperature < 0) {
+    set_error("Must call setup before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  int grid_period[3] = {0, 0, 0};
+  double lo[3], hi[3];
+  int never_inside = 1;
+  for (unsigned int d = 0; d < b->dim; d++) {
+    b->bper[d] = 0;
+    if (fabs(boxlo[d] - b->min[d]) < 0.000001 && fabs(boxhi[d] - b->max[d]) < 0.000001) b->bper[d] = b_periodic[d];
+  }
+  for (unsigned int d = 0; d < b->dim; d++) {
+    lo[d] = sublo[d];
+    hi[d] = subhi[d];
+    if (fabs(sublo[d] - b->min[d]) < 0.000001 && fabs(subhi[d] - b->max[d]) < 0.000001) {
+      grid_period[d] = b_periodic[d];
+      never_inside = 0;
+    } else {
+      lo[d] -= skin[d];
+      hi[d] += skin[d];
+    }
+    never_inside &= (lo[d] >= b->max[d] || hi[d] <= b->min[d]);
+  }
+  int rc = edm_hip_gauss_create(&b->bias, (int)b->dim, lo, hi, b->bias_dx.data(), grid_period, 1, b->bias_sigma.data());
+  if (rc) return rc;
+  rc = edm_hip_grid_create(&b->hist, (int)b->dim, lo, hi, b->bias_sigma.data(), grid_period);  // :163
+  if (rc) return rc;
+  rc = edm_hip_gauss_set_boundary(b->bias, b->min.data(), b->max.data(), b->bper.data());
+  if (rc) return rc;
+  if (!b->initial_bias_file.empty()) {
+    rc = edm_hip_gauss_add_from_file(b->bias, b->initial_bias_file.c_str(), 1.0, 0.0);
+    if (rc) return rc;
+  }
+  // :175-180 of the MPI build: density and prefactor become per-system quantities
+  if (b->nranks > 1 && !b->split_applied && b->hill_density > 0) {
+    b->hill_density /= b->nranks;
+    b->hill_prefactor /= b->nranks;
+    if (b->hill_density == 0) b->hill_density = 1;
+    b->split_applied = true;
+  }
+  if (never_inside) {
+    b->b_outofbounds = 1;
+    return EDM_HIP_OK;
+  }
+  double vol = 1;                                      // gaussian_grid.h:437-444
+  for (unsigned int d = 0; d < b->dim; d++) vol *= b->max[d] - b->min[d];
+  b->total_volume = 0;
+  b->total_volume += vol * (b->nranks > 1 ? b->nranks : 1);  // :211-220 (sum over replicas)
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_set_mask(edm_hip_bias *b, const int *d_mask) {
+  b->d_mask = d_mask;
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_update_forces(edm_hip_bias *b, long long n, const double *d_x, int x_stride, double *d_f,
+                               int f_stride, int apply_mask, double *energy) {
+  if (energy) *energy = 0;
+  if (b->b_outofbounds) return EDM_HIP_OK;             // :279-280
+  if (!b->bias) {
+    set_error("update_forces before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  return edm_hip_gauss_update_forces(b->bias, n, d_x, x_stride, d_f, f_stride, b->d_mask, apply_mask, energy);
+}
+
+int edm_hip_bias_pair_forces(edm_hip_bias *b, long long n, const double *d_r, double *d_force, double *energy) {
+  if (energy) *energy = 0;
+  if (b->b_outofbounds) {
+    if (n > 0) EDM_HIP_TRY(hipMemset(d_force, 0, sizeof(double) * (size_t)n));
+    return EDM_HIP_OK;
+  }
+  if (!b->bias) {
+    set_error("pair_forces before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  return edm_hip_gauss_pair_forces(b->bias, n, d_r, d_force, energy);
+}
+
+}  // extern "C"
+
+// ---- overflow buffer (edm_bias.cpp:498-523) -- reproduces the reference's
+// "increment before store" on the right end, which leaves slot 0 unwritten and the
+// newest record one past what the flush reads.
+static int overflow_push(edm_hip_bias *b, const double *pos, double h) {
+  const size_t w = b->dim + 1;
+  if (b->overflow_right == EDM_HIP_BIAS_BUFFER_SIZE) {
+    if (b->overflow_left == 0) {
+      set_error("The bias overflow buffer is full. Too many hills. Either increase & recompile, lower hill_density, or lower bias");
+      return EDM_HIP_ERR_OVERFLOW;
+    }
+    b->overflow_left--;
+    for (unsigned int d = 0; d < b->dim; d++) b->overflow[b->overflow_left * w + d] = pos[d];
+    b->overflow[b->overflow_left * w + b->dim] = h;
+  } else {
+    b->overflow_right++;
+    for (unsigned int d = 0; d < b->dim; d++) b->overflow[b->overflow_right * w + d] = pos[d];
+    b->overflow[b->overflow_right * w + b->dim] = h;
+  }
+  return EDM_HIP_OK;
+}
+
+// flush_bias_buffer (edm_bias.cpp:313-380) on the device
+static int flush_overflow(edm_hip_bias *b, double max_bias, double *bias_added) {
+  *bias_added = 0;
+  const size_t w = b->dim + 1;
+  const long long n = (long long)b->overflow_right - (long long)b->overflow_left;
+  if (n <= 0) {
+    if (b->overflow_left == b->overflow_right) b->overflow_left = b->overflow_right = 0;
+    return EDM_HIP_OK;
+  }
+  std::vector<double> xs((size_t)n * b->dim), hs((size_t)n);
+  for (long long i = 0; i < n; i++) {
+    const double *rec = &b->overflow[(b->overflow_left + (size_t)i) * w];
+    for (unsigned int d = 0; d < b->dim; d++) xs[(size_t)i * b->dim + d] = rec[d];
+    hs[(size_t)i] = rec[b->dim];
+  }
+  hipStream_t s = b->bias->stream;
+  EDM_HIP_TRY(b->stage_x.reserve(xs.size()));
+  EDM_HIP_TRY(b->stage_h.reserve(hs.size()));
+  EDM_HIP_TRY(hipMemcpyAsync(b->stage_x.p, xs.data(), sizeof(double) * xs.size(), hipMemcpyHostToDevice, s));
+  EDM_HIP_TRY(hipMemcpyAsync(b->stage_h.p, hs.data(), sizeof(double) * hs.size(), hipMemcpyHostToDevice, s));
+  ApplySpec spec;
+  spec.nh = n;
+  spec.d_x = b->stage_x.p;
+  spec.x_stride = (int)b->dim;
+  spec.d_h = b->stage_h.p;
+  spec.limited = true;
+  spec.flush_mode = 1;
+  spec.limit = max_bias;
+  spec.cum_in = 0;
+  ApplyOutcome oc;
+  int rc = apply_hills(b->bias, spec, &oc, false);
+  if (rc) return rc;
+  const int stop = oc.res.stop;              // index of the crossing hill, or n
+  const long long nrun = (stop < n) ? stop + 1 : n;
+  std::vector<double> added((size_t)nrun), h2((size_t)nrun), a2((size_t)nrun);
+  EDM_HIP_TRY(hipMemcpy(added.data(), b->bias->ws.added.p, sizeof(double) * (size_t)nrun, hipMemcpyDeviceToHost));
+  EDM_HIP_TRY(hipMemcpy(h2.data(), b->bias->ws.tail_h2.p, sizeof(double) * (size_t)nrun, hipMemcpyDeviceToHost));
+  EDM_HIP_TRY(hipMemcpy(a2.data(), b->bias->ws.tail_a2.p, sizeof(double) * (size_t)nrun, hipMemcpyDeviceToHost));
+  // histogram: +1 per replayed hill, -1 for the undo (edm_bias.cpp:601-610)
+  std::vector<double> wgt((size_t)nrun, 1.0);
+  EDM_HIP_TRY(launch_hist_add(b->hist->g, b->hist->values, nrun, b->stage_x.p, (int)b->dim, nullptr, nullptr, 1.0, s));
+  for (long long i = 0; i < nrun; i++) {
+    double *rec = &b->overflow[(b->overflow_left + (size_t)i) * w];
+    b->hills_added++;
+    log_hill(b, rec, rec[b->dim], added[(size_t)i], 'b');
+    if (i == stop) {
+      rec[b->dim] = -h2[(size_t)i];           // the remaining part stays buffered (:341)
+      log_hill(b, rec, h2[(size_t)i], a2[(size_t)i], 'v');
+      b->hills_added++;
+      EDM_HIP_TRY(launch_hist_add(b->hist->g, b->hist->values, 1, b->stage_x.p + (size_t)i * b->dim, (int)b->dim,
+                                  nullptr, nullptr, -1.0, s));
+    }
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(s));
+  if (stop < n)
+    b->overflow_left += (size_t)stop;
+  else
+    b->overflow_left = b->overflow_right;
+  if (b->overflow_left == b->overflow_right) b->overflow_left = b->overflow_right = 0;
+  *bias_added = oc.res.cum_out;
+  return EDM_HIP_OK;
+}
+
+// pre_add_hill (edm_bias.cpp:413-442)
+static int do_pre_add_hill(edm_hip_bias *b, long long est) {
+  if (b->b_outofbounds) return EDM_HIP_OK;
+  if (!b->bias) {
+    set_error("pre_add_hill before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  b->est_hill_count = est;
+  b->temp_hill_prefactor = b->hill_prefactor;
+  if (b->global_tempering > 0)
+    if (b->cum_bias / b->total_volume >= b->global_tempering)
+      b->temp_hill_prefactor *= exp(-(b->cum_bias / b->total_volume - b->global_tempering) /
+                                    (b->global_tempering * (b->bias_factor - 1) * b->boltzmann_factor));
+  b->temp_hill_cum = 0;
+  b->hills_added = 0;
+  double flushed = 0;
+  int rc = flush_overflow(b, b->bias_per_step, &flushed);
+  if (rc) return rc;
+  b->temp_hill_cum += flushed;
+  b->b_skip_hill_add = (b->overflow_left == 0 && b->overflow_right == 0) ? 0 : 1;
+  return EDM_HIP_OK;
+}
+
+// the add_hill loop of one cycle (edm_bias.cpp:528-563 and :444-526) over device arrays
+static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, int x_stride, const double *d_ru,
+                             int apply_mask) {
+  if (n <= 0) return EDM_HIP_OK;
+  if (b->temp_hill_prefactor < 0) {
+    set_error("Must call pre_add_hill before add_hill");
+    return EDM_HIP_ERR_STATE;
+  }
+  if (b->b_skip_hill_add) return EDM_HIP_OK;          // :534-535
+  if (b->b_outofbounds) return EDM_HIP_OK;
+  if (apply_mask >= 0 && !b->d_mask) {
+    set_error("add_hills: apply_mask >= 0 needs set_mask");
+    return EDM_HIP_ERR_ARG;
+  }
+  if (b->b_targeting || (b->b_tempering && b->global_tempering < 0)) {
+    set_error("targeting / local tempering heights are not implemented on the device yet (SURVEY 8f#3)");
+    return EDM_HIP_ERR_ARG;
+  }
+  hipStream_t s = b->bias->stream;
+  const int use_thr = !(b->hill_density < 0);
+  const double thr = b->hill_density / b->est_hill_count;   // :543
+  long long nh = n;
+  const long long *d_sel = nullptr;
+  if (use_thr || apply_mask >= 0) {
+    if (use_thr && !d_ru) {
+      set_error("add_hills: hill_density set but no uniform random numbers given");
+      return EDM_HIP_ERR_ARG;
+    }
+    EDM_HIP_TRY(b->sel.reserve((size_t)n));
+    EDM_HIP_TRY(b->count.reserve(2));
+    EDM_HIP_TRY(b->sel_scratch.reserve(select_scratch_ints(n)));
+    EDM_HIP_TRY(launch_select(n, d_ru, thr, use_thr, b->d_mask, apply_mask, b->sel.p, b->count.p, b->sel_scratch.p, s));
+    long long *hcount = reinterpret_cast<long long *>(b->bias->h_scalars + 32);
+    EDM_HIP_TRY(hipMemcpyAsync(hcount, b->count.p, sizeof(long long), hipMemcpyDeviceToHost, s));
+    EDM_HIP_TRY(hipStreamSynchronize(s));
+    nh = *hcount;
+    d_sel = b->sel.p;
+  }
+  if (nh <= 0) return EDM_HIP_OK;
+  // height (:537, :552-558); targeting/tempering factors are handled above
+  double this_h = b->temp_hill_prefactor;
+  if (b->hill_density < 0)
+    this_h /= b->est_hill_count;
+  else
+    this_h /= b->hill_density;
+  this_h = fmin(this_h, BIAS_CLAMP * b->bias_per_step);
+
+  ApplySpec spec;
+  spec.nh = nh;
+  spec.d_x = d_x;
+  spec.x_stride = x_stride;
+  spec.d_sel = d_sel;
+  spec.d_h = nullptr;
+  spec.h_const = this_h;
+  spec.limited = true;
+  spec.flush_mode = 0;
+  spec.limit = b->bias_per_step;
+  spec.cum_in = b->temp_hill_cum;
+  ApplyOutcome oc;
+  int rc = apply_hills(b->bias, spec, &oc, false);
+  if (rc) return rc;
+  const LimitResult &res = oc.res;
+  b->temp_hill_cum = res.cum_out;
+
+  // histogram: every hill logs an 'h' line (+1), every undo a 'u' line (-1)
+  EDM_HIP_TRY(launch_hist_add(b->hist->g, b->hist->values, nh, d_x, x_stride, d_sel, nullptr, 1.0, s));
+
+  const long long k = res.k;
+  const int ntail = res.n_tail;
+  const unsigned int dim = b->dim;
+  // ordered tail: undo weights, overflow appends
+  std::vector<int> flags((size_t)ntail);
+  std::vector<double> th2((size_t)ntail), ta2((size_t)ntail), tpos((size_t)ntail * dim);
+  if (ntail > 0) {
+    EDM_HIP_TRY(hipMemcpy(flags.data(), b->bias->ws.tail_flags.p, sizeof(int) * (size_t)ntail, hipMemcpyDeviceToHost));
+    EDM_HIP_TRY(hipMemcpy(th2.data(), b->bias->ws.tail_h2.p, sizeof(double) * (size_t)ntail, hipMemcpyDeviceToHost));
+    EDM_HIP_TRY(hipMemcpy(ta2.data(), b->bias->ws.tail_a2.p, sizeof(double) * (size_t)ntail, hipMemcpyDeviceToHost));
+  }
+  // original (un-remapped) positions of the hills the host needs: tail, or all when logging
+  const bool log_all = b->hill_log && b->hills_fp;
+  const long long first = log_all ? 0 : k;
+  const long long need = nh - first;
+  std::vector<double> pos((size_t)need * dim), added;
+  if (need > 0) {
+    // gather positions through the selection on the device (strided, maybe indirect)
+    EDM_HIP_TRY(b->hx0.reserve((size_t)need * dim));
+    std::vector<double> dummy;
+    // reuse the hist kernel's addressing by a tiny copy kernel: done with hipMemcpy2D when direct
+    if (!d_sel) {
+      EDM_HIP_TRY(hipMemcpy2DAsync(b->hx0.p, sizeof(double) * dim, d_x + (size_t)first * x_stride,
+                                   sizeof(double) * (size_t)x_stride, sizeof(double) * dim, (size_t)need,
+                                   hipMemcpyDeviceToDevice, s));
+      EDM_HIP_TRY(hipMemcpyAsync(pos.data(), b->hx0.p, sizeof(double) * pos.size(), hipMemcpyDeviceToHost, s));
+      EDM_HIP_TRY(hipStreamSynchronize(s));
+    } else {
+      std::vector<long long> hsel((size_t)need);
+      EDM_HIP_TRY(hipMemcpy(hsel.data(), d_sel + first, sizeof(long long) * (size_t)need, hipMemcpyDeviceToHost));
+      for (long long i = 0; i < need; i++)
+        EDM_HIP_TRY(hipMemcpyAsync(&pos[(size_t)i * dim], d_x + (size_t)hsel[(size_t)i] * x_stride, sizeof(double) * dim,
+                                   hipMemcpyDeviceToHost, s));
+      EDM_HIP_TRY(hipStreamSynchronize(s));
+    }
+  }
+  if (log_all) {
+    added.resize((size_t)nh);
+    EDM_HIP_TRY(hipMemcpy(added.data(), b->bias->ws.added.p, sizeof(double) * (size_t)nh, hipMemcpyDeviceToHost));
+    for (long long i = 0; i < k; i++) {
+      b->hills_added++;
+      log_hill(b, &pos[(size_t)i * dim], this_h, added[(size_t)i], 'h');
+    }
+  } else {
+    b->hills_added += (int)k;
+  }
+  for (int j = 0; j < ntail; j++) {
+    const double *p = &pos[(size_t)(k - first + j) * dim];
+    const int fl = flags[(size_t)j];
+    if (fl & 1) {
+      b->hills_added++;
+      log_hill(b, p, this_h, log_all ? added[(size_t)(k + j)] : 0.0, 'h');
+      if (fl & 2) {
+        b->hills_added++;
+        log_hill(b, p, th2[(size_t)j], ta2[(size_t)j], 'u');
+        EDM_HIP_TRY(b->tail_w.reserve(dim));
+        EDM_HIP_TRY(hipMemcpyAsync(b->tail_w.p, p, sizeof(double) * dim, hipMemcpyHostToDevice, s));
+        EDM_HIP_TRY(launch_hist_add(b->hist->g, b->hist->values, 1, b->tail_w.p, (int)dim, nullptr, nullptr, -1.0, s));
+        EDM_HIP_TRY(hipStreamSynchronize(s));
+        rc = overflow_push(b, p, -th2[(size_t)j]);   // remainder goes to the buffer (:489)
+        if (rc) return rc;
+      }
+    } else {
+      log_hill(b, p, 0, 0, 'h');                     // :493
+      rc = overflow_push(b, p, this_h);
+      if (rc) return rc;
+    }
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(s));
+  return EDM_HIP_OK;
+}
+
+// post_add_hill (edm_bias.cpp:565-583) + update_height (:922-931)
+static int do_post_add_hill(edm_hip_bias *b) {
+  double step_bias = b->temp_hill_cum;
+  if (b->comm && b->nranks > 1) {
+    // one 8-byte all-reduce over xGMI replaces MPI_Allreduce(:925)
+    double *d = b->bias->d_scalars + 4;
+    hipStream_t s = b->bias->stream;
+    EDM_HIP_TRY(hipMemcpyAsync(d, &step_bias, sizeof(double), hipMemcpyHostToDevice, s));
+    if (ncclAllReduce(d, d, 1, ncclDouble, ncclSum, b->comm, s) != ncclSuccess) {
+      set_error("ncclAllReduce(temp_hill_cum) failed");
+      return EDM_HIP_ERR_COMM;
+    }
+    EDM_HIP_TRY(hipMemcpyAsync(b->bias->h_scalars + 4, d, sizeof(double), hipMemcpyDeviceToHost, s));
+    EDM_HIP_TRY(hipStreamSynchronize(s));
+    step_bias = b->bias->h_scalars[4];
+  }
+  b->cum_bias += step_bias;
+  b->temp_hill_cum = -1;
+  b->temp_hill_prefactor = -1;
+  b->steps++;
+  if (b->hills_fp) fflush(b->hills_fp);
+  return EDM_HIP_OK;
+}
+
+extern "C" {
+
+int edm_hip_bias_add_hills(edm_hip_bias *b, long long n, const double *d_x, int x_stride, const double *d_runiform,
+                           int apply_mask, long long est_hill_count) {
+  int rc = do_pre_add_hill(b, est_hill_count < 0 ? n : est_hill_count);   // :404
+  if (rc) return rc;
+  if (!b->b_outofbounds) {
+    rc = process_new_hills(b, n, d_x, x_stride, d_runiform, apply_mask);
+    if (rc) return rc;
+  }
+  return do_post_add_hill(b);
+}
+
+int edm_hip_bias_pre_add_hill(edm_hip_bias *b, long long est_hill_count) {
+  b->staged_x.clear();
+  b->staged_u.clear();
+  b->in_cycle = true;
+  return do_pre_add_hill(b, est_hill_count);
+}
+
+int edm_hip_bias_add_hill(edm_hip_bias *b, const double *position, double runiform) {
+  if (b->temp_hill_prefactor < 0 && !b->b_outofbounds) {
+    set_error("Must call pre_add_hill before add_hill");
+    return EDM_HIP_ERR_STATE;
+  }
+  for (unsigned int d = 0; d < b->dim; d++) b->staged_x.push_back(position[d]);
+  b->staged_u.push_back(runiform);
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_post_add_hill(edm_hip_bias *b) {
+  int rc = EDM_HIP_OK;
+  const long long n = (long long)b->staged_u.size();
+  if (n > 0 && !b->b_outofbounds) {
+    hipStream_t s = b->bias->stream;
+    EDM_HIP_TRY(b->stage_x.reserve(b->staged_x.size()));
+    EDM_HIP_TRY(b->stage_u.reserve(b->staged_u.size()));
+    EDM_HIP_TRY(hipMemcpyAsync(b->stage_x.p, b->staged_x.data(), sizeof(double) * b->staged_x.size(), hipMemcpyHostToDevice, s));
+    EDM_HIP_TRY(hipMemcpyAsync(b->stage_u.p, b->staged_u.data(), sizeof(double) * b->staged_u.size(), hipMemcpyHostToDevice, s));
+    EDM_HIP_TRY(hipStreamSynchronize(s));
+    rc = process_new_hills(b, n, b->stage_x.p, (int)b->dim, b->stage_u.p, -1);
+    if (rc) return rc;
+  }
+  b->staged_x.clear();
+  b->staged_u.clear();
+  b->in_cycle = false;
+  return do_post_add_hill(b);
+}
+
+// edm_bias.cpp:224-262
+int edm_hip_bias_write_bias(const edm_hip_bias *b, const char *filename, int serial_format) {
+  if (!b->bias) return EDM_HIP_ERR_STATE;
+  return serial_format ? edm_hip_gauss_write(b->bias, filename) : edm_hip_gauss_multi_write(b->bias, filename, 0);
+}
+int edm_hip_bias_write_lammps_table(const edm_hip_bias *b, const char *filename, int serial_format) {
+  if (!b->bias) return EDM_HIP_ERR_STATE;
+  return serial_format ? edm_hip_gauss_write(b->bias, filename) : edm_hip_gauss_multi_write(b->bias, filename, 1);
+}
+int edm_hip_bias_write_histogram(const edm_hip_bias *b, int serial_format) {
+  if (!b->hist) return EDM_HIP_ERR_STATE;
+  (void)serial_format;  // the histogram has no derivatives; both builds list node values
+  return edm_hip_grid_write(b->hist, b->hist_output.c_str());
+}
+int edm_hip_bias_clear_histogram(edm_hip_bias *b) {
+  if (!b->hist) return EDM_HIP_ERR_STATE;
+  return edm_hip_grid_clear(b->hist);
+}
+edm_hip_gauss *edm_hip_bias_gauss(edm_hip_bias *b) { return b->bias; }
+edm_hip_grid *edm_hip_bias_histogram(edm_hip_bias *b) { return b->hist; }
+
+int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
+#define G(n, expr) if (strcmp(name, n) == 0) { *value = (double)(expr); return EDM_HIP_OK; }
+  G("dim", b->dim)
+  G("b_tempering", b->b_tempering)
+  G("b_targeting", b->b_targeting)
+  G("global_tempering", b->global_tempering)
+  G("bias_factor", b->bias_factor)
+  G("boltzmann_factor", b->boltzmann_factor)
+  G("temperature", b->temperature)
+  G("hill_prefactor", b->hill_prefactor)
+  G("bias_per_step", b->bias_per_step)
+  G("hill_density", b->hill_density)
+  G("cum_bias", b->cum_bias)
+  G("total_volume", b->total_volume)
+  G("expected_target", b->expected_target)
+  G("b_outofbounds", b->b_outofbounds)
+  G("overflow_left", b->overflow_left)
+  G("overflow_right", b->overflow_right)
+  G("b_skip_hill_add", b->b_skip_hill_add)
+  G("hills_added", b->hills_added)
+  G("steps", b->steps)
+  G("mpi_rank", b->mpi_rank)
+  G("mpi_size", b->mpi_size)
+#undef G
+  set_error(std::string("unknown EDMBias member ") + name);
+  return EDM_HIP_ERR_ARG;
+}
+
+int edm_hip_bias_set(edm_hip_bias *b, const char *name, double value) {
+#define S(n, lhs, type) if (strcmp(name, n) == 0) { lhs = (type)value; return EDM_HIP_OK; }
+  S("b_tempering", b->b_tempering, int)
+  S("global_tempering", b->global_tempering, double)
+  S("bias_factor", b->bias_factor, double)
+  S("hill_prefactor", b->hill_prefactor, double)
+  S("bias_per_step", b->bias_per_step, double)
+  S("hill_density", b->hill_density, double)
+  S("cum_bias", b->cum_bias, double)
+  S("total_volume", b->total_volume, double)
+#undef S
+  set_error(std::string("unknown or read-only EDMBias member ") + name);
+  return EDM_HIP_ERR_ARG;
+}
+
+int edm_hip_bias_get_array(const edm_hip_bias *b, const char *name, double *out) {
+  const std::vector<double> *v = nullptr;
+  if (strcmp(name, "bias_dx") == 0) v = &b->bias_dx;
+  if (strcmp(name, "bias_sigma") == 0) v = &b->bias_sigma;
+  if (strcmp(name, "min") == 0) v = &b->min;
+  if (strcmp(name, "max") == 0) v = &b->max;
+  if (!v) return EDM_HIP_ERR_ARG;
+  for (size_t i = 0; i < v->size(); i++) out[i] = (*v)[i];
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_set_hill_log(edm_hip_bias *b, int enabled) {
+  b->hill_log = enabled;
+  return EDM_HIP_OK;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------
+int edm_hip_comm_unique_id(void *id_bytes, size_t cap) {
+  if (cap < sizeof(ncclUniqueId)) return EDM_HIP_ERR_ARG;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) {
+    set_error("ncclGetUniqueId failed");
+    return EDM_HIP_ERR_COMM;
+  }
+  memcpy(id_bytes, &id, sizeof(id));
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_comm_init(edm_hip_bias *b, const void *id_bytes, int nranks, int rank) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) return EDM_HIP_ERR_ARG;
+  b->nranks = nranks;
+  b->rank = rank;
+  b->mpi_size = nranks;
+  if (rank != b->mpi_rank) {
+    // the HILLS log is per rank (<name>_<rank>, edm_bias.cpp:1104-1107)
+    if (b->hills_fp) {
+      fclose(b->hills_fp);
+      b->hills_fp = nullptr;
+      remove(clean_string(b->hills_name, true, b->mpi_rank).c_str());
+    }
+    b->mpi_rank = rank;
+    open_hills(b);
+  }
+  if (nranks == 1 && !id_bytes) return EDM_HIP_OK;
+  ncclUniqueId id;
+  memcpy(&id, id_bytes, sizeof(id));
+  if (ncclCommInitRank(&b->comm, nranks, id, rank) != ncclSuccess) {
+    set_error("ncclCommInitRank failed");
+    return EDM_HIP_ERR_COMM;
+  }
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_comm_destroy(edm_hip_bias *b) {
+  if (b->comm) {
+    (void)ncclCommDestroy(b->comm);
+    b->comm = nullptr;
+  }
+  return EDM_HIP_OK;
+}
+
+}  // extern "C"

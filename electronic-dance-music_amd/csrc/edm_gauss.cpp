@@ -1,0 +1,894 @@
+// edm_gauss.cpp -- runtime helpers, the device-resident grid / gaussian-grid objects
+// and the host text writers of libedm_hip.so.  Host arithmetic that defines grid
+// geometry and the boundary tables follows the reference's operation order
+// (citations: file:line in the reference tree) so it is bit-identical to it.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <limits>
+
+#include "edm_internal.h"
+
+namespace edm {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char *what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return EDM_HIP_ERR_HIP;
+}
+
+void HillWorkspace::release() {
+  hx.release(); ht.release(); added.release(); partial.release(); scratch.release();
+  tail_h1.release(); tail_h2.release(); tail_a2.release(); tail_cum.release();
+  hc.release(); tail_flags.release(); tile_flags.release(); tile_list.release(); result.release();
+}
+
+// grid.h:190-213
+void make_geometry(Geom &g, int dim, const double *min, const double *max, const double *spacing,
+                   const int *periodic, int has_deriv, int interpolate) {
+  memset(&g, 0, sizeof(g));
+  g.dim = dim;
+  g.interp = interpolate;
+  g.has_deriv = has_deriv;
+  g.rec = has_deriv ? (dim == 1 ? 2 : 4) : 1;
+  g.total = 1;
+  for (int d = 0; d < 3; d++) {
+    g.n[d] = 1;
+    g.bper[d] = 1;
+    g.bmin[d] = -std::numeric_limits<double>::infinity();
+    g.bmax[d] = std::numeric_limits<double>::infinity();
+  }
+  for (int d = 0; d < dim; d++) {
+    g.min[d] = min[d];
+    g.max[d] = max[d];
+    g.periodic[d] = periodic[d];
+    g.n[d] = (int)ceil((g.max[d] - g.min[d]) / spacing[d]);
+    g.dx[d] = (g.max[d] - g.min[d]) / g.n[d];
+    g.n[d] = g.periodic[d] ? g.n[d] : g.n[d] + 1;
+    if (!g.periodic[d]) g.max[d] += g.dx[d];
+    g.total *= g.n[d];
+  }
+}
+
+// grid.h:799-806
+void finish_read_geometry(Geom &g) {
+  g.total = 1;
+  for (int d = 0; d < g.dim; d++) {
+    g.dx[d] = (g.max[d] - g.min[d]) / g.n[d];
+    if (!g.periodic[d]) {
+      g.max[d] += g.dx[d];
+      g.n[d] += 1;
+    }
+    g.total *= g.n[d];
+  }
+}
+
+void fill_public_geometry(const Geom &g, edm_hip_geometry *out) {
+  memset(out, 0, sizeof(*out));
+  out->dim = g.dim;
+  out->interpolate = g.interp;
+  out->total = g.total;
+  for (int d = 0; d < g.dim; d++) {
+    out->n[d] = g.n[d];
+    out->periodic[d] = g.periodic[d];
+    out->min[d] = g.min[d];
+    out->max[d] = g.max[d];
+    out->dx[d] = g.dx[d];
+    out->sigma[d] = g.sigma[d];
+    out->boundary_periodic[d] = g.bper[d];
+    out->boundary_min[d] = g.bmin[d];
+    out->boundary_max[d] = g.bmax[d];
+    out->minisize[d] = g.msize[d];
+  }
+}
+
+static void one2multi(const Geom &g, long long index, long long *out) {
+  int d;
+  for (d = 0; d < g.dim - 1; d++) {
+    out[d] = index % g.n[d];
+    index = (index - out[d]) / g.n[d];
+  }
+  out[d] = index;
+}
+
+static void put_header(FILE *fp, int b_deriv, int dim, const long long *bins, const double *lo, const double *hi,
+                       const int *pbc) {
+  fprintf(fp, "#! FORCE %d\n", b_deriv);
+  fprintf(fp, "#! NVAR %d\n", dim);
+  fprintf(fp, "#! TYPE ");
+  for (int d = 0; d < dim; d++) fprintf(fp, "%d ", EDM_GRID_TYPE);
+  fprintf(fp, "\n#! BIN ");
+  for (int d = 0; d < dim; d++) fprintf(fp, "%lld ", bins[d]);
+  fprintf(fp, "\n#! MIN ");
+  for (int d = 0; d < dim; d++) fprintf(fp, "%g ", lo[d]);
+  fprintf(fp, "\n#! MAX ");
+  for (int d = 0; d < dim; d++) fprintf(fp, "%g ", hi[d]);
+  fprintf(fp, "\n#! PBC ");
+  for (int d = 0; d < dim; d++) fprintf(fp, "%d ", pbc[d]);
+  fprintf(fp, "\n");
+}
+
+// grid.h:448-503
+int write_plumed(const Geom &g, const double *values, const double *derivs, const char *filename) {
+  FILE *fp = fopen(filename, "w");
+  if (!fp) {
+    set_error(std::string("cannot open ") + filename);
+    return EDM_HIP_ERR_IO;
+  }
+  long long bins[3], idx[3];
+  double hi[3];
+  for (int d = 0; d < g.dim; d++) {
+    bins[d] = g.periodic[d] ? g.n[d] : g.n[d] - 1;
+    hi[d] = g.periodic[d] ? g.max[d] : g.max[d] - g.dx[d];
+  }
+  put_header(fp, derivs ? 1 : 0, g.dim, bins, g.min, hi, g.periodic);
+  for (long long i = 0; i < g.total; i++) {
+    one2multi(g, i, idx);
+    for (int d = 0; d < g.dim; d++) fprintf(fp, "%.8f ", g.min[d] + g.dx[d] * (size_t)idx[d]);
+    fprintf(fp, "%.8f ", values[i]);
+    if (derivs)
+      for (int d = 0; d < g.dim; d++) fprintf(fp, "%.8f ", -derivs[i * g.dim + d]);
+    fprintf(fp, "\n");
+    if (idx[0] == g.n[0] - 1) fprintf(fp, "\n");
+  }
+  fclose(fp);
+  return EDM_HIP_OK;
+}
+
+static bool next_word(FILE *fp, char *buf, size_t cap) {
+  char fmt[32];
+  snprintf(fmt, sizeof fmt, "%%%zus", cap - 1);
+  return fscanf(fp, fmt, buf) == 1;
+}
+
+// grid.h:712-835
+int read_plumed(int dim, const char *filename, int b_interpolate, GridFile &out) {
+  FILE *fp = fopen(filename, "r");
+  if (!fp) {
+    set_error(std::string("Cannot open input file \"") + filename + "\"");
+    return EDM_HIP_ERR_IO;
+  }
+  Geom &g = out.g;
+  memset(&g, 0, sizeof(g));
+  g.dim = dim;
+  g.interp = b_interpolate;
+  for (int d = 0; d < 3; d++) {
+    g.n[d] = 1;
+    g.bper[d] = 1;
+    g.bmin[d] = -std::numeric_limits<double>::infinity();
+    g.bmax[d] = std::numeric_limits<double>::infinity();
+  }
+  char w[256];
+  int b_deriv = 0, ok = 1;
+  auto expect = [&](const char *key) {
+    ok = ok && next_word(fp, w, sizeof w) && next_word(fp, w, sizeof w) && strcmp(w, key) == 0;
+    return ok;
+  };
+  if (expect("FORCE")) ok = ok && fscanf(fp, "%d", &b_deriv) == 1;
+  if (ok && expect("NVAR")) {
+    int nv = 0;
+    ok = ok && fscanf(fp, "%d", &nv) == 1 && nv == dim;
+  }
+  if (ok && expect("TYPE"))
+    for (int d = 0; d < dim; d++) {
+      int t;
+      ok = ok && fscanf(fp, "%d", &t) == 1;
+    }
+  if (ok && expect("BIN"))
+    for (int d = 0; d < dim; d++) ok = ok && fscanf(fp, "%d", &g.n[d]) == 1;
+  if (ok && expect("MIN"))
+    for (int d = 0; d < dim; d++) ok = ok && fscanf(fp, "%lf", &g.min[d]) == 1;
+  if (ok && expect("MAX"))
+    for (int d = 0; d < dim; d++) ok = ok && fscanf(fp, "%lf", &g.max[d]) == 1;
+  if (ok && expect("PBC"))
+    for (int d = 0; d < dim; d++) ok = ok && fscanf(fp, "%d", &g.periodic[d]) == 1;
+  if (!ok) {
+    fclose(fp);
+    set_error(std::string("Mangled grid file: ") + filename);
+    return EDM_HIP_ERR_IO;
+  }
+  finish_read_geometry(g);
+  g.has_deriv = b_deriv;
+  g.rec = b_deriv ? (dim == 1 ? 2 : 4) : 1;
+  out.values.assign((size_t)g.total, 0.0);
+  out.derivs.assign(b_deriv ? (size_t)g.total * dim : 0, 0.0);
+  for (long long i = 0; i < g.total; i++) {
+    for (int d = 0; d < dim; d++) next_word(fp, w, sizeof w);
+    if (fscanf(fp, "%lf", &out.values[(size_t)i]) != 1) out.values[(size_t)i] = 0;
+    if (b_deriv)
+      for (int d = 0; d < dim; d++) {
+        double t = 0;
+        if (fscanf(fp, "%lf", &t) != 1) t = 0;
+        out.derivs[(size_t)i * dim + d] = t;
+        out.derivs[(size_t)i * dim + d] *= -1;  // files store the force, grids the gradient (:828)
+      }
+  }
+  fclose(fp);
+  return EDM_HIP_OK;
+}
+
+}  // namespace edm
+
+using namespace edm;
+
+edm::Tables edm_hip_gauss::tables() const {
+  Tables t;
+  for (int d = 0; d < 3; d++) {
+    t.denom[d] = tab[d][0];
+    t.dderiv[d] = tab[d][1];
+  }
+  return t;
+}
+
+extern "C" {
+
+// ---- runtime ----------------------------------------------------------------
+const char *edm_hip_last_error(void) { return g_last_error.c_str(); }
+const char *edm_hip_version(void) { return "edm-hip 0.1 (gfx950)"; }
+
+int edm_hip_device_count(int *count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    (void)hipGetLastError();
+    return hip_fail(e, "hipGetDeviceCount");
+  }
+  *count = n;
+  return EDM_HIP_OK;
+}
+int edm_hip_set_device(int device) {
+  EDM_HIP_TRY(hipSetDevice(device));
+  return EDM_HIP_OK;
+}
+int edm_hip_device_info(char *name, size_t cap, int *compute_units, size_t *hbm_bytes) {
+  int dev = 0;
+  EDM_HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  EDM_HIP_TRY(hipGetDeviceProperties(&p, dev));
+  if (name && cap) snprintf(name, cap, "%s (%s)", p.name, p.gcnArchName);
+  if (compute_units) *compute_units = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+  return EDM_HIP_OK;
+}
+int edm_hip_malloc(void **d_ptr, size_t bytes) {
+  EDM_HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 8));
+  return EDM_HIP_OK;
+}
+int edm_hip_free(void *d_ptr) {
+  if (d_ptr) EDM_HIP_TRY(hipFree(d_ptr));
+  return EDM_HIP_OK;
+}
+int edm_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes) {
+  EDM_HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return EDM_HIP_OK;
+}
+int edm_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes) {
+  EDM_HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return EDM_HIP_OK;
+}
+int edm_hip_memset(void *d_dst, int value, size_t bytes) {
+  EDM_HIP_TRY(hipMemset(d_dst, value, bytes));
+  return EDM_HIP_OK;
+}
+int edm_hip_device_synchronize(void) {
+  EDM_HIP_TRY(hipDeviceSynchronize());
+  return EDM_HIP_OK;
+}
+
+// ---- plain grid ---------------------------------------------------------------
+int edm_hip_grid_create(edm_hip_grid **out, int dim, const double *min, const double *max, const double *spacing,
+                        const int *periodic) {
+  if (!out || dim < 1 || dim > 3) {
+    set_error("edm_hip_grid_create: bad arguments");
+    return EDM_HIP_ERR_ARG;
+  }
+  edm_hip_grid *g = new edm_hip_grid;
+  make_geometry(g->g, dim, min, max, spacing, periodic, 0, 0);
+  EDM_HIP_TRY(hipStreamCreate(&g->stream));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->values), sizeof(double) * (size_t)g->g.total));
+  EDM_HIP_TRY(hipMemset(g->values, 0, sizeof(double) * (size_t)g->g.total));
+  *out = g;
+  return EDM_HIP_OK;
+}
+int edm_hip_grid_destroy(edm_hip_grid *g) {
+  if (!g) return EDM_HIP_OK;
+  if (g->values) (void)hipFree(g->values);
+  if (g->stream) (void)hipStreamDestroy(g->stream);
+  delete g;
+  return EDM_HIP_OK;
+}
+int edm_hip_grid_geometry(const edm_hip_grid *g, edm_hip_geometry *out) {
+  fill_public_geometry(g->g, out);
+  return EDM_HIP_OK;
+}
+int edm_hip_grid_download(const edm_hip_grid *g, double *h_values) {
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  EDM_HIP_TRY(hipMemcpy(h_values, g->values, sizeof(double) * (size_t)g->g.total, hipMemcpyDeviceToHost));
+  return EDM_HIP_OK;
+}
+int edm_hip_grid_upload(edm_hip_grid *g, const double *h_values) {
+  EDM_HIP_TRY(hipMemcpy(g->values, h_values, sizeof(double) * (size_t)g->g.total, hipMemcpyHostToDevice));
+  return EDM_HIP_OK;
+}
+int edm_hip_grid_clear(edm_hip_grid *g) {
+  EDM_HIP_TRY(hipMemsetAsync(g->values, 0, sizeof(double) * (size_t)g->g.total, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return EDM_HIP_OK;
+}
+int edm_hip_grid_add_values(edm_hip_grid *g, long long n, const double *d_x, int x_stride, const double *d_w,
+                            double w_const) {
+  EDM_HIP_TRY(launch_hist_add(g->g, g->values, n, d_x, x_stride, nullptr, d_w, w_const, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return EDM_HIP_OK;
+}
+int edm_hip_grid_write(const edm_hip_grid *g, const char *filename) {
+  std::vector<double> v((size_t)g->g.total);
+  int rc = edm_hip_grid_download(g, v.data());
+  if (rc) return rc;
+  return write_plumed(g->g, v.data(), nullptr, filename);
+}
+
+// ---- gaussian grid ------------------------------------------------------------
+static int gauss_alloc(edm_hip_gauss *g) {
+  const size_t bytes = sizeof(double) * (size_t)g->g.total * g->g.rec;
+  EDM_HIP_TRY(hipStreamCreate(&g->stream));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->rec), bytes));
+  EDM_HIP_TRY(hipMemset(g->rec, 0, bytes));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->scratch), sizeof(double) * lookup_scratch_doubles()));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_scalars), sizeof(double) * 16));
+  EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_scalars), sizeof(double) * 64, hipHostMallocDefault));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_dirty), sizeof(int) * 4));
+  EDM_HIP_TRY(hipMemset(g->d_dirty, 0, sizeof(int) * 4));
+  return EDM_HIP_OK;
+}
+
+// gaussian_grid.h:559-569
+static void update_minigrid(Geom &g) {
+  for (int d = 0; d < g.dim; d++) {
+    const double dist = sqrt(2 * EDM_GAUSS_SUPPORT) * g.sigma[d];
+    g.msize[d] = ifloor(dist / g.dx[d]);
+  }
+}
+
+int edm_hip_gauss_create(edm_hip_gauss **out, int dim, const double *min, const double *max, const double *spacing,
+                         const int *periodic, int b_interpolate, const double *sigma) {
+  if (!out || dim < 1 || dim > 3) {
+    set_error("edm_hip_gauss_create: bad arguments");
+    return EDM_HIP_ERR_ARG;
+  }
+  edm_hip_gauss *g = new edm_hip_gauss;
+  make_geometry(g->g, dim, min, max, spacing, periodic, 1, b_interpolate);  // gaussian_grid.h:70
+  for (int d = 0; d < dim; d++) g->g.sigma[d] = sigma[d] * sqrt(2.);        // gaussian_grid.h:75
+  int rc = gauss_alloc(g);
+  if (rc) return rc;
+  rc = edm_hip_gauss_set_boundary(g, min, max, periodic);                    // gaussian_grid.h:78
+  if (rc) return rc;
+  update_minigrid(g->g);
+  *out = g;
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_destroy(edm_hip_gauss *g) {
+  if (!g) return EDM_HIP_OK;
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  for (int d = 0; d < 3; d++)
+    for (int k = 0; k < 2; k++)
+      if (g->tab[d][k]) (void)hipFree(g->tab[d][k]);
+  if (g->rec) (void)hipFree(g->rec);
+  if (g->scratch) (void)hipFree(g->scratch);
+  if (g->d_scalars) (void)hipFree(g->d_scalars);
+  if (g->h_scalars) (void)hipHostFree(g->h_scalars);
+  if (g->d_dirty) (void)hipFree(g->d_dirty);
+  if (g->ev0) (void)hipEventDestroy(g->ev0);
+  if (g->ev1) (void)hipEventDestroy(g->ev1);
+  g->ws.release();
+  if (g->stream) (void)hipStreamDestroy(g->stream);
+  delete g;
+  return EDM_HIP_OK;
+}
+
+// gaussian_grid.h:378-435.  libm erf/exp on the host: table bits equal the reference's.
+int edm_hip_gauss_set_boundary(edm_hip_gauss *g, const double *min, const double *max, const int *periodic) {
+  Geom &q = g->g;
+  for (int d = 0; d < q.dim; d++) {
+    q.bmin[d] = min[d];
+    q.bmax[d] = max[d];
+    q.bper[d] = periodic[d];
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  EDM_HIP_TRY(hipMemset(g->d_dirty, 0, sizeof(int)));
+  std::vector<double> den(EDM_BC_TABLE_SIZE), dder(EDM_BC_TABLE_SIZE);
+  for (int d = 0; d < q.dim; d++) {
+    if (q.bper[d]) continue;
+    const double lo = q.bmin[d], hi = q.bmax[d], sg = q.sigma[d];
+    for (size_t j = 0; j < EDM_BC_TABLE_SIZE; j++) {
+      const double s = j * (hi - lo) / (EDM_BC_TABLE_SIZE - 1) + lo;
+      const double t1 = sqrt(M_PI) * sg / 2. * (erf((s - lo) / sg) + erf((hi - s) / sg));
+      const double t2 = sqrt(M_PI) * sg / 2. * erf((hi - lo) / sg);
+      den[j] = t1;
+      den[j] += (t2 - t1) * smooth_step((s - lo) / (EDM_BC_MAR * sg));
+      den[j] += (t2 - t1) * smooth_step((hi - s) / (EDM_BC_MAR * sg));
+      const double t3 = 1. * (exp(-((s - lo) * (s - lo)) / (sg * sg)) - exp(-((hi - s) * (hi - s)) / (sg * sg)));
+      dder[j] = t3;
+      dder[j] += (t2 - t1) * smooth_step_dt((s - lo) / (EDM_BC_MAR * sg)) / (EDM_BC_MAR * sg) -
+                 t3 * smooth_step((s - lo) / (EDM_BC_MAR * sg));
+      dder[j] += -(t2 - t1) * smooth_step_dt((hi - s) / (EDM_BC_MAR * sg)) / (EDM_BC_MAR * sg) -
+                 t3 * smooth_step((hi - s) / (EDM_BC_MAR * sg));
+    }
+    for (int k = 0; k < 2; k++) {
+      if (!g->tab[d][k])
+        EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->tab[d][k]), sizeof(double) * EDM_BC_TABLE_SIZE));
+      EDM_HIP_TRY(hipMemcpy(g->tab[d][k], k ? dder.data() : den.data(), sizeof(double) * EDM_BC_TABLE_SIZE,
+                            hipMemcpyHostToDevice));
+    }
+  }
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_geometry(const edm_hip_gauss *g, edm_hip_geometry *out) {
+  fill_public_geometry(g->g, out);
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_download(const edm_hip_gauss *g, double *h_values, double *h_derivs) {
+  const Geom &q = g->g;
+  double *dv = nullptr, *dd = nullptr;
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dv), sizeof(double) * (size_t)q.total));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dd), sizeof(double) * (size_t)q.total * q.dim));
+  EDM_HIP_TRY(launch_unpack(q, g->rec, dv, dd, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  if (h_values) EDM_HIP_TRY(hipMemcpy(h_values, dv, sizeof(double) * (size_t)q.total, hipMemcpyDeviceToHost));
+  if (h_derivs) EDM_HIP_TRY(hipMemcpy(h_derivs, dd, sizeof(double) * (size_t)q.total * q.dim, hipMemcpyDeviceToHost));
+  (void)hipFree(dv);
+  (void)hipFree(dd);
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_upload(edm_hip_gauss *g, const double *h_values, const double *h_derivs) {
+  const Geom &q = g->g;
+  double *dv = nullptr, *dd = nullptr;
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dv), sizeof(double) * (size_t)q.total));
+  EDM_HIP_TRY(hipMemcpy(dv, h_values, sizeof(double) * (size_t)q.total, hipMemcpyHostToDevice));
+  if (h_derivs) {
+    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dd), sizeof(double) * (size_t)q.total * q.dim));
+    EDM_HIP_TRY(hipMemcpy(dd, h_derivs, sizeof(double) * (size_t)q.total * q.dim, hipMemcpyHostToDevice));
+  }
+  EDM_HIP_TRY(launch_pack(q, g->rec, dv, dd, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  (void)hipFree(dv);
+  if (dd) (void)hipFree(dd);
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_clear(edm_hip_gauss *g) {
+  EDM_HIP_TRY(hipMemsetAsync(g->rec, 0, sizeof(double) * (size_t)g->g.total * g->g.rec, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_device_buffer(edm_hip_gauss *g, double **d_records, int *doubles_per_node, long long *nodes) {
+  if (d_records) *d_records = g->rec;
+  if (doubles_per_node) *doubles_per_node = g->g.rec;
+  if (nodes) *nodes = g->g.total;
+  return EDM_HIP_OK;
+}
+
+static void profile_collect(const edm_hip_gauss *gc) {
+  edm_hip_gauss *g = const_cast<edm_hip_gauss *>(gc);
+  if (!g->profiling) return;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, g->ev0, g->ev1) == hipSuccess) {
+    g->prof_ms += ms;
+    g->prof_launches += 1;
+  }
+}
+
+static int fetch_scalar(const edm_hip_gauss *g, int slot, double *out) {
+  EDM_HIP_TRY(hipMemcpyAsync(g->h_scalars + slot, g->d_scalars + slot, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  *out = g->h_scalars[slot];
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_get_value_deriv(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride,
+                                  double *d_energy, double *d_deriv) {
+  if (n <= 0) return EDM_HIP_OK;
+  LookupArgs a{};
+  a.n = n; a.x = d_x; a.x_stride = x_stride; a.energy = d_energy; a.f = d_deriv; a.apply_mask = -1;
+  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_VALUES, a, g->scratch, nullptr, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_sample_index(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride,
+                               long long *d_flat) {
+  if (n <= 0) return EDM_HIP_OK;
+  LookupArgs a{};
+  a.n = n; a.x = d_x; a.x_stride = x_stride; a.flat = d_flat; a.apply_mask = -1;
+  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_INDEX, a, g->scratch, nullptr, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_update_forces(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride, double *d_f,
+                                int f_stride, const int *d_mask, int apply_mask, double *energy) {
+  if (energy) *energy = 0;
+  if (n <= 0) return EDM_HIP_OK;
+  if (apply_mask >= 0 && !d_mask) {
+    set_error("update_forces: apply_mask >= 0 needs a mask");
+    return EDM_HIP_ERR_ARG;
+  }
+  LookupArgs a{};
+  a.n = n; a.x = d_x; a.x_stride = x_stride; a.f = d_f; a.f_stride = f_stride; a.mask = d_mask; a.apply_mask = apply_mask;
+  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, a, g->scratch, g->d_scalars, g->stream,
+                            g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr));
+  double e = 0;
+  int rc = fetch_scalar(g, 0, &e);
+  if (rc) return rc;
+  profile_collect(g);
+  if (energy) *energy = e;
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_pair_forces(const edm_hip_gauss *g, long long n, const double *d_r, double *d_force,
+                              double *energy) {
+  if (energy) *energy = 0;
+  if (g->g.dim != 1) {
+    set_error("pair_forces: the pair-distance CV is 1-D (fix_edm_pair.cpp:52)");
+    return EDM_HIP_ERR_ARG;
+  }
+  if (n <= 0) return EDM_HIP_OK;
+  EDM_HIP_TRY(launch_pair_forces(g->g, g->rec, n, d_r, d_force, g->scratch, g->d_scalars, g->stream,
+                                 g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr));
+  double e = 0;
+  int rc = fetch_scalar(g, 0, &e);
+  if (rc) return rc;
+  profile_collect(g);
+  if (energy) *energy = e;
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_profile_enable(edm_hip_gauss *g, int enabled) {
+  if (enabled && !g->ev0) {
+    EDM_HIP_TRY(hipEventCreate(&g->ev0));
+    EDM_HIP_TRY(hipEventCreate(&g->ev1));
+  }
+  g->profiling = enabled ? 1 : 0;
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_profile_read(edm_hip_gauss *g, double *kernel_ms_total, long long *launches, int reset) {
+  if (kernel_ms_total) *kernel_ms_total = g->prof_ms;
+  if (launches) *launches = g->prof_launches;
+  if (reset) {
+    g->prof_ms = 0;
+    g->prof_launches = 0;
+  }
+  return EDM_HIP_OK;
+}
+
+}  // extern "C"
+
+// ---- hill application pipeline --------------------------------------------------
+namespace edm {
+
+int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool want_total) {
+  const Geom &q = g->g;
+  HillWorkspace &ws = g->ws;
+  const long long nh = spec.nh;
+  if (out) {
+    memset(&out->res, 0, sizeof(out->res));
+    out->res.cum_out = spec.cum_in;
+    out->res.k = nh;
+    out->total_added = 0;
+  }
+  if (nh <= 0) return EDM_HIP_OK;
+  hipStream_t s = g->stream;
+  EDM_HIP_TRY(ws.hx.reserve((size_t)nh * q.dim));
+  EDM_HIP_TRY(ws.ht.reserve((size_t)nh * 2 * q.dim));
+  EDM_HIP_TRY(ws.hc.reserve((size_t)nh * q.dim));
+  EDM_HIP_TRY(ws.added.reserve((size_t)nh));
+  EDM_HIP_TRY(ws.result.reserve(sizeof(LimitResult)));
+  EDM_HIP_TRY(ws.tail_h1.reserve(EDM_TAIL_CAP));
+  EDM_HIP_TRY(ws.tail_h2.reserve(EDM_TAIL_CAP));
+  EDM_HIP_TRY(ws.tail_a2.reserve(EDM_TAIL_CAP));
+  EDM_HIP_TRY(ws.tail_cum.reserve(EDM_TAIL_CAP));
+  EDM_HIP_TRY(ws.tail_flags.reserve(EDM_TAIL_CAP));
+  size_t scratch_need = limit_scratch_doubles(nh);
+  if (scratch_need < lookup_scratch_doubles()) scratch_need = lookup_scratch_doubles();
+  EDM_HIP_TRY(ws.scratch.reserve(scratch_need));
+
+  HillList hl;
+  hl.nh = nh;
+  hl.x = spec.d_x;
+  hl.x_stride = spec.x_stride;
+  hl.sel = spec.d_sel;
+  hl.hx = ws.hx.p;
+  hl.hc = ws.hc.p;
+  hl.ht = ws.ht.p;
+  const Tables tabs = g->tables();
+  EDM_HIP_TRY(launch_hill_prep(q, hl, s));
+
+  HillHeights hh;
+  hh.h = spec.d_h;
+  hh.h_const = spec.h_const;
+  hh.k = nh;
+  hh.tail_h1 = ws.tail_h1.p;
+  hh.tail_h2 = ws.tail_h2.p;
+
+  LimitResult res;
+  memset(&res, 0, sizeof(res));
+  res.k = nh;
+  res.cum_out = spec.cum_in;
+  if (spec.limited || want_total) EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, ws.added.p, s));
+  if (spec.limited) {
+    LimitTail tail{ws.tail_h1.p, ws.tail_h2.p, ws.tail_a2.p, ws.tail_cum.p, ws.tail_flags.p};
+    LimitResult *dres = reinterpret_cast<LimitResult *>(ws.result.p);
+    EDM_HIP_TRY(launch_limit(nh, ws.added.p, spec.d_h, spec.h_const, spec.limit, spec.cum_in, spec.flush_mode, tail,
+                             dres, ws.scratch.p, s));
+    LimitResult *hres = reinterpret_cast<LimitResult *>(g->h_scalars + 8);
+    EDM_HIP_TRY(hipMemcpyAsync(hres, dres, sizeof(LimitResult), hipMemcpyDeviceToHost, s));
+    EDM_HIP_TRY(hipStreamSynchronize(s));
+    res = *hres;
+    if (res.error) {
+      set_error("The bias overflow buffer is full. Too many hills. Either increase & recompile, lower hill_density, or lower bias");
+      return EDM_HIP_ERR_OVERFLOW;
+    }
+    hh.k = res.k;
+  } else if (want_total) {
+    EDM_HIP_TRY(launch_sum(nh, ws.added.p, g->d_scalars + 1, ws.scratch.p, s));
+  }
+
+  // gather plan: hill groups when a small grid meets a long hill list, tile culling
+  // when a large grid meets a short one
+  GatherPlan plan;
+  plan.groups = 1;
+  plan.partial = nullptr;
+  plan.tile_flags = nullptr;
+  plan.tile_list = nullptr;
+  plan.tile_bound = 0;
+  const long long ntiles = gather_tiles(q);
+  if (nh >= 4096 && ntiles < 1024) {
+    long long G = (2048 + ntiles - 1) / ntiles;
+    if (G > 64) G = 64;
+    if (G > nh / 256) G = nh / 256;
+    if (G < 1) G = 1;
+    plan.groups = (int)G;
+    if (G > 1) {
+      EDM_HIP_TRY(ws.partial.reserve((size_t)G * (size_t)q.total * q.rec));
+      plan.partial = ws.partial.p;
+    }
+  } else if (ntiles > 2048) {
+    static const int T1[3] = {256, 1, 1}, T2[3] = {16, 16, 1}, T3[3] = {8, 8, 4};
+    const int *T = q.dim == 1 ? T1 : q.dim == 2 ? T2 : T3;
+    long long per_hill = 1;
+    for (int d = 0; d < q.dim; d++) per_hill *= (2 * q.msize[d]) / T[d] + 2;
+    if (nh * per_hill < ntiles / 2) {
+      EDM_HIP_TRY(ws.tile_flags.reserve((size_t)ntiles));
+      EDM_HIP_TRY(ws.tile_list.reserve((size_t)ntiles + 1));
+      plan.tile_flags = ws.tile_flags.p;
+      plan.tile_list = ws.tile_list.p;
+      plan.tile_bound = nh * per_hill;
+    }
+  }
+  EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, hl, hh, plan, g->d_dirty, s));
+  EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
+  if (want_total && !spec.limited) {
+    double t = 0;
+    int rc = fetch_scalar(g, 1, &t);
+    if (rc) return rc;
+    if (out) out->total_added = t;
+  } else {
+    EDM_HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (out) out->res = res;
+  return EDM_HIP_OK;
+}
+
+}  // namespace edm
+
+extern "C" {
+
+int edm_hip_gauss_add_values(edm_hip_gauss *g, long long n, const double *d_x, int x_stride, const double *d_h,
+                             double h_const, double *d_added, double *total_added) {
+  if (total_added) *total_added = 0;
+  if (n <= 0) return EDM_HIP_OK;
+  ApplySpec spec;
+  spec.nh = n;
+  spec.d_x = d_x;
+  spec.x_stride = x_stride;
+  spec.d_h = d_h;
+  spec.h_const = h_const;
+  ApplyOutcome outc;
+  const bool want = (d_added != nullptr) || (total_added != nullptr);
+  int rc = apply_hills(g, spec, &outc, want);
+  if (rc) return rc;
+  if (d_added) EDM_HIP_TRY(hipMemcpy(d_added, g->ws.added.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice));
+  if (total_added) *total_added = outc.total_added;
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_hill_integrals(const edm_hip_gauss *gc, long long n, const double *d_x, int x_stride,
+                                 const double *d_h, double h_const, double *d_added) {
+  if (n <= 0) return EDM_HIP_OK;
+  edm_hip_gauss *g = const_cast<edm_hip_gauss *>(gc);
+  HillWorkspace &ws = g->ws;
+  const Geom &q = g->g;
+  EDM_HIP_TRY(ws.hx.reserve((size_t)n * q.dim));
+  EDM_HIP_TRY(ws.ht.reserve((size_t)n * 2 * q.dim));
+  EDM_HIP_TRY(ws.hc.reserve((size_t)n * q.dim));
+  HillList hl;
+  hl.nh = n; hl.x = d_x; hl.x_stride = x_stride; hl.sel = nullptr;
+  hl.hx = ws.hx.p; hl.hc = ws.hc.p; hl.ht = ws.ht.p;
+  EDM_HIP_TRY(launch_hill_prep(q, hl, g->stream));
+  EDM_HIP_TRY(launch_hill_integrals(q, g->tables(), hl, d_h, h_const, d_added, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return EDM_HIP_OK;
+}
+
+int edm_hip_gauss_write(const edm_hip_gauss *g, const char *filename) {
+  const Geom &q = g->g;
+  std::vector<double> v((size_t)q.total), dv((size_t)q.total * q.dim);
+  int rc = edm_hip_gauss_download(g, v.data(), dv.data());
+  if (rc) return rc;
+  return write_plumed(q, v.data(), dv.data(), filename);
+}
+
+// grid.h:509-674 for one rank: points box_min + k*dx that are in_grid are re-sampled
+// by INTERPOLATION (a batched device lookup without the gaussian boundary handling,
+// because multi_write calls DimmedGrid::get_value_deriv directly).
+int edm_hip_gauss_multi_write(const edm_hip_gauss *g, const char *filename, int b_lammps_format) {
+  const Geom &q = g->g;
+  if (b_lammps_format == 1 && q.dim > 1) {
+    set_error("Lammps format only valid for 1D grids");
+    return EDM_HIP_ERR_ARG;
+  }
+  const double *box_min = q.bmin, *box_max = q.bmax;
+  const int *b_periodic = q.bper;
+  unsigned int counts[3] = {1, 1, 1}, extra_n = 0;
+  if (b_lammps_format) extra_n = (unsigned int)(box_min[0] / q.dx[0]);
+  size_t total = 1;
+  for (int d = 0; d < q.dim; d++) {
+    counts[d] = (unsigned int)(int)ceil((box_max[d] - box_min[d]) / q.dx[d]);
+    counts[d] = b_periodic[d] ? counts[d] : counts[d] + 1;
+    total *= counts[d];
+  }
+  // sample coordinates and the in_grid filter (host geometry only)
+  std::vector<double> xs;
+  std::vector<size_t> which;
+  std::vector<unsigned int> sup0;
+  xs.reserve(total * q.dim);
+  for (size_t i = 0; i < total; i++) {
+    size_t tmp = i, sup[3] = {0, 0, 0};
+    double x[3];
+    int d;
+    for (d = 0; d < q.dim - 1; d++) {
+      sup[d] = tmp % counts[d];
+      tmp = (tmp - sup[d]) / counts[d];
+      x[d] = sup[d] * q.dx[d] + box_min[d];
+    }
+    sup[d] = tmp;
+    x[d] = sup[d] * q.dx[d] + box_min[d];
+    bool in = true;
+    for (d = 0; d < q.dim; d++)
+      if (!q.periodic[d] && (x[d] < q.min[d] || x[d] >= q.max[d] - q.dx[d])) in = false;
+    if (!in) continue;
+    which.push_back(i);
+    sup0.push_back((unsigned int)sup[0]);
+    for (d = 0; d < q.dim; d++) xs.push_back(x[d]);
+  }
+  const size_t m = which.size();
+  std::vector<double> E(m), der(m * q.dim);
+  if (m) {
+    Geom plain = q;  // DimmedGrid lookup: no boundary test, no remap
+    for (int d = 0; d < 3; d++) {
+      plain.bper[d] = 1;
+      plain.bmin[d] = -std::numeric_limits<double>::infinity();
+      plain.bmax[d] = std::numeric_limits<double>::infinity();
+    }
+    double *dx = nullptr, *dE = nullptr, *dD = nullptr;
+    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dx), sizeof(double) * m * q.dim));
+    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dE), sizeof(double) * m));
+    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dD), sizeof(double) * m * q.dim));
+    EDM_HIP_TRY(hipMemcpy(dx, xs.data(), sizeof(double) * m * q.dim, hipMemcpyHostToDevice));
+    LookupArgs a{};
+    a.n = (long long)m; a.x = dx; a.x_stride = q.dim; a.energy = dE; a.f = dD; a.apply_mask = -1;
+    EDM_HIP_TRY(launch_lookup(plain, g->rec, LOOKUP_VALUES, a, g->scratch, nullptr, g->stream));
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    EDM_HIP_TRY(hipMemcpy(E.data(), dE, sizeof(double) * m, hipMemcpyDeviceToHost));
+    EDM_HIP_TRY(hipMemcpy(der.data(), dD, sizeof(double) * m * q.dim, hipMemcpyDeviceToHost));
+    (void)hipFree(dx);
+    (void)hipFree(dE);
+    (void)hipFree(dD);
+  }
+  FILE *fp = fopen(filename, "w");
+  if (!fp) {
+    set_error(std::string("cannot open ") + filename);
+    return EDM_HIP_ERR_IO;
+  }
+  if (!b_lammps_format) {
+    long long bins[3];
+    for (int d = 0; d < q.dim; d++) bins[d] = b_periodic[d] ? (long long)counts[d] : (long long)counts[d] - 1;
+    edm::put_header(fp, 1, q.dim, bins, box_min, box_max, b_periodic);
+  } else {
+    fprintf(fp, "#Auto generated by electronic-dance-music\n\n");
+    fprintf(fp, "EDM\n");
+    fprintf(fp, "N %u R %g %g\n\n", extra_n + counts[0], q.dx[0], box_max[0]);
+    for (size_t i = 1; i < extra_n; i++) fprintf(fp, "%zu %g 0.0 0.0\n", i, i * q.dx[0]);
+  }
+  for (size_t j = 0; j < m; j++) {
+    if (b_lammps_format) fprintf(fp, "%zu ", which[j] + extra_n);
+    for (int d = 0; d < q.dim; d++) fprintf(fp, "%.8f ", xs[j * q.dim + d]);
+    fprintf(fp, "%.8f ", E[j]);
+    for (int d = 0; d < q.dim; d++) fprintf(fp, "%.8f ", -der[j * q.dim + d]);
+    fprintf(fp, "\n");
+    if (sup0[j] == counts[0] - 1) fprintf(fp, "\n");
+  }
+  fclose(fp);
+  return EDM_HIP_OK;
+}
+
+// Grid::add (grid.h:275-290): this += scale * other(x_node) + offset with `other` read from
+// a PLUMED file and evaluated by interpolation at every node of this grid.
+int edm_hip_gauss_add_from_file(edm_hip_gauss *g, const char *filename, double scale, double offset) {
+  const Geom &q = g->g;
+  GridFile gf;
+  int rc = read_plumed(q.dim, filename, 1, gf);
+  if (rc) return rc;
+  if (!gf.g.has_deriv) {
+    set_error("initial bias file has no derivatives (FORCE 0)");
+    return EDM_HIP_ERR_IO;
+  }
+  // upload `other` as a temporary record array
+  edm_hip_gauss tmp;
+  tmp.g = gf.g;
+  tmp.stream = g->stream;
+  const size_t bytes = sizeof(double) * (size_t)gf.g.total * gf.g.rec;
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp.rec), bytes));
+  double *dv = nullptr, *dd = nullptr;
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dv), sizeof(double) * gf.values.size()));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dd), sizeof(double) * gf.derivs.size()));
+  EDM_HIP_TRY(hipMemcpy(dv, gf.values.data(), sizeof(double) * gf.values.size(), hipMemcpyHostToDevice));
+  EDM_HIP_TRY(hipMemcpy(dd, gf.derivs.data(), sizeof(double) * gf.derivs.size(), hipMemcpyHostToDevice));
+  EDM_HIP_TRY(launch_pack(gf.g, tmp.rec, dv, dd, g->stream));
+  // node coordinates of this grid
+  std::vector<double> xs((size_t)q.total * q.dim);
+  for (long long i = 0; i < q.total; i++) {
+    long long idx[3];
+    edm::one2multi(q, i, idx);
+    for (int d = 0; d < q.dim; d++) xs[(size_t)i * q.dim + d] = q.min[d] + q.dx[d] * (size_t)idx[d];
+  }
+  double *dx = nullptr, *dE = nullptr, *dD = nullptr;
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dx), sizeof(double) * xs.size()));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dE), sizeof(double) * (size_t)q.total));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dD), sizeof(double) * xs.size()));
+  EDM_HIP_TRY(hipMemcpy(dx, xs.data(), sizeof(double) * xs.size(), hipMemcpyHostToDevice));
+  LookupArgs a{};
+  a.n = q.total; a.x = dx; a.x_stride = q.dim; a.energy = dE; a.f = dD; a.apply_mask = -1;
+  EDM_HIP_TRY(launch_lookup(gf.g, tmp.rec, LOOKUP_VALUES, a, g->scratch, nullptr, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  std::vector<double> E((size_t)q.total), D(xs.size()), v((size_t)q.total), dvv(xs.size());
+  EDM_HIP_TRY(hipMemcpy(E.data(), dE, sizeof(double) * E.size(), hipMemcpyDeviceToHost));
+  EDM_HIP_TRY(hipMemcpy(D.data(), dD, sizeof(double) * D.size(), hipMemcpyDeviceToHost));
+  rc = edm_hip_gauss_download(g, v.data(), dvv.data());
+  if (rc) return rc;
+  for (size_t i = 0; i < E.size(); i++) {
+    v[i] += scale * E[i] + offset;
+    for (int d = 0; d < q.dim; d++) dvv[i * q.dim + d] += scale * D[i * q.dim + d];
+  }
+  rc = edm_hip_gauss_upload(g, v.data(), dvv.data());
+  (void)hipFree(dx); (void)hipFree(dE); (void)hipFree(dD); (void)hipFree(dv); (void)hipFree(dd); (void)hipFree(tmp.rec);
+  tmp.rec = nullptr;
+  tmp.stream = nullptr;
+  return rc;
+}
+
+}  // extern "C"

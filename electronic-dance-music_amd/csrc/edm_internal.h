@@ -1,0 +1,121 @@
+// edm_internal.h -- host-side objects behind the opaque handles of include/edm_hip.h.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/edm_hip.h"
+#include "edm_common.h"
+#include "edm_kernels.h"
+
+namespace edm {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+
+#define EDM_HIP_TRY(expr)                                   \
+  do {                                                      \
+    hipError_t e__ = (expr);                                \
+    if (e__ != hipSuccess) return edm::hip_fail(e__, #expr); \
+  } while (0)
+
+// grows a device allocation (contents are NOT preserved)
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      if (e != hipSuccess) return e;
+      p = nullptr;
+      cap = 0;
+    }
+    size_t want = n + n / 4 + 64;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
+    if (e != hipSuccess) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// workspace of the hill path, shared by add_values / the controller
+struct HillWorkspace {
+  DevBuf<double> hx, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum;
+  DevBuf<int> hc, tail_flags, tile_flags, tile_list;
+  DevBuf<char> result;      // LimitResult
+  void release();
+};
+
+// derived DimmedGrid geometry from the constructor arguments (grid.h:190-213)
+void make_geometry(Geom &g, int dim, const double *min, const double *max, const double *spacing,
+                   const int *periodic, int has_deriv, int interpolate);
+// geometry from PLUMED-file header fields (grid.h:799-806)
+void finish_read_geometry(Geom &g);
+void fill_public_geometry(const Geom &g, edm_hip_geometry *out);
+
+// host text writers (byte-identical to grid.h:448-503 / :509-674)
+int write_plumed(const Geom &g, const double *values, const double *derivs, const char *filename);
+
+// parsed PLUMED grid file (grid.h:712-835)
+struct GridFile {
+  Geom g;
+  std::vector<double> values, derivs;
+};
+int read_plumed(int dim, const char *filename, int b_interpolate, GridFile &out);
+
+}  // namespace edm
+
+struct edm_hip_grid {
+  edm::Geom g;
+  double *values = nullptr;   // device, g.total doubles
+  hipStream_t stream = nullptr;
+};
+
+struct edm_hip_gauss {
+  edm::Geom g;
+  double *rec = nullptr;                 // device node records
+  double *tab[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // denom, dderiv per dim
+  hipStream_t stream = nullptr;
+  double *scratch = nullptr;             // lookup partial sums
+  double *d_scalars = nullptr;           // small device result slots
+  double *h_scalars = nullptr;           // pinned host mirror
+  int *d_dirty = nullptr;
+  // bench support: HIP events around the dominant lookup kernel
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int profiling = 0;
+  double prof_ms = 0;
+  long long prof_launches = 0;
+  edm::HillWorkspace ws;
+  edm::Tables tables() const;
+};
+
+// internal entry points shared between edm_gauss and edm_bias
+namespace edm {
+struct ApplySpec {
+  long long nh = 0;
+  const double *d_x = nullptr;     // sample positions
+  int x_stride = 1;
+  const long long *d_sel = nullptr;
+  const double *d_h = nullptr;     // per-hill heights or NULL
+  double h_const = 0;
+  bool limited = false;            // run the limiter
+  int flush_mode = 0;
+  double limit = 0, cum_in = 0;
+};
+struct ApplyOutcome {
+  LimitResult res;
+  double total_added = 0;          // unlimited mode: sum of added
+};
+// prep -> integrals -> (limiter) -> ordered gather -> boundary duplication.
+// Leaves per-hill `added` in g->ws.added and the tail arrays in g->ws.tail_*.
+int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool want_total);
+}  // namespace edm

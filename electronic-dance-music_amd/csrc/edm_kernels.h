@@ -1,0 +1,128 @@
+// edm_kernels.h -- host-callable launchers of the gfx950 kernels (edm_kernels.hip).
+// Internal to libedm_hip.so; the public boundary is include/edm_hip.h.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include "edm_common.h"
+
+namespace edm {
+
+// McGovern-De Pablo tables in HBM: [dim][65536] doubles each (NULL rows for
+// periodic boundary dimensions).
+struct Tables {
+  const double *denom[3];
+  const double *dderiv[3];
+};
+
+// ---- lookup path (K1/K2/K8) ------------------------------------------------
+enum LookupMode {
+  LOOKUP_FORCES = 0,   // f[i][d] -= dV/ds_d, masked, energy sum       (edm_bias.cpp:276-295)
+  LOOKUP_VALUES = 1,   // energy[i] = V, deriv[i][d] = dV/ds_d          (gaussian_grid.h:118-138)
+  LOOKUP_INDEX = 2     // flat[i] = start node or -1                     (grid.h:264-273)
+};
+
+struct LookupArgs {
+  long long n;
+  const double *x;
+  int x_stride;
+  double *f;          // FORCES: forces; VALUES: deriv [n][dim]
+  int f_stride;
+  double *energy;     // VALUES: per-sample energy (may be NULL)
+  long long *flat;    // INDEX
+  const int *mask;
+  int apply_mask;
+};
+
+// energy_out: device double receiving the (deterministic, fixed-order) sum of V;
+// scratch: device doubles, at least lookup_scratch_doubles() of them.
+size_t lookup_scratch_doubles();
+// ev0/ev1 (may be NULL) are recorded on `s` directly around the main kernel, so a caller can
+// time exactly that launch with hipEventElapsedTime.
+hipError_t launch_lookup(const Geom &g, const double *rec, LookupMode mode, const LookupArgs &a,
+                         double *scratch, double *energy_out, hipStream_t s,
+                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// 1-D pair-distance form: force[i] = -dV/dr(r_i)
+hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, const double *r,
+                              double *force, double *scratch, double *energy_out, hipStream_t s,
+                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+
+// ---- record layout conversion ---------------------------------------------------
+hipError_t launch_pack(const Geom &g, double *rec, const double *values, const double *derivs, hipStream_t s);
+hipError_t launch_unpack(const Geom &g, const double *rec, double *values, double *derivs, hipStream_t s);
+
+// ---- plain-grid histogram add (K7) ------------------------------------------
+hipError_t launch_hist_add(const Geom &g, double *values, long long n, const double *x, int x_stride,
+                           const long long *sel, const double *w, double w_const, hipStream_t s);
+
+// ---- hill path (K3/K4/K5/K6) -----------------------------------------------
+// order-preserving selection of accepted samples (edm_bias.cpp:543 and the mask
+// tests of :406): sel[j] = index of the j-th accepted sample, *count = how many.
+size_t select_scratch_ints(long long n);
+hipError_t launch_select(long long n, const double *runiform, double threshold, int use_threshold,
+                         const int *mask, int apply_mask, long long *sel, long long *count,
+                         int *scratch, hipStream_t s);
+
+struct HillList {
+  long long nh;
+  const double *x;        // sample positions [.. ][x_stride]
+  int x_stride;
+  const long long *sel;   // optional indirection into x (NULL = identity)
+  // prepared per-hill records (device, capacity >= nh):
+  double *hx;             // remapped position            [nh][dim]
+  int *hc;                // centre node index (INT_MIN in hc[i*dim] = rejected) [nh][dim]
+  double *ht;             // (t1, t3) of gaussian_grid.h:310,:312 per dim [nh][2*dim]
+};
+hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s);
+
+struct HillHeights {
+  const double *h;        // per-hill base height or NULL
+  double h_const;
+  long long k;            // hills [0,k) use (base height, 0); hills >= k use the tail arrays
+  const double *tail_h1;  // first add (0 = hill deferred, not applied)
+  const double *tail_h2;  // second add (the "undo" hill) or 0
+};
+// per-hill integrated bias for the BASE heights (the value add_value returns)
+hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList &h, const double *heights,
+                                 double h_const, double *added, hipStream_t s);
+
+struct GatherPlan {
+  int groups;             // hill groups (partial buffers) -- 1 = accumulate in place
+  double *partial;        // [groups][total][rec] when groups > 1
+  int *tile_flags;        // [ntiles] scratch when culling, else NULL
+  int *tile_list;         // [ntiles + 1] (list + count at the end)
+  long long tile_bound;   // launch bound for culled gathers
+};
+long long gather_tiles(const Geom &g);
+// applies the hills to the record array in list order; dirty_flag (device int) is set
+// when any boundary correction was non-zero (gaussian_grid.h:357-358)
+hipError_t launch_hill_gather(const Geom &g, const Tables &t, double *rec, const HillList &h,
+                              const HillHeights &hh, const GatherPlan &plan, int *dirty_flag, hipStream_t s);
+// gaussian_grid.h:571-630, executed iff *dirty_flag != 0; clears the flag
+hipError_t launch_duplicate_boundary(const Geom &g, double *rec, int *dirty_flag, hipStream_t s);
+
+// limiter (edm_bias.cpp:444-526 for new hills, :313-380 for the overflow flush)
+#define EDM_TAIL_CAP 12288
+#define EDM_CHUNK 4096
+struct LimitResult {
+  double cum_out;          // temp_hill_cum_ after the batch (flush: bias added by the flush)
+  long long k;             // first hill handled by the ordered tail
+  int n_tail;              // nh - k
+  int stop;                // flush mode: tail-relative index where the flush stopped, or n_tail
+  int n_deferred;          // new-hill mode: hills (whole or remainder) to append to the overflow buffer
+  int error;               // 1 = tail longer than EDM_TAIL_CAP
+};
+// flags per tail hill: bit0 = applied (an 'h'/'b' hill was added), bit1 = undo hill
+// added too ('u'/'v'), bit2 = deferred to the overflow buffer
+struct LimitTail {
+  double *h1, *h2, *added2, *cum_after;
+  int *flags;
+};
+size_t limit_scratch_doubles(long long nh);
+hipError_t launch_limit(long long nh, const double *added, const double *heights, double h_const,
+                        double limit, double cum_in, int flush_mode, const LimitTail &tail,
+                        LimitResult *result_dev, double *scratch, hipStream_t s);
+
+hipError_t launch_sum(long long n, const double *v, double *out, double *scratch, hipStream_t s);
+
+}  // namespace edm

@@ -1,0 +1,1248 @@
+// edm_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the EDM bias hot path.
+//
+// No MFMA anywhere: the path is gather (cubic-Hermite lookup), transcendental
+// stencil evaluation and ordered accumulation.  All arithmetic is IEEE double in
+// the reference's operation order (-ffp-contract=off), so node indices are
+// bit-exact and values differ from the CPU reference only through exp() ulps and
+// the documented reduction orders.
+//
+//   K1/K2  k_lookup / k_pair_forces   bias-grid interpolation, force update, energy sum
+//   K3     k_hill_integrals           per-hill integrated bias (value add_value returns)
+//   K4     k_chunk_stats/k_limit      ordered bias limiter (undo + overflow decisions)
+//   K5     k_hill_gather              tile-owned, ORDER-PRESERVING gather of hills onto nodes
+//   K6     k_duplicate_boundary       boundary value duplication
+//   K7     k_hist_add                 CV histogram
+//   K8     block/wave reductions      fixed-order energy and bias sums
+#include "edm_kernels.h"
+
+#include <limits.h>
+
+namespace edm {
+
+static constexpr int BLOCK = 256;
+static constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 resident 256-thread blocks
+
+// ---------------------------------------------------------------------------
+// fixed-order reductions (deterministic: same launch shape -> same bits)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// sum over the block, valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double *lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum(v);
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; w++) r += lds[w];
+  }
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_sum_partials(const double *__restrict__ v, long long n, double *out) {
+  __shared__ double lds[BLOCK / 64];
+  double acc = 0;
+  for (long long i = threadIdx.x; i < n; i += BLOCK) acc += v[i];
+  double r = block_sum(acc, lds);
+  if (threadIdx.x == 0) *out = r;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_block_sums(const double *__restrict__ v, long long n, double *partial) {
+  __shared__ double lds[BLOCK / 64];
+  double acc = 0;
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) acc += v[i];
+  double r = block_sum(acc, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+hipError_t launch_sum(long long n, const double *v, double *out, double *scratch, hipStream_t s) {
+  int blocks = (int)((n + BLOCK - 1) / BLOCK);
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_block_sums, dim3(blocks), dim3(BLOCK), 0, s, v, n, scratch);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, s, scratch, (long long)blocks, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K1/K2: lookup  (gaussian_grid.h:118-138 -> grid.h:390-446 -> interp grid.h:52-139)
+// ---------------------------------------------------------------------------
+template <int R>
+struct Rec;
+template <>
+struct Rec<2> {
+  double v[2];
+  __device__ __forceinline__ void load(const double *__restrict__ rec, long long node) {
+    const double2 t = reinterpret_cast<const double2 *>(rec)[node];
+    v[0] = t.x;
+    v[1] = t.y;
+  }
+};
+template <>
+struct Rec<4> {
+  double v[4];
+  __device__ __forceinline__ void load(const double *__restrict__ rec, long long node) {
+    const double4 t = reinterpret_cast<const double4 *>(rec)[node];
+    v[0] = t.x;
+    v[1] = t.y;
+    v[2] = t.z;
+    v[3] = t.w;
+  }
+};
+
+// Returns the flat start node (or -1 where the reference returns 0) and the
+// interpolated value / POSITIVE gradient.
+template <int DIM>
+__device__ __forceinline__ long long lookup_one(const Geom &g, const double *__restrict__ rec,
+                                                const double *xin, double &value, double *der) {
+  constexpr int R = (DIM == 1) ? 2 : 4;
+  double xx[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    xx[d] = xin[d];
+    der[d] = 0;
+  }
+  value = 0;
+  if (!in_bounds<DIM>(g, xx)) {
+    remap<DIM>(g, xx);
+    if (!in_bounds<DIM>(g, xx)) return -1;
+  }
+  if (!in_grid<DIM>(g, xx)) return -1;
+
+  long long idx[DIM], stride[DIM];
+  double where[DIM];
+  stride[0] = 1;
+#pragma unroll
+  for (int d = 1; d < DIM; d++) stride[d] = stride[d - 1] * g.n[d - 1];
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    double w;
+    idx[d] = node_index(g, d, xx[d], &w);
+    // the reference reads one node past the array when the periodic wrap rounds
+    // up to max exactly (undefined there); stay inside the allocation instead
+    if (idx[d] > g.n[d] - 1) idx[d] = g.n[d] - 1;
+    if (idx[d] < 0) idx[d] = 0;
+    where[d] = w - g.min[d] - idx[d] * g.dx[d];
+  }
+  long long flat = idx[DIM - 1];
+#pragma unroll
+  for (int d = DIM - 1; d > 0; d--) flat = flat * g.n[d - 1] + idx[d - 1];
+
+  if (!g.interp) {
+    Rec<R> r;
+    r.load(rec, flat);
+    value = r.v[0];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) der[d] = r.v[1 + d];
+    return flat;
+  }
+#pragma unroll
+  for (int d = 0; d < DIM; d++)
+    if (g.periodic[d] && idx[d] == g.n[d] - 1) stride[d] *= (1 - g.n[d]);
+
+  // scaled coordinate and its powers per dimension do not depend on the corner's node
+  double f = 0;
+#pragma unroll
+  for (int corner = 0; corner < (1 << DIM); corner++) {
+    long long shift = 0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) shift += stride[d] * ((corner >> d) & 1);
+    Rec<R> r;
+    r.load(rec, flat + shift);
+    const double tf = r.v[0];
+    double C[DIM], D[DIM];
+    double ff = 1.0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      const int bit = (corner >> d) & 1;
+      const int sgn = bit ? -1 : 1;
+      const double X = fabs(where[d] / g.dx[d] - bit);
+      const double X2 = X * X;
+      const double X3 = X2 * X;
+      double qq;
+      if (fabs(tf) < 0.0000001)  // grid.h:113-116: derivative term dropped near zero
+        qq = 0.0;
+      else
+        qq = -r.v[1 + d] / tf;
+      C[d] = (1 - 3 * X2 + 2 * X3) - sgn * qq * (X - 2 * X2 + X3) * g.dx[d];
+      D[d] = (-6 * X + 6 * X2) - sgn * qq * (1 - 4 * X + 3 * X2) * g.dx[d];
+      D[d] *= sgn / g.dx[d];
+      ff *= C[d];
+    }
+    f += tf * ff;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      double fd = D[d];
+#pragma unroll
+      for (int e = 0; e < DIM; e++)
+        if (e != d) fd *= C[e];
+      der[d] += tf * fd;
+    }
+  }
+  value = f;
+  return flat;
+}
+
+template <int DIM, int MODE>
+__global__ void __launch_bounds__(BLOCK) k_lookup(Geom g, const double *__restrict__ rec, LookupArgs a,
+                                                  double *__restrict__ block_energy) {
+  __shared__ double lds[BLOCK / 64];
+  double e_acc = 0;
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += stride) {
+    if (MODE == LOOKUP_FORCES && !(a.apply_mask < 0 || (a.mask[i] & a.apply_mask))) continue;
+    double xin[DIM], der[DIM], v;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) xin[d] = a.x[i * a.x_stride + d];
+    const long long flat = lookup_one<DIM>(g, rec, xin, v, der);
+    if (MODE == LOOKUP_FORCES) {
+      e_acc += v;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) a.f[i * a.f_stride + d] -= der[d];
+    } else if (MODE == LOOKUP_VALUES) {
+      if (a.energy) a.energy[i] = v;
+      if (a.f) {
+#pragma unroll
+        for (int d = 0; d < DIM; d++) a.f[i * DIM + d] = der[d];
+      }
+      e_acc += v;
+    } else {
+      a.flat[i] = flat;
+    }
+  }
+  double r = block_sum(e_acc, lds);
+  if (threadIdx.x == 0) block_energy[blockIdx.x] = r;
+}
+
+size_t lookup_scratch_doubles() { return MAX_BLOCKS + 8; }
+
+template <int DIM>
+static hipError_t lookup_dim(const Geom &g, const double *rec, LookupMode mode, const LookupArgs &a,
+                             double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  int blocks = (int)((a.n + BLOCK - 1) / BLOCK);
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  if (ev0) (void)hipEventRecord(ev0, s);
+  switch (mode) {
+    case LOOKUP_FORCES:
+      hipLaunchKernelGGL((k_lookup<DIM, LOOKUP_FORCES>), dim3(blocks), dim3(BLOCK), 0, s, g, rec, a, scratch);
+      break;
+    case LOOKUP_VALUES:
+      hipLaunchKernelGGL((k_lookup<DIM, LOOKUP_VALUES>), dim3(blocks), dim3(BLOCK), 0, s, g, rec, a, scratch);
+      break;
+    default:
+      hipLaunchKernelGGL((k_lookup<DIM, LOOKUP_INDEX>), dim3(blocks), dim3(BLOCK), 0, s, g, rec, a, scratch);
+      break;
+  }
+  if (ev1) (void)hipEventRecord(ev1, s);
+  if (energy_out)
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, s, scratch, (long long)blocks, energy_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_lookup(const Geom &g, const double *rec, LookupMode mode, const LookupArgs &a,
+                         double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  switch (g.dim) {
+    case 1: return lookup_dim<1>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1);
+    case 2: return lookup_dim<2>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1);
+    default: return lookup_dim<3>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1);
+  }
+}
+
+// 1-D pair-distance form (fix_edm_pair.cpp:215-217 batched): 16 B in / 16 B out
+// per lane (two samples), grid-stride, energy reduced in-kernel.
+__global__ void __launch_bounds__(BLOCK) k_pair_forces(Geom g, const double *__restrict__ rec, long long n,
+                                                       const double *__restrict__ r, double *__restrict__ force,
+                                                       double *__restrict__ block_energy) {
+  __shared__ double lds[BLOCK / 64];
+  double e_acc = 0;
+  const long long npair = n >> 1;
+  const long long stride = (long long)gridDim.x * BLOCK;
+  const double2 *r2 = reinterpret_cast<const double2 *>(r);
+  double2 *f2 = reinterpret_cast<double2 *>(force);
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < npair; i += stride) {
+    const double2 rr = r2[i];
+    double v0, v1, d0, d1;
+    lookup_one<1>(g, rec, &rr.x, v0, &d0);
+    lookup_one<1>(g, rec, &rr.y, v1, &d1);
+    e_acc += v0;
+    e_acc += v1;
+    double2 out;
+    out.x = 0.0 - d0;
+    out.y = 0.0 - d1;
+    f2[i] = out;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double v, d;
+    lookup_one<1>(g, rec, &r[n - 1], v, &d);
+    e_acc += v;
+    force[n - 1] = 0.0 - d;
+  }
+  double s = block_sum(e_acc, lds);
+  if (threadIdx.x == 0) block_energy[blockIdx.x] = s;
+}
+
+hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, const double *r, double *force,
+                              double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  long long work = (n >> 1) + 1;
+  int blocks = (int)((work + BLOCK - 1) / BLOCK);
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  if (ev0) (void)hipEventRecord(ev0, s);
+  hipLaunchKernelGGL(k_pair_forces, dim3(blocks), dim3(BLOCK), 0, s, g, rec, n, r, force, scratch);
+  if (ev1) (void)hipEventRecord(ev1, s);
+  if (energy_out)
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, s, scratch, (long long)blocks, energy_out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// record layout conversion (host SoA values[]/derivs[][dim]  <->  device AoS)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_pack(Geom g, double *__restrict__ rec, const double *__restrict__ values,
+                                                const double *__restrict__ derivs) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < g.total; i += stride) {
+    rec[i * g.rec] = values[i];
+    for (int d = 0; d < g.rec - 1; d++)
+      rec[i * g.rec + 1 + d] = (d < g.dim && derivs) ? derivs[i * g.dim + d] : 0.0;
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_unpack(Geom g, const double *__restrict__ rec, double *__restrict__ values,
+                                                  double *__restrict__ derivs) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < g.total; i += stride) {
+    if (values) values[i] = rec[i * g.rec];
+    if (derivs)
+      for (int d = 0; d < g.dim; d++) derivs[i * g.dim + d] = rec[i * g.rec + 1 + d];
+  }
+}
+static int blocks_for(long long n) {
+  long long b = (n + BLOCK - 1) / BLOCK;
+  if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+hipError_t launch_pack(const Geom &g, double *rec, const double *values, const double *derivs, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack, dim3(blocks_for(g.total)), dim3(BLOCK), 0, s, g, rec, values, derivs);
+  return hipGetLastError();
+}
+hipError_t launch_unpack(const Geom &g, const double *rec, double *values, double *derivs, hipStream_t s) {
+  hipLaunchKernelGGL(k_unpack, dim3(blocks_for(g.total)), dim3(BLOCK), 0, s, g, rec, values, derivs);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K7: histogram  (DimmedGrid::add_value grid.h:370-385 on cv_hist_, edm_bias.cpp:601-610)
+// Bin contents are integer-valued doubles, so the atomic order cannot change bits.
+// ---------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_hist_add(Geom g, double *__restrict__ values, long long n,
+                                                    const double *__restrict__ x, int x_stride,
+                                                    const long long *__restrict__ sel, const double *__restrict__ w,
+                                                    double w_const) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    const double wi = w ? w[i] : w_const;
+    if (wi == 0.0) continue;
+    const long long src = sel ? sel[i] : i;
+    double xx[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) xx[d] = x[src * x_stride + d];
+    if (!in_grid<DIM>(g, xx)) continue;
+    long long idx[DIM];
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      double wr;
+      idx[d] = node_index(g, d, xx[d], &wr);
+      if (idx[d] < 0 || idx[d] >= g.n[d]) ok = false;  // reference: out-of-array write
+    }
+    if (!ok) continue;
+    long long flat = idx[DIM - 1];
+#pragma unroll
+    for (int d = DIM - 1; d > 0; d--) flat = flat * g.n[d - 1] + idx[d - 1];
+    atomicAdd(&values[flat], wi);
+  }
+}
+hipError_t launch_hist_add(const Geom &g, double *values, long long n, const double *x, int x_stride,
+                           const long long *sel, const double *w, double w_const, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int b = blocks_for(n);
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL(k_hist_add<1>, dim3(b), dim3(BLOCK), 0, s, g, values, n, x, x_stride, sel, w, w_const); break;
+    case 2: hipLaunchKernelGGL(k_hist_add<2>, dim3(b), dim3(BLOCK), 0, s, g, values, n, x, x_stride, sel, w, w_const); break;
+    default: hipLaunchKernelGGL(k_hist_add<3>, dim3(b), dim3(BLOCK), 0, s, g, values, n, x, x_stride, sel, w, w_const); break;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// order-preserving selection of accepted samples (edm_bias.cpp:406, :543)
+// ---------------------------------------------------------------------------
+static constexpr int SEL_PER_THREAD = 8;
+static constexpr int SEL_CHUNK = BLOCK * SEL_PER_THREAD;
+
+__device__ __forceinline__ bool sel_flag(long long i, long long n, const double *__restrict__ ru, double thr,
+                                         int use_thr, const int *__restrict__ mask, int apply_mask) {
+  if (i >= n) return false;
+  if (!(apply_mask < 0 || (apply_mask & mask[i]))) return false;
+  if (use_thr && !(ru[i] < thr)) return false;
+  return true;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_sel_count(long long n, const double *__restrict__ ru, double thr,
+                                                     int use_thr, const int *__restrict__ mask, int apply_mask,
+                                                     int *__restrict__ counts) {
+  __shared__ int lds[BLOCK / 64];
+  const long long base = (long long)blockIdx.x * SEL_CHUNK + (long long)threadIdx.x * SEL_PER_THREAD;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < SEL_PER_THREAD; j++) c += sel_flag(base + j, n, ru, thr, use_thr, mask, apply_mask) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < BLOCK / 64; w++) t += lds[w];
+    counts[blockIdx.x] = t;
+  }
+}
+
+// exclusive scan of the per-block counts by one block (counts -> offsets, total)
+__global__ void __launch_bounds__(BLOCK) k_sel_scan(int nblocks, const int *__restrict__ counts,
+                                                    long long *__restrict__ offsets, long long *__restrict__ total) {
+  __shared__ long long carry;
+  __shared__ int buf[BLOCK];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += BLOCK) {
+    const int i = base + threadIdx.x;
+    buf[threadIdx.x] = (i < nblocks) ? counts[i] : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long c = carry;
+      const int lim = (nblocks - base < BLOCK) ? nblocks - base : BLOCK;
+      for (int j = 0; j < lim; j++) {
+        offsets[base + j] = c;
+        c += buf[j];
+      }
+      carry = c;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_sel_scatter(long long n, const double *__restrict__ ru, double thr,
+                                                       int use_thr, const int *__restrict__ mask, int apply_mask,
+                                                       const long long *__restrict__ offsets,
+                                                       long long *__restrict__ sel) {
+  __shared__ int lds[BLOCK];
+  const long long base = (long long)blockIdx.x * SEL_CHUNK + (long long)threadIdx.x * SEL_PER_THREAD;
+  bool fl[SEL_PER_THREAD];
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < SEL_PER_THREAD; j++) {
+    fl[j] = sel_flag(base + j, n, ru, thr, use_thr, mask, apply_mask);
+    c += fl[j] ? 1 : 0;
+  }
+  lds[threadIdx.x] = c;
+  __syncthreads();
+  // exclusive scan over the 256 thread counts (Hillis-Steele in LDS)
+  for (int o = 1; o < BLOCK; o <<= 1) {
+    int v = (threadIdx.x >= o) ? lds[threadIdx.x - o] : 0;
+    __syncthreads();
+    lds[threadIdx.x] += v;
+    __syncthreads();
+  }
+  long long pos = offsets[blockIdx.x] + (lds[threadIdx.x] - c);
+#pragma unroll
+  for (int j = 0; j < SEL_PER_THREAD; j++)
+    if (fl[j]) sel[pos++] = base + j;
+}
+
+size_t select_scratch_ints(long long n) {
+  const long long nb = (n + SEL_CHUNK - 1) / SEL_CHUNK;
+  return (size_t)(nb + 2) * 3;  // counts (int) + offsets (long long) in int units
+}
+
+hipError_t launch_select(long long n, const double *ru, double thr, int use_thr, const int *mask, int apply_mask,
+                         long long *sel, long long *count, int *scratch, hipStream_t s) {
+  const int nb = (int)((n + SEL_CHUNK - 1) / SEL_CHUNK);
+  if (nb == 0) return hipMemsetAsync(count, 0, sizeof(long long), s);
+  int *counts = scratch;
+  long long *offsets = reinterpret_cast<long long *>(scratch + ((nb + 2) & ~1));
+  hipLaunchKernelGGL(k_sel_count, dim3(nb), dim3(BLOCK), 0, s, n, ru, thr, use_thr, mask, apply_mask, counts);
+  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(BLOCK), 0, s, nb, counts, offsets, count);
+  hipLaunchKernelGGL(k_sel_scatter, dim3(nb), dim3(BLOCK), 0, s, n, ru, thr, use_thr, mask, apply_mask, offsets, sel);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// hill preparation: remap, rejection, centre node, hill-only exponentials
+// (gaussian_grid.h:206-224 and the temp1/temp3 terms of :310,:312)
+// ---------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_hill_prep(Geom g, HillList h) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < h.nh; i += stride) {
+    const long long src = h.sel ? h.sel[i] : i;
+    double x[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) x[d] = h.x[src * h.x_stride + d];
+    remap<DIM>(g, x);
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < DIM; d++)
+      if (!g.bper[d] && (x[d] < g.bmin[d] || x[d] > g.bmax[d])) ok = false;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      h.hx[i * DIM + d] = x[d];
+      h.hc[i * DIM + d] = ifloor((x[d] - g.min[d]) / g.dx[d]);
+      double t1 = 0, t3 = 0;
+      if (!g.bper[d]) {
+        const double sg = g.sigma[d];
+        t1 = exp(-((x[d] - g.bmin[d]) * (x[d] - g.bmin[d])) / (sg * sg));
+        t3 = exp(-((x[d] - g.bmax[d]) * (x[d] - g.bmax[d])) / (sg * sg));
+      }
+      h.ht[i * 2 * DIM + 2 * d] = t1;
+      h.ht[i * 2 * DIM + 2 * d + 1] = t3;
+    }
+    if (!ok) h.hc[i * DIM] = INT_MIN;
+  }
+}
+hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s) {
+  if (h.nh <= 0) return hipSuccess;
+  const int b = blocks_for(h.nh);
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL(k_hill_prep<1>, dim3(b), dim3(BLOCK), 0, s, g, h); break;
+    case 2: hipLaunchKernelGGL(k_hill_prep<2>, dim3(b), dim3(BLOCK), 0, s, g, h); break;
+    default: hipLaunchKernelGGL(k_hill_prep<3>, dim3(b), dim3(BLOCK), 0, s, g, h); break;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// node-side and pair-side pieces of one stencil term (gaussian_grid.h:284-355)
+// ---------------------------------------------------------------------------
+template <int DIM>
+struct NodeTerms {
+  double xx[DIM];                    // node coordinate                     (:270)
+  double t2[DIM], t4[DIM];           // zero-force blend at the two walls   (:311,:313)
+  double t6[DIM], t7[DIM];           // its derivatives                     (:322-323)
+  double den[DIM], dden[DIM];        // table entries at bc_index           (:308,:318,:335)
+  bool inside;                       // node lies within every non-periodic boundary (:273)
+};
+
+template <int DIM>
+__device__ __forceinline__ void node_terms(const Geom &g, const Tables &t, const int *p, NodeTerms<DIM> &nt) {
+  nt.inside = true;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    const double xx = g.min[d] + g.dx[d] * (size_t)p[d];
+    nt.xx[d] = xx;
+    nt.t2[d] = nt.t4[d] = nt.t6[d] = nt.t7[d] = 0;
+    nt.den[d] = 1;
+    nt.dden[d] = 0;
+    if (!g.bper[d]) {
+      if (xx < g.bmin[d] || xx > g.bmax[d]) {
+        nt.inside = false;
+      } else {
+        const double sg = g.sigma[d];
+        const size_t ti = (size_t)((EDM_BC_TABLE_SIZE - 1) * (xx - g.bmin[d]) / (g.bmax[d] - g.bmin[d]));
+        nt.t2[d] = smooth_step((xx - g.bmin[d]) / (sg * EDM_BC_MAR));
+        nt.t4[d] = smooth_step((g.bmax[d] - xx) / (sg * EDM_BC_MAR));
+        nt.t6[d] = smooth_step_dt((xx - g.bmin[d]) / (sg * EDM_BC_MAR)) / (EDM_BC_MAR * sg);
+        nt.t7[d] = -smooth_step_dt((g.bmax[d] - xx) / (sg * EDM_BC_MAR)) / (EDM_BC_MAR * sg);
+        nt.den[d] = t.denom[d][ti];
+        nt.dden[d] = t.dderiv[d][ti];
+      }
+    }
+  }
+}
+
+// One (node, hill) term: val multiplies the height for V, dval[d] for dV/ds_d.
+// Returns false when the node is outside the hill's support (dp2 >= 8).
+template <int DIM>
+__device__ __forceinline__ bool pair_term(const Geom &g, const NodeTerms<DIM> &nt, const double *hx,
+                                          const double *ht, double &val, double *dval, bool &corr_nonzero) {
+  double dp[DIM];
+  double dp2 = 0;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    dp[d] = nt.xx[d] - hx[d];
+    if (g.periodic[d]) dp[d] -= round_half(dp[d] / (g.max[d] - g.min[d])) * (g.max[d] - g.min[d]);
+    dp[d] /= g.sigma[d];
+    dp2 += dp[d] * dp[d];
+  }
+  if (!(dp2 < EDM_GAUSS_SUPPORT)) return false;
+  double expo = exp(-dp2);
+  double denom = 1.0, corr = 0;
+  double force[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    force[d] = 0;
+    if (!g.bper[d]) {
+      const double sg = g.sigma[d];
+      const double t1 = ht[2 * d], t3 = ht[2 * d + 1];
+      corr = (t1 - expo) * nt.t2[d] + (t3 - expo) * nt.t4[d];  // overwritten per dim (:316)
+      denom *= nt.den[d];
+      const double t5 = -2 * dp[d] / sg;
+      double F = t5 * expo;
+      F += (t1 - expo) * nt.t6[d] - t5 * expo * nt.t2[d] + (t3 - expo) * nt.t7[d] - t5 * expo * nt.t4[d];
+      F = F * denom - nt.dden[d] * (expo + corr);
+      F /= denom * denom;
+      corr /= denom;
+      force[d] = F;
+    } else {
+      denom *= sqrt(M_PI) * g.sigma[d];
+    }
+  }
+  expo /= denom;
+  val = expo + corr;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    if (g.bper[d])
+      dval[d] = -(2 * dp[d] / g.sigma[d] * expo);
+    else
+      dval[d] = force[d];
+  }
+  corr_nonzero = (corr * corr > 0);
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// K3: per-hill integrated bias -- one wave per hill walks the reference's stencil
+// (gaussian_grid.h:227-281) and reduces h*(expo+corr)*vol in a fixed order.
+// ---------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, HillList h,
+                                                          const double *__restrict__ heights, double h_const,
+                                                          double *__restrict__ added) {
+  const int lane = threadIdx.x & 63;
+  const long long hill = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  if (hill >= h.nh) return;
+  double acc = 0;
+  const int c0 = h.hc[hill * DIM];
+  if (c0 != INT_MIN) {
+    int c[DIM];
+    double hx[DIM], ht[2 * DIM];
+    double vol = 1;
+    long long total = 1;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      c[d] = h.hc[hill * DIM + d];
+      hx[d] = h.hx[hill * DIM + d];
+      ht[2 * d] = h.ht[hill * 2 * DIM + 2 * d];
+      ht[2 * d + 1] = h.ht[hill * 2 * DIM + 2 * d + 1];
+      vol *= g.dx[d];
+      total *= (2 * g.msize[d] + 1);
+    }
+    const double height = heights ? heights[hill] : h_const;
+    for (long long s = lane; s < total; s += 64) {
+      int p[DIM];
+      long long rest = s;
+      bool skip = false;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        const int w = 2 * g.msize[d] + 1;
+        int off;
+        if (d < DIM - 1) {
+          off = (int)(rest % w);
+          rest = (rest - off) / w;
+        } else {
+          off = (int)rest;
+        }
+        int idx = off - g.msize[d] + c[d];
+        if (idx >= g.n[d]) {
+          if (g.periodic[d]) idx %= g.n[d]; else skip = true;
+        }
+        if (idx < 0) {
+          if (g.periodic[d]) idx += g.n[d]; else skip = true;
+          if (idx < 0) skip = true;  // reference: undefined (stencil wider than two grid lengths)
+        }
+        p[d] = idx;
+      }
+      if (skip) continue;
+      NodeTerms<DIM> nt;
+      node_terms<DIM>(g, t, p, nt);
+      if (!nt.inside) continue;
+      double val, dval[DIM];
+      bool nz;
+      if (!pair_term<DIM>(g, nt, hx, ht, val, dval, nz)) continue;
+      acc += height * val * vol;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) added[hill] = acc;
+}
+
+hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList &h, const double *heights,
+                                 double h_const, double *added, hipStream_t s) {
+  if (h.nh <= 0) return hipSuccess;
+  const long long nb = (h.nh + (BLOCK / 64) - 1) / (BLOCK / 64);
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL(k_hill_integrals<1>, dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+    case 2: hipLaunchKernelGGL(k_hill_integrals<2>, dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+    default: hipLaunchKernelGGL(k_hill_integrals<3>, dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K5: tile-owned gather.  Each 256-thread workgroup owns one tile of nodes (one
+// node per thread) and walks the hill list IN ORDER, so every node accumulates
+// its contributions in exactly the order the reference's sequential add_value
+// calls would -- no atomics, bit-reproducible, identical on every GPU of a
+// replicated run.  Node-only terms (table reads, wall blends) are computed once
+// per node and amortised over all hills.
+// ---------------------------------------------------------------------------
+template <int DIM> struct Tile;
+template <> struct Tile<1> { static constexpr int T[3] = {256, 1, 1}; };
+template <> struct Tile<2> { static constexpr int T[3] = {16, 16, 1}; };
+template <> struct Tile<3> { static constexpr int T[3] = {8, 8, 4}; };
+
+__host__ __device__ inline long long floordiv(long long a, long long b) {
+  long long q = a / b;
+  if ((a % b != 0) && ((a < 0) != (b < 0))) q--;
+  return q;
+}
+__host__ __device__ inline long long ceildiv(long long a, long long b) { return -floordiv(-a, b); }
+
+// number of stencil offsets of a hill centred at node c that land on node range
+// [p0, p1] of dimension d under the reference's wrap rules (:251-266): index
+// c+o with o in [-m, m]; >= n wraps by %, < 0 wraps by a single +n.
+__host__ __device__ inline int images(const Geom &g, int d, int c, int p0, int p1) {
+  const long long n = g.n[d], m = g.msize[d];
+  long long lo = (long long)c - m, hi = (long long)c + m;
+  if (!g.periodic[d]) return (lo <= p1 && hi >= p0) ? 1 : 0;
+  if (lo < -n) lo = -n;
+  const long long kmin = ceildiv(lo - p1, n), kmax = floordiv(hi - p0, n);
+  return kmax >= kmin ? (int)(kmax - kmin + 1) : 0;
+}
+
+long long gather_tiles(const Geom &g) {
+  long long t = 1;
+  for (int d = 0; d < g.dim; d++) {
+    const int T = (g.dim == 1) ? Tile<1>::T[d] : (g.dim == 2) ? Tile<2>::T[d] : Tile<3>::T[d];
+    t *= (g.n[d] + T - 1) / T;
+  }
+  return t;
+}
+
+// device-side twin of gather_tiles()
+__device__ __forceinline__ long long gather_tiles_dev(const Geom &g) {
+  long long t = 1;
+  for (int d = 0; d < g.dim; d++) {
+    const int T = (g.dim == 1) ? Tile<1>::T[d] : (g.dim == 2) ? Tile<2>::T[d] : Tile<3>::T[d];
+    t *= (g.n[d] + T - 1) / T;
+  }
+  return t;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
+                                                       HillHeights hh, GatherPlan plan, int use_list,
+                                                       int *__restrict__ dirty_flag) {
+  constexpr int R = (DIM == 1) ? 2 : 4;
+  long long tile = blockIdx.x;
+  if (use_list) {
+    if (tile >= plan.tile_list[gather_tiles_dev(g)]) return;
+    tile = plan.tile_list[tile];
+  }
+  // tile origin and this thread's node
+  int t0[DIM], p[DIM];
+  {
+    long long rest = tile;
+    int lrest = threadIdx.x;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      const int T = Tile<DIM>::T[d];
+      const int nt_d = (g.n[d] + T - 1) / T;
+      t0[d] = (int)(rest % nt_d) * T;
+      rest /= nt_d;
+      p[d] = t0[d] + (lrest % T);
+      lrest /= T;
+    }
+  }
+  bool active = true;
+#pragma unroll
+  for (int d = 0; d < DIM; d++)
+    if (p[d] >= g.n[d]) active = false;
+  long long flat = 0;
+  if (active) {
+    flat = p[DIM - 1];
+#pragma unroll
+    for (int d = DIM - 1; d > 0; d--) flat = flat * g.n[d - 1] + p[d - 1];
+  }
+  NodeTerms<DIM> nt;
+  if (active) {
+    node_terms<DIM>(g, t, p, nt);
+    if (!nt.inside) active = false;
+  }
+  const int G = plan.groups;
+  const int grp = blockIdx.y;
+  const long long per = (h.nh + G - 1) / G;
+  const long long hbeg = per * grp;
+  const long long hend = (hbeg + per < h.nh) ? hbeg + per : h.nh;
+
+  double acc[1 + DIM];
+  if (G == 1 && active) {
+    // in-place: start from the stored record so the adds follow the reference's
+    // sequence V0 + h0*t0 + h1*t1 + ... exactly
+#pragma unroll
+    for (int j = 0; j <= DIM; j++) acc[j] = rec[flat * R + j];
+  } else {
+#pragma unroll
+    for (int j = 0; j <= DIM; j++) acc[j] = 0;
+  }
+  bool any_corr = false;
+
+  for (long long i = hbeg; i < hend; i++) {
+    // wave-uniform part: centre node and tile overlap (scalar loads)
+    int c[DIM];
+    c[0] = h.hc[i * DIM];
+    if (c[0] == INT_MIN) continue;
+    bool overlap = true;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      if (d > 0) c[d] = h.hc[i * DIM + d];
+      const int T = Tile<DIM>::T[d];
+      int t1 = t0[d] + T - 1;
+      if (t1 > g.n[d] - 1) t1 = g.n[d] - 1;
+      if (images(g, d, c[d], t0[d], t1) == 0) overlap = false;
+    }
+    if (!overlap) continue;
+    double h1, h2;
+    if (i < hh.k) {
+      h1 = hh.h ? hh.h[i] : hh.h_const;
+      h2 = 0;
+    } else {
+      h1 = hh.tail_h1[i - hh.k];
+      h2 = hh.tail_h2[i - hh.k];
+    }
+    if (h1 == 0 && h2 == 0) continue;  // hill deferred to the overflow buffer: add_value is never called
+    if (!active) continue;
+    int mult = 1;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) mult *= images(g, d, c[d], p[d], p[d]);
+    if (mult == 0) continue;
+    double hx[DIM], ht[2 * DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      hx[d] = h.hx[i * DIM + d];
+      ht[2 * d] = h.ht[i * 2 * DIM + 2 * d];
+      ht[2 * d + 1] = h.ht[i * 2 * DIM + 2 * d + 1];
+    }
+    double val, dval[DIM];
+    bool nz;
+    if (!pair_term<DIM>(g, nt, hx, ht, val, dval, nz)) continue;
+    any_corr |= nz;
+    for (int rep = 0; rep < mult; rep++) {
+      acc[0] += h1 * val;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) acc[1 + d] += h1 * dval[d];
+    }
+    if (h2 != 0) {
+      for (int rep = 0; rep < mult; rep++) {
+        acc[0] += h2 * val;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) acc[1 + d] += h2 * dval[d];
+      }
+    }
+  }
+  if (active) {
+    double *dst = (G == 1) ? rec + flat * R : plan.partial + ((long long)grp * g.total + flat) * R;
+#pragma unroll
+    for (int j = 0; j <= DIM; j++) dst[j] = acc[j];
+    if (any_corr) *dirty_flag = 1;
+  } else if (G > 1) {
+    // inactive nodes of a partial buffer must read as zero in the reduction
+    bool in_grid_node = true;
+#pragma unroll
+    for (int d = 0; d < DIM; d++)
+      if (p[d] >= g.n[d]) in_grid_node = false;
+    if (in_grid_node) {
+      long long fl = p[DIM - 1];
+#pragma unroll
+      for (int d = DIM - 1; d > 0; d--) fl = fl * g.n[d - 1] + p[d - 1];
+      double *dst = plan.partial + ((long long)grp * g.total + fl) * R;
+#pragma unroll
+      for (int j = 0; j <= DIM; j++) dst[j] = 0;
+    }
+  }
+}
+
+// rec[p] += partial[0][p] + partial[1][p] + ... in group (= hill list) order
+__global__ void __launch_bounds__(BLOCK) k_reduce_partials(Geom g, double *__restrict__ rec,
+                                                           const double *__restrict__ partial, int groups) {
+  const long long n = g.total * g.rec;
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    double v = rec[i];
+    for (int q = 0; q < groups; q++) v += partial[(long long)q * n + i];
+    rec[i] = v;
+  }
+}
+
+// tile culling for large grids with few hills: mark tiles touched by any hill
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *__restrict__ flags) {
+  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= h.nh) return;
+  if (h.hc[i * DIM] == INT_MIN) return;
+  int ntile[DIM], steps[DIM], c[DIM];
+  long long combos = 1;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    const int T = Tile<DIM>::T[d];
+    ntile[d] = (g.n[d] + T - 1) / T;
+    c[d] = h.hc[i * DIM + d];
+    steps[d] = (2 * g.msize[d]) / T + 2;  // offsets -m, -m+T, ... plus the end point +m
+    combos *= steps[d];
+  }
+  for (long long q = 0; q < combos; q++) {
+    long long rest = q, tflat = 0, tstride = 1;
+    bool skip = false;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      const int T = Tile<DIM>::T[d];
+      const int sidx = (int)(rest % steps[d]);
+      rest /= steps[d];
+      int off = -g.msize[d] + sidx * T;
+      if (off > g.msize[d]) off = g.msize[d];
+      int idx = c[d] + off;
+      if (idx >= g.n[d]) {
+        if (g.periodic[d]) idx %= g.n[d]; else skip = true;
+      }
+      if (idx < 0) {
+        if (g.periodic[d]) idx += g.n[d]; else skip = true;
+        if (idx < 0) skip = true;
+      }
+      if (!skip) tflat += (long long)(idx / T) * tstride;
+      tstride *= ntile[d];
+    }
+    if (!skip) flags[tflat] = 1;
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_compact_tiles(long long ntiles, const int *__restrict__ flags,
+                                                         int *__restrict__ list) {
+  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < ntiles && flags[i]) {
+    const int pos = atomicAdd(&list[ntiles], 1);
+    list[pos] = (int)i;
+  }
+}
+
+template <int DIM>
+static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const HillList &h, const HillHeights &hh,
+                             const GatherPlan &plan, int *dirty_flag, hipStream_t s) {
+  const long long ntiles = gather_tiles(g);
+  int use_list = 0;
+  long long launch_tiles = ntiles;
+  if (plan.tile_flags && plan.tile_list && plan.groups == 1) {
+    hipError_t e = hipMemsetAsync(plan.tile_flags, 0, sizeof(int) * (size_t)ntiles, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(plan.tile_list + ntiles, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_mark_tiles<DIM>, dim3((unsigned)((h.nh + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, g, h, plan.tile_flags);
+    hipLaunchKernelGGL(k_compact_tiles, dim3((unsigned)((ntiles + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, ntiles,
+                       plan.tile_flags, plan.tile_list);
+    use_list = 1;
+    launch_tiles = plan.tile_bound < ntiles ? plan.tile_bound : ntiles;
+  }
+  hipLaunchKernelGGL(k_hill_gather<DIM>, dim3((unsigned)launch_tiles, (unsigned)plan.groups), dim3(BLOCK), 0, s, g, t, rec, h,
+                     hh, plan, use_list, dirty_flag);
+  if (plan.groups > 1)
+    hipLaunchKernelGGL(k_reduce_partials, dim3(blocks_for(g.total * g.rec)), dim3(BLOCK), 0, s, g, rec, plan.partial,
+                       plan.groups);
+  return hipGetLastError();
+}
+
+hipError_t launch_hill_gather(const Geom &g, const Tables &t, double *rec, const HillList &h, const HillHeights &hh,
+                              const GatherPlan &plan, int *dirty_flag, hipStream_t s) {
+  if (h.nh <= 0) return hipSuccess;
+  switch (g.dim) {
+    case 1: return gather_dim<1>(g, t, rec, h, hh, plan, dirty_flag, s);
+    case 2: return gather_dim<2>(g, t, rec, h, hh, plan, dirty_flag, s);
+    default: return gather_dim<3>(g, t, rec, h, hh, plan, dirty_flag, s);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K6: duplicate_boundary (gaussian_grid.h:571-630): copies the VALUE of the first /
+// last in-boundary node to its outward neighbour for the 4^dim index combinations.
+// ---------------------------------------------------------------------------
+struct DupPlan {
+  unsigned long long lo[3], hi[3];
+};
+__global__ void k_duplicate_boundary(Geom g, double *__restrict__ rec, DupPlan dp, int *__restrict__ dirty_flag) {
+  if (*dirty_flag == 0) return;
+  int combos = 1;
+  for (int d = 0; d < g.dim; d++) combos *= 4;
+  const int c = threadIdx.x;
+  bool do_copy = false;
+  long long outer_flat = 0, inner_flat = 0;
+  if (c < combos) {
+    unsigned long long outer[3], inner[3];
+    int rest = c;
+    bool skip = false;
+    for (int d = 0; d < g.dim; d++) {
+      const int which = rest % 4;
+      rest /= 4;
+      switch (which) {
+        case 0:
+          skip |= (g.bper[d] != 0);
+          skip |= (dp.lo[d] == 0);
+          outer[d] = dp.lo[d] - 1;
+          inner[d] = dp.lo[d];
+          break;
+        case 1:
+          outer[d] = dp.lo[d];
+          inner[d] = dp.lo[d];
+          break;
+        case 2:
+          outer[d] = dp.hi[d];
+          inner[d] = dp.hi[d];
+          break;
+        default:
+          skip |= (g.bper[d] != 0);
+          skip |= (dp.hi[d] == (unsigned long long)(g.n[d] - 1));
+          outer[d] = dp.hi[d] + 1;
+          inner[d] = dp.hi[d];
+          break;
+      }
+    }
+    if (!skip) {
+      bool oob = false;
+      for (int d = 0; d < g.dim; d++)
+        if (outer[d] >= (unsigned long long)g.n[d] || inner[d] >= (unsigned long long)g.n[d]) oob = true;
+      if (!oob) {  // the reference would write out of bounds here
+        outer_flat = (long long)outer[g.dim - 1];
+        inner_flat = (long long)inner[g.dim - 1];
+        for (int d = g.dim - 1; d > 0; d--) {
+          outer_flat = outer_flat * g.n[d - 1] + (long long)outer[d - 1];
+          inner_flat = inner_flat * g.n[d - 1] + (long long)inner[d - 1];
+        }
+        do_copy = true;
+      }
+    }
+  }
+  // inner nodes lie inside the boundary, non-trivial outer nodes outside it, so the
+  // copies are independent of each other: read all, then write all
+  double v = 0;
+  if (do_copy) v = rec[inner_flat * g.rec];
+  __syncthreads();
+  if (do_copy) rec[outer_flat * g.rec] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) *dirty_flag = 0;
+}
+
+hipError_t launch_duplicate_boundary(const Geom &g, double *rec, int *dirty_flag, hipStream_t s) {
+  // grid.h:264-273 applied to the boundary corners, then the two while loops of
+  // gaussian_grid.h:582-588 (host arithmetic, identical to the reference)
+  DupPlan dp;
+  for (int d = 0; d < 3; d++) dp.lo[d] = dp.hi[d] = 0;
+  for (int d = 0; d < g.dim; d++) {
+    double w;
+    unsigned long long lo = (unsigned long long)node_index(g, d, g.bmin[d], &w);
+    unsigned long long hi = (unsigned long long)node_index(g, d, g.bmax[d], &w);
+    long long guard = 0;
+    while ((double)lo * g.dx[d] + g.min[d] < g.bmin[d] && guard++ < (1LL << 31)) lo += 1;
+    guard = 0;
+    while (((double)hi * g.dx[d] + g.min[d] > g.bmax[d] || hi == (unsigned long long)g.n[d]) && guard++ < (1LL << 31)) hi -= 1;
+    dp.lo[d] = lo;
+    dp.hi[d] = hi;
+  }
+  hipLaunchKernelGGL(k_duplicate_boundary, dim3(1), dim3(64), 0, s, g, rec, dp, dirty_flag);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K4: ordered bias limiter
+//   new hills : edm_bias.cpp:465-495  (add, maybe undo, maybe defer)
+//   flush     : edm_bias.cpp:323-356  (replay until the limit, undo the crossing hill)
+// Hills [0,k) provably precede the first crossing and keep their full height; the
+// ordered tail [k, nh) is walked by one thread exactly like the reference's loop.
+// ---------------------------------------------------------------------------
+// per chunk of EDM_CHUNK hills: sum and the maximum inclusive prefix
+__global__ void __launch_bounds__(BLOCK) k_chunk_stats(long long nh, const double *__restrict__ added,
+                                                       double *__restrict__ chunk_sum, double *__restrict__ chunk_max) {
+  __shared__ double lds[BLOCK];
+  constexpr int PER = EDM_CHUNK / BLOCK;
+  const long long base = (long long)blockIdx.x * EDM_CHUNK + (long long)threadIdx.x * PER;
+  double loc[PER];
+  double s = 0, mx = -1e308;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    loc[j] = (base + j < nh) ? added[base + j] : 0.0;
+    s += loc[j];
+    if (base + j < nh && s > mx) mx = s;
+  }
+  lds[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // exclusive prefix over thread sums (sequential: 256 adds)
+    double run = 0;
+    for (int j = 0; j < BLOCK; j++) {
+      const double v = lds[j];
+      lds[j] = run;
+      run += v;
+    }
+    chunk_sum[blockIdx.x] = run;
+  }
+  __syncthreads();
+  double my = (mx > -1e307) ? mx + lds[threadIdx.x] : -1e308;
+  __syncthreads();
+  // block max
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double other = __shfl_down(my, o, 64);
+    if (other > my) my = other;
+  }
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = my;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = lds[0];
+    for (int w = 1; w < BLOCK / 64; w++)
+      if (lds[w] > m) m = lds[w];
+    chunk_max[blockIdx.x] = m;
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_limit(long long nh, const double *__restrict__ added,
+                                                 const double *__restrict__ heights, double h_const, double limit,
+                                                 double cum_in, int flush_mode, LimitTail tail,
+                                                 LimitResult *__restrict__ res, long long nchunks,
+                                                 const double *__restrict__ chunk_sum,
+                                                 const double *__restrict__ chunk_max) {
+  __shared__ long long k_sh;
+  __shared__ double cum_sh;
+  __shared__ double a_sh[BLOCK];
+  __shared__ double h_sh[BLOCK];
+  if (threadIdx.x == 0) {
+    long long k = 0;
+    double cum = cum_in;
+    // skip whole chunks that cannot reach the limit (not in flush mode: the flush list is short)
+    if (!flush_mode && nchunks > 0) {
+      long long c = 0;
+      for (; c < nchunks; c++) {
+        if (!(cum < limit)) break;
+        if (cum + chunk_max[c] >= limit) break;
+        cum += chunk_sum[c];
+      }
+      k = c * EDM_CHUNK;
+      if (k > nh) k = nh;
+    }
+    k_sh = k;
+    cum_sh = cum;
+  }
+  __syncthreads();
+  const long long k = k_sh;
+  const long long ntail = nh - k;
+  if (ntail > EDM_TAIL_CAP) {
+    if (threadIdx.x == 0) {
+      res->cum_out = cum_sh;
+      res->k = k;
+      res->n_tail = 0;
+      res->stop = 0;
+      res->n_deferred = 0;
+      res->error = 1;
+    }
+    return;
+  }
+  double cum = cum_sh;        // new-hill mode: temp_hill_cum_; flush mode: bias added by this flush
+  int n_def = 0;
+  int stop = (int)ntail;
+  bool stopped = false;
+  for (long long base = 0; base < ntail; base += BLOCK) {
+    const long long i = k + base + threadIdx.x;
+    a_sh[threadIdx.x] = (i < nh) ? added[i] : 0.0;
+    h_sh[threadIdx.x] = (i < nh) ? (heights ? heights[i] : h_const) : 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int lim = (ntail - base < BLOCK) ? (int)(ntail - base) : BLOCK;
+      for (int j = 0; j < lim; j++) {
+        const long long ti = base + j;
+        const double a = a_sh[j], hgt = h_sh[j];
+        double h1 = 0, h2 = 0, a2 = 0;
+        int fl = 0;
+        if (flush_mode) {
+          if (!stopped) {
+            h1 = hgt;
+            fl = 1;
+            cum += a;                                   // bias_added += temp            (:328)
+            if (cum > limit) {                          //                               (:334)
+              h2 = fmax(limit - cum, -hgt);             //                               (:338)
+              a2 = (hgt != 0.0) ? h2 * (a / hgt) : 0.0; // add_value(pos, h) is linear in h
+              cum += a2;
+              fl |= 2;
+              stop = (int)ti;
+              stopped = true;
+            }
+          }
+        } else {
+          if (cum < limit) {                            //                               (:465)
+            h1 = hgt;
+            fl = 1;
+            cum += a;
+            if (cum > limit) {                          //                               (:474)
+              h2 = fmax(limit - cum, -hgt);             //                               (:479)
+              a2 = (hgt != 0.0) ? h2 * (a / hgt) : 0.0;
+              cum += a2;
+              fl |= 2 | 4;
+              n_def++;
+            }
+          } else {
+            fl = 4;                                     // whole hill deferred           (:493-494)
+            n_def++;
+          }
+        }
+        tail.h1[ti] = h1;
+        tail.h2[ti] = h2;
+        tail.added2[ti] = a2;
+        tail.cum_after[ti] = cum;
+        tail.flags[ti] = fl;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    res->cum_out = cum;
+    res->k = k;
+    res->n_tail = (int)ntail;
+    res->stop = stop;
+    res->n_deferred = n_def;
+    res->error = 0;
+  }
+}
+
+size_t limit_scratch_doubles(long long nh) { return (size_t)(2 * ((nh + EDM_CHUNK - 1) / EDM_CHUNK) + 8); }
+
+hipError_t launch_limit(long long nh, const double *added, const double *heights, double h_const, double limit,
+                        double cum_in, int flush_mode, const LimitTail &tail, LimitResult *result_dev,
+                        double *scratch, hipStream_t s) {
+  long long nchunks = 0;
+  double *csum = scratch, *cmax = scratch;
+  if (!flush_mode && nh > EDM_CHUNK) {
+    nchunks = (nh + EDM_CHUNK - 1) / EDM_CHUNK;
+    csum = scratch;
+    cmax = scratch + nchunks;
+    hipLaunchKernelGGL(k_chunk_stats, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, nh, added, csum, cmax);
+  }
+  hipLaunchKernelGGL(k_limit, dim3(1), dim3(BLOCK), 0, s, nh, added, heights, h_const, limit, cum_in, flush_mode, tail,
+                     result_dev, nchunks, csum, cmax);
+  return hipGetLastError();
+}
+
+}  // namespace edm

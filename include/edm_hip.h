@@ -1,0 +1,232 @@
+/*
+ * edm_hip.h -- C ABI of libedm_hip.so: the MI355X (gfx950) implementation of the
+ * EDM per-timestep bias hot path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no HIP, torch or
+ * C++ types.  Each entry point names the reference interface it replaces
+ * (file:line relative to the reference tree).  The C++ classes in
+ * the include/edm/ headers (EDM::EDMBias, EDM::GaussGrid, EDM::Grid -- source compatible
+ * with the reference's lib/ headers) are thin wrappers over these calls, and the
+ * LAMMPS fixes call those classes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns an int status (EDM_HIP_OK == 0).  Nothing aborts:
+ *     the C++ layer turns a non-zero status into EDM::edm_error() -> abort(),
+ *     which is the reference's convention (lib/edm.cpp:4-7).
+ *   - "d_" parameters are DEVICE pointers (HBM of the current device); "h_" or
+ *     unprefixed pointers are host memory, borrowed for the call only.
+ *   - handles own their device memory.  One HIP stream per handle; calls are
+ *     synchronous at return unless the name ends in _async.
+ *   - positions/forces use the LAMMPS layout: row-major [n][stride] doubles, of
+ *     which the first `dim` columns are read/updated.
+ *   - there is NO CPU fallback behind any of these calls.
+ */
+#ifndef EDM_HIP_H_
+#define EDM_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDM_HIP_OK 0
+#define EDM_HIP_ERR_HIP 1          /* a HIP runtime call failed; see edm_hip_last_error() */
+#define EDM_HIP_ERR_ARG 2          /* invalid argument */
+#define EDM_HIP_ERR_NO_DEVICE 3    /* no gfx950 device visible */
+#define EDM_HIP_ERR_OVERFLOW 4     /* bias overflow buffer full (edm_bias.cpp:501-507) */
+#define EDM_HIP_ERR_STATE 5        /* call order violated (e.g. add_hill before pre_add_hill) */
+#define EDM_HIP_ERR_IO 6           /* file could not be opened / parsed */
+#define EDM_HIP_ERR_COMM 7         /* RCCL failure */
+
+#define EDM_HIP_MAXDIM 3
+#define EDM_HIP_BIAS_BUFFER_SIZE 2048   /* edm_bias.h:15 */
+
+typedef struct edm_hip_gauss edm_hip_gauss; /* device-resident DimmedGaussGrid<DIM> */
+typedef struct edm_hip_grid edm_hip_grid;   /* device-resident plain DimmedGrid<DIM> (histogram, target) */
+typedef struct edm_hip_bias edm_hip_bias;   /* EDMBias controller */
+
+/* ---- runtime ---------------------------------------------------------- */
+const char *edm_hip_last_error(void);
+const char *edm_hip_version(void);
+int edm_hip_device_count(int *count);
+int edm_hip_set_device(int device);
+/* name, CU count and HBM bytes of the current device */
+int edm_hip_device_info(char *name, size_t cap, int *compute_units, size_t *hbm_bytes);
+/* device memory helpers so that a C / ctypes / cgo host needs no HIP headers */
+int edm_hip_malloc(void **d_ptr, size_t bytes);
+int edm_hip_free(void *d_ptr);
+int edm_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
+int edm_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
+int edm_hip_memset(void *d_dst, int value, size_t bytes);
+int edm_hip_device_synchronize(void);
+
+/* ---- geometry (read-only view of a grid's derived fields) --------------- */
+typedef struct {
+  int dim;
+  int interpolate;                         /* b_interpolate_ */
+  int n[EDM_HIP_MAXDIM];                   /* grid_number_ (grid.h:204-207) */
+  int periodic[EDM_HIP_MAXDIM];            /* b_periodic_ of the grid */
+  double min[EDM_HIP_MAXDIM];
+  double max[EDM_HIP_MAXDIM];              /* includes the +dx of non-periodic dims (grid.h:209-210) */
+  double dx[EDM_HIP_MAXDIM];               /* re-fitted spacing (grid.h:205) */
+  double sigma[EDM_HIP_MAXDIM];            /* sigma * sqrt(2) (gaussian_grid.h:75) */
+  int boundary_periodic[EDM_HIP_MAXDIM];   /* b_periodic_boundary_ */
+  double boundary_min[EDM_HIP_MAXDIM];
+  double boundary_max[EDM_HIP_MAXDIM];
+  int minisize[EDM_HIP_MAXDIM];            /* gaussian_grid.h:559-569 */
+  long long total;                         /* grid_size_ */
+} edm_hip_geometry;
+
+/* ---- plain grid: DimmedGrid<DIM> without interpolation (lib/grid.h) ------ */
+/* make_grid (grid.h:911, grid.cpp:3-20) with b_derivatives = b_interpolate = 0 */
+int edm_hip_grid_create(edm_hip_grid **out, int dim, const double *min, const double *max,
+                        const double *spacing, const int *periodic);
+int edm_hip_grid_destroy(edm_hip_grid *g);
+int edm_hip_grid_geometry(const edm_hip_grid *g, edm_hip_geometry *out);
+/* Grid::get_grid / clear (grid.h:841, :679) */
+int edm_hip_grid_download(const edm_hip_grid *g, double *h_values);
+int edm_hip_grid_upload(edm_hip_grid *g, const double *h_values);
+int edm_hip_grid_clear(edm_hip_grid *g);
+/* DimmedGrid::add_value batched (grid.h:370-385): values[bin(x_i)] += w_i, silently
+ * ignoring samples outside in_grid.  d_w may be NULL (w = w_const). */
+int edm_hip_grid_add_values(edm_hip_grid *g, long long n, const double *d_x, int x_stride,
+                            const double *d_w, double w_const);
+/* DimmedGrid::write (grid.h:448-503), byte-identical text */
+int edm_hip_grid_write(const edm_hip_grid *g, const char *filename);
+
+/* ---- gaussian grid: DimmedGaussGrid<DIM> (lib/gaussian_grid.h) ----------- */
+/* make_gauss_grid (gaussian_grid.h:636, gaussian_grid.cpp:3-18) */
+int edm_hip_gauss_create(edm_hip_gauss **out, int dim, const double *min, const double *max,
+                         const double *spacing, const int *periodic, int b_interpolate,
+                         const double *sigma);
+int edm_hip_gauss_destroy(edm_hip_gauss *g);
+/* GaussGrid::set_boundary (gaussian_grid.h:378-435): rebuilds the two 65536-entry
+ * McGovern-De Pablo tables per non-periodic dimension on the host with libm erf
+ * (bit-identical to the reference) and uploads them. */
+int edm_hip_gauss_set_boundary(edm_hip_gauss *g, const double *min, const double *max,
+                               const int *periodic);
+int edm_hip_gauss_geometry(const edm_hip_gauss *g, edm_hip_geometry *out);
+/* Grid::get_grid + grid_deriv_ (grid.h:879-880): host layout values[total],
+ * derivs[total][dim]; the device keeps one (V, dV/ds_0..) record per node. */
+int edm_hip_gauss_download(const edm_hip_gauss *g, double *h_values, double *h_derivs);
+int edm_hip_gauss_upload(edm_hip_gauss *g, const double *h_values, const double *h_derivs);
+int edm_hip_gauss_clear(edm_hip_gauss *g);
+/* the raw device record array ((1+dim) doubles per node padded to 2 or 4) for
+ * collectives: pointer, doubles per node, node count */
+int edm_hip_gauss_device_buffer(edm_hip_gauss *g, double **d_records, int *doubles_per_node,
+                                long long *nodes);
+
+/* GaussGrid::get_value_deriv batched (gaussian_grid.h:118-138 -> grid.h:390-446 ->
+ * interp<DIM> grid.h:52-139).  Per sample: d_energy[i] = V (may be NULL),
+ * d_deriv[i*dim + j] = dV/ds_j (positive gradient, may be NULL). */
+int edm_hip_gauss_get_value_deriv(const edm_hip_gauss *g, long long n, const double *d_x,
+                                  int x_stride, double *d_energy, double *d_deriv);
+/* flat node index the lookup of each sample starts from (grid.h:264-273,:315-325) after
+ * bounds/remap handling, or -1 where the reference returns 0: the integer half of parity */
+int edm_hip_gauss_sample_index(const edm_hip_gauss *g, long long n, const double *d_x,
+                               int x_stride, long long *d_flat);
+
+/* EDMBias::update_forces (edm_bias.cpp:276-295): for every sample with
+ * (apply_mask < 0 || d_mask[i] & apply_mask): E += V(x_i); f[i][j] -= dV/ds_j.
+ * d_mask may be NULL when apply_mask < 0.  *energy = sum of V (host double). */
+int edm_hip_gauss_update_forces(const edm_hip_gauss *g, long long n, const double *d_x,
+                                int x_stride, double *d_f, int f_stride, const int *d_mask,
+                                int apply_mask, double *energy);
+/* the fix_edm_pair inner loop (fix_edm_pair.cpp:215-217) batched over a 1-D
+ * distance array: d_force[i] = -dV/dr(r_i) (i.e. edm_force[0] after
+ * update_force on a zeroed accumulator); *energy = sum V(r_i). */
+int edm_hip_gauss_pair_forces(const edm_hip_gauss *g, long long n, const double *d_r,
+                              double *d_force, double *energy);
+
+/* measurement support (no reference counterpart): records HIP events on the handle's own
+ * stream directly around the dominant lookup kernel of update_forces / pair_forces and
+ * accumulates hipEventElapsedTime over the calls made while enabled. */
+int edm_hip_gauss_profile_enable(edm_hip_gauss *g, int enabled);
+int edm_hip_gauss_profile_read(edm_hip_gauss *g, double *kernel_ms_total, long long *launches, int reset);
+
+/* GaussGrid::add_value batched (gaussian_grid.h:176-372).  Applies n hills
+ * (positions d_x, heights d_h or h_const when d_h == NULL) IN LIST ORDER and
+ * writes each hill's integrated bias to d_added (may be NULL).  No limiting.
+ * *total_added (host, may be NULL) = sum of d_added. */
+int edm_hip_gauss_add_values(edm_hip_gauss *g, long long n, const double *d_x, int x_stride,
+                             const double *d_h, double h_const, double *d_added,
+                             double *total_added);
+/* per-hill integrated bias WITHOUT touching the grid (the return value of
+ * add_value, which does not depend on grid contents) */
+int edm_hip_gauss_hill_integrals(const edm_hip_gauss *g, long long n, const double *d_x,
+                                 int x_stride, const double *d_h, double h_const,
+                                 double *d_added);
+/* DimmedGrid::write / multi_write on the underlying grid (grid.h:448-503, :509-674;
+ * multi_write evaluated for one rank, lammps != 0 selects the LAMMPS table format) */
+int edm_hip_gauss_write(const edm_hip_gauss *g, const char *filename);
+int edm_hip_gauss_multi_write(const edm_hip_gauss *g, const char *filename, int b_lammps_format);
+/* Grid::add (grid.h:275-290) from a PLUMED grid file read with interpolation:
+ * the initial_bias_filename path of EDMBias::subdivide (edm_bias.cpp:166-167) */
+int edm_hip_gauss_add_from_file(edm_hip_gauss *g, const char *filename, double scale, double offset);
+
+/* ---- EDMBias controller (lib/edm_bias.h) ---------------------------------- */
+/* EDMBias::EDMBias(const std::string&) + read_input (edm_bias.cpp:34-69, :986-1095) */
+int edm_hip_bias_create(edm_hip_bias **out, const char *input_filename);
+int edm_hip_bias_destroy(edm_hip_bias *b);
+/* EDMBias::setup (edm_bias.cpp:264-269) */
+int edm_hip_bias_setup(edm_hip_bias *b, double temperature, double boltzmann_constant);
+/* EDMBias::subdivide (edm_bias.cpp:98-222); arrays hold dim entries */
+int edm_hip_bias_subdivide(edm_hip_bias *b, const double *sublo, const double *subhi,
+                           const double *boxlo, const double *boxhi, const int *b_periodic,
+                           const double *skin);
+/* EDMBias::set_mask (edm_bias.cpp:982-984); device pointer, borrowed until replaced */
+int edm_hip_bias_set_mask(edm_hip_bias *b, const int *d_mask);
+/* EDMBias::update_forces (edm_bias.cpp:276-295) */
+int edm_hip_bias_update_forces(edm_hip_bias *b, long long n, const double *d_x, int x_stride,
+                               double *d_f, int f_stride, int apply_mask, double *energy);
+/* batched EDMBias::update_force over pair distances (edm_bias.cpp:297-311) */
+int edm_hip_bias_pair_forces(edm_hip_bias *b, long long n, const double *d_r, double *d_force,
+                             double *energy);
+/* EDMBias::add_hills (edm_bias.cpp:401-411): pre_add_hill(n); add_hill for every
+ * masked sample with uniform d_runiform[i]; post_add_hill.  est_hill_count < 0
+ * means "use n" (add_hills semantics); fix_edm_pair passes its own estimate. */
+int edm_hip_bias_add_hills(edm_hip_bias *b, long long n, const double *d_x, int x_stride,
+                           const double *d_runiform, int apply_mask, long long est_hill_count);
+/* EDMBias::pre_add_hill / add_hill / post_add_hill (edm_bias.cpp:413-442, :528-563,
+ * :565-583).  add_hill stages the sample (host values); the staged batch is
+ * applied on the device, in call order, at post_add_hill. */
+int edm_hip_bias_pre_add_hill(edm_hip_bias *b, long long est_hill_count);
+int edm_hip_bias_add_hill(edm_hip_bias *b, const double *position, double runiform);
+int edm_hip_bias_post_add_hill(edm_hip_bias *b);
+/* EDMBias::write_bias / write_lammps_table / write_histogram / clear_histogram
+ * (edm_bias.cpp:224-262).  serial_format != 0 reproduces the EDM_SERIAL build
+ * (all three fall back to DimmedGrid::write), 0 the MPI build's multi_write. */
+int edm_hip_bias_write_bias(const edm_hip_bias *b, const char *filename, int serial_format);
+int edm_hip_bias_write_lammps_table(const edm_hip_bias *b, const char *filename, int serial_format);
+int edm_hip_bias_write_histogram(const edm_hip_bias *b, int serial_format);
+int edm_hip_bias_clear_histogram(edm_hip_bias *b);
+/* the owned grids (bias_ and cv_hist_); NULL before subdivide */
+edm_hip_gauss *edm_hip_bias_gauss(edm_hip_bias *b);
+edm_hip_grid *edm_hip_bias_histogram(edm_hip_bias *b);
+/* public data members of EDMBias by name (edm_bias.h:118-157 and the private limiter
+ * state): dim, b_tempering, b_targeting, global_tempering, bias_factor, boltzmann_factor,
+ * temperature, hill_prefactor, bias_per_step, hill_density, cum_bias, total_volume,
+ * expected_target, b_outofbounds, overflow_left, overflow_right, b_skip_hill_add,
+ * hills_added, steps, mpi_rank, mpi_size.  Unknown name -> EDM_HIP_ERR_ARG. */
+int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value);
+int edm_hip_bias_set(edm_hip_bias *b, const char *name, double value);
+/* bias_dx, bias_sigma, min, max (dim doubles) */
+int edm_hip_bias_get_array(const edm_hip_bias *b, const char *name, double *out);
+/* 1 (default): write the per-rank HILLS log like the reference (edm_bias.cpp:586-599);
+ * 0: skip the text log (the CV histogram is still updated). */
+int edm_hip_bias_set_hill_log(edm_hip_bias *b, int enabled);
+
+/* ---- multi-GPU: one rank per GPU, RCCL over xGMI ---------------------------- */
+/* replaces the MPI hill exchange of EDMBias::flush_buffers / update_height
+ * (edm_bias.cpp:630-706, :922-931).  id_bytes is an ncclUniqueId (128 bytes)
+ * created by rank 0 and distributed by the host program (MPI_Bcast in LAMMPS,
+ * torch.distributed in bench.py). */
+int edm_hip_comm_unique_id(void *id_bytes, size_t cap);
+int edm_hip_bias_comm_init(edm_hip_bias *b, const void *id_bytes, int nranks, int rank);
+int edm_hip_bias_comm_destroy(edm_hip_bias *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDM_HIP_H_ */

@@ -1,0 +1,388 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (include/edm_hip.h),
+against (a) the golden fixtures the real reference produced and (b) the CPU oracle on
+seeded inputs, plus size-independent properties at BASELINE.json's full sizes.
+
+Bars (BASELINE.json north_star): node indices, histogram counts and limiter decisions
+bit-exact; energies / forces / grid values within 1e-6 relative.  The tolerances asserted
+below are much tighter (they are what the kernels achieve: differences come only from
+device exp() ulps and fixed-order tree reductions) and are written next to each check.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import edm_amd.hip as H
+import edm_amd.workloads as W
+from oracle import binding as B
+
+import golden_util as GU
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9      # asserted relative tolerance for doubles (bar: 1e-6)
+ATOL_GRID = 1e-13  # absolute floor for values that cancel to ~0
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    H.require_gpu()  # fail loudly: there is no CPU fallback
+    yield
+
+
+def close(a, b, rtol=RTOL, atol=0.0, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = np.maximum(np.abs(a), np.abs(b))
+    bad = np.abs(a - b) > (atol + rtol * scale)
+    assert not bad.any(), "%s: %d/%d differ, worst %g (rel %g)" % (
+        what, bad.sum(), bad.size, np.abs(a - b).max(), (np.abs(a - b) / np.maximum(scale, 1e-300)).max())
+
+
+def make_pair(sc, oracle_lib):
+    g = H.Gauss.create(sc["lo"], sc["hi"], sc["sp"], sc["per"], 1, sc["sg"])
+    o = B.Gauss.create(oracle_lib, sc["lo"], sc["hi"], sc["sp"], sc["per"], 1, sc["sg"])
+    if sc.get("bnd"):
+        g.set_boundary(*sc["bnd"])
+        o.set_boundary(*sc["bnd"])
+    return g, o
+
+
+# ---------------------------------------------------------------------------------
+# golden fixtures (outputs of the real reference)
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("sc", GU.gauss_scenarios(), ids=lambda s: s["name"])
+def test_gauss_golden(sc):
+    d = GU.gauss_data(sc["name"])
+    g = H.Gauss.create(sc["lo"], sc["hi"], sc["sp"], sc["per"], 1, sc["sg"])
+    if sc["bnd"]:
+        g.set_boundary(*sc["bnd"])
+    # geometry: integers exact, host-computed doubles exact
+    assert [int(v) for v in g.number] == sc["grid_number"]
+    assert g.minisize == sc["minisize"]
+    assert [float(v) for v in g.dx] == sc["dx"]
+    assert [float(v) for v in g.max] == sc["grid_max"]
+    assert [float(v) for v in g.sigma] == sc["sigma_eff"]
+    dim = g.dim
+    pad = np.zeros((len(d["hill_x"]), 3))
+    pad[:, :dim] = d["hill_x"]
+    added = g.add_values(pad, d["hill_h"])
+    close(added, d["bias_added"], rtol=1e-10, atol=1e-15, what="bias_added")
+    v, dv = g.download()
+    vmax = np.abs(d["grid_values"]).max()
+    close(v, d["grid_values"], rtol=1e-10, atol=1e-13 * vmax, what="grid values")
+    close(dv, d["grid_derivs"], rtol=1e-10, atol=1e-12 * np.abs(d["grid_derivs"]).max(), what="grid derivs")
+    q = np.zeros((len(d["queries"]), 3))
+    q[:, :dim] = d["queries"]
+    E, der = g.get_value_deriv(q)
+    close(E, d["E"], rtol=1e-9, atol=1e-13 * vmax, what="E")
+    close(der, d["der"], rtol=1e-9, atol=1e-11 * np.abs(d["der"]).max(), what="der")
+    flat = g.sample_index(q)
+    assert np.array_equal(flat, d["flat_index"]), "node indices must be bit-exact"
+
+
+def _parse_hills(path):
+    rows = []
+    for line in open(path):
+        t = line.split()
+        rows.append((int(t[0]), t[1], int(t[2])) + tuple(float(v) for v in t[3:]))
+    return rows
+
+
+def _grid_file_numbers(path):
+    head, nums = [], []
+    for line in open(path):
+        if line.startswith("#"):
+            head.append(line)
+        elif line.strip():
+            nums.append([float(v) for v in line.split()])
+    return head, np.array(nums)
+
+
+@pytest.mark.parametrize("case", GU.controller_cases(), ids=lambda c: c["name"])
+def test_controller_golden(case, workdir):
+    name = case["name"]
+    hills = str(workdir / ("HILLS_" + name))
+    cfg = str(workdir / (name + ".edm"))
+    with open(cfg, "w") as fh:
+        fh.write(case["cfg"] + "\nhills_filename %s\nhistogram_filename %s.hist\n" % (hills, hills))
+    b = H.Bias(cfg)
+    dim = int(b.get("dim"))
+    b.setup(1.0, 1.0)
+    lo, hi = b.array("min"), b.array("max")
+    b.subdivide(lo, hi, lo, hi, case["per"], case["skin"])
+    if name == "local_tempering":
+        pos, ru, mask = GU.controller_inputs(case, 0, dim, lo, hi)
+        with pytest.raises(H.EdmHipError):
+            b.add_hills(pos, ru, -1)  # serial-dependence path: fails loudly until implemented
+        return
+    for step in range(case["steps"]):
+        pos, ru, mask = GU.controller_inputs(case, step, dim, lo, hi)
+        forces = np.zeros_like(pos)
+        apply_mask = 1 if step % 2 else -1
+        b.set_mask(mask)
+        e = b.update_forces(pos, forces, apply_mask)
+        close(e, case["E"][step], rtol=1e-9, atol=1e-13, what="energy step %d" % step)
+        close(forces[:8, :dim], case["forces_head"][step], rtol=1e-8, atol=1e-11, what="forces")
+        if case["mode"] == "explicit":
+            b.pre_add_hill(1)
+            for k in range(case["n"]):
+                b.add_hill(pos[k], float(ru[k]))
+            b.post_add_hill()
+        else:
+            b.add_hills(pos, ru, apply_mask)
+        close(b.get("cum_bias"), case["cum"][step], rtol=1e-10, what="cum_bias")
+        got = [int(b.get("overflow_left")), int(b.get("overflow_right")), int(b.get("b_skip_hill_add"))]
+        assert got == case["overflow"][step], "limiter decisions must match exactly (step %d)" % step
+    d = GU.controller_data(name)
+    v, dv = b.gauss.download()
+    close(v, d["grid_values"], rtol=1e-9, atol=1e-13 * np.abs(d["grid_values"]).max(), what="grid")
+    close(dv, d["grid_derivs"], rtol=1e-9, atol=1e-11 * max(np.abs(d["grid_derivs"]).max(), 1e-300), what="derivs")
+    assert np.array_equal(b.hist.values, d["hist"]), "histogram counts are integers: exact"
+    b.write_bias(str(workdir / "BIAS"))
+    b.write_histogram()
+    del b
+    # HILLS log: same events in the same order; numbers to the printed precision
+    got = _parse_hills(hills + "_0")
+    want = _parse_hills(os.path.join(GU.GOLDEN, "ctrl_%s.hills.txt" % name))
+    assert len(got) == len(want)
+    for a, w in zip(got, want):
+        assert a[:3] == w[:3], (a, w)
+        close(a[3:], w[3:], rtol=0, atol=2e-8, what="HILLS line")
+    # histogram file is integer-valued: byte-identical
+    assert open(hills + ".hist").read() == open(os.path.join(GU.GOLDEN, "ctrl_%s.hist.grid" % name)).read()
+    gold_bias = os.path.join(GU.GOLDEN, "ctrl_%s.bias.grid" % name)
+    if os.path.exists(gold_bias):
+        h1, n1 = _grid_file_numbers(str(workdir / "BIAS"))
+        h2, n2 = _grid_file_numbers(gold_bias)
+        assert h1 == h2, "grid file header must be byte-identical"
+        close(n1, n2, rtol=0, atol=1.01e-8, what="bias grid file body")
+
+
+def test_known_answers(workdir):
+    k = GU.kats()
+    fx = GU.FIXTURES
+    cfg = str(workdir / "nb.edm")
+    open(cfg, "w").write(open(os.path.join(fx, "notebook_input.edm")).read() + "\nhills_filename %s/H1\n" % workdir)
+    b = H.Bias(cfg)
+    b.setup(1, 1)
+    b.subdivide([0], [10], [0], [10], [0], [0])
+    b.pre_add_hill(1)
+    b.add_hill([0.25], 1.0)
+    b.post_add_hill()
+    E, der = b.gauss.get_value_deriv([[0.24]])
+    close([E[0], der[0, 0]], k["notebook"]["published"], rtol=1e-12, what="notebook KAT (EDM.ipynb:103)")
+    close(b.get("cum_bias"), k["notebook"]["cum_bias"], rtol=1e-12, what="cum_bias")
+    b.gauss.multi_write("mw.grid", 0)
+    b.gauss.multi_write("lt.ltab", 1)
+    for got, want in (("mw.grid", "file_notebook_multiwrite.grid"), ("lt.ltab", "file_notebook_lammps.ltab")):
+        a = open(got).read().split()
+        w = open(os.path.join(GU.GOLDEN, want)).read().split()
+        assert len(a) == len(w)
+        same = sum(x == y for x, y in zip(a, w))
+        assert same >= len(a) - 2, "%s: %d/%d tokens differ" % (want, len(a) - same, len(a))
+    cfg = str(workdir / "sanity.edm")
+    open(cfg, "w").write(open(os.path.join(fx, "sanity.edm")).read() + "\nhills_filename %s/H2\n" % workdir)
+    b = H.Bias(cfg)
+    b.setup(1, 1)
+    b.subdivide([0], [10], [0], [10], [1], [0])
+    b.add_hills(np.array([[5.0]]), [1.0])
+    s = k["sanity"]
+    E, _ = b.gauss.get_value_deriv([[5.0]])
+    close(E[0], s["value_at_5"], rtol=1e-12, what="edm_sanity value (edm_test.cpp:886)")
+    close(b.get("cum_bias"), s["cum_bias"], rtol=1e-12, what="edm_sanity cum_bias")
+    assert b.gauss.size == s["grid_size"]
+    _, d = b.gauss.get_value_deriv([[4.99], [5.01]])
+    assert d[0, 0] > 0 > d[1, 0]  # forces point away from the hill (edm_test.cpp:889-899)
+    b.write_bias("sanity.grid")
+    h1, n1 = _grid_file_numbers("sanity.grid")
+    h2, n2 = _grid_file_numbers(os.path.join(GU.GOLDEN, "file_sanity_bias.grid"))
+    assert h1 == h2
+    close(n1, n2, rtol=0, atol=1.01e-8, what="sanity bias file")
+
+
+# ---------------------------------------------------------------------------------
+# seeded inputs against the CPU oracle (sizes the oracle finishes in seconds)
+# ---------------------------------------------------------------------------------
+ORACLE_CASES = [
+    dict(name="c1d", lo=[0.0], hi=[2.8], sp=[0.00025], per=[0], sg=[0.025], nh=300, nq=20000),
+    dict(name="c1d_periodic", lo=[0.0], hi=[2.8], sp=[0.0005], per=[1], sg=[0.025], nh=200, nq=20000),
+    dict(name="tiny_periodic_stencil_wider_than_grid", lo=[2.0], hi=[10.0], sp=[1.0], per=[1], sg=[1.0], nh=6, nq=200),
+    dict(name="c2d_256", lo=[0.0, 0.0], hi=[8.0, 8.0], sp=[1 / 32.0] * 2, per=[1, 1], sg=[0.125] * 2, nh=120, nq=20000),
+    dict(name="c2d_mixed", lo=[0.0, 0.0], hi=[8.0, 6.0], sp=[0.05, 0.04], per=[1, 0], sg=[0.2, 0.15], nh=100, nq=10000),
+    dict(name="c3d_64", lo=[0.0] * 3, hi=[8.0] * 3, sp=[0.125] * 3, per=[1, 1, 1], sg=[0.25] * 3, nh=60, nq=10000),
+    dict(name="c3d_nonperiodic", lo=[0.0] * 3, hi=[4.0] * 3, sp=[0.1, 0.125, 0.2], per=[0, 0, 0], sg=[0.3] * 3, nh=24, nq=5000),
+]
+
+
+@pytest.mark.parametrize("c", ORACLE_CASES, ids=lambda c: c["name"])
+def test_vs_oracle_seeded(c, oracle_lib):
+    g, o = make_pair(c, oracle_lib)
+    dim = g.dim
+    lo, hi = np.array(c["lo"]), np.array(c["hi"])
+    hx = np.zeros((c["nh"], 3))
+    hx[:, :dim] = lo + W.uniform(101, c["nh"] * dim).reshape(-1, dim) * (hi - lo) * 1.1 - 0.05 * (hi - lo)
+    hh = 0.05 + W.uniform(102, c["nh"])
+    added = g.add_values(hx, hh)
+    ref_added = np.array([o.add_value(x[:dim], float(h)) for x, h in zip(hx, hh)])
+    close(added, ref_added, rtol=1e-10, atol=1e-15, what="bias_added")
+    # hill integrals do not depend on grid contents: the read-only entry point agrees too
+    close(g.hill_integrals(hx, hh), ref_added, rtol=1e-10, atol=1e-15, what="hill_integrals")
+    v, dv = g.download()
+    og = o.grid
+    close(v, og.values, rtol=1e-10, atol=1e-13 * np.abs(og.values).max(), what="grid")
+    close(dv, og.derivs, rtol=1e-10, atol=1e-12 * np.abs(og.derivs).max(), what="derivs")
+    q = np.zeros((c["nq"], 3))
+    q[:, :dim] = lo + (W.uniform(103, c["nq"] * dim).reshape(-1, dim) * 1.3 - 0.15) * (hi - lo)
+    E, der = g.get_value_deriv(q)
+    flat = g.sample_index(q)
+    refE = np.zeros(c["nq"])
+    refD = np.zeros((c["nq"], dim))
+    refI = np.full(c["nq"], -1, dtype=np.int64)
+    for i, x in enumerate(q[:, :dim]):
+        refE[i], refD[i] = o.get_value_deriv(x)
+        xr = x.copy()
+        if not o.in_bounds(xr):
+            xr = o.remap(xr)
+        if o.in_bounds(xr) and og.in_grid(xr):
+            refI[i] = og.multi2one(og.get_index(xr))
+    assert np.array_equal(flat, refI), "node indices must be bit-exact"
+    vmax = np.abs(og.values).max()
+    close(E, refE, rtol=1e-9, atol=1e-13 * vmax, what="E")
+    close(der, refD, rtol=1e-9, atol=1e-11 * np.abs(refD).max(), what="der")
+    # update_forces with a group mask (edm_bias.cpp:287-293)
+    mask = (W.splitmix64(104, c["nq"]) % np.uint64(4)).astype(np.int32)
+    f = W.uniform(105, c["nq"] * 3).reshape(-1, 3)
+    f_ref = f.copy()
+    e = g.update_forces(q, f, mask, 2)
+    sel = (mask & 2) != 0
+    f_ref[sel, :dim] -= refD[sel]
+    close(e, refE[sel].sum(), rtol=1e-10, what="masked energy")
+    close(f, f_ref, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(refD).max()), what="masked forces")
+    assert np.array_equal(f[~sel], f_ref[~sel]), "unmasked rows must not be touched"
+
+
+def test_stochastic_controller_vs_oracle(oracle_lib, workdir):
+    """fix_edm_pair-like hill step: 200k samples, hill_density 250, limit = prefactor."""
+    text = ("tempering 0\nhill_prefactor 0.5\nhill_density 250\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+            "bias_spacing 0.00025\nbias_sigma 0.025\n")
+    cfgs = {}
+    for tag in ("gpu", "ora"):
+        cfgs[tag] = str(workdir / (tag + ".edm"))
+        open(cfgs[tag], "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+    b = H.Bias(cfgs["gpu"])
+    o = B.Bias(oracle_lib, cfgs["ora"])
+    for x in (b, o):
+        x.setup(1.0, 1.0)
+        x.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    n = 200_000
+    for step in range(4):
+        r = W.pair_distances(n, 300 + step).reshape(-1, 1)
+        u = W.uniform(400 + step, n)
+        fg = np.zeros((n, 1))
+        fo = np.zeros((n, 1))
+        eg = b.update_forces(r, fg)
+        eo = o.update_forces(r, fo)
+        close(eg, eo, rtol=1e-10, atol=1e-13, what="energy")
+        close(fg, fo, rtol=1e-8, atol=1e-11, what="forces")
+        b.add_hills(r, u, -1, est=2 * n)
+        o.pre_add_hill(2 * n)
+        for i in np.nonzero(u < 250.0 / (2 * n))[0]:
+            o.add_hill(r[i], float(u[i]))
+        o.post_add_hill()
+        close(b.get("cum_bias"), o.get("cum_bias"), rtol=1e-10, what="cum_bias")
+        assert [b.get(k) for k in ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added")] == \
+               [o.get(k) for k in ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added")]
+    v, dv = b.gauss.download()
+    close(v, o.gauss.grid.values, rtol=1e-9, atol=1e-13 * np.abs(v).max(), what="grid")
+    assert np.array_equal(b.hist.values, o.hist.values)
+
+
+# ---------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties + sub-sampled oracle checks
+# ---------------------------------------------------------------------------------
+def _populate(g, o, dim, lo, hi, nh, seed, h=1e-3):
+    hx = np.zeros((nh, 3))
+    hx[:, :dim] = np.asarray(lo) + W.uniform(seed, nh * dim).reshape(-1, dim) * (np.asarray(hi) - np.asarray(lo))
+    g.add_values(hx, h)
+    if o is not None:
+        for x in hx:
+            o.add_value(x[:dim], h)
+    return hx
+
+
+@pytest.mark.parametrize("npairs", [W.W1_PAIRS, W.W2_PAIRS], ids=["W1_1M_pairs", "W2_38.8M_pairs"])
+def test_c1d_full_size(npairs, oracle_lib):
+    c = W.C1D
+    sc = dict(lo=c["lo"], hi=c["hi"], sp=c["spacing"], per=c["periodic"], sg=c["sigma"])
+    g, o = make_pair(sc, oracle_lib)
+    hx = _populate(g, o, 1, [0.85], [2.8], 512, 2)
+    r = W.pair_distances(npairs, 1 if npairs == W.W1_PAIRS else 11)
+    d_r = H.DeviceArray.from_host(r)
+    d_f = H.DeviceArray((npairs,))
+    e = g.pair_forces_device(d_r, d_f, npairs)
+    f = d_f.to_host()
+    # property 1: the strided update_forces kernel and the pair kernel agree bit for bit
+    d_f2 = H.DeviceArray.zeros((npairs,))
+    e2 = H.C.c_double(0)
+    H.check(H.lib().edm_hip_gauss_update_forces(g.h, npairs, d_r.ptr, 1, d_f2.ptr, 1, None, -1, H.C.byref(e2)))
+    assert np.array_equal(d_f2.to_host(), f)
+    close(e, e2.value, rtol=1e-12, what="energy of the two kernels")
+    # property 2: the in-kernel energy reduction equals the sum of per-sample energies
+    d_E = H.DeviceArray((npairs,))
+    H.check(H.lib().edm_hip_gauss_get_value_deriv(g.h, npairs, d_r.ptr, 1, d_E.ptr, None))
+    close(e, float(np.sum(d_E.to_host())), rtol=1e-11, what="energy sum")
+    # sub-sampled oracle check
+    idx = (W.splitmix64(7, 20000) % np.uint64(npairs)).astype(np.int64)
+    ref = np.array([o.get_value_deriv([r[i]])[1][0] for i in idx])
+    close(f[idx], -ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max(), what="forces vs oracle")
+    # property 3: linearity -- adding the same hills with the opposite height cancels
+    pad = np.zeros((len(hx), 3))
+    pad[:, 0] = hx[:, 0]
+    g.add_values(pad, -1e-3)
+    v, dv = g.download()
+    assert np.abs(v).max() < 1e-15 and np.abs(dv).max() < 1e-13
+
+
+def test_c2d_full_size(oracle_lib):
+    c = W.C2D
+    sc = dict(lo=c["lo"], hi=c["hi"], sp=c["spacing"], per=c["periodic"], sg=c["sigma"])
+    g, o = make_pair(sc, oracle_lib)
+    assert list(g.number) == [2048, 2048]
+    _populate(g, o, 2, c["lo"], c["hi"], 250, 22, h=0.01)
+    n = 262144
+    x = W.atom_positions(n, 21)
+    f = np.zeros((n, 3))
+    e = g.update_forces(x, f)
+    idx = (W.splitmix64(8, 5000) % np.uint64(n)).astype(np.int64)
+    ref = np.array([o.get_value_deriv(x[i, :2])[1] for i in idx])
+    close(f[idx, :2], -ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max(), what="2-D forces vs oracle")
+    assert not f[:, 2].any()
+    E, _ = g.get_value_deriv(x)
+    close(e, E.sum(), rtol=1e-11, what="2-D energy sum")
+    v, _ = g.download()
+    close(v, o.grid.values, rtol=1e-10, atol=1e-13 * np.abs(v).max(), what="2-D grid after 250 hills")
+
+
+def test_c3d_full_size_properties():
+    """512^3 bias grid (4.3 GB of node records): index round trip, linearity, locality."""
+    c = W.C3D
+    g = H.Gauss.create(c["lo"], c["hi"], c["spacing"], c["periodic"], 1, c["sigma"])
+    assert list(g.number) == [512, 512, 512] and g.minisize == [11, 11, 11]
+    n = 262144
+    x = W.atom_positions(n, 31)
+    flat = g.sample_index(x)
+    want = (np.floor(x / 0.125).astype(np.int64) * np.array([1, 512, 512 * 512])).sum(axis=1)
+    assert np.array_equal(flat, want), "3-D node indices"
+    hx = x[:64].copy()
+    added = g.add_values(hx, 0.02)
+    close(added, np.full(64, 0.02), rtol=1e-6, what="periodic 3-D hills integrate to their height")
+    f = np.zeros((n, 3))
+    e = g.update_forces(x, f)
+    assert e > 0 and np.isfinite(f).all()
+    # a sample sitting on a hill centre feels (almost) no force from that hill, and the energy is the peak
+    E, der = g.get_value_deriv(hx[:1])
+    assert E[0] >= 0.02 / (np.pi ** 1.5 * (0.25 * np.sqrt(2)) ** 3) * 0.99
+    g.add_values(hx, -0.02)
+    E2, _ = g.get_value_deriv(x[:4096])
+    assert np.abs(E2).max() < 1e-15, "hills followed by their negatives leave an empty grid"
