@@ -375,31 +375,25 @@ static int flush_overflow(edm_hip_bias *b, double max_bias, double *bias_added) 
   spec.flush_mode = 1;
   spec.limit = max_bias;
   spec.cum_in = 0;
+  spec.hist_g = &b->hist->g;
+  spec.hist_values = b->hist->values;
+  spec.fetch_all = true;
   ApplyOutcome oc;
   int rc = apply_hills(b->bias, spec, &oc, false);
   if (rc) return rc;
   const int stop = oc.res.stop;              // index of the crossing hill, or n
   const long long nrun = (stop < n) ? stop + 1 : n;
-  std::vector<double> added((size_t)nrun), h2((size_t)nrun), a2((size_t)nrun);
-  EDM_HIP_TRY(hipMemcpy(added.data(), b->bias->ws.added.p, sizeof(double) * (size_t)nrun, hipMemcpyDeviceToHost));
-  EDM_HIP_TRY(hipMemcpy(h2.data(), b->bias->ws.tail_h2.p, sizeof(double) * (size_t)nrun, hipMemcpyDeviceToHost));
-  EDM_HIP_TRY(hipMemcpy(a2.data(), b->bias->ws.tail_a2.p, sizeof(double) * (size_t)nrun, hipMemcpyDeviceToHost));
-  // histogram: +1 per replayed hill, -1 for the undo (edm_bias.cpp:601-610)
-  std::vector<double> wgt((size_t)nrun, 1.0);
-  EDM_HIP_TRY(launch_hist_add(b->hist->g, b->hist->values, nrun, b->stage_x.p, (int)b->dim, nullptr, nullptr, 1.0, s));
   for (long long i = 0; i < nrun; i++) {
     double *rec = &b->overflow[(b->overflow_left + (size_t)i) * w];
     b->hills_added++;
-    log_hill(b, rec, rec[b->dim], added[(size_t)i], 'b');
+    log_hill(b, rec, rec[b->dim], oc.added[(size_t)i], 'b');
     if (i == stop) {
-      rec[b->dim] = -h2[(size_t)i];           // the remaining part stays buffered (:341)
-      log_hill(b, rec, h2[(size_t)i], a2[(size_t)i], 'v');
+      const double h2 = oc.h2[(size_t)i];
+      rec[b->dim] = -h2;                      // the remaining part stays buffered (:341)
+      log_hill(b, rec, h2, oc.a2[(size_t)i], 'v');
       b->hills_added++;
-      EDM_HIP_TRY(launch_hist_add(b->hist->g, b->hist->values, 1, b->stage_x.p + (size_t)i * b->dim, (int)b->dim,
-                                  nullptr, nullptr, -1.0, s));
     }
   }
-  EDM_HIP_TRY(hipStreamSynchronize(s));
   if (stop < n)
     b->overflow_left += (size_t)stop;
   else
@@ -490,84 +484,47 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   spec.flush_mode = 0;
   spec.limit = b->bias_per_step;
   spec.cum_in = b->temp_hill_cum;
+  spec.hist_g = &b->hist->g;
+  spec.hist_values = b->hist->values;
+  const bool log_all = b->hill_log && b->hills_fp;
+  spec.fetch_all = log_all;
   ApplyOutcome oc;
   int rc = apply_hills(b->bias, spec, &oc, false);
   if (rc) return rc;
   const LimitResult &res = oc.res;
   b->temp_hill_cum = res.cum_out;
 
-  // histogram: every hill logs an 'h' line (+1), every undo a 'u' line (-1)
-  EDM_HIP_TRY(launch_hist_add(b->hist->g, b->hist->values, nh, d_x, x_stride, d_sel, nullptr, 1.0, s));
-
   const long long k = res.k;
   const int ntail = res.n_tail;
   const unsigned int dim = b->dim;
-  // ordered tail: undo weights, overflow appends
-  std::vector<int> flags((size_t)ntail);
-  std::vector<double> th2((size_t)ntail), ta2((size_t)ntail), tpos((size_t)ntail * dim);
-  if (ntail > 0) {
-    EDM_HIP_TRY(hipMemcpy(flags.data(), b->bias->ws.tail_flags.p, sizeof(int) * (size_t)ntail, hipMemcpyDeviceToHost));
-    EDM_HIP_TRY(hipMemcpy(th2.data(), b->bias->ws.tail_h2.p, sizeof(double) * (size_t)ntail, hipMemcpyDeviceToHost));
-    EDM_HIP_TRY(hipMemcpy(ta2.data(), b->bias->ws.tail_a2.p, sizeof(double) * (size_t)ntail, hipMemcpyDeviceToHost));
-  }
-  // original (un-remapped) positions of the hills the host needs: tail, or all when logging
-  const bool log_all = b->hill_log && b->hills_fp;
-  const long long first = log_all ? 0 : k;
-  const long long need = nh - first;
-  std::vector<double> pos((size_t)need * dim), added;
-  if (need > 0) {
-    // gather positions through the selection on the device (strided, maybe indirect)
-    EDM_HIP_TRY(b->hx0.reserve((size_t)need * dim));
-    std::vector<double> dummy;
-    // reuse the hist kernel's addressing by a tiny copy kernel: done with hipMemcpy2D when direct
-    if (!d_sel) {
-      EDM_HIP_TRY(hipMemcpy2DAsync(b->hx0.p, sizeof(double) * dim, d_x + (size_t)first * x_stride,
-                                   sizeof(double) * (size_t)x_stride, sizeof(double) * dim, (size_t)need,
-                                   hipMemcpyDeviceToDevice, s));
-      EDM_HIP_TRY(hipMemcpyAsync(pos.data(), b->hx0.p, sizeof(double) * pos.size(), hipMemcpyDeviceToHost, s));
-      EDM_HIP_TRY(hipStreamSynchronize(s));
-    } else {
-      std::vector<long long> hsel((size_t)need);
-      EDM_HIP_TRY(hipMemcpy(hsel.data(), d_sel + first, sizeof(long long) * (size_t)need, hipMemcpyDeviceToHost));
-      for (long long i = 0; i < need; i++)
-        EDM_HIP_TRY(hipMemcpyAsync(&pos[(size_t)i * dim], d_x + (size_t)hsel[(size_t)i] * x_stride, sizeof(double) * dim,
-                                   hipMemcpyDeviceToHost, s));
-      EDM_HIP_TRY(hipStreamSynchronize(s));
-    }
-  }
+  const long long first = oc.first;
   if (log_all) {
-    added.resize((size_t)nh);
-    EDM_HIP_TRY(hipMemcpy(added.data(), b->bias->ws.added.p, sizeof(double) * (size_t)nh, hipMemcpyDeviceToHost));
     for (long long i = 0; i < k; i++) {
       b->hills_added++;
-      log_hill(b, &pos[(size_t)i * dim], this_h, added[(size_t)i], 'h');
+      log_hill(b, &oc.pos[(size_t)(i - first) * dim], this_h, oc.added[(size_t)(i - first)], 'h');
     }
   } else {
     b->hills_added += (int)k;
   }
+  // ordered tail: the log lines, and the overflow appends of edm_bias.cpp:498-523
   for (int j = 0; j < ntail; j++) {
-    const double *p = &pos[(size_t)(k - first + j) * dim];
-    const int fl = flags[(size_t)j];
+    const double *p = &oc.pos[(size_t)(k - first + j) * dim];
+    const int fl = oc.flags[(size_t)j];
     if (fl & 1) {
       b->hills_added++;
-      log_hill(b, p, this_h, log_all ? added[(size_t)(k + j)] : 0.0, 'h');
+      log_hill(b, p, this_h, oc.added.empty() ? 0.0 : oc.added[(size_t)(k - first + j)], 'h');
       if (fl & 2) {
         b->hills_added++;
-        log_hill(b, p, th2[(size_t)j], ta2[(size_t)j], 'u');
-        EDM_HIP_TRY(b->tail_w.reserve(dim));
-        EDM_HIP_TRY(hipMemcpyAsync(b->tail_w.p, p, sizeof(double) * dim, hipMemcpyHostToDevice, s));
-        EDM_HIP_TRY(launch_hist_add(b->hist->g, b->hist->values, 1, b->tail_w.p, (int)dim, nullptr, nullptr, -1.0, s));
-        EDM_HIP_TRY(hipStreamSynchronize(s));
-        rc = overflow_push(b, p, -th2[(size_t)j]);   // remainder goes to the buffer (:489)
+        log_hill(b, p, oc.h2[(size_t)j], oc.a2[(size_t)j], 'u');
+        rc = overflow_push(b, p, -oc.h2[(size_t)j]);   // remainder goes to the buffer (:489)
         if (rc) return rc;
       }
     } else {
-      log_hill(b, p, 0, 0, 'h');                     // :493
+      log_hill(b, p, 0, 0, 'h');                       // :493
       rc = overflow_push(b, p, this_h);
       if (rc) return rc;
     }
   }
-  EDM_HIP_TRY(hipStreamSynchronize(s));
   return EDM_HIP_OK;
 }
 

@@ -25,7 +25,7 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 void HillWorkspace::release() {
-  hx.release(); ht.release(); added.release(); partial.release(); scratch.release();
+  hx.release(); hx0.release(); ht.release(); added.release(); partial.release(); scratch.release();
   tail_h1.release(); tail_h2.release(); tail_a2.release(); tail_cum.release();
   hc.release(); tail_flags.release(); tile_flags.release(); tile_list.release(); result.release();
 }
@@ -345,6 +345,8 @@ static int gauss_alloc(edm_hip_gauss *g) {
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->scratch), sizeof(double) * lookup_scratch_doubles()));
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_scalars), sizeof(double) * 16));
   EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_scalars), sizeof(double) * 64, hipHostMallocDefault));
+  g->h_stage_bytes = (size_t)4096 * (sizeof(int) + sizeof(double) * (3 + 3)) + 256;
+  EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_stage), g->h_stage_bytes, hipHostMallocDefault));
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_dirty), sizeof(int) * 4));
   EDM_HIP_TRY(hipMemset(g->d_dirty, 0, sizeof(int) * 4));
   return EDM_HIP_OK;
@@ -386,6 +388,7 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
   if (g->scratch) (void)hipFree(g->scratch);
   if (g->d_scalars) (void)hipFree(g->d_scalars);
   if (g->h_scalars) (void)hipHostFree(g->h_scalars);
+  if (g->h_stage) (void)hipHostFree(g->h_stage);
   if (g->d_dirty) (void)hipFree(g->d_dirty);
   if (g->ev0) (void)hipEventDestroy(g->ev0);
   if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -580,6 +583,8 @@ int edm_hip_gauss_profile_read(edm_hip_gauss *g, double *kernel_ms_total, long l
 // ---- hill application pipeline --------------------------------------------------
 namespace edm {
 
+static const long long SMALL_BATCH = 4096;  // read-back of a batch this small is one async burst
+
 int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool want_total) {
   const Geom &q = g->g;
   HillWorkspace &ws = g->ws;
@@ -589,12 +594,16 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     out->res.cum_out = spec.cum_in;
     out->res.k = nh;
     out->total_added = 0;
+    out->flags.clear(); out->h2.clear(); out->a2.clear(); out->pos.clear(); out->added.clear();
+    out->first = nh;
   }
   if (nh <= 0) return EDM_HIP_OK;
   hipStream_t s = g->stream;
-  EDM_HIP_TRY(ws.hx.reserve((size_t)nh * q.dim));
-  EDM_HIP_TRY(ws.ht.reserve((size_t)nh * 2 * q.dim));
-  EDM_HIP_TRY(ws.hc.reserve((size_t)nh * q.dim));
+  const int dim = q.dim;
+  EDM_HIP_TRY(ws.hx.reserve((size_t)nh * dim));
+  EDM_HIP_TRY(ws.hx0.reserve((size_t)nh * dim));
+  EDM_HIP_TRY(ws.ht.reserve((size_t)nh * 2 * dim));
+  EDM_HIP_TRY(ws.hc.reserve((size_t)nh * dim));
   EDM_HIP_TRY(ws.added.reserve((size_t)nh));
   EDM_HIP_TRY(ws.result.reserve(sizeof(LimitResult)));
   EDM_HIP_TRY(ws.tail_h1.reserve(EDM_TAIL_CAP));
@@ -614,6 +623,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hl.hx = ws.hx.p;
   hl.hc = ws.hc.p;
   hl.ht = ws.ht.p;
+  hl.hx0 = ws.hx0.p;
   const Tables tabs = g->tables();
   EDM_HIP_TRY(launch_hill_prep(q, hl, s));
 
@@ -623,26 +633,15 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hh.k = nh;
   hh.tail_h1 = ws.tail_h1.p;
   hh.tail_h2 = ws.tail_h2.p;
+  hh.res_dev = nullptr;
 
-  LimitResult res;
-  memset(&res, 0, sizeof(res));
-  res.k = nh;
-  res.cum_out = spec.cum_in;
+  LimitResult *dres = reinterpret_cast<LimitResult *>(ws.result.p);
   if (spec.limited || want_total) EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, ws.added.p, s));
   if (spec.limited) {
     LimitTail tail{ws.tail_h1.p, ws.tail_h2.p, ws.tail_a2.p, ws.tail_cum.p, ws.tail_flags.p};
-    LimitResult *dres = reinterpret_cast<LimitResult *>(ws.result.p);
     EDM_HIP_TRY(launch_limit(nh, ws.added.p, spec.d_h, spec.h_const, spec.limit, spec.cum_in, spec.flush_mode, tail,
                              dres, ws.scratch.p, s));
-    LimitResult *hres = reinterpret_cast<LimitResult *>(g->h_scalars + 8);
-    EDM_HIP_TRY(hipMemcpyAsync(hres, dres, sizeof(LimitResult), hipMemcpyDeviceToHost, s));
-    EDM_HIP_TRY(hipStreamSynchronize(s));
-    res = *hres;
-    if (res.error) {
-      set_error("The bias overflow buffer is full. Too many hills. Either increase & recompile, lower hill_density, or lower bias");
-      return EDM_HIP_ERR_OVERFLOW;
-    }
-    hh.k = res.k;
+    hh.res_dev = dres;  // the gather reads k on the device: no host round trip here
   } else if (want_total) {
     EDM_HIP_TRY(launch_sum(nh, ws.added.p, g->d_scalars + 1, ws.scratch.p, s));
   }
@@ -681,15 +680,80 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   }
   EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, hl, hh, plan, g->d_dirty, s));
   EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
-  if (want_total && !spec.limited) {
-    double t = 0;
-    int rc = fetch_scalar(g, 1, &t);
-    if (rc) return rc;
-    if (out) out->total_added = t;
-  } else {
-    EDM_HIP_TRY(hipStreamSynchronize(s));
+
+  // CV histogram (edm_bias.cpp:601-610): new hills log one 'h' line each (+1) and a 'u' line
+  // per undo (-1); a flush logs 'b' (+1) for replayed hills only and 'v' (-1) for its undo
+  if (spec.hist_g && spec.hist_values) {
+    if (!spec.limited || !spec.flush_mode)
+      EDM_HIP_TRY(launch_hist_add(*spec.hist_g, spec.hist_values, nh, ws.hx0.p, dim, nullptr, nullptr, 1.0, s));
+    if (spec.limited)
+      EDM_HIP_TRY(launch_hist_tail(*spec.hist_g, spec.hist_values, dres, ws.tail_flags.p, ws.hx0.p,
+                                   spec.flush_mode ? 1 : 0, s));
   }
-  if (out) out->res = res;
+
+  // ---- read-back: one async burst for small batches ----
+  LimitResult res;
+  memset(&res, 0, sizeof(res));
+  res.k = nh;
+  res.cum_out = spec.cum_in;
+  LimitResult *hres = reinterpret_cast<LimitResult *>(g->h_scalars + 8);
+  const bool small = (nh <= SMALL_BATCH) && out && spec.limited;
+  char *stage = g->h_stage;
+  int *st_flags = reinterpret_cast<int *>(stage);
+  double *st_h2 = reinterpret_cast<double *>(stage + sizeof(int) * SMALL_BATCH);
+  double *st_a2 = st_h2 + SMALL_BATCH;
+  double *st_added = st_a2 + SMALL_BATCH;
+  double *st_pos = st_added + SMALL_BATCH;
+  if (spec.limited) EDM_HIP_TRY(hipMemcpyAsync(hres, dres, sizeof(LimitResult), hipMemcpyDeviceToHost, s));
+  if (want_total && !spec.limited)
+    EDM_HIP_TRY(hipMemcpyAsync(g->h_scalars + 1, g->d_scalars + 1, sizeof(double), hipMemcpyDeviceToHost, s));
+  if (small) {
+    EDM_HIP_TRY(hipMemcpyAsync(st_flags, ws.tail_flags.p, sizeof(int) * (size_t)nh, hipMemcpyDeviceToHost, s));
+    EDM_HIP_TRY(hipMemcpyAsync(st_h2, ws.tail_h2.p, sizeof(double) * (size_t)nh, hipMemcpyDeviceToHost, s));
+    EDM_HIP_TRY(hipMemcpyAsync(st_a2, ws.tail_a2.p, sizeof(double) * (size_t)nh, hipMemcpyDeviceToHost, s));
+    EDM_HIP_TRY(hipMemcpyAsync(st_added, ws.added.p, sizeof(double) * (size_t)nh, hipMemcpyDeviceToHost, s));
+    EDM_HIP_TRY(hipMemcpyAsync(st_pos, ws.hx0.p, sizeof(double) * (size_t)nh * dim, hipMemcpyDeviceToHost, s));
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(s));
+  if (spec.limited) {
+    res = *hres;
+    if (res.error) {
+      set_error("The bias overflow buffer is full. Too many hills. Either increase & recompile, lower hill_density, or lower bias");
+      return EDM_HIP_ERR_OVERFLOW;
+    }
+  }
+  if (out) {
+    out->res = res;
+    if (want_total && !spec.limited) out->total_added = g->h_scalars[1];
+    const long long k = res.k;
+    const int ntail = spec.limited ? res.n_tail : 0;
+    const long long first = spec.fetch_all ? 0 : k;
+    out->first = first;
+    const long long need = nh - first;
+    if (small) {
+      out->flags.assign(st_flags, st_flags + ntail);
+      out->h2.assign(st_h2, st_h2 + ntail);
+      out->a2.assign(st_a2, st_a2 + ntail);
+      out->pos.assign(st_pos + (size_t)first * dim, st_pos + (size_t)nh * dim);
+      out->added.assign(st_added + first, st_added + nh);
+    } else if (spec.limited || spec.fetch_all) {
+      if (ntail > 0) {
+        out->flags.resize((size_t)ntail);
+        out->h2.resize((size_t)ntail);
+        out->a2.resize((size_t)ntail);
+        EDM_HIP_TRY(hipMemcpy(out->flags.data(), ws.tail_flags.p, sizeof(int) * (size_t)ntail, hipMemcpyDeviceToHost));
+        EDM_HIP_TRY(hipMemcpy(out->h2.data(), ws.tail_h2.p, sizeof(double) * (size_t)ntail, hipMemcpyDeviceToHost));
+        EDM_HIP_TRY(hipMemcpy(out->a2.data(), ws.tail_a2.p, sizeof(double) * (size_t)ntail, hipMemcpyDeviceToHost));
+      }
+      if (need > 0) {
+        out->pos.resize((size_t)need * dim);
+        EDM_HIP_TRY(hipMemcpy(out->pos.data(), ws.hx0.p + (size_t)first * dim, sizeof(double) * (size_t)need * dim,
+                              hipMemcpyDeviceToHost));
+        out->added.resize((size_t)need);
+        EDM_HIP_TRY(hipMemcpy(out->added.data(), ws.added.p + first, sizeof(double) * (size_t)need, hipMemcpyDeviceToHost));
+      }
+    }
+  }
   return EDM_HIP_OK;
 }
 
@@ -727,7 +791,7 @@ int edm_hip_gauss_hill_integrals(const edm_hip_gauss *gc, long long n, const dou
   EDM_HIP_TRY(ws.hc.reserve((size_t)n * q.dim));
   HillList hl;
   hl.nh = n; hl.x = d_x; hl.x_stride = x_stride; hl.sel = nullptr;
-  hl.hx = ws.hx.p; hl.hc = ws.hc.p; hl.ht = ws.ht.p;
+  hl.hx = ws.hx.p; hl.hc = ws.hc.p; hl.ht = ws.ht.p; hl.hx0 = nullptr;
   EDM_HIP_TRY(launch_hill_prep(q, hl, g->stream));
   EDM_HIP_TRY(launch_hill_integrals(q, g->tables(), hl, d_h, h_const, d_added, g->stream));
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));

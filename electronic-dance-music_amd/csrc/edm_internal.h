@@ -49,7 +49,7 @@ struct DevBuf {
 
 // workspace of the hill path, shared by add_values / the controller
 struct HillWorkspace {
-  DevBuf<double> hx, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum;
+  DevBuf<double> hx, hx0, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum;
   DevBuf<int> hc, tail_flags, tile_flags, tile_list;
   DevBuf<char> result;      // LimitResult
   void release();
@@ -88,6 +88,8 @@ struct edm_hip_gauss {
   double *scratch = nullptr;             // lookup partial sums
   double *d_scalars = nullptr;           // small device result slots
   double *h_scalars = nullptr;           // pinned host mirror
+  char *h_stage = nullptr;               // pinned staging for batched result read-back
+  size_t h_stage_bytes = 0;
   int *d_dirty = nullptr;
   // bench support: HIP events around the dominant lookup kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -110,10 +112,20 @@ struct ApplySpec {
   bool limited = false;            // run the limiter
   int flush_mode = 0;
   double limit = 0, cum_in = 0;
+  // CV histogram to update on the device (output_hill, edm_bias.cpp:601-610); NULL = none
+  const Geom *hist_g = nullptr;
+  double *hist_values = nullptr;
+  bool fetch_all = false;          // host wants position + bias_added of EVERY hill (HILLS log)
 };
 struct ApplyOutcome {
   LimitResult res;
   double total_added = 0;          // unlimited mode: sum of added
+  // ordered tail (res.n_tail entries): limiter flags, undo height, undo bias_added
+  std::vector<int> flags;
+  std::vector<double> h2, a2;
+  // original positions (and bias_added when fetch_all) of hills [first, nh)
+  long long first = 0;
+  std::vector<double> pos, added;
 };
 // prep -> integrals -> (limiter) -> ordered gather -> boundary duplication.
 // Leaves per-hill `added` in g->ws.added and the tail arrays in g->ws.tail_*.

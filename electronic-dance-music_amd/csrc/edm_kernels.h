@@ -72,15 +72,19 @@ struct HillList {
   double *hx;             // remapped position            [nh][dim]
   int *hc;                // centre node index (INT_MIN in hc[i*dim] = rejected) [nh][dim]
   double *ht;             // (t1, t3) of gaussian_grid.h:310,:312 per dim [nh][2*dim]
+  double *hx0;            // original (un-remapped) position, compacted [nh][dim] (may be NULL)
 };
 hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s);
 
+struct LimitResult;
 struct HillHeights {
   const double *h;        // per-hill base height or NULL
   double h_const;
   long long k;            // hills [0,k) use (base height, 0); hills >= k use the tail arrays
   const double *tail_h1;  // first add (0 = hill deferred, not applied)
   const double *tail_h2;  // second add (the "undo" hill) or 0
+  const LimitResult *res_dev;  // when set, k (and the error flag) are read from the limiter's
+                               // device-side result: no host round trip between K4 and K5
 };
 // per-hill integrated bias for the BASE heights (the value add_value returns)
 hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList &h, const double *heights,
@@ -122,6 +126,12 @@ size_t limit_scratch_doubles(long long nh);
 hipError_t launch_limit(long long nh, const double *added, const double *heights, double h_const,
                         double limit, double cum_in, int flush_mode, const LimitTail &tail,
                         LimitResult *result_dev, double *scratch, hipStream_t s);
+
+// histogram side of output_hill for the ordered tail: -1 for every hill whose undo was added
+// (flags bit1) and, when plus_for_applied, +1 for every hill that was applied (bit0), at its
+// original position hx0[(k + j)]
+hipError_t launch_hist_tail(const Geom &hist, double *values, const LimitResult *res_dev, const int *flags,
+                            const double *hx0, int plus_for_applied, hipStream_t s);
 
 hipError_t launch_sum(long long n, const double *v, double *out, double *scratch, hipStream_t s);
 

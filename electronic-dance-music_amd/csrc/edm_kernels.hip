@@ -290,15 +290,177 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces(Geom g, const double *__r
   if (threadIdx.x == 0) block_energy[blockIdx.x] = s;
 }
 
+// ---------------------------------------------------------------------------
+// K1 fast path: 1-D, interpolating, non-periodic grid (the fix_edm_pair geometry).
+//  * the node records of a window [w0, w0+W) are staged ONCE per workgroup into LDS
+//    (up to 10224 nodes = 159.75 KiB of the CU's 160 KiB) by coalesced 16-B loads;
+//    the two corners of a sample are then two ds_read_b128 instead of two L2 gathers.
+//    Samples whose cell falls outside the window take the global-memory path.
+//  * the cubic-Hermite blend is evaluated without divisions: f*C = f*A(X) + s*d*B(X)*dx
+//    is algebraically what grid.h:113-123 computes with qq = -d/f (the |f| < 1e-7
+//    special case is kept); X = where * (1/dx).  Values move by ~1e-16 relative.
+//  * the node index stays BIT-EXACT: floor((x-min)*(1/dx)) is used only when it cannot
+//    differ from the reference's floor((x-min)/dx); near an integer the division is done.
+// ---------------------------------------------------------------------------
+static constexpr int FAST_BLOCK = 1024;
+static constexpr int LDS_WINDOW_MAX = 10224;  // nodes: 10224*16 B + 256 B of reduction scratch = 163840 B
+
+typedef double v2d __attribute__((ext_vector_type(2)));  // native vector: usable with nontemporal builtins
+
+__device__ __forceinline__ void hermite_1d(double fa, double da, double fb, double db, double X, double dx,
+                                           double inv_dx, double &value, double &der) {
+#pragma clang fp contract(fast)
+  // corner a (bit 0, s=+1) at distance X, corner b (bit 1, s=-1) at distance 1-X
+  const double Y = fabs(X - 1.0);
+  const double X2 = X * X, X3 = X2 * X, Y2 = Y * Y, Y3 = Y2 * Y;
+  const double Aa = 1 - 3 * X2 + 2 * X3, Ab = 1 - 3 * Y2 + 2 * Y3;
+  const double Ba = X - 2 * X2 + X3, Bb = Y - 2 * Y2 + Y3;
+  const double Apa = -6 * X + 6 * X2, Apb = -6 * Y + 6 * Y2;
+  const double Bpa = 1 - 4 * X + 3 * X2, Bpb = 1 - 4 * Y + 3 * Y2;
+  const double ga = (fabs(fa) < 0.0000001) ? 0.0 : da * dx;  // grid.h:113-116
+  const double gb = (fabs(fb) < 0.0000001) ? 0.0 : db * dx;
+  value = (fa * Aa + ga * Ba) + (fb * Ab - gb * Bb);
+  der = ((fa * Apa + ga * Bpa) - (fb * Apb - gb * Bpb)) * inv_dx;
+}
+
+typedef __attribute__((address_space(3))) const v2d lds_v2d;
+
+// Fast-path precondition (checked by the launcher): 1-D, interpolating, grid and boundary both
+// non-periodic, so remap() is the identity and a sample outside [bmin,bmax] or outside the
+// grid's in_grid range simply contributes (0, 0) (gaussian_grid.h:128-135, grid.h:398-409).
+template <bool USE_LDS>
+__device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict__ rec, lds_v2d *win,
+                                         long long w0, long long w1, double inv_dx, double x, double &v,
+                                         double &d) {
+  v = 0;
+  d = 0;
+  if (!(x >= g.bmin[0] && x <= g.bmax[0] && x >= g.min[0] && x < g.max[0] - g.dx[0])) return;
+  const double q = (x - g.min[0]) * inv_dx;
+  long long idx = (long long)floor(q);
+  // floor(q) can differ from the reference's floor((x-min)/dx) only within rounding of an integer:
+  // there (rare, divergent) do the exact division
+  if (fabs(q - rint(q)) <= 1e-11 * fmax(1.0, q)) idx = (long long)floor((x - g.min[0]) / g.dx[0]);
+  if (idx > g.n[0] - 2) idx = g.n[0] - 2;
+  const double where = x - g.min[0] - idx * g.dx[0];
+  const double X = where * inv_dx;
+  v2d a, b;
+  if (USE_LDS && idx >= w0 && idx + 1 < w1) {
+    a = win[idx - w0];
+    b = win[idx - w0 + 1];
+  } else {
+    a = reinterpret_cast<const v2d *>(rec)[idx];
+    b = reinterpret_cast<const v2d *>(rec)[idx + 1];
+  }
+  hermite_1d(a.x, a.y, b.x, b.y, X, g.dx[0], inv_dx, v, d);
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(FAST_BLOCK) k_pair_forces_fast(Geom g, const double *__restrict__ rec, long long n,
+                                                                 const double *__restrict__ r,
+                                                                 double *__restrict__ force,
+                                                                 double *__restrict__ block_energy, long long w0,
+                                                                 int wn, double inv_dx) {
+  extern __shared__ double2 lds_all[];
+  double *red = reinterpret_cast<double *>(lds_all);  // first 256 B: reduction scratch
+  if (USE_LDS) {
+    const double2 *src = reinterpret_cast<const double2 *>(rec) + w0;
+    for (int i = threadIdx.x; i < wn; i += FAST_BLOCK) lds_all[16 + i] = src[i];
+    __syncthreads();
+  }
+  lds_v2d *win = (lds_v2d *)(lds_all + 16);
+  const long long w1 = w0 + wn;
+  double e_acc = 0;
+  const long long npair = n >> 1;
+  const long long stride = (long long)gridDim.x * FAST_BLOCK;
+  const v2d *r2 = reinterpret_cast<const v2d *>(r);
+  v2d *f2 = reinterpret_cast<v2d *>(force);
+  // two independent 16-B loads in flight per lane per iteration (64 B of HBM traffic per lane)
+  for (long long i = (long long)blockIdx.x * FAST_BLOCK + threadIdx.x; i < npair; i += 2 * stride) {
+    const long long j = i + stride;
+    const bool has_b = j < npair;
+    const v2d ra = __builtin_nontemporal_load(&r2[i]);
+    const v2d rb = has_b ? __builtin_nontemporal_load(&r2[j]) : ra;
+    double v0, v1, v2, v3, d0, d1, d2, d3;
+    pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.x, v0, d0);
+    pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.y, v1, d1);
+    pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, rb.x, v2, d2);
+    pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, rb.y, v3, d3);
+    e_acc += v0;
+    e_acc += v1;
+    v2d oa;
+    oa.x = 0.0 - d0;
+    oa.y = 0.0 - d1;
+    __builtin_nontemporal_store(oa, &f2[i]);
+    if (has_b) {
+      e_acc += v2;
+      e_acc += v3;
+      v2d ob;
+      ob.x = 0.0 - d2;
+      ob.y = 0.0 - d3;
+      __builtin_nontemporal_store(ob, &f2[j]);
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double v, d;
+    pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, r[n - 1], v, d);
+    e_acc += v;
+    force[n - 1] = 0.0 - d;
+  }
+  double s = block_sum(e_acc, red);
+  if (threadIdx.x == 0) block_energy[blockIdx.x] = s;
+}
+
 hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, const double *r, double *force,
                               double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-  long long work = (n >> 1) + 1;
-  int blocks = (int)((work + BLOCK - 1) / BLOCK);
-  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
-  if (blocks < 1) blocks = 1;
-  if (ev0) (void)hipEventRecord(ev0, s);
-  hipLaunchKernelGGL(k_pair_forces, dim3(blocks), dim3(BLOCK), 0, s, g, rec, n, r, force, scratch);
-  if (ev1) (void)hipEventRecord(ev1, s);
+  int blocks;
+  const bool fast = (g.dim == 1 && g.interp && !g.periodic[0] && !g.bper[0] && g.n[0] >= 2);
+  if (fast) {
+    static int n_cu = 0;
+    static bool attr_set = false;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        n_cu = prop.multiProcessorCount;
+      if (n_cu <= 0) n_cu = 256;
+    }
+    const double inv_dx = 1.0 / g.dx[0];
+    // LDS staging costs ~160 KB of L2 reads per workgroup: worth it only for long sample arrays
+    const bool use_lds = n >= (1LL << 22);
+    if (use_lds) {
+      int wn = g.n[0] < LDS_WINDOW_MAX ? g.n[0] : LDS_WINDOW_MAX;
+      long long w0 = (long long)g.n[0] - wn;  // top-aligned: pair distances populate the upper range
+      const size_t lds_bytes = 256 + (size_t)wn * 16;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_forces_fast<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 256 + LDS_WINDOW_MAX * 16);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+      }
+      blocks = n_cu;
+      if (ev0) (void)hipEventRecord(ev0, s);
+      hipLaunchKernelGGL(k_pair_forces_fast<true>, dim3(blocks), dim3(FAST_BLOCK), lds_bytes, s, g, rec, n, r, force,
+                         scratch, w0, wn, inv_dx);
+      if (ev1) (void)hipEventRecord(ev1, s);
+    } else {
+      long long work = (n >> 1) + 1;
+      blocks = (int)((work + FAST_BLOCK - 1) / FAST_BLOCK);
+      if (blocks > 2 * n_cu) blocks = 2 * n_cu;
+      if (blocks < 1) blocks = 1;
+      if (ev0) (void)hipEventRecord(ev0, s);
+      hipLaunchKernelGGL(k_pair_forces_fast<false>, dim3(blocks), dim3(FAST_BLOCK), 256, s, g, rec, n, r, force, scratch,
+                         0LL, 0, inv_dx);
+      if (ev1) (void)hipEventRecord(ev1, s);
+    }
+  } else {
+    long long work = (n >> 1) + 1;
+    blocks = (int)((work + BLOCK - 1) / BLOCK);
+    if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    if (ev0) (void)hipEventRecord(ev0, s);
+    hipLaunchKernelGGL(k_pair_forces, dim3(blocks), dim3(BLOCK), 0, s, g, rec, n, r, force, scratch);
+    if (ev1) (void)hipEventRecord(ev1, s);
+  }
   if (energy_out)
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, s, scratch, (long long)blocks, energy_out);
   return hipGetLastError();
@@ -381,6 +543,49 @@ hipError_t launch_hist_add(const Geom &g, double *values, long long n, const dou
     case 1: hipLaunchKernelGGL(k_hist_add<1>, dim3(b), dim3(BLOCK), 0, s, g, values, n, x, x_stride, sel, w, w_const); break;
     case 2: hipLaunchKernelGGL(k_hist_add<2>, dim3(b), dim3(BLOCK), 0, s, g, values, n, x, x_stride, sel, w, w_const); break;
     default: hipLaunchKernelGGL(k_hist_add<3>, dim3(b), dim3(BLOCK), 0, s, g, values, n, x, x_stride, sel, w, w_const); break;
+  }
+  return hipGetLastError();
+}
+
+// forward declaration target: LimitResult is defined in edm_kernels.h
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_hist_tail(Geom g, double *__restrict__ values,
+                                                     const LimitResult *__restrict__ res,
+                                                     const int *__restrict__ flags, const double *__restrict__ hx0,
+                                                     int plus_for_applied) {
+  if (res->error) return;
+  const int ntail = res->n_tail;
+  const long long k = res->k;
+  for (int j = threadIdx.x; j < ntail; j += BLOCK) {
+    double wgt = 0;
+    if (plus_for_applied && (flags[j] & 1)) wgt += 1.0;
+    if (flags[j] & 2) wgt -= 1.0;
+    if (wgt == 0.0) continue;
+    double xx[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) xx[d] = hx0[(k + j) * DIM + d];
+    if (!in_grid<DIM>(g, xx)) continue;
+    long long idx[DIM];
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      double wr;
+      idx[d] = node_index(g, d, xx[d], &wr);
+      if (idx[d] < 0 || idx[d] >= g.n[d]) ok = false;
+    }
+    if (!ok) continue;
+    long long flat = idx[DIM - 1];
+#pragma unroll
+    for (int d = DIM - 1; d > 0; d--) flat = flat * g.n[d - 1] + idx[d - 1];
+    atomicAdd(&values[flat], wgt);
+  }
+}
+hipError_t launch_hist_tail(const Geom &g, double *values, const LimitResult *res_dev, const int *flags,
+                            const double *hx0, int plus_for_applied, hipStream_t s) {
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL(k_hist_tail<1>, dim3(1), dim3(BLOCK), 0, s, g, values, res_dev, flags, hx0, plus_for_applied); break;
+    case 2: hipLaunchKernelGGL(k_hist_tail<2>, dim3(1), dim3(BLOCK), 0, s, g, values, res_dev, flags, hx0, plus_for_applied); break;
+    default: hipLaunchKernelGGL(k_hist_tail<3>, dim3(1), dim3(BLOCK), 0, s, g, values, res_dev, flags, hx0, plus_for_applied); break;
   }
   return hipGetLastError();
 }
@@ -500,6 +705,10 @@ __global__ void __launch_bounds__(BLOCK) k_hill_prep(Geom g, HillList h) {
     double x[DIM];
 #pragma unroll
     for (int d = 0; d < DIM; d++) x[d] = h.x[src * h.x_stride + d];
+    if (h.hx0) {
+#pragma unroll
+      for (int d = 0; d < DIM; d++) h.hx0[i * DIM + d] = x[d];
+    }
     remap<DIM>(g, x);
     bool ok = true;
 #pragma unroll
@@ -790,6 +999,11 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
     node_terms<DIM>(g, t, p, nt);
     if (!nt.inside) active = false;
   }
+  long long k_first_tail = hh.k;
+  if (hh.res_dev) {
+    if (hh.res_dev->error) return;  // limiter overflow: the host reports it, nothing is applied
+    k_first_tail = hh.res_dev->k;
+  }
   const int G = plan.groups;
   const int grp = blockIdx.y;
   const long long per = (h.nh + G - 1) / G;
@@ -824,12 +1038,12 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
     }
     if (!overlap) continue;
     double h1, h2;
-    if (i < hh.k) {
+    if (i < k_first_tail) {
       h1 = hh.h ? hh.h[i] : hh.h_const;
       h2 = 0;
     } else {
-      h1 = hh.tail_h1[i - hh.k];
-      h2 = hh.tail_h2[i - hh.k];
+      h1 = hh.tail_h1[i - k_first_tail];
+      h2 = hh.tail_h2[i - k_first_tail];
     }
     if (h1 == 0 && h2 == 0) continue;  // hill deferred to the overflow buffer: add_value is never called
     if (!active) continue;

@@ -322,11 +322,14 @@ def test_c1d_full_size(npairs, oracle_lib):
     d_f = H.DeviceArray((npairs,))
     e = g.pair_forces_device(d_r, d_f, npairs)
     f = d_f.to_host()
-    # property 1: the strided update_forces kernel and the pair kernel agree bit for bit
+    # property 1: the generic strided update_forces kernel (reference operation order) and the
+    # division-free / LDS-window pair kernel agree to rounding (1e-12 relative; bar 1e-6)
     d_f2 = H.DeviceArray.zeros((npairs,))
     e2 = H.C.c_double(0)
     H.check(H.lib().edm_hip_gauss_update_forces(g.h, npairs, d_r.ptr, 1, d_f2.ptr, 1, None, -1, H.C.byref(e2)))
-    assert np.array_equal(d_f2.to_host(), f)
+    # (dV/dr is a difference of O(V/dx) terms: ~1e-12 of absolute rounding noise is inherent,
+    #  in the reference's own arithmetic too)
+    close(d_f2.to_host(), f, rtol=1e-10, atol=1e-11 * np.abs(f).max(), what="pair kernel vs generic kernel")
     close(e, e2.value, rtol=1e-12, what="energy of the two kernels")
     # property 2: the in-kernel energy reduction equals the sum of per-sample energies
     d_E = H.DeviceArray((npairs,))
@@ -364,7 +367,7 @@ def test_c2d_full_size(oracle_lib):
     close(v, o.grid.values, rtol=1e-10, atol=1e-13 * np.abs(v).max(), what="2-D grid after 250 hills")
 
 
-def test_c3d_full_size_properties():
+def test_c3d_full_size_properties(oracle_lib):
     """512^3 bias grid (4.3 GB of node records): index round trip, linearity, locality."""
     c = W.C3D
     g = H.Gauss.create(c["lo"], c["hi"], c["spacing"], c["periodic"], 1, c["sigma"])
@@ -376,7 +379,12 @@ def test_c3d_full_size_properties():
     assert np.array_equal(flat, want), "3-D node indices"
     hx = x[:64].copy()
     added = g.add_values(hx, 0.02)
-    close(added, np.full(64, 0.02), rtol=1e-6, what="periodic 3-D hills integrate to their height")
+    # a periodic grid's hill integral depends only on the position inside the cell: the oracle on a
+    # 64^3 grid of the same spacing/sigma at x mod 8 (= 64 cells exactly) must give the same numbers
+    o = B.Gauss.create(oracle_lib, [0.0] * 3, [8.0] * 3, c["spacing"], [1, 1, 1], 1, c["sigma"])
+    ref = np.array([o.add_value(np.mod(p, 8.0), 0.02) for p in hx[:16]])
+    close(added[:16], ref, rtol=1e-9, what="3-D hill integrals vs oracle on the equivalent 64^3 grid")
+    assert np.all(np.abs(added / 0.02 - 1) < 2e-3)  # support cut at dp2 < 8 loses ~0.1% of the mass
     f = np.zeros((n, 3))
     e = g.update_forces(x, f)
     assert e > 0 and np.isfinite(f).all()
