@@ -38,6 +38,26 @@ CFG = ("tempering 0\nhill_prefactor 0.5\nhill_density 250\ndimension 1\nbox_low 
        "bias_spacing 0.00025\nbias_sigma 0.025\n")
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 --pmc capture of this
+    same command (profiles/rNN_summary.json, written by profiles/summarize.py; FETCH_SIZE and
+    WRITE_SIZE collected in separate passes, read side doubled per the gfx950 note of the guide).
+    None when no capture is committed: bench.py itself never runs the profiler."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+    if not files:
+        return None
+    try:
+        pmc = json.load(open(files[-1])).get("pmc", {})
+    except Exception:  # noqa: BLE001
+        return None
+    for key, e in pmc.items():
+        if key.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e:
+            return e["hbm_bytes_per_launch"]
+    return None
+
+
 def make_bias(mod, tmpdir, tag, rank=0):
     cfg = os.path.join(tmpdir, "bench_%s_%d.edm" % (tag, rank))
     with open(cfg, "w") as fh:
@@ -209,7 +229,8 @@ def main():
         g.profile_enable(False)
         a2 = BYTES_PER_EVAL * n2 / (ms2 / l2 * 1e-3) / 1e9
         roof_w2 = dict(workload="W2: %d pair distances" % n2, bound="hbm", achieved=a2, peak=HBM_PEAK_GBS, unit="GB/s",
-                       frac=a2 / HBM_PEAK_GBS, kernel_ms=ms2 / l2, traffic=None)
+                       frac=a2 / HBM_PEAK_GBS, kernel_ms=ms2 / l2, kernel="k_pair_forces_fast<true> (LDS-staged window)",
+                       bytes_per_launch=BYTES_PER_EVAL * n2, traffic=pmc_traffic("edm::k_pair_forces_fast<true>"))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -237,13 +258,13 @@ def main():
                 "parallelism": "replicated bias grid, samples sharded, dp%d" % world,
             },
             "roofline": {
-                "kernel": "k_pair_forces",
+                "kernel": "k_pair_forces_fast<false>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic("edm::k_pair_forces_fast<false>"),
                 "kernel_us": k_ms / max(k_launches, 1) * 1e3,
                 "launches": k_launches,
                 "bytes_per_launch": BYTES_PER_EVAL * npairs,

@@ -1,9 +1,13 @@
 """MI355X-native implementation of the EDM per-timestep bias hot path.
 
 The product is the C-ABI library ``csrc/libedm_hip.so`` (include/edm_hip.h) and
-the C++ class layer ``libedm.so`` (include/edm/*.h); this Python package is the
-thin ctypes mirror of the reference's operator interface used by tests and
-bench.py.  It never falls back to a CPU path: importing ``edm_amd.hip`` without
-the built HIP library raises.
+the C++ class layer over it (include/edm/*.h); this Python package is the thin
+host mirror used by tests and bench.py:
+
+  hip        ctypes binding of the C ABI (GaussGrid / EDMBias operator interface)
+  workloads  deterministic synthetic inputs
+  parallel   torch.distributed mirror of the multi-GPU hill-exchange protocol
+
+There is no CPU fallback: ``hip`` raises if the HIP library is missing or no GPU is visible.
 """
-__all__ = ["workloads"]
+__all__ = ["hip", "workloads", "parallel"]

@@ -58,6 +58,8 @@ struct edm_hip_bias {
   DevBuf<int> sel_scratch;
   DevBuf<double> stage_x, stage_u, stage_h, tail_w;
   DevBuf<double> hx0;
+  DevBuf<double> xchg_send, xchg_recv, xchg_all;
+  DevBuf<long long> xchg_cnt;
   // multi-GPU
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
@@ -426,10 +428,64 @@ static int do_pre_add_hill(edm_hip_bias *b, long long est) {
   return EDM_HIP_OK;
 }
 
+// Hill exchange: replaces EDMBias::flush_buffers (edm_bias.cpp:630-706).  The reference
+// broadcasts every rank's (position, height) records and each rank replays them; here one RCCL
+// all-gather over xGMI collects the records and EVERY rank replays the same rank-major global
+// list through the same deterministic kernels, so the replicated grids, limiter decisions and
+// overflow buffers stay bit-identical on all GPUs (the reference's per-rank replay order lets
+// them drift apart).  Two collectives per hill step: counts (8 B per rank), then the padded
+// records; heights are identical on all ranks by construction and are not sent.
+static int exchange_hills(edm_hip_bias *b, long long nh_local, const double *d_x, int x_stride,
+                          const long long *d_sel, long long *nh_global, const double **d_global) {
+  hipStream_t s = b->bias->stream;
+  const int N = b->nranks;
+  const int dim = (int)b->dim;
+  EDM_HIP_TRY(b->xchg_cnt.reserve((size_t)N + 1));
+  long long *h_cnt = reinterpret_cast<long long *>(b->bias->h_scalars + 40);  // N <= 16 slots
+  if (N > 16) {
+    set_error("exchange_hills: more than 16 ranks per node are not supported");
+    return EDM_HIP_ERR_ARG;
+  }
+  h_cnt[0] = nh_local;
+  EDM_HIP_TRY(hipMemcpyAsync(b->xchg_cnt.p + N, h_cnt, sizeof(long long), hipMemcpyHostToDevice, s));
+  if (ncclAllGather(b->xchg_cnt.p + N, b->xchg_cnt.p, 1, ncclInt64, b->comm, s) != ncclSuccess) {
+    set_error("ncclAllGather(hill counts) failed");
+    return EDM_HIP_ERR_COMM;
+  }
+  EDM_HIP_TRY(hipMemcpyAsync(h_cnt, b->xchg_cnt.p, sizeof(long long) * (size_t)N, hipMemcpyDeviceToHost, s));
+  EDM_HIP_TRY(hipStreamSynchronize(s));
+  long long counts[16], total = 0, maxc = 0;
+  for (int r = 0; r < N; r++) {
+    counts[r] = h_cnt[r];
+    total += counts[r];
+    if (counts[r] > maxc) maxc = counts[r];
+  }
+  *nh_global = total;
+  *d_global = nullptr;
+  if (total == 0) return EDM_HIP_OK;
+  EDM_HIP_TRY(b->xchg_send.reserve((size_t)maxc * dim));
+  EDM_HIP_TRY(b->xchg_recv.reserve((size_t)maxc * dim * N));
+  EDM_HIP_TRY(b->xchg_all.reserve((size_t)total * dim));
+  EDM_HIP_TRY(launch_gather_positions(nh_local, d_x, x_stride, d_sel, dim, b->xchg_send.p, s));
+  if (ncclAllGather(b->xchg_send.p, b->xchg_recv.p, (size_t)maxc * dim, ncclDouble, b->comm, s) != ncclSuccess) {
+    set_error("ncclAllGather(hill records) failed");
+    return EDM_HIP_ERR_COMM;
+  }
+  long long off = 0;
+  for (int r = 0; r < N; r++) {   // rank-major global order
+    if (counts[r] > 0)
+      EDM_HIP_TRY(hipMemcpyAsync(b->xchg_all.p + (size_t)off * dim, b->xchg_recv.p + (size_t)r * maxc * dim,
+                                 sizeof(double) * (size_t)counts[r] * dim, hipMemcpyDeviceToDevice, s));
+    off += counts[r];
+  }
+  *d_global = b->xchg_all.p;
+  return EDM_HIP_OK;
+}
+
 // the add_hill loop of one cycle (edm_bias.cpp:528-563 and :444-526) over device arrays
 static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, int x_stride, const double *d_ru,
                              int apply_mask) {
-  if (n <= 0) return EDM_HIP_OK;
+  if (n <= 0 && !b->comm) return EDM_HIP_OK;  // with a communicator every rank must reach the exchange
   if (b->temp_hill_prefactor < 0) {
     set_error("Must call pre_add_hill before add_hill");
     return EDM_HIP_ERR_STATE;
@@ -463,6 +519,16 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     EDM_HIP_TRY(hipStreamSynchronize(s));
     nh = *hcount;
     d_sel = b->sel.p;
+  }
+  if (b->comm) {
+    const double *d_all = nullptr;
+    long long nh_all = 0;
+    int rc = exchange_hills(b, nh, d_x, x_stride, d_sel, &nh_all, &d_all);
+    if (rc) return rc;
+    nh = nh_all;
+    d_x = d_all;
+    x_stride = (int)b->dim;
+    d_sel = nullptr;
   }
   if (nh <= 0) return EDM_HIP_OK;
   // height (:537, :552-558); targeting/tempering factors are handled above
@@ -531,7 +597,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
 // post_add_hill (edm_bias.cpp:565-583) + update_height (:922-931)
 static int do_post_add_hill(edm_hip_bias *b) {
   double step_bias = b->temp_hill_cum;
-  if (b->comm && b->nranks > 1) {
+  if (b->comm) {
     // one 8-byte all-reduce over xGMI replaces MPI_Allreduce(:925)
     double *d = b->bias->d_scalars + 4;
     hipStream_t s = b->bias->stream;
@@ -585,7 +651,7 @@ int edm_hip_bias_add_hill(edm_hip_bias *b, const double *position, double runifo
 int edm_hip_bias_post_add_hill(edm_hip_bias *b) {
   int rc = EDM_HIP_OK;
   const long long n = (long long)b->staged_u.size();
-  if (n > 0 && !b->b_outofbounds) {
+  if ((n > 0 || b->comm) && !b->b_outofbounds) {
     hipStream_t s = b->bias->stream;
     EDM_HIP_TRY(b->stage_x.reserve(b->staged_x.size()));
     EDM_HIP_TRY(b->stage_u.reserve(b->staged_u.size()));
@@ -708,7 +774,7 @@ int edm_hip_bias_comm_init(edm_hip_bias *b, const void *id_bytes, int nranks, in
     b->mpi_rank = rank;
     open_hills(b);
   }
-  if (nranks == 1 && !id_bytes) return EDM_HIP_OK;
+  if (!id_bytes) return EDM_HIP_OK;  // rank bookkeeping only, no communicator
   ncclUniqueId id;
   memcpy(&id, id_bytes, sizeof(id));
   if (ncclCommInitRank(&b->comm, nranks, id, rank) != ncclSuccess) {

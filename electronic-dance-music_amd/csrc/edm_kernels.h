@@ -133,6 +133,10 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
 hipError_t launch_hist_tail(const Geom &hist, double *values, const LimitResult *res_dev, const int *flags,
                             const double *hx0, int plus_for_applied, hipStream_t s);
 
+// out[i][0..dim) = x[(sel ? sel[i] : i) * x_stride + 0..dim): contiguous hill records for the exchange
+hipError_t launch_gather_positions(long long n, const double *x, int x_stride, const long long *sel, int dim,
+                                   double *out, hipStream_t s);
+
 hipError_t launch_sum(long long n, const double *v, double *out, double *scratch, hipStream_t s);
 
 }  // namespace edm

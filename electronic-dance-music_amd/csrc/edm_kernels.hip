@@ -63,6 +63,24 @@ __global__ void __launch_bounds__(BLOCK) k_block_sums(const double *__restrict__
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
+__global__ void __launch_bounds__(BLOCK) k_gather_positions(long long n, const double *__restrict__ x, int x_stride,
+                                                            const long long *__restrict__ sel, int dim,
+                                                            double *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    const long long src = sel ? sel[i] : i;
+    for (int d = 0; d < dim; d++) out[i * dim + d] = x[src * x_stride + d];
+  }
+}
+hipError_t launch_gather_positions(long long n, const double *x, int x_stride, const long long *sel, int dim,
+                                   double *out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  long long b = (n + BLOCK - 1) / BLOCK;
+  if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+  hipLaunchKernelGGL(k_gather_positions, dim3((unsigned)b), dim3(BLOCK), 0, s, n, x, x_stride, sel, dim, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_sum(long long n, const double *v, double *out, double *scratch, hipStream_t s) {
   int blocks = (int)((n + BLOCK - 1) / BLOCK);
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;

@@ -394,3 +394,29 @@ def test_c3d_full_size_properties(oracle_lib):
     g.add_values(hx, -0.02)
     E2, _ = g.get_value_deriv(x[:4096])
     assert np.abs(E2).max() < 1e-15, "hills followed by their negatives leave an empty grid"
+
+
+def test_single_rank_rccl_exchange_matches_plain(workdir):
+    """The RCCL hill exchange (all-gather of hill records + all-reduce of the step's bias) with a
+    one-rank communicator must reproduce the communicator-free controller bit for bit."""
+    text = ("tempering 0\nhill_prefactor 0.5\nhill_density 60\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+            "bias_spacing 0.001\nbias_sigma 0.05\n")
+    state = []
+    for tag in ("plain", "rccl"):
+        cfg = str(workdir / (tag + ".edm"))
+        open(cfg, "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+        b = H.Bias(cfg)
+        if tag == "rccl":
+            b.comm_init(H.comm_unique_id(), 1, 0)
+        b.setup(1.0, 1.0)
+        b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+        n = 50_000
+        for step in range(5):
+            r = W.pair_distances(n, 900 + step).reshape(-1, 1)
+            b.add_hills(r, W.uniform(950 + step, n), -1, est=2 * n)
+        v, dv = b.gauss.download()
+        state.append((v, dv, b.hist.values, b.get("cum_bias"), b.get("overflow_right"), b.get("hills_added")))
+        del b
+    for a, c in zip(state[0], state[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(c))
+    assert state[0][0].max() > 0
