@@ -678,8 +678,8 @@ int edm_hip_bias_write_lammps_table(const edm_hip_bias *b, const char *filename,
 }
 int edm_hip_bias_write_histogram(const edm_hip_bias *b, int serial_format) {
   if (!b->hist) return EDM_HIP_ERR_STATE;
-  (void)serial_format;  // the histogram has no derivatives; both builds list node values
-  return edm_hip_grid_write(b->hist, b->hist_output.c_str());
+  if (serial_format) return edm_hip_grid_write(b->hist, b->hist_output.c_str());
+  return edm_hip_grid_multi_write(b->hist, b->hist_output.c_str(), b->min.data(), b->max.data(), b->bper.data(), 0);
 }
 int edm_hip_bias_clear_histogram(edm_hip_bias *b) {
   if (!b->hist) return EDM_HIP_ERR_STATE;

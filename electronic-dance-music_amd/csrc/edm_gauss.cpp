@@ -336,6 +336,75 @@ int edm_hip_grid_write(const edm_hip_grid *g, const char *filename) {
   return write_plumed(g->g, v.data(), nullptr, filename);
 }
 
+// grid.h:509-674 for one rank, no derivatives: nodes are re-sampled by the nearest-lower lookup
+// of DimmedGrid::get_value (grid.h:343-365) -- plain indexing of the downloaded bins
+int edm_hip_grid_multi_write(const edm_hip_grid *g, const char *filename, const double *box_min,
+                             const double *box_max, const int *b_periodic, int b_lammps_format) {
+  const Geom &q = g->g;
+  if (b_lammps_format == 1 && q.dim > 1) {
+    set_error("Lammps format only valid for 1D grids");
+    return EDM_HIP_ERR_ARG;
+  }
+  std::vector<double> v((size_t)q.total);
+  int rc = edm_hip_grid_download(g, v.data());
+  if (rc) return rc;
+  unsigned int counts[3] = {1, 1, 1}, extra_n = 0;
+  if (b_lammps_format) extra_n = (unsigned int)(box_min[0] / q.dx[0]);
+  size_t total = 1;
+  for (int d = 0; d < q.dim; d++) {
+    counts[d] = (unsigned int)(int)ceil((box_max[d] - box_min[d]) / q.dx[d]);
+    counts[d] = b_periodic[d] ? counts[d] : counts[d] + 1;
+    total *= counts[d];
+  }
+  FILE *fp = fopen(filename, "w");
+  if (!fp) {
+    set_error(std::string("cannot open ") + filename);
+    return EDM_HIP_ERR_IO;
+  }
+  if (!b_lammps_format) {
+    long long bins[3];
+    for (int d = 0; d < q.dim; d++) bins[d] = b_periodic[d] ? (long long)counts[d] : (long long)counts[d] - 1;
+    edm::put_header(fp, 0, q.dim, bins, box_min, box_max, b_periodic);
+  } else {
+    fprintf(fp, "#Auto generated by electronic-dance-music\n\n");
+    fprintf(fp, "EDM\n");
+    fprintf(fp, "N %u R %g %g\n\n", extra_n + counts[0], q.dx[0], box_max[0]);
+    for (size_t i = 1; i < extra_n; i++) fprintf(fp, "%zu %g 0.0 0.0\n", i, i * q.dx[0]);
+  }
+  for (size_t i = 0; i < total; i++) {
+    size_t tmp = i, sup[3] = {0, 0, 0};
+    double x[3];
+    int d;
+    for (d = 0; d < q.dim - 1; d++) {
+      sup[d] = tmp % counts[d];
+      tmp = (tmp - sup[d]) / counts[d];
+      x[d] = sup[d] * q.dx[d] + box_min[d];
+    }
+    sup[d] = tmp;
+    x[d] = sup[d] * q.dx[d] + box_min[d];
+    bool in = true;
+    for (d = 0; d < q.dim; d++)
+      if (!q.periodic[d] && (x[d] < q.min[d] || x[d] >= q.max[d] - q.dx[d])) in = false;
+    if (!in) continue;
+    long long flat = 0, mul = 1;
+    for (d = 0; d < q.dim; d++) {
+      double w;
+      long long idx = node_index(q, d, x[d], &w);
+      if (idx < 0) idx = 0;
+      if (idx > q.n[d] - 1) idx = q.n[d] - 1;
+      flat += idx * mul;
+      mul *= q.n[d];
+    }
+    if (b_lammps_format) fprintf(fp, "%zu ", i + extra_n);
+    for (d = 0; d < q.dim; d++) fprintf(fp, "%.8f ", x[d]);
+    fprintf(fp, "%.8f ", v[(size_t)flat]);
+    fprintf(fp, "\n");
+    if (sup[0] == counts[0] - 1) fprintf(fp, "\n");
+  }
+  fclose(fp);
+  return EDM_HIP_OK;
+}
+
 // ---- gaussian grid ------------------------------------------------------------
 static int gauss_alloc(edm_hip_gauss *g) {
   const size_t bytes = sizeof(double) * (size_t)g->g.total * g->g.rec;

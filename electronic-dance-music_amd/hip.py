@@ -56,6 +56,7 @@ _PROTOS = {
     "edm_hip_grid_clear": (C.c_int, [vp]),
     "edm_hip_grid_add_values": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_double]),
     "edm_hip_grid_write": (C.c_int, [vp, C.c_char_p]),
+    "edm_hip_grid_multi_write": (C.c_int, [vp, C.c_char_p, c_dp, c_dp, c_ip, C.c_int]),
     "edm_hip_gauss_create": (C.c_int, [C.POINTER(vp), C.c_int, c_dp, c_dp, c_dp, c_ip, C.c_int, c_dp]),
     "edm_hip_gauss_destroy": (C.c_int, [vp]),
     "edm_hip_gauss_set_boundary": (C.c_int, [vp, c_dp, c_dp, c_ip]),
@@ -289,6 +290,10 @@ class Grid(_Geom):
 
     def write(self, filename):
         check(lib().edm_hip_grid_write(self.h, os.fsencode(filename)))
+
+    def multi_write(self, filename, box_min, box_max, periodic, lammps=0):
+        check(lib().edm_hip_grid_multi_write(self.h, os.fsencode(filename), _dp(_vec(box_min)), _dp(_vec(box_max)),
+                                             _ivec(periodic).ctypes.data_as(c_ip), lammps))
 
 
 class Gauss(_Geom):

@@ -1,0 +1,607 @@
+// edm_host.cpp -- libedm.so: the reference's C++ API (EDM::EDMBias, EDM::GaussGrid, EDM::Grid,
+// EDM::edm_error; lib/edm_bias.h, lib/gaussian_grid.h, lib/grid.h, lib/edm.h) implemented as thin
+// wrappers over the C ABI of libedm_hip.so (include/edm_hip.h).  Plain host C++ (g++), no HIP
+// headers: the GPU is reached only through the C ABI.  Error convention of the reference:
+// a failing call prints "[EDM:<where>] <message>" and abort()s (lib/edm.cpp:4-7).
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/edm/edm_bias.h"
+#include "../../include/edm_hip.h"
+
+namespace EDM {
+
+void edm_error(const char* error, const char* location) {
+  std::cerr << "[EDM:" << location << "] " << error << std::endl;
+  abort();
+}
+
+namespace {
+
+void check(int rc, const char* where) {
+  if (rc != EDM_HIP_OK) edm_error(edm_hip_last_error(), where);
+}
+
+// a growing device allocation owned by the host layer
+struct DevMem {
+  void* p;
+  size_t cap;
+  DevMem() : p(NULL), cap(0) {}
+  ~DevMem() {
+    if (p) edm_hip_free(p);
+  }
+  void* reserve(size_t bytes) {
+    if (bytes > cap) {
+      if (p) edm_hip_free(p);
+      p = NULL;
+      size_t want = bytes + bytes / 4 + 256;
+      check(edm_hip_malloc(&p, want), "edm_host:reserve");
+      cap = want;
+    }
+    return p;
+  }
+};
+
+// LAMMPS-style double** (rows of one contiguous block): returns the row stride in doubles, or 0
+// when the rows are not evenly spaced and have to be packed
+long row_stride(int n, const double* const* rows, unsigned int dim) {
+  if (n <= 1) return (long)dim;
+  const long stride = (long)(rows[1] - rows[0]);
+  if (stride < (long)dim) return 0;
+  if (rows[n - 1] != rows[0] + (long)(n - 1) * stride) return 0;
+  return stride;
+}
+
+}  // namespace
+
+// ================================================================================
+// HipGrid
+// ================================================================================
+void HipGrid::refresh_geometry() {
+  edm_hip_geometry g;
+  check(edm_hip_grid_geometry(h_, &g), "grid.h:geometry");
+  dim_ = (unsigned int)g.dim;
+  grid_size_ = (size_t)g.total;
+  for (int d = 0; d < 3; d++) {
+    dx_[d] = g.dx[d];
+    min_[d] = g.min[d];
+    max_[d] = g.max[d];
+    grid_number_[d] = g.n[d];
+    b_periodic_[d] = g.periodic[d];
+  }
+}
+
+HipGrid::HipGrid(unsigned int dim, const double* min, const double* max, const double* bin_spacing,
+                 const int* b_periodic)
+    : h_(NULL), owned_(true) {
+  check(edm_hip_grid_create(&h_, (int)dim, min, max, bin_spacing, b_periodic), "grid.h:DimmedGrid");
+  refresh_geometry();
+}
+
+HipGrid::HipGrid(edm_hip_grid* borrowed) : h_(borrowed), owned_(false) { refresh_geometry(); }
+
+HipGrid::~HipGrid() {
+  if (owned_ && h_) edm_hip_grid_destroy(h_);
+}
+
+double* HipGrid::get_grid() {
+  snapshot_.resize(grid_size_ ? grid_size_ : 1);
+  check(edm_hip_grid_download(h_, snapshot_.data()), "grid.h:get_grid");
+  return snapshot_.data();
+}
+
+// grid.h:343-365 without interpolation: the value of the nearest-lower node
+double HipGrid::get_value(const double* x) const {
+  for (unsigned int d = 0; d < dim_; d++)
+    if (!b_periodic_[d] && (x[d] < min_[d] || x[d] >= max_[d] - dx_[d])) return 0;
+  const double* v = const_cast<HipGrid*>(this)->get_grid();
+  size_t flat = 0, mul = 1;
+  for (unsigned int d = 0; d < dim_; d++) {
+    double xi = x[d];
+    if (b_periodic_[d]) xi -= (max_[d] - min_[d]) * std::floor((xi - min_[d]) / (max_[d] - min_[d]));
+    size_t idx = (size_t)std::floor((xi - min_[d]) / dx_[d]);
+    if (idx >= (size_t)grid_number_[d]) idx = (size_t)grid_number_[d] - 1;
+    flat += idx * mul;
+    mul *= (size_t)grid_number_[d];
+  }
+  return v[flat];
+}
+
+double HipGrid::get_value_deriv(const double* x, double* der) const {
+  for (unsigned int d = 0; d < dim_; d++) der[d] = 0;
+  return get_value(x);
+}
+
+double HipGrid::add_value(const double* x0, double value) {
+  DevMem dx;
+  dx.reserve(sizeof(double) * dim_);
+  check(edm_hip_memcpy_h2d(dx.p, x0, sizeof(double) * dim_), "grid.h:add_value");
+  for (unsigned int d = 0; d < dim_; d++)
+    if (!b_periodic_[d] && (x0[d] < min_[d] || x0[d] >= max_[d] - dx_[d])) return 0;
+  check(edm_hip_grid_add_values(h_, 1, (const double*)dx.p, (int)dim_, NULL, value), "grid.h:add_value");
+  return value;
+}
+
+void HipGrid::write(const std::string& filename) const { check(edm_hip_grid_write(h_, filename.c_str()), "grid.h:write"); }
+void HipGrid::multi_write(const std::string& filename, const double* box_low, const double* box_high,
+                          const int* b_periodic, int b_lammps_format) const {
+  check(edm_hip_grid_multi_write(h_, filename.c_str(), box_low, box_high, b_periodic, b_lammps_format), "grid.h:multi_write");
+}
+void HipGrid::read(const std::string&) { edm_error("reading into a device histogram grid is not supported", "grid.h:read"); }
+void HipGrid::set_interpolation(int b_interpolate) {
+  if (b_interpolate) edm_error("the device histogram grid has no derivatives to interpolate with", "grid.h:set_interpolation");
+}
+const double* HipGrid::get_dx() const { return dx_; }
+const double* HipGrid::get_max() const { return max_; }
+const double* HipGrid::get_min() const { return min_; }
+double HipGrid::max_value() const {
+  const double* v = const_cast<HipGrid*>(this)->get_grid();
+  double m = v[0];
+  for (size_t i = 0; i < grid_size_; i++) m = std::fmax(m, v[i]);
+  return m;
+}
+double HipGrid::min_value() const {
+  const double* v = const_cast<HipGrid*>(this)->get_grid();
+  double m = v[0];
+  for (size_t i = 0; i < grid_size_; i++) m = std::fmin(m, v[i]);
+  return m;
+}
+void HipGrid::add(const Grid*, double, double) { edm_error("Grid::add is only available on the bias grid", "grid.h:add"); }
+size_t HipGrid::get_grid_size() const { return grid_size_; }
+void HipGrid::one2multi(size_t index, size_t* result) const {
+  unsigned int d;
+  for (d = 0; d < dim_ - 1; d++) {
+    result[d] = index % (size_t)grid_number_[d];
+    index = (index - result[d]) / (size_t)grid_number_[d];
+  }
+  result[d] = index;
+}
+double HipGrid::expected_bias() const {
+  const double* v = const_cast<HipGrid*>(this)->get_grid();
+  double Z = 0, offset = 0, avg = 0;
+  for (size_t i = 0; i < grid_size_; i++) offset = std::fmax(offset, v[i]);
+  for (size_t i = 0; i < grid_size_; i++) Z += std::exp(-v[i] - offset);
+  for (size_t i = 0; i < grid_size_; i++) avg += v[i] * std::exp(-v[i] - offset);
+  return avg / Z;
+}
+void HipGrid::clear() { check(edm_hip_grid_clear(h_), "grid.h:clear"); }
+
+Grid* make_grid(unsigned int dim, const double* min, const double* max, const double* bin_spacing,
+                const int* b_periodic, int b_derivatives, int b_interpolate) {
+  if (dim < 1 || dim > 3) return NULL;
+  if (b_derivatives || b_interpolate)
+    edm_error("device grids with derivatives are GaussGrids: use make_gauss_grid", "grid.cpp:make_grid");
+  return new HipGrid(dim, min, max, bin_spacing, b_periodic);
+}
+
+// ================================================================================
+// HipGaussGrid
+// ================================================================================
+void HipGaussGrid::refresh_geometry() {
+  edm_hip_geometry g;
+  check(edm_hip_gauss_geometry(h_, &g), "gaussian_grid.h:geometry");
+  dim_ = (unsigned int)g.dim;
+  grid_size_ = (size_t)g.total;
+  for (int d = 0; d < 3; d++) {
+    dx_[d] = g.dx[d];
+    min_[d] = g.min[d];
+    max_[d] = g.max[d];
+    grid_number_[d] = g.n[d];
+    b_periodic_[d] = g.periodic[d];
+    sigma_[d] = g.sigma[d];
+    boundary_min_[d] = g.boundary_min[d];
+    boundary_max_[d] = g.boundary_max[d];
+    b_periodic_boundary_[d] = g.boundary_periodic[d];
+    minisize_[d] = (size_t)g.minisize[d];
+  }
+}
+
+HipGaussGrid::HipGaussGrid(unsigned int dim, const double* min, const double* max, const double* bin_spacing,
+                           const int* b_periodic, int b_interpolate, const double* sigma)
+    : h_(NULL), owned_(true) {
+  check(edm_hip_gauss_create(&h_, (int)dim, min, max, bin_spacing, b_periodic, b_interpolate, sigma),
+        "gaussian_grid.h:DimmedGaussGrid");
+  refresh_geometry();
+}
+HipGaussGrid::HipGaussGrid(edm_hip_gauss* borrowed) : h_(borrowed), owned_(false) { refresh_geometry(); }
+HipGaussGrid::~HipGaussGrid() {
+  if (owned_ && h_) edm_hip_gauss_destroy(h_);
+}
+
+double HipGaussGrid::get_value_deriv_batch(size_t n, const double* x, int stride, double* energy, double* deriv) const {
+  if (n == 0) return 0;
+  DevMem dx, dE, dD;
+  dx.reserve(sizeof(double) * n * stride);
+  dE.reserve(sizeof(double) * n);
+  dD.reserve(sizeof(double) * n * dim_);
+  check(edm_hip_memcpy_h2d(dx.p, x, sizeof(double) * n * stride), "gaussian_grid.h:get_value_deriv");
+  check(edm_hip_gauss_get_value_deriv(h_, (long long)n, (const double*)dx.p, stride, (double*)dE.p, (double*)dD.p),
+        "gaussian_grid.h:get_value_deriv");
+  std::vector<double> e(n);
+  check(edm_hip_memcpy_d2h(e.data(), dE.p, sizeof(double) * n), "gaussian_grid.h:get_value_deriv");
+  if (deriv) check(edm_hip_memcpy_d2h(deriv, dD.p, sizeof(double) * n * dim_), "gaussian_grid.h:get_value_deriv");
+  double sum = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (energy) energy[i] = e[i];
+    sum += e[i];
+  }
+  return sum;
+}
+
+double HipGaussGrid::get_value_deriv(const double* x, double* der) const {
+  double e = 0;
+  get_value_deriv_batch(1, x, (int)dim_, &e, der);
+  return e;
+}
+double HipGaussGrid::get_value(const double* x) const {
+  double der[3];
+  return get_value_deriv(x, der);
+}
+
+void HipGaussGrid::add_values(size_t n, const double* x, int stride, const double* heights, double* added) {
+  if (n == 0) return;
+  DevMem dx, dh, da;
+  dx.reserve(sizeof(double) * n * stride);
+  dh.reserve(sizeof(double) * n);
+  da.reserve(sizeof(double) * n);
+  check(edm_hip_memcpy_h2d(dx.p, x, sizeof(double) * n * stride), "gaussian_grid.h:add_value");
+  check(edm_hip_memcpy_h2d(dh.p, heights, sizeof(double) * n), "gaussian_grid.h:add_value");
+  check(edm_hip_gauss_add_values(h_, (long long)n, (const double*)dx.p, stride, (const double*)dh.p, 0.0,
+                                 added ? (double*)da.p : NULL, NULL),
+        "gaussian_grid.h:add_value");
+  if (added) check(edm_hip_memcpy_d2h(added, da.p, sizeof(double) * n), "gaussian_grid.h:add_value");
+}
+
+double HipGaussGrid::add_value(const double* x0, double height) {
+  double added = 0;
+  add_values(1, x0, (int)dim_, &height, &added);
+  return added;
+}
+
+void HipGaussGrid::read(const std::string&) {
+  edm_error("use EDMBias' initial_bias_filename (Grid::add from a file) to load a bias", "gaussian_grid.h:read");
+}
+void HipGaussGrid::write(const std::string& filename) const { check(edm_hip_gauss_write(h_, filename.c_str()), "gaussian_grid.h:write"); }
+void HipGaussGrid::multi_write(const std::string& filename) const {
+  check(edm_hip_gauss_multi_write(h_, filename.c_str(), 0), "gaussian_grid.h:multi_write");
+}
+void HipGaussGrid::lammps_multi_write(const std::string& filename) const {
+  check(edm_hip_gauss_multi_write(h_, filename.c_str(), 1), "gaussian_grid.h:lammps_multi_write");
+}
+// gaussian_grid.h:160-166 ignores the box arguments' format flag and writes with its own boundary
+void HipGaussGrid::multi_write(const std::string& filename, const double*, const double*, const int*, int) const {
+  check(edm_hip_gauss_multi_write(h_, filename.c_str(), 0), "gaussian_grid.h:multi_write");
+}
+void HipGaussGrid::set_interpolation(int b_interpolate) {
+  if (!b_interpolate) edm_error("the device bias grid always interpolates (INTERPOLATE 1, edm_bias.h:18)", "gaussian_grid.h:set_interpolation");
+}
+void HipGaussGrid::set_boundary(const double* min, const double* max, const int* b_periodic) {
+  check(edm_hip_gauss_set_boundary(h_, min, max, b_periodic), "gaussian_grid.h:set_boundary");
+  refresh_geometry();
+}
+double HipGaussGrid::get_volume() const {
+  double vol = 1;
+  for (unsigned int d = 0; d < dim_; d++) vol *= boundary_max_[d] - boundary_min_[d];
+  return vol;
+}
+void HipGaussGrid::one2multi(size_t index, size_t* result) const {
+  unsigned int d;
+  for (d = 0; d < dim_ - 1; d++) {
+    result[d] = index % (size_t)grid_number_[d];
+    index = (index - result[d]) / (size_t)grid_number_[d];
+  }
+  result[d] = index;
+}
+double* HipGaussGrid::get_grid() {
+  snapshot_.resize(grid_size_ ? grid_size_ : 1);
+  check(edm_hip_gauss_download(h_, snapshot_.data(), NULL), "gaussian_grid.h:get_grid");
+  return snapshot_.data();
+}
+const double* HipGaussGrid::get_grid_deriv() {
+  snapshot_deriv_.resize((grid_size_ ? grid_size_ : 1) * dim_);
+  check(edm_hip_gauss_download(h_, NULL, snapshot_deriv_.data()), "gaussian_grid.h:get_grid_deriv");
+  return snapshot_deriv_.data();
+}
+void HipGaussGrid::set_grid(const double* values, const double* derivs) {
+  check(edm_hip_gauss_upload(h_, values, derivs), "gaussian_grid.h:set_grid");
+}
+const double* HipGaussGrid::get_dx() const { return dx_; }
+const double* HipGaussGrid::get_min() const { return min_; }
+const double* HipGaussGrid::get_max() const { return max_; }
+double HipGaussGrid::max_value() const {
+  const double* v = const_cast<HipGaussGrid*>(this)->get_grid();
+  double m = v[0];
+  for (size_t i = 0; i < grid_size_; i++) m = std::fmax(m, v[i]);
+  return m;
+}
+double HipGaussGrid::min_value() const {
+  const double* v = const_cast<HipGaussGrid*>(this)->get_grid();
+  double m = v[0];
+  for (size_t i = 0; i < grid_size_; i++) m = std::fmin(m, v[i]);
+  return m;
+}
+void HipGaussGrid::add(const Grid*, double, double) {
+  edm_error("Grid::add takes a PLUMED grid file on the device path (initial_bias_filename)", "gaussian_grid.h:add");
+}
+double HipGaussGrid::expected_bias() const {
+  const double* v = const_cast<HipGaussGrid*>(this)->get_grid();
+  double Z = 0, offset = 0, avg = 0;
+  for (size_t i = 0; i < grid_size_; i++) offset = std::fmax(offset, v[i]);
+  for (size_t i = 0; i < grid_size_; i++) Z += std::exp(-v[i] - offset);
+  for (size_t i = 0; i < grid_size_; i++) avg += v[i] * std::exp(-v[i] - offset);
+  return avg / Z;
+}
+void HipGaussGrid::clear() { check(edm_hip_gauss_clear(h_), "gaussian_grid.h:clear"); }
+size_t HipGaussGrid::get_grid_size() const { return grid_size_; }
+int HipGaussGrid::in_bounds(const double* x) const {
+  for (unsigned int d = 0; d < dim_; d++)
+    if (x[d] < boundary_min_[d] || x[d] > boundary_max_[d]) return 0;
+  return 1;
+}
+
+GaussGrid* make_gauss_grid(unsigned int dim, const double* min, const double* max, const double* bin_spacing,
+                           const int* b_periodic, int b_interpolate, const double* sigma) {
+  if (dim < 1 || dim > 3) return NULL;
+  return new HipGaussGrid(dim, min, max, bin_spacing, b_periodic, b_interpolate, sigma);
+}
+
+// ================================================================================
+// EDMBias
+// ================================================================================
+struct EDMBias::Stage {
+  DevMem x, f, mask, u, r, fr;
+  std::vector<double> pack_x, pack_f;
+};
+
+EDMBias::EDMBias(const std::string& input_filename)
+    : b_tempering_(0), b_targeting_(0), mpi_rank_(0), mpi_size_(0), dim_(0), global_tempering_(0), bias_factor_(0),
+      boltzmann_factor_(0), temperature_(-1.0), hill_prefactor_(0), bias_per_step_(0), hill_density_(-1), cum_bias_(0),
+      total_volume_(0), expected_target_(0), b_outofbounds_(0), bias_dx_(NULL), bias_sigma_(NULL), min_(NULL), max_(NULL),
+      b_periodic_boundary_(NULL), target_(NULL), initial_bias_(NULL), bias_(NULL), mask_(NULL), mpi_neighbor_count_(0),
+      mpi_neighbors_(NULL), h_(NULL), cv_hist_(NULL), serial_format_(0), st_(new Stage) {
+  read_input(input_filename);
+}
+
+EDMBias::~EDMBias() {
+  delete bias_;
+  delete cv_hist_;
+  if (h_) edm_hip_bias_destroy(h_);
+  free(bias_dx_);
+  free(bias_sigma_);
+  free(min_);
+  free(max_);
+  free(b_periodic_boundary_);
+  delete st_;
+}
+
+// edm_bias.cpp:986-1095.  Like the reference the constructor ignores the result; a handle that
+// failed to parse reports its error on first use.
+int EDMBias::read_input(const std::string& input_filename) {
+  if (h_) {
+    edm_hip_bias_destroy(h_);
+    h_ = NULL;
+  }
+  const int rc = edm_hip_bias_create(&h_, input_filename.c_str());
+  if (rc != EDM_HIP_OK) {
+    std::cerr << edm_hip_last_error() << std::endl;
+    return 0;
+  }
+  double d = 0;
+  edm_hip_bias_get(h_, "dim", &d);
+  dim_ = (unsigned int)d;
+  free(bias_dx_); free(bias_sigma_); free(min_); free(max_); free(b_periodic_boundary_);
+  bias_dx_ = (double*)malloc(sizeof(double) * dim_);
+  bias_sigma_ = (double*)malloc(sizeof(double) * dim_);
+  min_ = (double*)malloc(sizeof(double) * dim_);
+  max_ = (double*)malloc(sizeof(double) * dim_);
+  b_periodic_boundary_ = (int*)calloc(dim_, sizeof(int));
+  edm_hip_bias_get_array(h_, "bias_dx", bias_dx_);
+  edm_hip_bias_get_array(h_, "bias_sigma", bias_sigma_);
+  edm_hip_bias_get_array(h_, "min", min_);
+  edm_hip_bias_get_array(h_, "max", max_);
+  refresh();
+  return 1;
+}
+
+void EDMBias::refresh() const {
+  EDMBias* s = const_cast<EDMBias*>(this);
+  double v = 0;
+#define PULL(name, member, type) if (edm_hip_bias_get(h_, name, &v) == EDM_HIP_OK) s->member = (type)v
+  PULL("b_tempering", b_tempering_, int);
+  PULL("b_targeting", b_targeting_, int);
+  PULL("mpi_rank", mpi_rank_, int);
+  PULL("mpi_size", mpi_size_, int);
+  PULL("global_tempering", global_tempering_, double);
+  PULL("bias_factor", bias_factor_, double);
+  PULL("boltzmann_factor", boltzmann_factor_, double);
+  PULL("temperature", temperature_, double);
+  PULL("hill_prefactor", hill_prefactor_, double);
+  PULL("bias_per_step", bias_per_step_, double);
+  PULL("hill_density", hill_density_, double);
+  PULL("cum_bias", cum_bias_, double);
+  PULL("total_volume", total_volume_, double);
+  PULL("expected_target", expected_target_, double);
+  PULL("b_outofbounds", b_outofbounds_, int);
+#undef PULL
+}
+
+void EDMBias::setup(double temperature, double boltzmann_constant) {
+  check(edm_hip_bias_setup(h_, temperature, boltzmann_constant), "edm_bias.cpp:setup");
+  refresh();
+}
+
+void EDMBias::subdivide(const double sublo[3], const double subhi[3], const double boxlo[3], const double boxhi[3],
+                        const int b_periodic[3], const double skin[3]) {
+  if (bias_ != NULL) return;  // edm_bias.cpp:121-122
+  if (temperature_ < 0) edm_error("Must call setup before subdivide", "edm_bias.cpp:subdivide");
+  check(edm_hip_bias_subdivide(h_, sublo, subhi, boxlo, boxhi, b_periodic, skin), "edm_bias.cpp:subdivide");
+  bias_ = new HipGaussGrid(edm_hip_bias_gauss(h_));
+  cv_hist_ = new HipGrid(edm_hip_bias_histogram(h_));
+  HipGaussGrid* g = static_cast<HipGaussGrid*>(bias_);
+  for (unsigned int d = 0; d < dim_; d++) b_periodic_boundary_[d] = g->b_periodic_boundary_[d];
+  refresh();
+}
+
+void EDMBias::set_mask(const int* mask) { mask_ = mask; }
+
+double EDMBias::update_forces(int nlocal, const double* const* positions, double** forces) const {
+  return update_forces(nlocal, positions, forces, -1);
+}
+
+// edm_bias.cpp:276-295 with LAMMPS' host arrays staged through HBM
+double EDMBias::update_forces(int nlocal, const double* const* positions, double** forces, int apply_mask) const {
+  if (b_outofbounds_ || nlocal <= 0) return 0.0;
+  if (apply_mask >= 0 && mask_ == NULL) edm_error("update_forces with a group mask needs set_mask", "edm_bias.cpp:update_forces");
+  Stage& st = *st_;
+  const size_t n = (size_t)nlocal;
+  long xs = row_stride(nlocal, positions, dim_);
+  long fs = row_stride(nlocal, const_cast<const double* const*>(forces), dim_);
+  const double* xsrc = positions[0];
+  double* fsrc = forces[0];
+  if (xs == 0) {  // rows are not evenly spaced: pack
+    xs = (long)dim_;
+    st.pack_x.resize(n * dim_);
+    for (size_t i = 0; i < n; i++)
+      for (unsigned int d = 0; d < dim_; d++) st.pack_x[i * dim_ + d] = positions[i][d];
+    xsrc = st.pack_x.data();
+  }
+  const bool pack_f = (fs == 0);
+  if (pack_f) {
+    fs = (long)dim_;
+    st.pack_f.resize(n * dim_);
+    for (size_t i = 0; i < n; i++)
+      for (unsigned int d = 0; d < dim_; d++) st.pack_f[i * dim_ + d] = forces[i][d];
+    fsrc = st.pack_f.data();
+  }
+  const size_t xbytes = sizeof(double) * ((n - 1) * (size_t)xs + dim_);
+  const size_t fbytes = sizeof(double) * ((n - 1) * (size_t)fs + dim_);
+  st.x.reserve(xbytes);
+  st.f.reserve(fbytes);
+  check(edm_hip_memcpy_h2d(st.x.p, xsrc, xbytes), "edm_bias.cpp:update_forces");
+  check(edm_hip_memcpy_h2d(st.f.p, fsrc, fbytes), "edm_bias.cpp:update_forces");
+  if (apply_mask >= 0) {
+    st.mask.reserve(sizeof(int) * n);
+    check(edm_hip_memcpy_h2d(st.mask.p, mask_, sizeof(int) * n), "edm_bias.cpp:update_forces");
+    check(edm_hip_bias_set_mask(h_, (const int*)st.mask.p), "edm_bias.cpp:set_mask");
+  }
+  double energy = 0;
+  check(edm_hip_bias_update_forces(h_, nlocal, (const double*)st.x.p, (int)xs, (double*)st.f.p, (int)fs, apply_mask, &energy),
+        "edm_bias.cpp:update_forces");
+  check(edm_hip_memcpy_d2h(fsrc, st.f.p, fbytes), "edm_bias.cpp:update_forces");
+  if (pack_f)
+    for (size_t i = 0; i < n; i++)
+      for (unsigned int d = 0; d < dim_; d++) forces[i][d] = st.pack_f[i * dim_ + d];
+  return energy;
+}
+
+// edm_bias.cpp:297-311: a batch of one
+double EDMBias::update_force(const double* positions, double* forces) const {
+  if (b_outofbounds_) return 0.0;
+  double der[3] = {0, 0, 0};
+  const double e = bias_->get_value_deriv(positions, der);
+  for (unsigned int d = 0; d < dim_; d++) forces[d] -= der[d];
+  return e;
+}
+
+double EDMBias::update_pair_forces(int npairs, const double* r, double* force_r) const {
+  if (npairs <= 0) return 0.0;
+  Stage& st = *st_;
+  const size_t bytes = sizeof(double) * (size_t)npairs;
+  st.r.reserve(bytes);
+  st.fr.reserve(bytes);
+  check(edm_hip_memcpy_h2d(st.r.p, r, bytes), "edm_bias.cpp:update_force");
+  double energy = 0;
+  check(edm_hip_bias_pair_forces(h_, npairs, (const double*)st.r.p, (double*)st.fr.p, &energy), "edm_bias.cpp:update_force");
+  check(edm_hip_memcpy_d2h(force_r, st.fr.p, bytes), "edm_bias.cpp:update_force");
+  return energy;
+}
+
+void EDMBias::add_hills(int nlocal, const double* const* positions, const double* runiform) {
+  add_hills(nlocal, positions, runiform, -1);
+}
+
+// edm_bias.cpp:401-411
+void EDMBias::add_hills(int nlocal, const double* const* positions, const double* runiform, int apply_mask) {
+  Stage& st = *st_;
+  const size_t n = (size_t)(nlocal > 0 ? nlocal : 0);
+  long xs = (long)dim_;
+  if (n > 0) {
+    xs = row_stride(nlocal, positions, dim_);
+    const double* xsrc = positions[0];
+    if (xs == 0) {
+      xs = (long)dim_;
+      st.pack_x.resize(n * dim_);
+      for (size_t i = 0; i < n; i++)
+        for (unsigned int d = 0; d < dim_; d++) st.pack_x[i * dim_ + d] = positions[i][d];
+      xsrc = st.pack_x.data();
+    }
+    const size_t xbytes = sizeof(double) * ((n - 1) * (size_t)xs + dim_);
+    st.x.reserve(xbytes);
+    check(edm_hip_memcpy_h2d(st.x.p, xsrc, xbytes), "edm_bias.cpp:add_hills");
+    if (runiform) {
+      st.u.reserve(sizeof(double) * n);
+      check(edm_hip_memcpy_h2d(st.u.p, runiform, sizeof(double) * n), "edm_bias.cpp:add_hills");
+    }
+    if (apply_mask >= 0) {
+      if (mask_ == NULL) edm_error("add_hills with a group mask needs set_mask", "edm_bias.cpp:add_hills");
+      st.mask.reserve(sizeof(int) * n);
+      check(edm_hip_memcpy_h2d(st.mask.p, mask_, sizeof(int) * n), "edm_bias.cpp:add_hills");
+      check(edm_hip_bias_set_mask(h_, (const int*)st.mask.p), "edm_bias.cpp:set_mask");
+    }
+  }
+  check(edm_hip_bias_add_hills(h_, nlocal, (const double*)st.x.p, (int)xs, runiform ? (const double*)st.u.p : NULL,
+                               apply_mask, -1),
+        "edm_bias.cpp:add_hills");
+  refresh();
+}
+
+void EDMBias::add_pair_hills(int n, const double* r, const double* runiform, int est_hill_count) {
+  Stage& st = *st_;
+  const size_t bytes = sizeof(double) * (size_t)(n > 0 ? n : 0);
+  if (n > 0) {
+    st.r.reserve(bytes);
+    st.u.reserve(bytes);
+    check(edm_hip_memcpy_h2d(st.r.p, r, bytes), "edm_bias.cpp:add_hill");
+    check(edm_hip_memcpy_h2d(st.u.p, runiform, bytes), "edm_bias.cpp:add_hill");
+  }
+  check(edm_hip_bias_add_hills(h_, n, (const double*)st.r.p, 1, (const double*)st.u.p, -1, est_hill_count),
+        "edm_bias.cpp:add_hill");
+  refresh();
+}
+
+void EDMBias::pre_add_hill(int est_hill_count) { check(edm_hip_bias_pre_add_hill(h_, est_hill_count), "edm_bias.cpp:pre_add_hill"); }
+void EDMBias::add_hill(const double* position, double runiform) {
+  check(edm_hip_bias_add_hill(h_, position, runiform), "edm_bias.cpp:add_hill");
+}
+void EDMBias::post_add_hill() {
+  check(edm_hip_bias_post_add_hill(h_), "edm_bias.cpp:post_add_hill");
+  refresh();
+}
+
+void EDMBias::write_bias(const std::string& output) const {
+  check(edm_hip_bias_write_bias(h_, output.c_str(), serial_format_), "edm_bias.cpp:write_bias");
+}
+void EDMBias::write_histogram() const { check(edm_hip_bias_write_histogram(h_, serial_format_), "edm_bias.cpp:write_histogram"); }
+void EDMBias::clear_histogram() { check(edm_hip_bias_clear_histogram(h_), "edm_bias.cpp:clear_histogram"); }
+void EDMBias::write_lammps_table(const std::string& output) const {
+  check(edm_hip_bias_write_lammps_table(h_, output.c_str(), serial_format_), "edm_bias.cpp:write_lammps_table");
+}
+
+void EDMBias::select_device(int rank) {
+  int n = 0;
+  check(edm_hip_device_count(&n), "edm_bias.cpp:select_device");
+  if (n < 1) edm_error("no MI355X visible: the EDM bias path has no CPU fallback", "edm_bias.cpp:select_device");
+  check(edm_hip_set_device(rank % n), "edm_bias.cpp:select_device");
+}
+void EDMBias::make_comm_id(char id[128]) { check(edm_hip_comm_unique_id(id, 128), "edm_bias.cpp:make_comm_id"); }
+void EDMBias::init_comm(const char id[128], int nranks, int rank) {
+  check(edm_hip_bias_comm_init(h_, id, nranks, rank), "edm_bias.cpp:init_comm");
+  refresh();
+}
+void EDMBias::set_hill_log(int enabled) { check(edm_hip_bias_set_hill_log(h_, enabled), "edm_bias.cpp:set_hill_log"); }
+
+}  // namespace EDM

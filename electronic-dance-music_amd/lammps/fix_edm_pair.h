@@ -1,0 +1,55 @@
+/* fix edm_pair -- pairwise-distance EDM bias for LAMMPS (USER-EDM), MI355X build.
+   Same fix style, arguments and semantics as the reference's lammps/fix_edm_pair.{h,cpp};
+   the per-pair update_force/add_hill calls are batched per timestep onto the GPU. */
+#ifdef FIX_CLASS
+
+FixStyle(edm_pair,FixEDMPair)
+
+#else
+
+#ifndef LMP_FIX_EDM_PAIR_H
+#define LMP_FIX_EDM_PAIR_H
+
+#include "fix.h"
+#include <edm/edm_bias.h>
+#include <vector>
+
+namespace LAMMPS_NS {
+
+class FixEDMPair : public Fix {
+ public:
+  FixEDMPair(class LAMMPS *, int, char **);
+  ~FixEDMPair();
+  int setmask();
+  void init();
+  void setup(int);
+  void min_setup(int);
+  void post_force(int);
+  void post_force_respa(int, int, int);
+  void min_post_force(int);
+  void init_list(int, class NeighList *);
+  double compute_scalar();
+
+ private:
+  class EDM::EDMBias *bias;
+  char bias_file[512];
+  char lammps_table_file[512];
+  double temperature;
+  double edm_energy;
+  int stride;
+  int write_stride;
+  class RanMars *random;
+  class NeighList *list;  // half neighbor list
+  unsigned int seed;
+  int nlevels_respa;
+  int last_calls;  // an estimate of the number of add_hill calls on this processor
+  int ipair, jpair;
+  // per-step batch of pair records (host staging, reused across steps)
+  std::vector<double> pair_r, pair_f, pair_del;
+  std::vector<int> pair_i, pair_j;
+};
+
+}
+
+#endif
+#endif

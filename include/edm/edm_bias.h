@@ -1,0 +1,118 @@
+// edm/edm_bias.h -- source-compatible EDMBias of the EDM library over the MI355X implementation
+// (reference: lib/edm_bias.h:29-225).  The LAMMPS fixes compile against this header unchanged:
+//   #include <edm/edm_bias.h>   and   -ledm
+// All heavy lifting happens in libedm_hip.so behind include/edm_hip.h; this class keeps the
+// reference's method signatures and public data members and stages LAMMPS' host arrays
+// (atom->x, atom->f, atom->mask, uniform randoms) through HBM for each batched call.
+#ifndef EDM_BIAS_H_
+#define EDM_BIAS_H_
+
+#include <string>
+#include <vector>
+
+#include "edm.h"
+#include "gaussian_grid.h"
+#include "grid.h"
+
+#define BIAS_CLAMP 1.0
+#define BIAS_BUFFER_SIZE 2048
+#define BIAS_BUFFER_DBLS 8192
+#define NO_COMM_PARTNER -1
+#define INTERPOLATE 1
+
+#define NEIGH_HILL 'n'
+#define BUFF_HILL 'b'
+#define BUFF_UNDO_HILL 'v'
+#define ADD_HILL 'h'
+#define ADD_UNDO_HILL 'u'
+#define BUFF_ZERO_HILL 'z'
+
+struct edm_hip_bias;
+
+namespace EDM {
+
+class EDMBias {
+ public:
+  EDMBias(const std::string& input_filename);
+  ~EDMBias();
+
+  void subdivide(const double sublo[3], const double subhi[3], const double boxlo[3], const double boxhi[3],
+                 const int b_periodic[3], const double skin[3]);
+  void setup(double temperature, double boltzmann_constant);
+  int read_input(const std::string& input_filename);
+
+  double update_forces(int nlocal, const double* const* positions, double** forces, int apply_mask) const;
+  double update_forces(int nlocal, const double* const* positions, double** forces) const;
+  double update_force(const double* positions, double* forces) const;
+  void set_mask(const int* mask);
+  void add_hills(int nlocal, const double* const* positions, const double* runiform);
+  void add_hills(int nlocal, const double* const* positions, const double* runiform, int apply_mask);
+  void pre_add_hill(int est_hill_count);
+  void add_hill(const double* position, double runiform);
+  void post_add_hill();
+
+  void write_bias(const std::string& output) const;
+  void write_histogram() const;
+  void clear_histogram();
+  void write_lammps_table(const std::string& output) const;
+
+  // ---- batched additions used by the rewritten USER-EDM fixes ----
+  // fix_edm_pair's inner loop (fix_edm_pair.cpp:215-217) over an array of pair distances:
+  // force_r[i] = edm_force[0] after update_force(&r[i], edm_force) on a zeroed accumulator.
+  double update_pair_forces(int npairs, const double* r, double* force_r) const;
+  // one hill cycle over a flat distance array: pre_add_hill(est); add_hill(&r[i], runiform[i]); post
+  void add_pair_hills(int n, const double* r, const double* runiform, int est_hill_count);
+  // one rank per GPU: id is an ncclUniqueId made by make_comm_id() on rank 0 and broadcast by the
+  // caller (MPI_Bcast in LAMMPS); must be called before subdivide
+  // binds this process to GPU (rank % visible devices); call before constructing an EDMBias
+  static void select_device(int rank);
+  static void make_comm_id(char id[128]);
+  void init_comm(const char id[128], int nranks, int rank);
+  // serial_format = 1 reproduces the reference's EDM_SERIAL writers (all plain PLUMED grids),
+  // 0 the MPI build's multi_write / LAMMPS table (default: the MPI build, like an installed LAMMPS)
+  void set_serial_format(int serial_format) { serial_format_ = serial_format; }
+  void set_hill_log(int enabled);
+  edm_hip_bias* handle() const { return h_; }
+
+  // public data members (edm_bias.h:118-157); refreshed from the controller after every call
+  int b_tempering_;
+  int b_targeting_;
+  int mpi_rank_;
+  int mpi_size_;
+  unsigned int dim_;
+  double global_tempering_;
+  double bias_factor_;
+  double boltzmann_factor_;
+  double temperature_;
+  double hill_prefactor_;
+  double bias_per_step_;
+  double hill_density_;
+  double cum_bias_;
+  double total_volume_;
+  double expected_target_;
+  int b_outofbounds_;
+  double* bias_dx_;
+  double* bias_sigma_;
+  double* min_;
+  double* max_;
+  int* b_periodic_boundary_;
+  Grid* target_;
+  Grid* initial_bias_;
+  GaussGrid* bias_;
+  const int* mask_;
+  unsigned int mpi_neighbor_count_;
+  int* mpi_neighbors_;
+
+ private:
+  EDMBias(const EDMBias& that);  // just disable copy constructor
+  void refresh() const;
+  edm_hip_bias* h_;
+  Grid* cv_hist_;
+  int serial_format_;
+  // device staging of host arrays
+  struct Stage;
+  Stage* st_;
+};
+
+}  // namespace EDM
+#endif  // EDM_BIAS_H_

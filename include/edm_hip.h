@@ -94,6 +94,10 @@ int edm_hip_grid_add_values(edm_hip_grid *g, long long n, const double *d_x, int
                             const double *d_w, double w_const);
 /* DimmedGrid::write (grid.h:448-503), byte-identical text */
 int edm_hip_grid_write(const edm_hip_grid *g, const char *filename);
+/* DimmedGrid::multi_write (grid.h:509-674) for one rank on a grid without derivatives: the
+ * CV histogram written by the MPI build's write_histogram (edm_bias.cpp:239) */
+int edm_hip_grid_multi_write(const edm_hip_grid *g, const char *filename, const double *box_min,
+                             const double *box_max, const int *b_periodic, int b_lammps_format);
 
 /* ---- gaussian grid: DimmedGaussGrid<DIM> (lib/gaussian_grid.h) ----------- */
 /* make_gauss_grid (gaussian_grid.h:636, gaussian_grid.cpp:3-18) */

@@ -1,0 +1,454 @@
+// edm_api_test.cpp -- the reference's unit tests (tests/edm_test.cpp, Boost.Test) restated
+// against the source-compatible C++ API of this build (include/edm/*.h over libedm_hip.so).
+// Expectations and tolerances are the reference's own (cited per case); needs an MI355X.
+//   usage: edm_api_test <fixture-dir> <scratch-dir>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include <edm/edm_bias.h>
+#include <edm/gaussian_grid.h>
+#include <edm/grid.h>
+
+using namespace EDM;
+
+#define EPSILON 1e-10
+static int g_fail = 0, g_checks = 0;
+#define REQUIRE(cond)                                                         \
+  do {                                                                        \
+    g_checks++;                                                               \
+    if (!(cond)) {                                                            \
+      g_fail++;                                                               \
+      std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);             \
+    }                                                                         \
+  } while (0)
+
+static unsigned long long lcg_state = 12345;
+static int lcg_rand() {  // deterministic stand-in for rand() of the reference tests
+  lcg_state = lcg_state * 6364136223846793005ULL + 1442695040888963407ULL;
+  return (int)((lcg_state >> 33) & 0x7fffffff);
+}
+
+static HipGaussGrid* gauss(unsigned dim, const double* mn, const double* mx, const double* sp, const int* per, int interp,
+                           const double* sg) {
+  return static_cast<HipGaussGrid*>(make_gauss_grid(dim, mn, mx, sp, per, interp, sg));
+}
+
+static void grid_1d_sanity() {  // edm_test.cpp:25-59
+  double mn[] = {0}, mx[] = {10}, sp[] = {1};
+  int per[] = {0};
+  HipGrid* g = static_cast<HipGrid*>(make_grid(1, mn, mx, sp, per, 0, 0));
+  REQUIRE(g->grid_number_[0] == 11);
+  REQUIRE(g->grid_size_ == 11);
+  size_t tmp[1];
+  g->one2multi(5, tmp);
+  REQUIRE(tmp[0] == 5);
+  for (int i = 0; i < 10; i++) {
+    double x[] = {i + 0.25};
+    g->add_value(x, i);
+  }
+  double x[] = {3.5};
+  REQUIRE(std::pow(g->get_value(x) - 3, 2) < 0.000001);
+  x[0] = 0;
+  g->get_value(x);
+  x[0] = 10;
+  REQUIRE(g->get_value(x) == 0);
+  delete g;
+}
+
+static void grid_3d_sanity() {  // edm_test.cpp:61-107
+  double mn[] = {-2, -5, -3}, mx[] = {125, 63, 78}, sp[] = {1.27, 1.36, 0.643};
+  int per[] = {0, 1, 1};
+  HipGrid* g = static_cast<HipGrid*>(make_grid(3, mn, mx, sp, per, 0, 0));
+  REQUIRE(g->grid_number_[0] == 101);
+  REQUIRE(g->grid_number_[1] == 50);
+  REQUIRE(g->grid_number_[2] == 126);
+  size_t tmp[3];
+  for (int t = 0; t < 200; t++) {
+    size_t a[3] = {(size_t)(lcg_rand() % 100), (size_t)(lcg_rand() % 50), (size_t)(lcg_rand() % 126)};
+    size_t flat = (a[2] * 50 + a[1]) * 101 + a[0];
+    g->one2multi(flat, tmp);
+    REQUIRE(tmp[0] == a[0] && tmp[1] == a[1] && tmp[2] == a[2]);
+    double p[3] = {a[0] * g->dx_[0] + g->min_[0] + EPSILON, a[1] * g->dx_[1] + g->min_[1] + EPSILON,
+                   a[2] * g->dx_[2] + g->min_[2] + EPSILON};
+    g->clear();
+    g->add_value(p, 7.0);
+    REQUIRE(g->get_grid()[flat] == 7.0);
+  }
+  delete g;
+}
+
+static void interpolation_1d() {  // edm_test.cpp:182-218
+  double mn[] = {0}, mx[] = {10}, sp[] = {1}, sg[] = {0.1};
+  int per[] = {0};
+  HipGaussGrid* g = gauss(1, mn, mx, sp, per, 1, sg);
+  std::vector<double> v(11), d(11);
+  for (int i = 0; i < 11; i++) {
+    v[i] = std::log((double)i);
+    d[i] = 1. / i;
+  }
+  g->set_grid(v.data(), d.data());
+  double x[] = {5.3}, der[1];
+  double fhat = g->get_value_deriv(x, der);
+  REQUIRE(fhat > std::log(5.) && fhat < std::log(6.));
+  REQUIRE(der[0] < 1. / 5 && der[0] > 1. / 6.);
+  REQUIRE(std::pow(fhat - std::log(5.3), 2) < 0.1);
+  REQUIRE(std::pow(der[0] - 1. / 5.3, 2) < 0.1);
+  x[0] = 5.0; g->get_value(x);
+  x[0] = 5.5; g->get_value(x);
+  x[0] = 0.0; g->get_value(x);
+  x[0] = 10.0; g->get_value(x);
+  delete g;
+}
+
+static void interp_1d_periodic() {  // edm_test.cpp:220-250
+  double mn[] = {-M_PI}, mx[] = {M_PI}, sp[] = {M_PI / 100}, sg[] = {0.1};
+  int per[] = {1};
+  HipGaussGrid* g = gauss(1, mn, mx, sp, per, 1, sg);
+  std::vector<double> v(g->grid_size_), d(g->grid_size_);
+  for (size_t i = 0; i < g->grid_size_; i++) {
+    v[i] = std::sin(g->min_[0] + i * g->dx_[0]);
+    d[i] = std::cos(g->min_[0] + i * g->dx_[0]);
+  }
+  g->set_grid(v.data(), d.data());
+  double x[] = {M_PI / 4}, der[1];
+  double fhat = g->get_value_deriv(x, der);
+  REQUIRE(std::pow(fhat - std::sin(x[0]), 2) < 0.1);
+  REQUIRE(std::pow(der[0] - std::cos(x[0]), 2) < 0.1);
+  REQUIRE(std::fabs(fhat - std::sin(x[0])) < 1e-6);
+  x[0] = 5 * M_PI / 4;  // wraps
+  fhat = g->get_value_deriv(x, der);
+  REQUIRE(std::pow(fhat - std::sin(x[0]), 2) < 0.1);
+  REQUIRE(std::pow(der[0] - std::cos(x[0]), 2) < 0.1);
+  delete g;
+}
+
+static void interp_3d_mixed() {  // edm_test.cpp:392-430
+  double mn[] = {-M_PI, -M_PI, 0}, mx[] = {M_PI, M_PI, 10}, sp[] = {M_PI / 100, M_PI / 100, 1}, sg[] = {.1, .1, .1};
+  int per[] = {1, 1, 0};
+  HipGaussGrid* g = gauss(3, mn, mx, sp, per, 1, sg);
+  std::vector<double> v(g->grid_size_), d(g->grid_size_ * 3);
+  size_t idx = 0;
+  for (int i = 0; i < g->grid_number_[2]; i++)
+    for (int j = 0; j < g->grid_number_[1]; j++)
+      for (int k = 0; k < g->grid_number_[0]; k++) {
+        double x = g->min_[0] + k * g->dx_[0], y = g->min_[1] + j * g->dx_[1], z = g->min_[2] + i * g->dx_[2];
+        v[idx] = std::cos(x) * std::sin(y) * z;
+        d[idx * 3 + 0] = -std::sin(x) * std::sin(y) * z;
+        d[idx * 3 + 1] = std::cos(x) * std::cos(y) * z;
+        d[idx * 3 + 2] = std::cos(x) * std::sin(y);
+        idx++;
+      }
+  g->set_grid(v.data(), d.data());
+  // inside the boundary of the gaussian grid the lookup is DimmedGrid::get_value_deriv
+  double a[] = {0.75 * M_PI / 2, -0.43 * M_PI / 2, 3.5}, der[3];
+  double fhat = g->get_value_deriv(a, der);
+  double f = std::cos(a[0]) * std::sin(a[1]) * a[2];
+  double td[] = {-std::sin(a[0]) * std::sin(a[1]) * a[2], std::cos(a[0]) * std::cos(a[1]) * a[2], std::cos(a[0]) * std::sin(a[1])};
+  REQUIRE(std::pow(f - fhat, 2) < 0.1);
+  for (int k = 0; k < 3; k++) REQUIRE(std::pow(der[k] - td[k], 2) < 0.1);
+  REQUIRE(std::fabs(f - fhat) < 1e-3);
+  delete g;
+}
+
+static void boundary_remap_wrap_3() {  // edm_test.cpp:336-360
+  double mn[] = {-2}, mx[] = {7}, sp[] = {0.1}, sg[] = {0.1};
+  int per[] = {0};
+  HipGaussGrid* g = gauss(1, mn, mx, sp, per, 1, sg);
+  double bmn[] = {0}, bmx[] = {10};
+  int bper[] = {1};
+  g->set_boundary(bmn, bmx, bper);
+  double p[] = {0.01}, der[1];
+  g->add_value(p, 1);
+  p[0] = 0;
+  g->get_value_deriv(p, der);
+  REQUIRE(std::fabs(der[0]) > 0.1);
+  // boundary_remap_wrap_2 (:300-333) seen through lookups: 9 is remapped to -1
+  double a[] = {9.0}, b[] = {-1.0};
+  REQUIRE(g->get_value(a) == g->get_value(b));
+  delete g;
+}
+
+static void gauss_grid_add_check() {  // edm_test.cpp:432-457
+  double mn[] = {-10}, mx[] = {10}, sg[] = {1}, sp[] = {1};
+  int per[] = {1};
+  HipGaussGrid* g = gauss(1, mn, mx, sp, per, 1, sg);
+  double x[] = {0}, der[1];
+  g->add_value(x, 1);
+  REQUIRE(std::pow(g->get_value(x) - 1 / std::sqrt(2 * M_PI), 2) < EPSILON);
+  for (int i = -6; i < 7; i++) {
+    x[0] = i;
+    double value = g->get_value_deriv(x, der);
+    REQUIRE(std::pow(value - std::exp(-x[0] * x[0] / 2.) / std::sqrt(2 * M_PI), 2) < 0.01);
+    REQUIRE(std::pow(der[0] - (-x[0] * std::exp(-x[0] * x[0] / 2.)) / std::sqrt(2 * M_PI), 2) < 0.01);
+  }
+  delete g;
+}
+
+static double rnd(double a) { return a < 0.0 ? std::ceil(a - 0.5) : std::floor(a + 0.5); }
+
+static void gauss_pbc_checks() {  // edm_test.cpp:460-534
+  {
+    double mn[] = {2}, mx[] = {10}, sg[] = {1}, sp[] = {1};
+    int per[] = {1};
+    HipGaussGrid* g = gauss(1, mn, mx, sp, per, 1, sg);
+    double x[] = {2}, der[1];
+    g->add_value(x, 1);
+    for (int i = -6; i < 7; i++) {
+      x[0] = i;
+      double dx = x[0] - 2;
+      dx -= rnd(dx / (mn[0] - mx[0])) * (mn[0] - mx[0]);
+      double value = g->get_value_deriv(x, der);
+      REQUIRE(std::pow(value - std::exp(-dx * dx / 2.) / std::sqrt(2 * M_PI), 2) < 0.01);
+      REQUIRE(std::pow(der[0] - (-dx * std::exp(-dx * dx / 2.)) / std::sqrt(2 * M_PI), 2) < 0.01);
+    }
+    delete g;
+  }
+  {
+    double mn[] = {2}, mx[] = {4}, sg[] = {1}, sp[] = {1}, loc[] = {11};
+    int per[] = {0};
+    HipGaussGrid* g = gauss(1, mn, mx, sp, per, 1, sg);
+    per[0] = 1;
+    mx[0] = 10;
+    g->set_boundary(mn, mx, per);
+    g->add_value(loc, 1);  // equivalent to 1 -> wrapped to the nearest image of the grid
+    double x[1], der[1];
+    for (int i = 2; i < 4; i++) {
+      x[0] = i;
+      double dx = x[0] - loc[0];
+      dx -= rnd(dx / (mn[0] - mx[0])) * (mn[0] - mx[0]);
+      double value = g->get_value_deriv(x, der);
+      REQUIRE(std::pow(value - std::exp(-dx * dx / 2.) / std::sqrt(2 * M_PI), 2) < 0.01);
+      REQUIRE(std::pow(der[0] - (-dx * std::exp(-dx * dx / 2.)) / std::sqrt(2 * M_PI), 2) < 0.01);
+    }
+    delete g;
+  }
+}
+
+static void gauss_grid_integral_tests() {  // edm_test.cpp:537-628
+  for (int mcgdp = 0; mcgdp < 2; mcgdp++) {
+    double mn[] = {-100}, mx[] = {100}, sg[] = {mcgdp ? 10.0 : 1.2}, sp[] = {1};
+    int per[] = {mcgdp ? 0 : 1};
+    HipGaussGrid* g = gauss(1, mn, mx, sp, per, 1, sg);
+    const int N = 20;
+    std::vector<double> xs, hs;
+    if (mcgdp) {
+      xs.push_back(-100.0);
+      xs.push_back(100.0);
+    }
+    // deterministic positions (the reference draws rand() % 200 - 100 + i/N; its loose bound on
+    // area - g_integral depends on how many hills land next to the wall)
+    for (int i = 0; i < N; i++) xs.push_back(-95 + 10 * i + i * (1. / N));
+    hs.assign(xs.size(), 1.5);
+    std::vector<double> added(xs.size());
+    g->add_values(xs.size(), xs.data(), 1, hs.data(), added.data());  // batched, in order
+    double g_integral = 0;
+    for (size_t i = 0; i < added.size(); i++) g_integral += added[i];
+    // integrate the grid by batched lookups
+    const double dx = 0.1;
+    const int bins = (int)(200 / dx);
+    std::vector<double> q(bins), e(bins);
+    for (int i = 0; i < bins; i++) q[i] = -100 + i * dx;
+    g->get_value_deriv_batch(bins, q.data(), 1, e.data(), NULL);
+    double area = 0;
+    for (int i = 0; i < bins; i++) area += e[i] * dx;
+    REQUIRE(std::pow(area - (double)xs.size() * 1.5, 2) < 1);
+    REQUIRE(std::pow(area - g_integral, 2) < 0.1);
+    delete g;
+  }
+}
+
+static void gauss_grid_derivative_tests() {  // edm_test.cpp:631-721
+  for (int mcgdp = 0; mcgdp < 2; mcgdp++) {
+    double mn[] = {-100}, mx[] = {100}, sg[] = {1.2}, sp[] = {1};
+    int per[] = {mcgdp ? 0 : 1};
+    HipGaussGrid* g = gauss(1, mn, mx, sp, per, 1, sg);
+    const int N = 20;
+    for (int i = 0; i < N; i++) {
+      double x[] = {lcg_rand() % 200 - 100 + i * (1. / N)};
+      g->add_value(x, 1.5);
+    }
+    const double dx = 0.1;
+    const int bins = (int)(200 / dx);
+    std::vector<double> q(bins), e(bins), d(bins);
+    for (int i = 0; i < bins; i++) q[i] = -100 + i * dx;
+    g->get_value_deriv_batch(bins, q.data(), 1, e.data(), d.data());
+    for (int i = 2; i < bins; i++) {
+      double approx = (e[i] - e[i - 2]) / (2 * dx);
+      REQUIRE(std::pow(approx - d[i - 1], 2) < (mcgdp ? 0.001 : 0.01));
+    }
+    if (mcgdp) {  // zero force at the non-periodic edges (:709, :719)
+      REQUIRE(std::pow(d[0], 2) < 0.001);
+      REQUIRE(std::pow(d[bins - 1], 2) < 0.01);
+    }
+    delete g;
+  }
+}
+
+static void gauss_grid_interp_test_mcgdp_1D() {  // edm_test.cpp:723-769
+  double mn[] = {-100}, mx[] = {100}, sg[] = {10.0}, sp[] = {1};
+  int per[] = {1};
+  HipGaussGrid* g = gauss(1, mn, mx, sp, per, 1, sg);
+  per[0] = 0;
+  mn[0] = -50;
+  mx[0] = 50;
+  g->set_boundary(mn, mx, per);
+  for (int i = 0; i < 20; i++) {
+    double x[] = {(double)(lcg_rand() % 200 - 100)};
+    g->add_value(x, 1.0);
+  }
+  const double* v = g->get_grid();
+  REQUIRE(std::pow(v[50] - v[49], 2) < EPSILON);    // boundaries were duplicated
+  REQUIRE(std::pow(v[150] - v[151], 2) < EPSILON);
+  // The reference's test expects V(50.1) == V(50.0) here (:752-755, :762-765), but the reference
+  // library itself returns 0 for a point outside a non-periodic boundary (gaussian_grid.h:109-113;
+  // confirmed by running the reference build: V(50.1) = 0, V(50.0) > 0), i.e. its own test fails
+  // at this line.  Parity is with the library's behaviour:
+  double x[] = {50.1}, der[1];
+  REQUIRE(g->get_value(x) == 0);
+  x[0] = 50.0;
+  REQUIRE(g->get_value(x) > 0);
+  g->get_value_deriv(x, der);
+  REQUIRE(der[0] * der[0] < EPSILON);   // zero force on the wall, even with interpolation (:758-759)
+  x[0] = -50.1;
+  REQUIRE(g->get_value(x) == 0);
+  x[0] = -50.0;
+  REQUIRE(g->get_value(x) > 0);
+  g->get_value_deriv(x, der);
+  REQUIRE(der[0] * der[0] < EPSILON);
+  delete g;
+}
+
+static void gauss_grid_interp_test_mcgdp_3D() {  // edm_test.cpp:771-818
+  double mn[] = {-10, -10, -10}, mx[] = {10, 10, 10}, sg[] = {3.0, 3.0, 3.0}, sp[] = {0.9, 1.1, 1.4};
+  int per[] = {1, 1, 1};
+  HipGaussGrid* g = gauss(3, mn, mx, sp, per, 1, sg);
+  per[0] = per[1] = per[2] = 0;
+  mn[0] = mn[1] = mn[2] = -5;
+  mx[0] = mx[1] = mx[2] = 5;
+  g->set_boundary(mn, mx, per);
+  for (int i = 0; i < 20; i++) {
+    double x[] = {(double)(lcg_rand() % 20 - 10), (double)(lcg_rand() % 20 - 10), (double)(lcg_rand() % 20 - 10)};
+    g->add_value(x, 5.0);
+  }
+  double x[3], der[3];
+  x[0] = x[2] = 50.1;
+  x[1] = 5.0;
+  double v = g->get_value(x);
+  x[0] = x[1] = 50.0;
+  REQUIRE(std::pow(v - g->get_value(x), 2) < EPSILON);
+  g->get_value_deriv(x, der);
+  REQUIRE(der[0] * der[0] < 0.001);
+  x[0] = -5.1;
+  x[2] = 5.1;
+  v = g->get_value(x);
+  x[0] = x[2] = -5.0;
+  REQUIRE(std::pow(v - g->get_value(x), 2) < 0.001);
+  g->get_value_deriv(x, der);
+  REQUIRE(der[0] * der[0] < EPSILON);
+  delete g;
+}
+
+static void gauss_grid_integral_regression_1() {  // edm_test.cpp:823-843
+  double mn[] = {0}, mx[] = {10}, sp[] = {0.009765625}, sg[] = {0.1};
+  int per[] = {1};
+  GaussGrid* g = make_gauss_grid(1, mn, mx, sp, per, 1, sg);
+  g->set_boundary(mn, mx, per);
+  double x[] = {-3.91944};
+  double added = g->add_value(x, 1.0);
+  REQUIRE(std::pow(added - 1.0, 2) < 0.1);
+  delete g;
+}
+
+static void edm_bias_tests(const std::string& fx, const std::string& scratch) {
+  // edm_sanity (edm_test.cpp:856-905)
+  std::string cfg = scratch + "/sanity_api.edm";
+  {
+    FILE* in = std::fopen((fx + "/sanity.edm").c_str(), "r");
+    FILE* out = std::fopen(cfg.c_str(), "w");
+    char buf[256];
+    while (in && std::fgets(buf, sizeof buf, in)) std::fputs(buf, out);
+    std::fprintf(out, "\nhills_filename %s/HILLS_api\nhistogram_filename %s/HIST_api\n", scratch.c_str(), scratch.c_str());
+    if (in) std::fclose(in);
+    std::fclose(out);
+  }
+  EDMBias bias(cfg);
+  bias.set_serial_format(1);
+  bias.setup(1, 1);
+  double low[] = {0, 0, 0}, high[] = {10, 0, 0}, skin[] = {0, 0, 0};
+  int p[] = {1, 0, 0};
+  bias.subdivide(low, high, low, high, p, skin);
+  REQUIRE(bias.dim_ == 1 && bias.b_tempering_ == 0);
+  double** positions = (double**)std::malloc(sizeof(double*));
+  positions[0] = (double*)std::malloc(sizeof(double) * 3);
+  double runiform[] = {1};
+  positions[0][0] = 5.0;
+  bias.add_hills(1, positions, runiform);
+  bias.write_bias(scratch + "/BIAS_api");
+  REQUIRE(std::pow(bias.bias_->get_value(positions[0]) - bias.hill_prefactor_ / std::sqrt(2 * M_PI) / bias.bias_sigma_[0], 2) < EPSILON);
+  REQUIRE(std::pow(bias.cum_bias_ - bias.hill_prefactor_, 2) < 0.001);
+  double der[1];
+  positions[0][0] = 4.99;
+  bias.bias_->get_value_deriv(positions[0], der);
+  REQUIRE(-der[0] < 0);
+  positions[0][0] = 5.01;
+  bias.bias_->get_value_deriv(positions[0], der);
+  REQUIRE(-der[0] > 0);
+  // update_forces on LAMMPS-style arrays with a group mask (edm_bias.cpp:276-295)
+  const int n = 1000;
+  double* xblock = (double*)std::malloc(sizeof(double) * n * 3);
+  double* fblock = (double*)std::calloc((size_t)n * 3, sizeof(double));
+  double** x = (double**)std::malloc(sizeof(double*) * n);
+  double** f = (double**)std::malloc(sizeof(double*) * n);
+  std::vector<int> mask(n);
+  for (int i = 0; i < n; i++) {
+    x[i] = xblock + 3 * i;
+    f[i] = fblock + 3 * i;
+    x[i][0] = 4.0 + 2.0 * i / n;
+    x[i][1] = x[i][2] = 99;
+    mask[i] = (i % 3 == 0) ? 2 : 1;
+  }
+  bias.set_mask(mask.data());
+  double e_all = bias.update_forces(n, x, f);
+  double e_sub = bias.update_forces(n, x, f, 2);
+  REQUIRE(e_all > e_sub && e_sub > 0);
+  double e1 = 0, f1[1] = {0};
+  e1 = bias.update_force(x[300], f1);
+  REQUIRE(std::fabs(f[300][0] - 2 * f1[0]) < 1e-12);  // row 300 is in the group: updated twice
+  REQUIRE(std::fabs(f[301][0] - f[301][0]) == 0 && f[301][1] == 0 && f[301][2] == 0);
+  REQUIRE(e1 > 0);
+  // the batched pair entry equals per-sample update_force
+  std::vector<double> r(n), fr(n);
+  for (int i = 0; i < n; i++) r[i] = x[i][0];
+  double ep = bias.update_pair_forces(n, r.data(), fr.data());
+  REQUIRE(std::fabs(ep - e_all) < 1e-9 * std::fabs(e_all));
+  REQUIRE(std::fabs(fr[300] - f1[0]) < 1e-9);
+  bias.write_histogram();
+  std::free(xblock); std::free(fblock); std::free(x); std::free(f);
+  std::free(positions[0]); std::free(positions);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::printf("usage: %s <fixture-dir> <scratch-dir>\n", argv[0]);
+    return 2;
+  }
+  grid_1d_sanity();
+  grid_3d_sanity();
+  interpolation_1d();
+  interp_1d_periodic();
+  interp_3d_mixed();
+  boundary_remap_wrap_3();
+  gauss_grid_add_check();
+  gauss_pbc_checks();
+  gauss_grid_integral_tests();
+  gauss_grid_derivative_tests();
+  gauss_grid_interp_test_mcgdp_1D();
+  gauss_grid_interp_test_mcgdp_3D();
+  gauss_grid_integral_regression_1();
+  edm_bias_tests(argv[1], argv[2]);
+  std::printf("%d checks, %d failed\n", g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}
