@@ -125,7 +125,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("EDM_BENCH_FORCE_DIST") == "1"  # exercise the N>1 plumbing with one rank
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist_mod
 
@@ -142,7 +143,7 @@ def main():
     npairs = args.pairs or W.W1_PAIRS
 
     b = H.Bias(make_bias(H, tmpdir, "gpu", rank))
-    if world > 1:
+    if dist is not None:
         import torch
 
         ident = [H.comm_unique_id() if rank == 0 else None]

@@ -496,8 +496,8 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     set_error("add_hills: apply_mask >= 0 needs set_mask");
     return EDM_HIP_ERR_ARG;
   }
-  if (b->b_targeting || (b->b_tempering && b->global_tempering < 0)) {
-    set_error("targeting / local tempering heights are not implemented on the device yet (SURVEY 8f#3)");
+  if (b->b_tempering && b->global_tempering < 0) {
+    set_error("local tempering (hill heights that depend on the bias under construction) is not implemented on the device yet (SURVEY 8f#3)");
     return EDM_HIP_ERR_ARG;
   }
   hipStream_t s = b->bias->stream;
@@ -538,13 +538,22 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   else
     this_h /= b->hill_density;
   this_h = fmin(this_h, BIAS_CLAMP * b->bias_per_step);
+  const double *d_heights = nullptr;
+  if (b->b_targeting) {
+    // per-hill heights: prefactor * exp(target(x) - <target>) / divisor, clamped (:545-558)
+    EDM_HIP_TRY(b->stage_h.reserve((size_t)nh));
+    const double divisor = (b->hill_density < 0) ? (double)b->est_hill_count : b->hill_density;
+    EDM_HIP_TRY(launch_target_heights(b->target->g, b->target->values, nh, d_x, x_stride, d_sel, b->temp_hill_prefactor,
+                                      b->expected_target, divisor, BIAS_CLAMP * b->bias_per_step, b->stage_h.p, s));
+    d_heights = b->stage_h.p;
+  }
 
   ApplySpec spec;
   spec.nh = nh;
   spec.d_x = d_x;
   spec.x_stride = x_stride;
   spec.d_sel = d_sel;
-  spec.d_h = nullptr;
+  spec.d_h = d_heights;
   spec.h_const = this_h;
   spec.limited = true;
   spec.flush_mode = 0;
@@ -564,10 +573,12 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   const int ntail = res.n_tail;
   const unsigned int dim = b->dim;
   const long long first = oc.first;
+  // base height of hill i (constant, or per hill when a target is set)
+  auto height_of = [&](long long i) { return oc.heights.empty() ? this_h : oc.heights[(size_t)(i - first)]; };
   if (log_all) {
     for (long long i = 0; i < k; i++) {
       b->hills_added++;
-      log_hill(b, &oc.pos[(size_t)(i - first) * dim], this_h, oc.added[(size_t)(i - first)], 'h');
+      log_hill(b, &oc.pos[(size_t)(i - first) * dim], height_of(i), oc.added[(size_t)(i - first)], 'h');
     }
   } else {
     b->hills_added += (int)k;
@@ -578,7 +589,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     const int fl = oc.flags[(size_t)j];
     if (fl & 1) {
       b->hills_added++;
-      log_hill(b, p, this_h, oc.added.empty() ? 0.0 : oc.added[(size_t)(k - first + j)], 'h');
+      log_hill(b, p, height_of(k + j), oc.added.empty() ? 0.0 : oc.added[(size_t)(k - first + j)], 'h');
       if (fl & 2) {
         b->hills_added++;
         log_hill(b, p, oc.h2[(size_t)j], oc.a2[(size_t)j], 'u');
@@ -587,7 +598,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       }
     } else {
       log_hill(b, p, 0, 0, 'h');                       // :493
-      rc = overflow_push(b, p, this_h);
+      rc = overflow_push(b, p, height_of(k + j));
       if (rc) return rc;
     }
   }

@@ -27,7 +27,7 @@ int hip_fail(hipError_t e, const char *what) {
 void HillWorkspace::release() {
   hx.release(); hx0.release(); ht.release(); added.release(); partial.release(); scratch.release();
   tail_h1.release(); tail_h2.release(); tail_a2.release(); tail_cum.release();
-  hc.release(); tail_flags.release(); tile_flags.release(); tile_list.release(); result.release();
+  hc.release(); tail_flags.release(); tile_flags.release(); tile_list.release(); result.release(); rb.release();
 }
 
 // grid.h:190-213
@@ -414,7 +414,7 @@ static int gauss_alloc(edm_hip_gauss *g) {
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->scratch), sizeof(double) * lookup_scratch_doubles()));
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_scalars), sizeof(double) * 16));
   EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_scalars), sizeof(double) * 64, hipHostMallocDefault));
-  g->h_stage_bytes = (size_t)4096 * (sizeof(int) + sizeof(double) * (3 + 3)) + 256;
+  g->h_stage_bytes = (size_t)4096 * (sizeof(int) + sizeof(double) * (3 + 3)) + 1024;
   EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_stage), g->h_stage_bytes, hipHostMallocDefault));
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_dirty), sizeof(int) * 4));
   EDM_HIP_TRY(hipMemset(g->d_dirty, 0, sizeof(int) * 4));
@@ -663,7 +663,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     out->res.cum_out = spec.cum_in;
     out->res.k = nh;
     out->total_added = 0;
-    out->flags.clear(); out->h2.clear(); out->a2.clear(); out->pos.clear(); out->added.clear();
+    out->flags.clear(); out->h2.clear(); out->a2.clear(); out->pos.clear(); out->added.clear(); out->heights.clear();
     out->first = nh;
   }
   if (nh <= 0) return EDM_HIP_OK;
@@ -684,6 +684,31 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   if (scratch_need < lookup_scratch_doubles()) scratch_need = lookup_scratch_doubles();
   EDM_HIP_TRY(ws.scratch.reserve(scratch_need));
 
+  // Small limited batches keep everything the host reads back -- limiter result, tail flags, undo
+  // heights/bias, per-hill bias and original positions -- in ONE packed device region, so the
+  // read-back is a single D2H copy.
+  const bool small = (nh <= SMALL_BATCH) && out && spec.limited;
+  LimitResult *dres = reinterpret_cast<LimitResult *>(ws.result.p);
+  int *p_flags = ws.tail_flags.p;
+  double *p_h2 = ws.tail_h2.p, *p_a2 = ws.tail_a2.p, *p_added = ws.added.p, *p_hx0 = ws.hx0.p;
+  size_t rb_bytes = 0;
+  const size_t off_flags = 64;
+  const size_t off_h2 = off_flags + ((sizeof(int) * (size_t)nh + 7) & ~(size_t)7);
+  const size_t off_a2 = off_h2 + sizeof(double) * (size_t)nh;
+  const size_t off_added = off_a2 + sizeof(double) * (size_t)nh;
+  const size_t off_pos = off_added + sizeof(double) * (size_t)nh;
+  if (small) {
+    rb_bytes = off_pos + sizeof(double) * (size_t)nh * dim;
+    EDM_HIP_TRY(ws.rb.reserve(rb_bytes));
+    char *base = ws.rb.p;
+    dres = reinterpret_cast<LimitResult *>(base);
+    p_flags = reinterpret_cast<int *>(base + off_flags);
+    p_h2 = reinterpret_cast<double *>(base + off_h2);
+    p_a2 = reinterpret_cast<double *>(base + off_a2);
+    p_added = reinterpret_cast<double *>(base + off_added);
+    p_hx0 = reinterpret_cast<double *>(base + off_pos);
+  }
+
   HillList hl;
   hl.nh = nh;
   hl.x = spec.d_x;
@@ -692,7 +717,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hl.hx = ws.hx.p;
   hl.hc = ws.hc.p;
   hl.ht = ws.ht.p;
-  hl.hx0 = ws.hx0.p;
+  hl.hx0 = p_hx0;
   const Tables tabs = g->tables();
   EDM_HIP_TRY(launch_hill_prep(q, hl, s));
 
@@ -701,18 +726,17 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hh.h_const = spec.h_const;
   hh.k = nh;
   hh.tail_h1 = ws.tail_h1.p;
-  hh.tail_h2 = ws.tail_h2.p;
+  hh.tail_h2 = p_h2;
   hh.res_dev = nullptr;
 
-  LimitResult *dres = reinterpret_cast<LimitResult *>(ws.result.p);
-  if (spec.limited || want_total) EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, ws.added.p, s));
+  if (spec.limited || want_total) EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s));
   if (spec.limited) {
-    LimitTail tail{ws.tail_h1.p, ws.tail_h2.p, ws.tail_a2.p, ws.tail_cum.p, ws.tail_flags.p};
-    EDM_HIP_TRY(launch_limit(nh, ws.added.p, spec.d_h, spec.h_const, spec.limit, spec.cum_in, spec.flush_mode, tail,
+    LimitTail tail{ws.tail_h1.p, p_h2, p_a2, ws.tail_cum.p, p_flags};
+    EDM_HIP_TRY(launch_limit(nh, p_added, spec.d_h, spec.h_const, spec.limit, spec.cum_in, spec.flush_mode, tail,
                              dres, ws.scratch.p, s));
     hh.res_dev = dres;  // the gather reads k on the device: no host round trip here
   } else if (want_total) {
-    EDM_HIP_TRY(launch_sum(nh, ws.added.p, g->d_scalars + 1, ws.scratch.p, s));
+    EDM_HIP_TRY(launch_sum(nh, p_added, g->d_scalars + 1, ws.scratch.p, s));
   }
 
   // gather plan: hill groups when a small grid meets a long hill list, tile culling
@@ -754,35 +778,31 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   // per undo (-1); a flush logs 'b' (+1) for replayed hills only and 'v' (-1) for its undo
   if (spec.hist_g && spec.hist_values) {
     if (!spec.limited || !spec.flush_mode)
-      EDM_HIP_TRY(launch_hist_add(*spec.hist_g, spec.hist_values, nh, ws.hx0.p, dim, nullptr, nullptr, 1.0, s));
+      EDM_HIP_TRY(launch_hist_add(*spec.hist_g, spec.hist_values, nh, p_hx0, dim, nullptr, nullptr, 1.0, s));
     if (spec.limited)
-      EDM_HIP_TRY(launch_hist_tail(*spec.hist_g, spec.hist_values, dres, ws.tail_flags.p, ws.hx0.p,
-                                   spec.flush_mode ? 1 : 0, s));
+      EDM_HIP_TRY(launch_hist_tail(*spec.hist_g, spec.hist_values, dres, p_flags, p_hx0, spec.flush_mode ? 1 : 0, s));
   }
 
-  // ---- read-back: one async burst for small batches ----
+  // ---- read-back ----
   LimitResult res;
   memset(&res, 0, sizeof(res));
   res.k = nh;
   res.cum_out = spec.cum_in;
   LimitResult *hres = reinterpret_cast<LimitResult *>(g->h_scalars + 8);
-  const bool small = (nh <= SMALL_BATCH) && out && spec.limited;
   char *stage = g->h_stage;
-  int *st_flags = reinterpret_cast<int *>(stage);
-  double *st_h2 = reinterpret_cast<double *>(stage + sizeof(int) * SMALL_BATCH);
-  double *st_a2 = st_h2 + SMALL_BATCH;
-  double *st_added = st_a2 + SMALL_BATCH;
-  double *st_pos = st_added + SMALL_BATCH;
-  if (spec.limited) EDM_HIP_TRY(hipMemcpyAsync(hres, dres, sizeof(LimitResult), hipMemcpyDeviceToHost, s));
+  if (small) {
+    EDM_HIP_TRY(hipMemcpyAsync(stage, ws.rb.p, rb_bytes, hipMemcpyDeviceToHost, s));
+    hres = reinterpret_cast<LimitResult *>(stage);
+  } else if (spec.limited) {
+    EDM_HIP_TRY(hipMemcpyAsync(hres, dres, sizeof(LimitResult), hipMemcpyDeviceToHost, s));
+  }
   if (want_total && !spec.limited)
     EDM_HIP_TRY(hipMemcpyAsync(g->h_scalars + 1, g->d_scalars + 1, sizeof(double), hipMemcpyDeviceToHost, s));
-  if (small) {
-    EDM_HIP_TRY(hipMemcpyAsync(st_flags, ws.tail_flags.p, sizeof(int) * (size_t)nh, hipMemcpyDeviceToHost, s));
-    EDM_HIP_TRY(hipMemcpyAsync(st_h2, ws.tail_h2.p, sizeof(double) * (size_t)nh, hipMemcpyDeviceToHost, s));
-    EDM_HIP_TRY(hipMemcpyAsync(st_a2, ws.tail_a2.p, sizeof(double) * (size_t)nh, hipMemcpyDeviceToHost, s));
-    EDM_HIP_TRY(hipMemcpyAsync(st_added, ws.added.p, sizeof(double) * (size_t)nh, hipMemcpyDeviceToHost, s));
-    EDM_HIP_TRY(hipMemcpyAsync(st_pos, ws.hx0.p, sizeof(double) * (size_t)nh * dim, hipMemcpyDeviceToHost, s));
-  }
+  const int *st_flags = reinterpret_cast<const int *>(stage + off_flags);
+  const double *st_h2 = reinterpret_cast<const double *>(stage + off_h2);
+  const double *st_a2 = reinterpret_cast<const double *>(stage + off_a2);
+  const double *st_added = reinterpret_cast<const double *>(stage + off_added);
+  const double *st_pos = reinterpret_cast<const double *>(stage + off_pos);
   EDM_HIP_TRY(hipStreamSynchronize(s));
   if (spec.limited) {
     res = *hres;
@@ -794,6 +814,13 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   if (out) {
     out->res = res;
     if (want_total && !spec.limited) out->total_added = g->h_scalars[1];
+    if (spec.d_h && spec.limited) {
+      const long long f0 = spec.fetch_all ? 0 : res.k;
+      if (nh - f0 > 0) {
+        out->heights.resize((size_t)(nh - f0));
+        EDM_HIP_TRY(hipMemcpy(out->heights.data(), spec.d_h + f0, sizeof(double) * (size_t)(nh - f0), hipMemcpyDeviceToHost));
+      }
+    }
     const long long k = res.k;
     const int ntail = spec.limited ? res.n_tail : 0;
     const long long first = spec.fetch_all ? 0 : k;
@@ -810,16 +837,16 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         out->flags.resize((size_t)ntail);
         out->h2.resize((size_t)ntail);
         out->a2.resize((size_t)ntail);
-        EDM_HIP_TRY(hipMemcpy(out->flags.data(), ws.tail_flags.p, sizeof(int) * (size_t)ntail, hipMemcpyDeviceToHost));
-        EDM_HIP_TRY(hipMemcpy(out->h2.data(), ws.tail_h2.p, sizeof(double) * (size_t)ntail, hipMemcpyDeviceToHost));
-        EDM_HIP_TRY(hipMemcpy(out->a2.data(), ws.tail_a2.p, sizeof(double) * (size_t)ntail, hipMemcpyDeviceToHost));
+        EDM_HIP_TRY(hipMemcpy(out->flags.data(), p_flags, sizeof(int) * (size_t)ntail, hipMemcpyDeviceToHost));
+        EDM_HIP_TRY(hipMemcpy(out->h2.data(), p_h2, sizeof(double) * (size_t)ntail, hipMemcpyDeviceToHost));
+        EDM_HIP_TRY(hipMemcpy(out->a2.data(), p_a2, sizeof(double) * (size_t)ntail, hipMemcpyDeviceToHost));
       }
       if (need > 0) {
         out->pos.resize((size_t)need * dim);
-        EDM_HIP_TRY(hipMemcpy(out->pos.data(), ws.hx0.p + (size_t)first * dim, sizeof(double) * (size_t)need * dim,
+        EDM_HIP_TRY(hipMemcpy(out->pos.data(), p_hx0 + (size_t)first * dim, sizeof(double) * (size_t)need * dim,
                               hipMemcpyDeviceToHost));
         out->added.resize((size_t)need);
-        EDM_HIP_TRY(hipMemcpy(out->added.data(), ws.added.p + first, sizeof(double) * (size_t)need, hipMemcpyDeviceToHost));
+        EDM_HIP_TRY(hipMemcpy(out->added.data(), p_added + first, sizeof(double) * (size_t)need, hipMemcpyDeviceToHost));
       }
     }
   }

@@ -52,6 +52,7 @@ struct HillWorkspace {
   DevBuf<double> hx, hx0, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum;
   DevBuf<int> hc, tail_flags, tile_flags, tile_list;
   DevBuf<char> result;      // LimitResult
+  DevBuf<char> rb;          // packed read-back region of small batches (one D2H instead of six)
   void release();
 };
 
@@ -126,6 +127,7 @@ struct ApplyOutcome {
   // original positions (and bias_added when fetch_all) of hills [first, nh)
   long long first = 0;
   std::vector<double> pos, added;
+  std::vector<double> heights;     // per-hill base heights of [first, nh) when spec.d_h was given
 };
 // prep -> integrals -> (limiter) -> ordered gather -> boundary duplication.
 // Leaves per-hill `added` in g->ws.added and the tail arrays in g->ws.tail_*.

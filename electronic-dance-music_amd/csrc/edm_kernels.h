@@ -133,6 +133,14 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
 hipError_t launch_hist_tail(const Geom &hist, double *values, const LimitResult *res_dev, const int *flags,
                             const double *hx0, int plus_for_applied, hipStream_t s);
 
+// hill heights with a target factor (edm_bias.cpp:537-558):
+//   h_i = min( prefactor * exp(T(x_i) - expected) / divisor , clamp )
+// T = Grid::get_value on the target grid read WITHOUT interpolation (nearest-lower node, 0 outside
+// in_grid; grid.h:343-365), evaluated at the un-remapped sample position.
+hipError_t launch_target_heights(const Geom &target, const double *target_values, long long n, const double *x,
+                                 int x_stride, const long long *sel, double prefactor, double expected,
+                                 double divisor, double clamp, double *out_h, hipStream_t s);
+
 // out[i][0..dim) = x[(sel ? sel[i] : i) * x_stride + 0..dim): contiguous hill records for the exchange
 hipError_t launch_gather_positions(long long n, const double *x, int x_stride, const long long *sel, int dim,
                                    double *out, hipStream_t s);

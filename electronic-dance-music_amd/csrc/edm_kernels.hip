@@ -63,6 +63,54 @@ __global__ void __launch_bounds__(BLOCK) k_block_sums(const double *__restrict__
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_target_heights(Geom g, const double *__restrict__ values, long long n,
+                                                          const double *__restrict__ x, int x_stride,
+                                                          const long long *__restrict__ sel, double prefactor,
+                                                          double expected, double divisor, double clamp,
+                                                          double *__restrict__ out_h) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    const long long src = sel ? sel[i] : i;
+    double xx[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) xx[d] = x[src * x_stride + d];
+    double t = 0;
+    if (in_grid<DIM>(g, xx)) {
+      long long idx[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        double w;
+        idx[d] = node_index(g, d, xx[d], &w);
+        if (idx[d] > g.n[d] - 1) idx[d] = g.n[d] - 1;
+        if (idx[d] < 0) idx[d] = 0;
+      }
+      long long flat = idx[DIM - 1];
+#pragma unroll
+      for (int d = DIM - 1; d > 0; d--) flat = flat * g.n[d - 1] + idx[d - 1];
+      t = values[flat];
+    }
+    double h = prefactor;
+    h *= exp(t - expected);   // :546
+    h /= divisor;             // :552-555
+    h = fmin(h, clamp);       // :558
+    out_h[i] = h;
+  }
+}
+hipError_t launch_target_heights(const Geom &target, const double *target_values, long long n, const double *x,
+                                 int x_stride, const long long *sel, double prefactor, double expected,
+                                 double divisor, double clamp, double *out_h, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  long long b = (n + BLOCK - 1) / BLOCK;
+  if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+  switch (target.dim) {
+    case 1: hipLaunchKernelGGL(k_target_heights<1>, dim3((unsigned)b), dim3(BLOCK), 0, s, target, target_values, n, x, x_stride, sel, prefactor, expected, divisor, clamp, out_h); break;
+    case 2: hipLaunchKernelGGL(k_target_heights<2>, dim3((unsigned)b), dim3(BLOCK), 0, s, target, target_values, n, x, x_stride, sel, prefactor, expected, divisor, clamp, out_h); break;
+    default: hipLaunchKernelGGL(k_target_heights<3>, dim3((unsigned)b), dim3(BLOCK), 0, s, target, target_values, n, x, x_stride, sel, prefactor, expected, divisor, clamp, out_h); break;
+  }
+  return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(BLOCK) k_gather_positions(long long n, const double *__restrict__ x, int x_stride,
                                                             const long long *__restrict__ sel, int dim,
                                                             double *__restrict__ out) {
@@ -767,21 +815,41 @@ struct NodeTerms {
   double xx[DIM];                    // node coordinate                     (:270)
   double t2[DIM], t4[DIM];           // zero-force blend at the two walls   (:311,:313)
   double t6[DIM], t7[DIM];           // its derivatives                     (:322-323)
-  double den[DIM], dden[DIM];        // table entries at bc_index           (:308,:318,:335)
+  double dden[DIM];                  // derivative-table entry at bc_index  (:335)
+  // bc_denom after dimension d is a product of node-only factors (table entries :318 or
+  // sqrt(pi)*sigma :340), so it and its reciprocals are computed ONCE per node:
+  double dprod[DIM], inv_dprod[DIM], inv_dprod2[DIM];
   bool inside;                       // node lies within every non-periodic boundary (:273)
 };
+
+// per-launch constants of the stencil term
+template <int DIM>
+struct TermConst {
+  double inv_sigma[DIM], period[DIM], inv_period[DIM];
+};
+template <int DIM>
+__device__ __forceinline__ void term_const(const Geom &g, TermConst<DIM> &tc) {
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    tc.inv_sigma[d] = 1.0 / g.sigma[d];
+    tc.period[d] = g.max[d] - g.min[d];
+    tc.inv_period[d] = 1.0 / (g.max[d] - g.min[d]);
+  }
+}
 
 template <int DIM>
 __device__ __forceinline__ void node_terms(const Geom &g, const Tables &t, const int *p, NodeTerms<DIM> &nt) {
   nt.inside = true;
+  double running = 1.0;
 #pragma unroll
   for (int d = 0; d < DIM; d++) {
     const double xx = g.min[d] + g.dx[d] * (size_t)p[d];
     nt.xx[d] = xx;
     nt.t2[d] = nt.t4[d] = nt.t6[d] = nt.t7[d] = 0;
-    nt.den[d] = 1;
     nt.dden[d] = 0;
+    double factor = sqrt(M_PI) * g.sigma[d];
     if (!g.bper[d]) {
+      factor = 1.0;
       if (xx < g.bmin[d] || xx > g.bmax[d]) {
         nt.inside = false;
       } else {
@@ -791,56 +859,78 @@ __device__ __forceinline__ void node_terms(const Geom &g, const Tables &t, const
         nt.t4[d] = smooth_step((g.bmax[d] - xx) / (sg * EDM_BC_MAR));
         nt.t6[d] = smooth_step_dt((xx - g.bmin[d]) / (sg * EDM_BC_MAR)) / (EDM_BC_MAR * sg);
         nt.t7[d] = -smooth_step_dt((g.bmax[d] - xx) / (sg * EDM_BC_MAR)) / (EDM_BC_MAR * sg);
-        nt.den[d] = t.denom[d][ti];
+        factor = t.denom[d][ti];
         nt.dden[d] = t.dderiv[d][ti];
       }
     }
+    running *= factor;
+    nt.dprod[d] = running;
+    nt.inv_dprod[d] = 1.0 / running;
+    nt.inv_dprod2[d] = 1.0 / (running * running);
   }
 }
 
-// One (node, hill) term: val multiplies the height for V, dval[d] for dV/ds_d.
-// Returns false when the node is outside the hill's support (dp2 >= 8).
+// One (node, hill) term: val multiplies the height for V, dval[d] for dV/ds_d.  Returns false when
+// the node is outside the hill's support (dp2 >= 8).  Same formulas as gaussian_grid.h:284-355 with
+// every division replaced by a multiplication with a node- or launch-constant reciprocal (values
+// move by ~1e-16 relative; the accumulation ORDER over hills is untouched).
 template <int DIM>
-__device__ __forceinline__ bool pair_term(const Geom &g, const NodeTerms<DIM> &nt, const double *hx,
-                                          const double *ht, double &val, double *dval, bool &corr_nonzero) {
-  double dp[DIM];
+__device__ __forceinline__ bool pair_term(const Geom &g, const TermConst<DIM> &tc, const NodeTerms<DIM> &nt,
+                                          const double *hx, const double *ht, double &val, double *dval,
+                                          bool &corr_nonzero) {
+  double dp[DIM], raw[DIM];
   double dp2 = 0;
+  bool edge = false;
 #pragma unroll
   for (int d = 0; d < DIM; d++) {
-    dp[d] = nt.xx[d] - hx[d];
-    if (g.periodic[d]) dp[d] -= round_half(dp[d] / (g.max[d] - g.min[d])) * (g.max[d] - g.min[d]);
-    dp[d] /= g.sigma[d];
+    raw[d] = nt.xx[d] - hx[d];
+    if (g.periodic[d]) {
+      const double turns = raw[d] * tc.inv_period[d];
+      // the nearest-image choice (:287-291) must match the reference's round(dp / period) exactly
+      if (fabs(fabs(turns - floor(turns)) - 0.5) < 1e-9) edge = true;
+      raw[d] -= round_half(turns) * tc.period[d];
+    }
+    dp[d] = raw[d] * tc.inv_sigma[d];
     dp2 += dp[d] * dp[d];
+  }
+  // ... and so must the support test dp2 < 8 (:299): within rounding of the edge (nodes that sit
+  // exactly sqrt(8) sigma away are common on coarse grids) redo it with the reference's divisions
+  if (edge || fabs(dp2 - EDM_GAUSS_SUPPORT) < 1e-9) {
+    dp2 = 0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      double e = nt.xx[d] - hx[d];
+      if (g.periodic[d]) e -= round_half(e / (g.max[d] - g.min[d])) * (g.max[d] - g.min[d]);
+      e /= g.sigma[d];
+      dp[d] = e;
+      dp2 += e * e;
+    }
   }
   if (!(dp2 < EDM_GAUSS_SUPPORT)) return false;
   double expo = exp(-dp2);
-  double denom = 1.0, corr = 0;
+  double corr = 0;
   double force[DIM];
 #pragma unroll
   for (int d = 0; d < DIM; d++) {
     force[d] = 0;
     if (!g.bper[d]) {
-      const double sg = g.sigma[d];
       const double t1 = ht[2 * d], t3 = ht[2 * d + 1];
       corr = (t1 - expo) * nt.t2[d] + (t3 - expo) * nt.t4[d];  // overwritten per dim (:316)
-      denom *= nt.den[d];
-      const double t5 = -2 * dp[d] / sg;
+      const double t5 = -2 * dp[d] * tc.inv_sigma[d];
       double F = t5 * expo;
       F += (t1 - expo) * nt.t6[d] - t5 * expo * nt.t2[d] + (t3 - expo) * nt.t7[d] - t5 * expo * nt.t4[d];
-      F = F * denom - nt.dden[d] * (expo + corr);
-      F /= denom * denom;
-      corr /= denom;
+      F = F * nt.dprod[d] - nt.dden[d] * (expo + corr);
+      F *= nt.inv_dprod2[d];
+      corr *= nt.inv_dprod[d];
       force[d] = F;
-    } else {
-      denom *= sqrt(M_PI) * g.sigma[d];
     }
   }
-  expo /= denom;
+  expo *= nt.inv_dprod[DIM - 1];
   val = expo + corr;
 #pragma unroll
   for (int d = 0; d < DIM; d++) {
     if (g.bper[d])
-      dval[d] = -(2 * dp[d] / g.sigma[d] * expo);
+      dval[d] = -(2 * dp[d] * tc.inv_sigma[d] * expo);
     else
       dval[d] = force[d];
   }
@@ -859,6 +949,8 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
   const int lane = threadIdx.x & 63;
   const long long hill = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   if (hill >= h.nh) return;
+  TermConst<DIM> tc;
+  term_const<DIM>(g, tc);
   double acc = 0;
   const int c0 = h.hc[hill * DIM];
   if (c0 != INT_MIN) {
@@ -906,7 +998,7 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
       if (!nt.inside) continue;
       double val, dval[DIM];
       bool nz;
-      if (!pair_term<DIM>(g, nt, hx, ht, val, dval, nz)) continue;
+      if (!pair_term<DIM>(g, tc, nt, hx, ht, val, dval, nz)) continue;
       acc += height * val * vol;
     }
   }
@@ -1040,58 +1132,110 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
   }
   bool any_corr = false;
 
-  for (long long i = hbeg; i < hend; i++) {
-    // wave-uniform part: centre node and tile overlap (scalar loads)
+  // The hill list is walked in order, a chunk of BLOCK hills at a time: every thread tests ONE hill
+  // of the chunk against this workgroup's tile (coalesced loads instead of a dependent scalar-load
+  // chain), the overlapping hills are compacted IN ORDER into LDS (ballot prefix), and all threads
+  // then walk that short list together -- ILP entries at a time so independent exp chains overlap
+  // -- accumulating strictly in list order: the sums are those of the sequential reference.
+  __shared__ int s_c[BLOCK][DIM];
+  __shared__ double s_x[BLOCK][DIM];
+  __shared__ double s_t[BLOCK][2 * DIM];
+  __shared__ double s_h1[BLOCK], s_h2[BLOCK];
+  __shared__ int s_wcnt[BLOCK / 64];
+  TermConst<DIM> tc;
+  term_const<DIM>(g, tc);
+  constexpr int ILP = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long long base = hbeg; base < hend; base += BLOCK) {
+    const long long cur = base + threadIdx.x;
+    bool take = false;
     int c[DIM];
-    c[0] = h.hc[i * DIM];
-    if (c[0] == INT_MIN) continue;
-    bool overlap = true;
+    double h1 = 0, h2 = 0;
+    if (cur < hend) {
+      c[0] = h.hc[cur * DIM];
+      if (c[0] != INT_MIN) {
+        take = true;
 #pragma unroll
-    for (int d = 0; d < DIM; d++) {
-      if (d > 0) c[d] = h.hc[i * DIM + d];
-      const int T = Tile<DIM>::T[d];
-      int t1 = t0[d] + T - 1;
-      if (t1 > g.n[d] - 1) t1 = g.n[d] - 1;
-      if (images(g, d, c[d], t0[d], t1) == 0) overlap = false;
-    }
-    if (!overlap) continue;
-    double h1, h2;
-    if (i < k_first_tail) {
-      h1 = hh.h ? hh.h[i] : hh.h_const;
-      h2 = 0;
-    } else {
-      h1 = hh.tail_h1[i - k_first_tail];
-      h2 = hh.tail_h2[i - k_first_tail];
-    }
-    if (h1 == 0 && h2 == 0) continue;  // hill deferred to the overflow buffer: add_value is never called
-    if (!active) continue;
-    int mult = 1;
-#pragma unroll
-    for (int d = 0; d < DIM; d++) mult *= images(g, d, c[d], p[d], p[d]);
-    if (mult == 0) continue;
-    double hx[DIM], ht[2 * DIM];
-#pragma unroll
-    for (int d = 0; d < DIM; d++) {
-      hx[d] = h.hx[i * DIM + d];
-      ht[2 * d] = h.ht[i * 2 * DIM + 2 * d];
-      ht[2 * d + 1] = h.ht[i * 2 * DIM + 2 * d + 1];
-    }
-    double val, dval[DIM];
-    bool nz;
-    if (!pair_term<DIM>(g, nt, hx, ht, val, dval, nz)) continue;
-    any_corr |= nz;
-    for (int rep = 0; rep < mult; rep++) {
-      acc[0] += h1 * val;
-#pragma unroll
-      for (int d = 0; d < DIM; d++) acc[1 + d] += h1 * dval[d];
-    }
-    if (h2 != 0) {
-      for (int rep = 0; rep < mult; rep++) {
-        acc[0] += h2 * val;
-#pragma unroll
-        for (int d = 0; d < DIM; d++) acc[1 + d] += h2 * dval[d];
+        for (int d = 0; d < DIM; d++) {
+          if (d > 0) c[d] = h.hc[cur * DIM + d];
+          const int T = Tile<DIM>::T[d];
+          int t1 = t0[d] + T - 1;
+          if (t1 > g.n[d] - 1) t1 = g.n[d] - 1;
+          if (images(g, d, c[d], t0[d], t1) == 0) take = false;
+        }
+        if (take) {
+          if (cur < k_first_tail) {
+            h1 = hh.h ? hh.h[cur] : hh.h_const;
+            h2 = 0;
+          } else {
+            h1 = hh.tail_h1[cur - k_first_tail];
+            h2 = hh.tail_h2[cur - k_first_tail];
+          }
+          if (h1 == 0 && h2 == 0) take = false;  // deferred to the overflow buffer: add_value is never called
+        }
       }
     }
+    const unsigned long long bal = __ballot(take);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int pos = __popcll(bal & ((1ull << lane) - 1ull));
+    int cnt = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) {
+      if (w < wave) pos += s_wcnt[w];
+      cnt += s_wcnt[w];
+    }
+    if (take) {
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        s_c[pos][d] = c[d];
+        s_x[pos][d] = h.hx[cur * DIM + d];
+        s_t[pos][2 * d] = h.ht[cur * 2 * DIM + 2 * d];
+        s_t[pos][2 * d + 1] = h.ht[cur * 2 * DIM + 2 * d + 1];
+      }
+      s_h1[pos] = h1;
+      s_h2[pos] = h2;
+    }
+    __syncthreads();
+    if (active) {
+      for (int q0 = 0; q0 < cnt; q0 += ILP) {
+        double val[ILP], dval[ILP][DIM];
+        int mult[ILP];
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+          mult[q] = 0;
+          if (q0 + q < cnt) {
+            int m = 1;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) m *= images(g, d, s_c[q0 + q][d], p[d], p[d]);
+            bool nz = false;
+            if (m > 0 && pair_term<DIM>(g, tc, nt, s_x[q0 + q], s_t[q0 + q], val[q], dval[q], nz)) {
+              mult[q] = m;
+              any_corr |= nz;
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+          if (mult[q] > 0) {
+            const double a1 = s_h1[q0 + q], a2 = s_h2[q0 + q];
+            for (int rep = 0; rep < mult[q]; rep++) {
+              acc[0] += a1 * val[q];
+#pragma unroll
+              for (int d = 0; d < DIM; d++) acc[1 + d] += a1 * dval[q][d];
+            }
+            if (a2 != 0) {
+              for (int rep = 0; rep < mult[q]; rep++) {
+                acc[0] += a2 * val[q];
+#pragma unroll
+                for (int d = 0; d < DIM; d++) acc[1 + d] += a2 * dval[q][d];
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
   }
   if (active) {
     double *dst = (G == 1) ? rec + flat * R : plan.partial + ((long long)grp * g.total + flat) * R;
@@ -1352,39 +1496,50 @@ __global__ void __launch_bounds__(BLOCK) k_chunk_stats(long long nh, const doubl
   }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_limit(long long nh, const double *__restrict__ added,
-                                                 const double *__restrict__ heights, double h_const, double limit,
-                                                 double cum_in, int flush_mode, LimitTail tail,
-                                                 LimitResult *__restrict__ res, long long nchunks,
-                                                 const double *__restrict__ chunk_sum,
-                                                 const double *__restrict__ chunk_max) {
-  __shared__ long long k_sh;
-  __shared__ double cum_sh;
-  __shared__ double a_sh[BLOCK];
-  __shared__ double h_sh[BLOCK];
-  if (threadIdx.x == 0) {
-    long long k = 0;
-    double cum = cum_in;
-    // skip whole chunks that cannot reach the limit (not in flush mode: the flush list is short)
-    if (!flush_mode && nchunks > 0) {
-      long long c = 0;
-      for (; c < nchunks; c++) {
-        if (!(cum < limit)) break;
-        if (cum + chunk_max[c] >= limit) break;
-        cum += chunk_sum[c];
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(64) k_limit(long long nh, const double *__restrict__ added,
+                                              const double *__restrict__ heights, double h_const, double limit,
+                                              double cum_in, int flush_mode, LimitTail tail,
+                                              LimitResult *__restrict__ res, long long nchunks,
+                                              const double *__restrict__ chunk_sum,
+                                              const double *__restrict__ chunk_max) {
+  // One wave.  Every lane runs the same (uniform) walk; the hills of a 64-wide slab sit one per
+  // lane in registers and are broadcast by v_readlane, so an iteration is a handful of dependent
+  // fp64 instructions instead of an LDS round trip; lane j keeps the outcome of hill j and the
+  // slab is stored coalesced.
+  const int lane = threadIdx.x;
+  long long k = 0;
+  double cum = cum_in;  // new-hill mode: temp_hill_cum_; flush mode: bias added by this flush
+  // skip whole chunks that cannot reach the limit (not in flush mode: the flush list is short)
+  if (!flush_mode && nchunks > 0) {
+    long long c = 0;
+    bool done = false;
+    for (long long cb = 0; cb < nchunks && !done; cb += 64) {
+      const double cs_l = (cb + lane < nchunks) ? chunk_sum[cb + lane] : 0.0;
+      const double cm_l = (cb + lane < nchunks) ? chunk_max[cb + lane] : 0.0;
+      const int lim = (nchunks - cb < 64) ? (int)(nchunks - cb) : 64;
+      for (int j = 0; j < lim; j++) {
+        const double cs = readlane_f64(cs_l, j), cm = readlane_f64(cm_l, j);
+        if (!(cum < limit) || cum + cm >= limit) {
+          done = true;
+          break;
+        }
+        cum += cs;
+        c++;
       }
-      k = c * EDM_CHUNK;
-      if (k > nh) k = nh;
     }
-    k_sh = k;
-    cum_sh = cum;
+    k = c * EDM_CHUNK;
+    if (k > nh) k = nh;
   }
-  __syncthreads();
-  const long long k = k_sh;
   const long long ntail = nh - k;
   if (ntail > EDM_TAIL_CAP) {
-    if (threadIdx.x == 0) {
-      res->cum_out = cum_sh;
+    if (lane == 0) {
+      res->cum_out = cum;
       res->k = k;
       res->n_tail = 0;
       res->stop = 0;
@@ -1393,63 +1548,92 @@ __global__ void __launch_bounds__(BLOCK) k_limit(long long nh, const double *__r
     }
     return;
   }
-  double cum = cum_sh;        // new-hill mode: temp_hill_cum_; flush mode: bias added by this flush
+  // Ordered walk, one 64-hill slab at a time.  Between two crossings of the limit nothing depends
+  // on more than the running sum, so each segment is one wave prefix-sum plus a ballot that finds
+  // the next hill at which edm_bias.cpp:465 / :474 (or :334 of the flush) change regime; the loop
+  // below runs (crossings + 1) times per slab instead of once per hill.
   int n_def = 0;
   int stop = (int)ntail;
   bool stopped = false;
-  for (long long base = 0; base < ntail; base += BLOCK) {
-    const long long i = k + base + threadIdx.x;
-    a_sh[threadIdx.x] = (i < nh) ? added[i] : 0.0;
-    h_sh[threadIdx.x] = (i < nh) ? (heights ? heights[i] : h_const) : 0.0;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int lim = (ntail - base < BLOCK) ? (int)(ntail - base) : BLOCK;
-      for (int j = 0; j < lim; j++) {
-        const long long ti = base + j;
-        const double a = a_sh[j], hgt = h_sh[j];
-        double h1 = 0, h2 = 0, a2 = 0;
-        int fl = 0;
-        if (flush_mode) {
-          if (!stopped) {
-            h1 = hgt;
-            fl = 1;
-            cum += a;                                   // bias_added += temp            (:328)
-            if (cum > limit) {                          //                               (:334)
-              h2 = fmax(limit - cum, -hgt);             //                               (:338)
-              a2 = (hgt != 0.0) ? h2 * (a / hgt) : 0.0; // add_value(pos, h) is linear in h
-              cum += a2;
-              fl |= 2;
-              stop = (int)ti;
-              stopped = true;
-            }
-          }
-        } else {
-          if (cum < limit) {                            //                               (:465)
-            h1 = hgt;
-            fl = 1;
-            cum += a;
-            if (cum > limit) {                          //                               (:474)
-              h2 = fmax(limit - cum, -hgt);             //                               (:479)
-              a2 = (hgt != 0.0) ? h2 * (a / hgt) : 0.0;
-              cum += a2;
-              fl |= 2 | 4;
-              n_def++;
-            }
-          } else {
-            fl = 4;                                     // whole hill deferred           (:493-494)
-            n_def++;
-          }
+  for (long long base = 0; base < ntail; base += 64) {
+    const long long mine = k + base + lane;
+    const double a_l = (mine < nh) ? added[mine] : 0.0;
+    const double h_l = (mine < nh) ? (heights ? heights[mine] : h_const) : 0.0;
+    // add_value(pos, h) is linear in h: the undo hill's bias is h2 * (added / height)
+    const double q_l = (h_l != 0.0) ? a_l / h_l : 0.0;
+    double o_h1 = 0, o_h2 = 0, o_a2 = 0, o_cum = 0;
+    int o_fl = 0;
+    const int lim = (ntail - base < 64) ? (int)(ntail - base) : 64;
+    int start = 0;
+    while (start < lim) {
+      if (flush_mode ? stopped : !(cum < limit)) {
+        // flush already stopped: nothing more is replayed; new hills: every remaining hill is deferred
+        if (lane >= start && lane < lim) {
+          o_fl = flush_mode ? 0 : 4;
+          o_cum = cum;
         }
-        tail.h1[ti] = h1;
-        tail.h2[ti] = h2;
-        tail.added2[ti] = a2;
-        tail.cum_after[ti] = cum;
-        tail.flags[ti] = fl;
+        if (!flush_mode) n_def += lim - start;
+        start = lim;
+        break;
       }
+      // inclusive prefix of the bias over lanes [start, lim)
+      double ps = (lane >= start && lane < lim) ? a_l : 0.0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(ps, o, 64);
+        if (lane >= o) ps += up;
+      }
+      const double P = cum + ps;
+      // first hill of the segment after which the regime changes
+      const bool hit = (lane >= start && lane < lim) && (flush_mode ? (P > limit) : !(P < limit));
+      const unsigned long long bal = __ballot(hit);
+      const int j1 = bal ? (int)__builtin_ctzll(bal) : lim;
+      if (lane >= start && lane < j1 && lane < lim) {  // added in full
+        o_h1 = h_l;
+        o_fl = 1;
+        o_cum = P;
+      }
+      if (j1 >= lim) {
+        cum = readlane_f64(P, lim - 1);
+        start = lim;
+        break;
+      }
+      // hill j1: added, and undone if it overshoots (:474-490 / :334-355)
+      const double Pj = readlane_f64(P, j1), hj = readlane_f64(h_l, j1), qj = readlane_f64(q_l, j1);
+      double h2 = 0, a2 = 0;
+      int fl = 1;
+      double after = Pj;
+      if (Pj > limit) {
+        h2 = fmax(limit - Pj, -hj);
+        a2 = h2 * qj;
+        after = Pj + a2;
+        fl = flush_mode ? 3 : 7;
+        if (!flush_mode) n_def++;
+        if (flush_mode) {
+          stop = (int)(base + j1);
+          stopped = true;
+        }
+      }
+      if (lane == j1) {
+        o_h1 = hj;
+        o_h2 = h2;
+        o_a2 = a2;
+        o_cum = after;
+        o_fl = fl;
+      }
+      cum = after;
+      start = j1 + 1;
     }
-    __syncthreads();
+    if (lane < lim) {
+      const long long ti = base + lane;
+      tail.h1[ti] = o_h1;
+      tail.h2[ti] = o_h2;
+      tail.added2[ti] = o_a2;
+      tail.cum_after[ti] = o_cum;
+      tail.flags[ti] = o_fl;
+    }
   }
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     res->cum_out = cum;
     res->k = k;
     res->n_tail = (int)ntail;
@@ -1472,7 +1656,7 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
     cmax = scratch + nchunks;
     hipLaunchKernelGGL(k_chunk_stats, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, nh, added, csum, cmax);
   }
-  hipLaunchKernelGGL(k_limit, dim3(1), dim3(BLOCK), 0, s, nh, added, heights, h_const, limit, cum_in, flush_mode, tail,
+  hipLaunchKernelGGL(k_limit, dim3(1), dim3(64), 0, s, nh, added, heights, h_const, limit, cum_in, flush_mode, tail,
                      result_dev, nchunks, csum, cmax);
   return hipGetLastError();
 }

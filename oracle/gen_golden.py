@@ -142,6 +142,10 @@ CTRL = {
         cfg="tempering 1\nbias_factor 5\nglobal_tempering 0.2\nhill_prefactor 0.4\ndimension 1\nbox_low 0\n"
             "box_high 2.8\nbias_spacing 0.001\nbias_sigma 0.05",
         per=[0], skin=[0.3], mode="array", steps=6, n=64),
+    "targeting_global_tempering": dict(
+        cfg="tempering 1\nbias_factor 5.0\nglobal_tempering 0.05\nhill_prefactor 0.2\nbias_per_step 0.15\nhill_density 30\n"
+            "target_filename @FIXTURES@/1.grid\ndimension 1\nbox_low 0\nbox_high 2.5\nbias_spacing 0.0025\nbias_sigma 0.05",
+        per=[0], skin=[0.3], mode="array", steps=6, n=2000),
     "density_2d_limit": dict(
         cfg="tempering 0\nhill_prefactor 0.3\nhill_density 10\nbias_per_step 0.12\ndimension 2\nbox_low 0 0\n"
             "box_high 8 8\nbias_spacing 0.25 0.25\nbias_sigma 0.5 0.4",
@@ -167,7 +171,8 @@ def run_controller(lib, name, spec, tmp):
     cfg = os.path.join(tmp, name + ".edm")
     hills = os.path.join(tmp, "HILLS_" + name)
     with open(cfg, "w") as fh:
-        fh.write(spec["cfg"] + "\nhills_filename %s\nhistogram_filename %s.hist\n" % (hills, hills))
+        fh.write(spec["cfg"].replace("@FIXTURES@", os.path.join(GOLDEN, "ref_fixtures"))
+                 + "\nhills_filename %s\nhistogram_filename %s.hist\n" % (hills, hills))
     b = B.Bias(lib, cfg)
     dim = int(b.get("dim"))
     b.setup(1.0, 1.0)

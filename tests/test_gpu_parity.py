@@ -105,7 +105,8 @@ def test_controller_golden(case, workdir):
     hills = str(workdir / ("HILLS_" + name))
     cfg = str(workdir / (name + ".edm"))
     with open(cfg, "w") as fh:
-        fh.write(case["cfg"] + "\nhills_filename %s\nhistogram_filename %s.hist\n" % (hills, hills))
+        fh.write(case["cfg"].replace("@FIXTURES@", GU.FIXTURES)
+                 + "\nhills_filename %s\nhistogram_filename %s.hist\n" % (hills, hills))
     b = H.Bias(cfg)
     dim = int(b.get("dim"))
     b.setup(1.0, 1.0)
