@@ -231,7 +231,7 @@ def main():
         a2 = BYTES_PER_EVAL * n2 / (ms2 / l2 * 1e-3) / 1e9
         roof_w2 = dict(workload="W2: %d pair distances" % n2, bound="hbm", achieved=a2, peak=HBM_PEAK_GBS, unit="GB/s",
                        frac=a2 / HBM_PEAK_GBS, kernel_ms=ms2 / l2, kernel="k_pair_forces_fast<true> (LDS-staged window)",
-                       bytes_per_launch=BYTES_PER_EVAL * n2, traffic=pmc_traffic("edm::k_pair_forces_fast<true>"))
+                       bytes_per_launch=BYTES_PER_EVAL * n2, traffic=pmc_traffic("edm::k_pair_forces_fast<true"))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -259,13 +259,13 @@ def main():
                 "parallelism": "replicated bias grid, samples sharded, dp%d" % world,
             },
             "roofline": {
-                "kernel": "k_pair_forces_fast<false>",
+                "kernel": "k_pair_forces_fast<false,256>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("edm::k_pair_forces_fast<false>"),
+                "traffic": pmc_traffic("edm::k_pair_forces_fast<false"),
                 "kernel_us": k_ms / max(k_launches, 1) * 1e3,
                 "launches": k_launches,
                 "bytes_per_launch": BYTES_PER_EVAL * npairs,

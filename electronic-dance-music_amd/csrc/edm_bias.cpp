@@ -54,7 +54,7 @@ struct edm_hip_bias {
   bool in_cycle = false;
   // device scratch owned by the controller
   DevBuf<long long> sel;
-  DevBuf<long long> count;
+  long long *h_count = nullptr, *d_count = nullptr;  // host-mapped pinned: the selection kernel writes the count here
   DevBuf<int> sel_scratch;
   DevBuf<double> stage_x, stage_u, stage_h, tail_w;
   DevBuf<double> hx0;
@@ -229,7 +229,8 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   edm_hip_grid_destroy(b->hist);
   edm_hip_grid_destroy(b->target);
   if (b->hills_fp) fclose(b->hills_fp);
-  b->sel.release(); b->count.release(); b->sel_scratch.release();
+  b->sel.release(); b->sel_scratch.release();
+  if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
   delete b;
   return EDM_HIP_OK;
@@ -511,13 +512,14 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       return EDM_HIP_ERR_ARG;
     }
     EDM_HIP_TRY(b->sel.reserve((size_t)n));
-    EDM_HIP_TRY(b->count.reserve(2));
+    if (!b->h_count) {
+      EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_count), 64, hipHostMallocMapped));
+      EDM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_count), b->h_count, 0));
+    }
     EDM_HIP_TRY(b->sel_scratch.reserve(select_scratch_ints(n)));
-    EDM_HIP_TRY(launch_select(n, d_ru, thr, use_thr, b->d_mask, apply_mask, b->sel.p, b->count.p, b->sel_scratch.p, s));
-    long long *hcount = reinterpret_cast<long long *>(b->bias->h_scalars + 32);
-    EDM_HIP_TRY(hipMemcpyAsync(hcount, b->count.p, sizeof(long long), hipMemcpyDeviceToHost, s));
+    EDM_HIP_TRY(launch_select(n, d_ru, thr, use_thr, b->d_mask, apply_mask, b->sel.p, b->d_count, b->sel_scratch.p, s));
     EDM_HIP_TRY(hipStreamSynchronize(s));
-    nh = *hcount;
+    nh = *b->h_count;
     d_sel = b->sel.p;
   }
   if (b->comm) {

@@ -414,6 +414,10 @@ static int gauss_alloc(edm_hip_gauss *g) {
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->scratch), sizeof(double) * lookup_scratch_doubles()));
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_scalars), sizeof(double) * 16));
   EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_scalars), sizeof(double) * 64, hipHostMallocDefault));
+  // block partial sums of the lookup kernels are written straight into host-mapped pinned memory
+  // and added up on the host in index order: no reduction kernel, no copy
+  EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_partials), sizeof(double) * lookup_scratch_doubles(), hipHostMallocMapped));
+  EDM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&g->d_partials), g->h_partials, 0));
   g->h_stage_bytes = (size_t)4096 * (sizeof(int) + sizeof(double) * (3 + 3)) + 1024;
   EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_stage), g->h_stage_bytes, hipHostMallocDefault));
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_dirty), sizeof(int) * 4));
@@ -458,6 +462,7 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
   if (g->d_scalars) (void)hipFree(g->d_scalars);
   if (g->h_scalars) (void)hipHostFree(g->h_scalars);
   if (g->h_stage) (void)hipHostFree(g->h_stage);
+  if (g->h_partials) (void)hipHostFree(g->h_partials);
   if (g->d_dirty) (void)hipFree(g->d_dirty);
   if (g->ev0) (void)hipEventDestroy(g->ev0);
   if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -600,11 +605,12 @@ int edm_hip_gauss_update_forces(const edm_hip_gauss *g, long long n, const doubl
   }
   LookupArgs a{};
   a.n = n; a.x = d_x; a.x_stride = x_stride; a.f = d_f; a.f_stride = f_stride; a.mask = d_mask; a.apply_mask = apply_mask;
-  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, a, g->scratch, g->d_scalars, g->stream,
-                            g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr));
+  int nblk = 0;
+  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, a, g->d_partials, nullptr, g->stream,
+                            g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr, &nblk));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
   double e = 0;
-  int rc = fetch_scalar(g, 0, &e);
-  if (rc) return rc;
+  for (int i = 0; i < nblk; i++) e += g->h_partials[i];
   profile_collect(g);
   if (energy) *energy = e;
   return EDM_HIP_OK;
@@ -618,11 +624,12 @@ int edm_hip_gauss_pair_forces(const edm_hip_gauss *g, long long n, const double 
     return EDM_HIP_ERR_ARG;
   }
   if (n <= 0) return EDM_HIP_OK;
-  EDM_HIP_TRY(launch_pair_forces(g->g, g->rec, n, d_r, d_force, g->scratch, g->d_scalars, g->stream,
-                                 g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr));
+  int nblk = 0;
+  EDM_HIP_TRY(launch_pair_forces(g->g, g->rec, n, d_r, d_force, g->d_partials, nullptr, g->stream,
+                                 g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr, &nblk));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
   double e = 0;
-  int rc = fetch_scalar(g, 0, &e);
-  if (rc) return rc;
+  for (int i = 0; i < nblk; i++) e += g->h_partials[i];
   profile_collect(g);
   if (energy) *energy = e;
   return EDM_HIP_OK;

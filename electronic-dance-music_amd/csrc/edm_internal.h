@@ -89,6 +89,8 @@ struct edm_hip_gauss {
   double *scratch = nullptr;             // lookup partial sums
   double *d_scalars = nullptr;           // small device result slots
   double *h_scalars = nullptr;           // pinned host mirror
+  double *h_partials = nullptr;          // host-mapped pinned block partial sums (energy)
+  double *d_partials = nullptr;          // device view of h_partials
   char *h_stage = nullptr;               // pinned staging for batched result read-back
   size_t h_stage_bytes = 0;
   int *d_dirty = nullptr;

@@ -39,13 +39,15 @@ struct LookupArgs {
 size_t lookup_scratch_doubles();
 // ev0/ev1 (may be NULL) are recorded on `s` directly around the main kernel, so a caller can
 // time exactly that launch with hipEventElapsedTime.
+// blocks_out (may be NULL) receives the number of per-block partial sums written to `scratch`;
+// a caller that passes energy_out == NULL can sum them itself in index order.
 hipError_t launch_lookup(const Geom &g, const double *rec, LookupMode mode, const LookupArgs &a,
                          double *scratch, double *energy_out, hipStream_t s,
-                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int *blocks_out = nullptr);
 // 1-D pair-distance form: force[i] = -dV/dr(r_i)
 hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, const double *r,
                               double *force, double *scratch, double *energy_out, hipStream_t s,
-                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int *blocks_out = nullptr);
 
 // ---- record layout conversion ---------------------------------------------------
 hipError_t launch_pack(const Geom &g, double *rec, const double *values, const double *derivs, hipStream_t s);

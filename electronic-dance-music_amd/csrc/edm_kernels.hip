@@ -292,7 +292,8 @@ size_t lookup_scratch_doubles() { return MAX_BLOCKS + 8; }
 
 template <int DIM>
 static hipError_t lookup_dim(const Geom &g, const double *rec, LookupMode mode, const LookupArgs &a,
-                             double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                             double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
+                             int *blocks_out) {
   int blocks = (int)((a.n + BLOCK - 1) / BLOCK);
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
@@ -309,17 +310,19 @@ static hipError_t lookup_dim(const Geom &g, const double *rec, LookupMode mode, 
       break;
   }
   if (ev1) (void)hipEventRecord(ev1, s);
+  if (blocks_out) *blocks_out = blocks;
   if (energy_out)
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, s, scratch, (long long)blocks, energy_out);
   return hipGetLastError();
 }
 
 hipError_t launch_lookup(const Geom &g, const double *rec, LookupMode mode, const LookupArgs &a,
-                         double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                         double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
+                         int *blocks_out) {
   switch (g.dim) {
-    case 1: return lookup_dim<1>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1);
-    case 2: return lookup_dim<2>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1);
-    default: return lookup_dim<3>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1);
+    case 1: return lookup_dim<1>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1, blocks_out);
+    case 2: return lookup_dim<2>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1, blocks_out);
+    default: return lookup_dim<3>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1, blocks_out);
   }
 }
 
@@ -420,8 +423,8 @@ __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict
   hermite_1d(a.x, a.y, b.x, b.y, X, g.dx[0], inv_dx, v, d);
 }
 
-template <bool USE_LDS>
-__global__ void __launch_bounds__(FAST_BLOCK) k_pair_forces_fast(Geom g, const double *__restrict__ rec, long long n,
+template <bool USE_LDS, int NT>
+__global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *__restrict__ rec, long long n,
                                                                  const double *__restrict__ r,
                                                                  double *__restrict__ force,
                                                                  double *__restrict__ block_energy, long long w0,
@@ -430,40 +433,49 @@ __global__ void __launch_bounds__(FAST_BLOCK) k_pair_forces_fast(Geom g, const d
   double *red = reinterpret_cast<double *>(lds_all);  // first 256 B: reduction scratch
   if (USE_LDS) {
     const double2 *src = reinterpret_cast<const double2 *>(rec) + w0;
-    for (int i = threadIdx.x; i < wn; i += FAST_BLOCK) lds_all[16 + i] = src[i];
+    for (int i = threadIdx.x; i < wn; i += NT) lds_all[16 + i] = src[i];
     __syncthreads();
   }
   lds_v2d *win = (lds_v2d *)(lds_all + 16);
   const long long w1 = w0 + wn;
   double e_acc = 0;
   const long long npair = n >> 1;
-  const long long stride = (long long)gridDim.x * FAST_BLOCK;
+  const long long stride = (long long)gridDim.x * NT;
   const v2d *r2 = reinterpret_cast<const v2d *>(r);
   v2d *f2 = reinterpret_cast<v2d *>(force);
   // two independent 16-B loads in flight per lane per iteration (64 B of HBM traffic per lane)
-  for (long long i = (long long)blockIdx.x * FAST_BLOCK + threadIdx.x; i < npair; i += 2 * stride) {
+  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < npair; i += 2 * stride) {
     const long long j = i + stride;
     const bool has_b = j < npair;
     const v2d ra = __builtin_nontemporal_load(&r2[i]);
-    const v2d rb = has_b ? __builtin_nontemporal_load(&r2[j]) : ra;
-    double v0, v1, v2, v3, d0, d1, d2, d3;
-    pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.x, v0, d0);
-    pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.y, v1, d1);
-    pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, rb.x, v2, d2);
-    pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, rb.y, v3, d3);
-    e_acc += v0;
-    e_acc += v1;
-    v2d oa;
-    oa.x = 0.0 - d0;
-    oa.y = 0.0 - d1;
-    __builtin_nontemporal_store(oa, &f2[i]);
-    if (has_b) {
+    if (has_b) {  // steady state: four independent lookups in flight per lane
+      const v2d rb = __builtin_nontemporal_load(&r2[j]);
+      double v0, v1, v2, v3, d0, d1, d2, d3;
+      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.x, v0, d0);
+      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.y, v1, d1);
+      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, rb.x, v2, d2);
+      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, rb.y, v3, d3);
+      e_acc += v0;
+      e_acc += v1;
       e_acc += v2;
       e_acc += v3;
-      v2d ob;
+      v2d oa, ob;
+      oa.x = 0.0 - d0;
+      oa.y = 0.0 - d1;
       ob.x = 0.0 - d2;
       ob.y = 0.0 - d3;
+      __builtin_nontemporal_store(oa, &f2[i]);
       __builtin_nontemporal_store(ob, &f2[j]);
+    } else {
+      double v0, v1, d0, d1;
+      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.x, v0, d0);
+      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.y, v1, d1);
+      e_acc += v0;
+      e_acc += v1;
+      v2d oa;
+      oa.x = 0.0 - d0;
+      oa.y = 0.0 - d1;
+      __builtin_nontemporal_store(oa, &f2[i]);
     }
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -477,7 +489,8 @@ __global__ void __launch_bounds__(FAST_BLOCK) k_pair_forces_fast(Geom g, const d
 }
 
 hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, const double *r, double *force,
-                              double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                              double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
+                              int *blocks_out) {
   int blocks;
   const bool fast = (g.dim == 1 && g.interp && !g.periodic[0] && !g.bper[0] && g.n[0] >= 2);
   if (fast) {
@@ -498,23 +511,24 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
       long long w0 = (long long)g.n[0] - wn;  // top-aligned: pair distances populate the upper range
       const size_t lds_bytes = 256 + (size_t)wn * 16;
       if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_forces_fast<true>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_forces_fast<true, FAST_BLOCK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 256 + LDS_WINDOW_MAX * 16);
         if (e != hipSuccess) return e;
         attr_set = true;
       }
       blocks = n_cu;
       if (ev0) (void)hipEventRecord(ev0, s);
-      hipLaunchKernelGGL(k_pair_forces_fast<true>, dim3(blocks), dim3(FAST_BLOCK), lds_bytes, s, g, rec, n, r, force,
+      hipLaunchKernelGGL((k_pair_forces_fast<true, FAST_BLOCK>), dim3(blocks), dim3(FAST_BLOCK), lds_bytes, s, g, rec, n, r, force,
                          scratch, w0, wn, inv_dx);
       if (ev1) (void)hipEventRecord(ev1, s);
     } else {
+      // short arrays: small workgroups spread over every CU (latency-bound regime)
       long long work = (n >> 1) + 1;
-      blocks = (int)((work + FAST_BLOCK - 1) / FAST_BLOCK);
-      if (blocks > 2 * n_cu) blocks = 2 * n_cu;
+      blocks = (int)((work + BLOCK - 1) / BLOCK);
+      if (blocks > 8 * n_cu) blocks = 8 * n_cu;
       if (blocks < 1) blocks = 1;
       if (ev0) (void)hipEventRecord(ev0, s);
-      hipLaunchKernelGGL(k_pair_forces_fast<false>, dim3(blocks), dim3(FAST_BLOCK), 256, s, g, rec, n, r, force, scratch,
+      hipLaunchKernelGGL((k_pair_forces_fast<false, BLOCK>), dim3(blocks), dim3(BLOCK), 256, s, g, rec, n, r, force, scratch,
                          0LL, 0, inv_dx);
       if (ev1) (void)hipEventRecord(ev1, s);
     }
@@ -527,6 +541,7 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
     hipLaunchKernelGGL(k_pair_forces, dim3(blocks), dim3(BLOCK), 0, s, g, rec, n, r, force, scratch);
     if (ev1) (void)hipEventRecord(ev1, s);
   }
+  if (blocks_out) *blocks_out = blocks;
   if (energy_out)
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, s, scratch, (long long)blocks, energy_out);
   return hipGetLastError();
