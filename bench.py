@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default W1 = 1,048,576)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--w2", action="store_true", help="also capture the 38.8M-pair interpolation roofline (W2)")
+    ap.add_argument("--nd", action="store_true", help="also time the 2-D (2048^2) and 3-D (512^3) coordinate-CV kernels")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -233,6 +234,41 @@ def main():
                        frac=a2 / HBM_PEAK_GBS, kernel_ms=ms2 / l2, kernel="k_pair_forces_fast<true> (LDS-staged window)",
                        bytes_per_launch=BYTES_PER_EVAL * n2, traffic=pmc_traffic("edm::k_pair_forces_fast<true"))
 
+    nd = None
+    if args.nd and rank == 0:
+        nd = {}
+        for tag, c, per_atom in (("c2d_2048sq", W.C2D, 156), ("c3d_512cube", W.C3D, 332)):
+            gg = H.Gauss.create(c["lo"], c["hi"], c["spacing"], c["periodic"], 1, c["sigma"])
+            dim = c["dim"]
+            natoms = 262144
+            x = W.atom_positions(natoms, 21 if dim == 2 else 31)
+            d_x = H.DeviceArray.from_host(x)
+            d_ff = H.DeviceArray.zeros((natoms, 3))
+            d_uu = H.DeviceArray.from_host(W.uniform(77, natoms))
+            hills = H.DeviceArray.from_host(np.ascontiguousarray(x[:250]))
+            tot = H.C.c_double(0)
+            H.check(H.lib().edm_hip_gauss_add_values(gg.h, 250, hills.ptr, 3, None, 0.01, None, H.C.byref(tot)))
+            e = H.C.c_double(0)
+            H.check(H.lib().edm_hip_gauss_update_forces(gg.h, natoms, d_x.ptr, 3, d_ff.ptr, 3, None, -1, H.C.byref(e)))
+            gg.profile_enable(True)
+            gg.profile_read(reset=True)
+            for _ in range(20):
+                H.check(H.lib().edm_hip_gauss_update_forces(gg.h, natoms, d_x.ptr, 3, d_ff.ptr, 3, None, -1, H.C.byref(e)))
+            ms, ln = gg.profile_read(reset=True)
+            gg.profile_enable(False)
+            H.synchronize()
+            t3 = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                H.check(H.lib().edm_hip_gauss_add_values(gg.h, 250, hills.ptr, 3, None, 0.01, None, H.C.byref(tot)))
+            H.synchronize()
+            t_h = (time.perf_counter() - t3) / reps
+            gbs = per_atom * natoms / (ms / ln * 1e-3) / 1e9
+            nd[tag] = dict(atoms=natoms, lookup_kernel_us=ms / ln * 1e3, million_atom_evals_per_s=natoms / (ms / ln * 1e-3) / 1e6,
+                           algorithmic_bytes_per_atom=per_atom, achieved_GBs=gbs, frac_of_hbm_peak=gbs / HBM_PEAK_GBS,
+                           hill_batch_250_ms=t_h * 1e3, hill_adds_per_s=250 / t_h)
+            del gg
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_pairs = npairs * world
@@ -276,6 +312,8 @@ def main():
         out.update(extra)
         if roof_w2:
             out["roofline_w2"] = roof_w2
+        if nd:
+            out["coordinate_cv"] = nd
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(tmpdir)
         elif world > 1:

@@ -497,10 +497,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     set_error("add_hills: apply_mask >= 0 needs set_mask");
     return EDM_HIP_ERR_ARG;
   }
-  if (b->b_tempering && b->global_tempering < 0) {
-    set_error("local tempering (hill heights that depend on the bias under construction) is not implemented on the device yet (SURVEY 8f#3)");
-    return EDM_HIP_ERR_ARG;
-  }
+  const bool local_tempering = (b->b_tempering && b->global_tempering < 0);  // :547
   hipStream_t s = b->bias->stream;
   const int use_thr = !(b->hill_density < 0);
   const double thr = b->hill_density / b->est_hill_count;   // :543
@@ -541,7 +538,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     this_h /= b->hill_density;
   this_h = fmin(this_h, BIAS_CLAMP * b->bias_per_step);
   const double *d_heights = nullptr;
-  if (b->b_targeting) {
+  if (b->b_targeting && !local_tempering) {
     // per-hill heights: prefactor * exp(target(x) - <target>) / divisor, clamped (:545-558)
     EDM_HIP_TRY(b->stage_h.reserve((size_t)nh));
     const double divisor = (b->hill_density < 0) ? (double)b->est_hill_count : b->hill_density;
@@ -565,6 +562,23 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   spec.hist_values = b->hist->values;
   const bool log_all = b->hill_log && b->hills_fp;
   spec.fetch_all = log_all;
+  if (local_tempering) {
+    // the height of hill i depends on the grid that already holds hills < i (:547-549):
+    // strictly ordered application by one workgroup
+    spec.ordered = true;
+    memset(&spec.op, 0, sizeof(spec.op));
+    spec.op.prefactor = b->temp_hill_prefactor;
+    spec.op.use_target = b->b_targeting;
+    if (b->b_targeting) {
+      spec.op.target = b->target->g;
+      spec.op.target_values = b->target->values;
+      spec.op.expected_target = b->expected_target;
+    }
+    spec.op.use_tempering = 1;
+    spec.op.temper_scale = (b->bias_factor - 1) * b->boltzmann_factor;
+    spec.op.divisor = (b->hill_density < 0) ? (double)b->est_hill_count : b->hill_density;
+    spec.op.clamp = BIAS_CLAMP * b->bias_per_step;
+  }
   ApplyOutcome oc;
   int rc = apply_hills(b->bias, spec, &oc, false);
   if (rc) return rc;

@@ -25,7 +25,7 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 void HillWorkspace::release() {
-  hx.release(); hx0.release(); ht.release(); added.release(); partial.release(); scratch.release();
+  heights.release(); hx.release(); hx0.release(); ht.release(); added.release(); partial.release(); scratch.release();
   tail_h1.release(); tail_h2.release(); tail_a2.release(); tail_cum.release();
   hc.release(); tail_flags.release(); tile_flags.release(); tile_list.release(); result.release(); rb.release();
 }
@@ -736,8 +736,25 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hh.tail_h2 = p_h2;
   hh.res_dev = nullptr;
 
-  if (spec.limited || want_total) EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s));
-  if (spec.limited) {
+  const double *base_heights = spec.d_h;
+  if (spec.ordered) {
+    if (nh > EDM_TAIL_CAP) {
+      set_error("ordered (locally tempered) hill batches are limited to EDM_TAIL_CAP hills per step");
+      return EDM_HIP_ERR_OVERFLOW;
+    }
+    EDM_HIP_TRY(ws.heights.reserve((size_t)nh));
+    OrderedParams op = spec.op;
+    op.limit = spec.limit;
+    op.cum_in = spec.cum_in;
+    LimitTail tail{ws.tail_h1.p, p_h2, p_a2, ws.tail_cum.p, p_flags};
+    EDM_HIP_TRY(launch_hills_ordered(q, tabs, g->rec, hl, op, tail, ws.heights.p, p_added, dres, g->d_dirty, s));
+    base_heights = ws.heights.p;
+  } else if (spec.limited || want_total) {
+    EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s));
+  }
+  if (spec.ordered) {
+    // everything was applied by the ordered kernel
+  } else if (spec.limited) {
     LimitTail tail{ws.tail_h1.p, p_h2, p_a2, ws.tail_cum.p, p_flags};
     EDM_HIP_TRY(launch_limit(nh, p_added, spec.d_h, spec.h_const, spec.limit, spec.cum_in, spec.flush_mode, tail,
                              dres, ws.scratch.p, s));
@@ -778,8 +795,10 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       plan.tile_bound = nh * per_hill;
     }
   }
-  EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, hl, hh, plan, g->d_dirty, s));
-  EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
+  if (!spec.ordered) {
+    EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, hl, hh, plan, g->d_dirty, s));
+    EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
+  }
 
   // CV histogram (edm_bias.cpp:601-610): new hills log one 'h' line each (+1) and a 'u' line
   // per undo (-1); a flush logs 'b' (+1) for replayed hills only and 'v' (-1) for its undo
@@ -821,11 +840,11 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   if (out) {
     out->res = res;
     if (want_total && !spec.limited) out->total_added = g->h_scalars[1];
-    if (spec.d_h && spec.limited) {
+    if (base_heights && spec.limited) {
       const long long f0 = spec.fetch_all ? 0 : res.k;
       if (nh - f0 > 0) {
         out->heights.resize((size_t)(nh - f0));
-        EDM_HIP_TRY(hipMemcpy(out->heights.data(), spec.d_h + f0, sizeof(double) * (size_t)(nh - f0), hipMemcpyDeviceToHost));
+        EDM_HIP_TRY(hipMemcpy(out->heights.data(), base_heights + f0, sizeof(double) * (size_t)(nh - f0), hipMemcpyDeviceToHost));
       }
     }
     const long long k = res.k;

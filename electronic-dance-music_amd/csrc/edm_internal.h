@@ -49,7 +49,7 @@ struct DevBuf {
 
 // workspace of the hill path, shared by add_values / the controller
 struct HillWorkspace {
-  DevBuf<double> hx, hx0, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum;
+  DevBuf<double> hx, hx0, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum, heights;
   DevBuf<int> hc, tail_flags, tile_flags, tile_list;
   DevBuf<char> result;      // LimitResult
   DevBuf<char> rb;          // packed read-back region of small batches (one D2H instead of six)
@@ -119,6 +119,9 @@ struct ApplySpec {
   const Geom *hist_g = nullptr;
   double *hist_values = nullptr;
   bool fetch_all = false;          // host wants position + bias_added of EVERY hill (HILLS log)
+  // heights that depend on the bias under construction (local tempering): strictly ordered kernel
+  bool ordered = false;
+  OrderedParams op;
 };
 struct ApplyOutcome {
   LimitResult res;

@@ -135,6 +135,27 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
 hipError_t launch_hist_tail(const Geom &hist, double *values, const LimitResult *res_dev, const int *flags,
                             const double *hx0, int plus_for_applied, hipStream_t s);
 
+// Ordered hill application for heights that depend on the bias under construction (local tempering,
+// edm_bias.cpp:547-549): ONE workgroup applies the hills strictly one after another -- height from the
+// current grid, integrated bias, limiter step, stencil update, boundary duplication -- with workgroup
+// barriers in between, exactly the reference's sequence.  Fills the same tail arrays as launch_limit
+// (k = 0, n_tail = nh <= EDM_TAIL_CAP), the per-hill heights and bias.
+struct OrderedParams {
+  double prefactor;        // temp_hill_prefactor_
+  int use_target;          // b_targeting_
+  Geom target;
+  const double *target_values;
+  double expected_target;
+  int use_tempering;       // b_tempering_ && global_tempering_ < 0
+  double temper_scale;     // (bias_factor_ - 1) * boltzmann_factor_
+  double divisor;          // est_hill_count_ or hill_density_
+  double clamp;            // BIAS_CLAMP * bias_per_step_
+  double limit, cum_in;
+};
+hipError_t launch_hills_ordered(const Geom &g, const Tables &t, double *rec, const HillList &h, const OrderedParams &op,
+                                const LimitTail &tail, double *heights_out, double *added_out,
+                                LimitResult *result_dev, int *dirty_flag, hipStream_t s);
+
 // hill heights with a target factor (edm_bias.cpp:537-558):
 //   h_i = min( prefactor * exp(T(x_i) - expected) / divisor , clamp )
 // T = Grid::get_value on the target grid read WITHOUT interpolation (nearest-lower node, 0 outside

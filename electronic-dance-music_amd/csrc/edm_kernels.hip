@@ -63,6 +63,24 @@ __global__ void __launch_bounds__(BLOCK) k_block_sums(const double *__restrict__
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
+// Grid::get_value on a grid read WITHOUT interpolation (grid.h:343-365): nearest-lower node, 0 outside
+template <int DIM>
+__device__ __forceinline__ double target_value(const Geom &g, const double *__restrict__ values, const double *xx) {
+  if (!in_grid<DIM>(g, xx)) return 0;
+  long long idx[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    double w;
+    idx[d] = node_index(g, d, xx[d], &w);
+    if (idx[d] > g.n[d] - 1) idx[d] = g.n[d] - 1;
+    if (idx[d] < 0) idx[d] = 0;
+  }
+  long long flat = idx[DIM - 1];
+#pragma unroll
+  for (int d = DIM - 1; d > 0; d--) flat = flat * g.n[d - 1] + idx[d - 1];
+  return values[flat];
+}
+
 template <int DIM>
 __global__ void __launch_bounds__(BLOCK) k_target_heights(Geom g, const double *__restrict__ values, long long n,
                                                           const double *__restrict__ x, int x_stride,
@@ -75,21 +93,7 @@ __global__ void __launch_bounds__(BLOCK) k_target_heights(Geom g, const double *
     double xx[DIM];
 #pragma unroll
     for (int d = 0; d < DIM; d++) xx[d] = x[src * x_stride + d];
-    double t = 0;
-    if (in_grid<DIM>(g, xx)) {
-      long long idx[DIM];
-#pragma unroll
-      for (int d = 0; d < DIM; d++) {
-        double w;
-        idx[d] = node_index(g, d, xx[d], &w);
-        if (idx[d] > g.n[d] - 1) idx[d] = g.n[d] - 1;
-        if (idx[d] < 0) idx[d] = 0;
-      }
-      long long flat = idx[DIM - 1];
-#pragma unroll
-      for (int d = DIM - 1; d > 0; d--) flat = flat * g.n[d - 1] + idx[d - 1];
-      t = values[flat];
-    }
+    const double t = target_value<DIM>(g, values, xx);
     double h = prefactor;
     h *= exp(t - expected);   // :546
     h /= divisor;             // :552-555
@@ -1371,14 +1375,207 @@ hipError_t launch_hill_gather(const Geom &g, const Tables &t, double *rec, const
 }
 
 // ---------------------------------------------------------------------------
-// K6: duplicate_boundary (gaussian_grid.h:571-630): copies the VALUE of the first /
-// last in-boundary node to its outward neighbour for the 4^dim index combinations.
+// Ordered (serial-dependence) hill application: one workgroup, hills strictly in sequence.
 // ---------------------------------------------------------------------------
+static constexpr int ORD_BLOCK = 1024;
+
 struct DupPlan {
   unsigned long long lo[3], hi[3];
 };
-__global__ void k_duplicate_boundary(Geom g, double *__restrict__ rec, DupPlan dp, int *__restrict__ dirty_flag) {
-  if (*dirty_flag == 0) return;
+__device__ __forceinline__ void duplicate_boundary_block(const Geom &g, double *__restrict__ rec, const DupPlan &dp);
+
+template <int DIM>
+__global__ void __launch_bounds__(ORD_BLOCK) k_hills_ordered(Geom g, Tables t, double *__restrict__ rec, HillList h,
+                                                             OrderedParams op, LimitTail tail,
+                                                             double *__restrict__ heights_out,
+                                                             double *__restrict__ added_out,
+                                                             LimitResult *__restrict__ res, DupPlan dp,
+                                                             int *__restrict__ dirty_flag) {
+  constexpr int R = (DIM == 1) ? 2 : 4;
+  __shared__ double red[ORD_BLOCK / 64];
+  __shared__ double s_height, s_h1, s_h2;
+  __shared__ int s_dirty;
+  TermConst<DIM> tc;
+  term_const<DIM>(g, tc);
+  double vol = 1;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) vol *= g.dx[d];
+  double cum = op.cum_in;  // meaningful in thread 0
+  int n_def = 0;
+  for (long long i = 0; i < h.nh; i++) {
+    // ---- 1. height from the CURRENT grid (edm_bias.cpp:537-558) ----
+    if (threadIdx.x == 0) {
+      double x0[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; d++) x0[d] = h.hx0[i * DIM + d];
+      double hgt = op.prefactor;
+      if (op.use_target) hgt *= exp(target_value<DIM>(op.target, op.target_values, x0) - op.expected_target);
+      if (op.use_tempering) {
+        double v, der[DIM];
+        lookup_one<DIM>(g, rec, x0, v, der);  // bias_->get_value(position)
+        hgt *= exp(-v / op.temper_scale);
+      }
+      hgt /= op.divisor;
+      hgt = fmin(hgt, op.clamp);
+      s_height = hgt;
+      s_dirty = 0;
+    }
+    __syncthreads();
+    const double height = s_height;
+    // the hill's distinct nodes: per dimension a run of `cnt` nodes starting at `lo` (wrapped)
+    const bool valid = (h.hc[i * DIM] != INT_MIN);
+    int c[DIM], lo[DIM], cntd[DIM];
+    double hx[DIM], ht[2 * DIM];
+    long long total = valid ? 1 : 0;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      c[d] = h.hc[i * DIM + d];
+      hx[d] = h.hx[i * DIM + d];
+      ht[2 * d] = h.ht[i * 2 * DIM + 2 * d];
+      ht[2 * d + 1] = h.ht[i * 2 * DIM + 2 * d + 1];
+      if (valid) {
+        const int m = g.msize[d];
+        if (g.periodic[d]) {
+          cntd[d] = (2 * m + 1 < g.n[d]) ? 2 * m + 1 : g.n[d];
+          lo[d] = (int)((((long long)c[d] - m) % g.n[d] + g.n[d]) % g.n[d]);
+        } else {
+          const int a = (c[d] - m > 0) ? c[d] - m : 0;
+          const int b = (c[d] + m < g.n[d] - 1) ? c[d] + m : g.n[d] - 1;
+          lo[d] = a;
+          cntd[d] = (b >= a) ? b - a + 1 : 0;
+        }
+        total *= cntd[d];
+      } else {
+        lo[d] = 0;
+        cntd[d] = 0;
+      }
+    }
+    // ---- 2. integrated bias of the hill (what add_value returns) ----
+    double part = 0;
+    for (long long sidx = threadIdx.x; sidx < total; sidx += ORD_BLOCK) {
+      int p[DIM];
+      long long rest = sidx;
+      int mult = 1;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        const int o = (int)(rest % cntd[d]);
+        rest /= cntd[d];
+        int idx = lo[d] + o;
+        if (g.periodic[d] && idx >= g.n[d]) idx -= g.n[d];
+        p[d] = idx;
+        mult *= images(g, d, c[d], idx, idx);
+      }
+      if (mult == 0) continue;
+      NodeTerms<DIM> nt;
+      node_terms<DIM>(g, t, p, nt);
+      if (!nt.inside) continue;
+      double val, dval[DIM];
+      bool nz;
+      if (!pair_term<DIM>(g, tc, nt, hx, ht, val, dval, nz)) continue;
+      for (int rep = 0; rep < mult; rep++) part += height * val * vol;
+    }
+    const double added = block_sum(part, red);
+    // ---- 3. limiter step (edm_bias.cpp:465-495), thread 0 ----
+    if (threadIdx.x == 0) {
+      double h1 = 0, h2 = 0, a2 = 0;
+      int fl = 0;
+      if (cum < op.limit) {
+        h1 = height;
+        fl = 1;
+        cum += added;
+        if (cum > op.limit) {
+          h2 = fmax(op.limit - cum, -height);
+          a2 = (height != 0.0) ? h2 * (added / height) : 0.0;
+          cum += a2;
+          fl |= 2 | 4;
+          n_def++;
+        }
+      } else {
+        fl = 4;
+        n_def++;
+      }
+      s_h1 = h1;
+      s_h2 = h2;
+      tail.h1[i] = h1;
+      tail.h2[i] = h2;
+      tail.added2[i] = a2;
+      tail.cum_after[i] = cum;
+      tail.flags[i] = fl;
+      heights_out[i] = height;
+      added_out[i] = (fl & 1) ? added : 0.0;
+    }
+    __syncthreads();
+    const double h1 = s_h1, h2 = s_h2;
+    // ---- 4. stencil update (plain stores: every node of the run is owned by one thread) ----
+    bool any_corr = false;
+    if (h1 != 0 || h2 != 0) {
+      for (long long sidx = threadIdx.x; sidx < total; sidx += ORD_BLOCK) {
+        int p[DIM];
+        long long rest = sidx;
+        int mult = 1;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+          const int o = (int)(rest % cntd[d]);
+          rest /= cntd[d];
+          int idx = lo[d] + o;
+          if (g.periodic[d] && idx >= g.n[d]) idx -= g.n[d];
+          p[d] = idx;
+          mult *= images(g, d, c[d], idx, idx);
+        }
+        if (mult == 0) continue;
+        NodeTerms<DIM> nt;
+        node_terms<DIM>(g, t, p, nt);
+        if (!nt.inside) continue;
+        double val, dval[DIM];
+        bool nz;
+        if (!pair_term<DIM>(g, tc, nt, hx, ht, val, dval, nz)) continue;
+        any_corr |= nz;
+        long long flat = p[DIM - 1];
+#pragma unroll
+        for (int d = DIM - 1; d > 0; d--) flat = flat * g.n[d - 1] + p[d - 1];
+        double acc[1 + DIM];
+#pragma unroll
+        for (int j = 0; j <= DIM; j++) acc[j] = rec[flat * R + j];
+        for (int rep = 0; rep < mult; rep++) {
+          acc[0] += h1 * val;
+#pragma unroll
+          for (int d = 0; d < DIM; d++) acc[1 + d] += h1 * dval[d];
+        }
+        if (h2 != 0)
+          for (int rep = 0; rep < mult; rep++) {
+            acc[0] += h2 * val;
+#pragma unroll
+            for (int d = 0; d < DIM; d++) acc[1 + d] += h2 * dval[d];
+          }
+#pragma unroll
+        for (int j = 0; j <= DIM; j++) rec[flat * R + j] = acc[j];
+      }
+    }
+    if (any_corr) s_dirty = 1;
+    __threadfence_block();
+    __syncthreads();
+    // ---- 5. boundary duplication (gaussian_grid.h:365-368) ----
+    if (s_dirty) duplicate_boundary_block(g, rec, dp);
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    res->cum_out = cum;
+    res->k = 0;
+    res->n_tail = (int)h.nh;
+    res->stop = (int)h.nh;
+    res->n_deferred = n_def;
+    res->error = 0;
+    *dirty_flag = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K6: duplicate_boundary (gaussian_grid.h:571-630): copies the VALUE of the first /
+// last in-boundary node to its outward neighbour for the 4^dim index combinations.
+// ---------------------------------------------------------------------------
+// copies for the 4^dim index combinations; must be called by >= 64 threads of one workgroup
+__device__ __forceinline__ void duplicate_boundary_block(const Geom &g, double *__restrict__ rec, const DupPlan &dp) {
   int combos = 1;
   for (int d = 0; d < g.dim; d++) combos *= 4;
   const int c = threadIdx.x;
@@ -1435,11 +1632,16 @@ __global__ void k_duplicate_boundary(Geom g, double *__restrict__ rec, DupPlan d
   if (do_copy) v = rec[inner_flat * g.rec];
   __syncthreads();
   if (do_copy) rec[outer_flat * g.rec] = v;
+}
+
+__global__ void k_duplicate_boundary(Geom g, double *__restrict__ rec, DupPlan dp, int *__restrict__ dirty_flag) {
+  if (*dirty_flag == 0) return;
+  duplicate_boundary_block(g, rec, dp);
   __syncthreads();
   if (threadIdx.x == 0) *dirty_flag = 0;
 }
 
-hipError_t launch_duplicate_boundary(const Geom &g, double *rec, int *dirty_flag, hipStream_t s) {
+static DupPlan make_dup_plan(const Geom &g) {
   // grid.h:264-273 applied to the boundary corners, then the two while loops of
   // gaussian_grid.h:582-588 (host arithmetic, identical to the reference)
   DupPlan dp;
@@ -1455,6 +1657,24 @@ hipError_t launch_duplicate_boundary(const Geom &g, double *rec, int *dirty_flag
     dp.lo[d] = lo;
     dp.hi[d] = hi;
   }
+  return dp;
+}
+
+hipError_t launch_hills_ordered(const Geom &g, const Tables &t, double *rec, const HillList &h, const OrderedParams &op,
+                                const LimitTail &tail, double *heights_out, double *added_out,
+                                LimitResult *result_dev, int *dirty_flag, hipStream_t s) {
+  if (h.nh <= 0) return hipSuccess;
+  const DupPlan dp = make_dup_plan(g);
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL(k_hills_ordered<1>, dim3(1), dim3(ORD_BLOCK), 0, s, g, t, rec, h, op, tail, heights_out, added_out, result_dev, dp, dirty_flag); break;
+    case 2: hipLaunchKernelGGL(k_hills_ordered<2>, dim3(1), dim3(ORD_BLOCK), 0, s, g, t, rec, h, op, tail, heights_out, added_out, result_dev, dp, dirty_flag); break;
+    default: hipLaunchKernelGGL(k_hills_ordered<3>, dim3(1), dim3(ORD_BLOCK), 0, s, g, t, rec, h, op, tail, heights_out, added_out, result_dev, dp, dirty_flag); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_duplicate_boundary(const Geom &g, double *rec, int *dirty_flag, hipStream_t s) {
+  const DupPlan dp = make_dup_plan(g);
   hipLaunchKernelGGL(k_duplicate_boundary, dim3(1), dim3(64), 0, s, g, rec, dp, dirty_flag);
   return hipGetLastError();
 }

@@ -112,11 +112,6 @@ def test_controller_golden(case, workdir):
     b.setup(1.0, 1.0)
     lo, hi = b.array("min"), b.array("max")
     b.subdivide(lo, hi, lo, hi, case["per"], case["skin"])
-    if name == "local_tempering":
-        pos, ru, mask = GU.controller_inputs(case, 0, dim, lo, hi)
-        with pytest.raises(H.EdmHipError):
-            b.add_hills(pos, ru, -1)  # serial-dependence path: fails loudly until implemented
-        return
     for step in range(case["steps"]):
         pos, ru, mask = GU.controller_inputs(case, step, dim, lo, hi)
         forces = np.zeros_like(pos)
@@ -421,3 +416,42 @@ def test_single_rank_rccl_exchange_matches_plain(workdir):
     for a, c in zip(state[0], state[1]):
         assert np.array_equal(np.asarray(a), np.asarray(c))
     assert state[0][0].max() > 0
+
+
+def test_initial_bias_and_2d_target_vs_oracle(oracle_lib, workdir):
+    """initial_bias_filename (Grid::add from a PLUMED file read with interpolation, edm_bias.cpp:166-167)
+    and target_filename in 2-D (nearest-lower lookup, :545-546) against the oracle."""
+    fx = GU.FIXTURES
+    text = ("tempering 0\nhill_prefactor 0.3\nhill_density 25\nbias_per_step 0.2\ndimension 2\nbox_low 0 -3.141593\n"
+            "box_high 2.5 3.141593\nbias_spacing 0.04 0.1\nbias_sigma 0.1 0.25\n"
+            "target_filename %s/2.grid\ninitial_bias_filename %s/2.grid\n" % (fx, fx))
+    cfg = {}
+    for tag in ("gpu", "ora"):
+        cfg[tag] = str(workdir / (tag + ".edm"))
+        open(cfg[tag], "w").write(text + "hills_filename %s/H_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+    b = H.Bias(cfg["gpu"])
+    o = B.Bias(oracle_lib, cfg["ora"])
+    lo, hi = [0, -3.141593], [2.5, 3.141593]
+    for x in (b, o):
+        x.setup(1.0, 1.0)
+        x.subdivide(lo, hi, lo, hi, [0, 1], [0.0, 0.0])
+    assert b.get("b_targeting") == 1
+    close(b.get("expected_target"), o.get("expected_target"), rtol=1e-14, what="expected_target")
+    v, dv = b.gauss.download()
+    og = o.gauss.grid
+    close(v, og.values, rtol=1e-10, atol=1e-13 * np.abs(og.values).max(), what="grid after initial bias")
+    close(dv, og.derivs, rtol=1e-10, atol=1e-12 * np.abs(og.derivs).max(), what="derivs after initial bias")
+    n = 3000
+    for step in range(3):
+        pos = np.zeros((n, 3))
+        pos[:, 0] = W.uniform(1200 + step, n) * 2.5
+        pos[:, 1] = (W.uniform(1300 + step, n) * 2 - 1) * 3.141593
+        u = W.uniform(1400 + step, n)
+        b.add_hills(pos, u)
+        o.add_hills(np.ascontiguousarray(pos), u)
+        close(b.get("cum_bias"), o.get("cum_bias"), rtol=1e-10, what="cum_bias")
+        assert [b.get(k) for k in ("overflow_left", "overflow_right", "hills_added")] == \
+               [o.get(k) for k in ("overflow_left", "overflow_right", "hills_added")]
+    v, dv = b.gauss.download()
+    close(v, og.values, rtol=1e-9, atol=1e-12 * np.abs(og.values).max(), what="grid")
+    assert np.array_equal(b.hist.values, o.hist.values)
