@@ -383,17 +383,21 @@ typedef double v2d __attribute__((ext_vector_type(2)));  // native vector: usabl
 __device__ __forceinline__ void hermite_1d(double fa, double da, double fb, double db, double X, double dx,
                                            double inv_dx, double &value, double &der) {
 #pragma clang fp contract(fast)
-  // corner a (bit 0, s=+1) at distance X, corner b (bit 1, s=-1) at distance 1-X
-  const double Y = fabs(X - 1.0);
-  const double X2 = X * X, X3 = X2 * X, Y2 = Y * Y, Y3 = Y2 * Y;
-  const double Aa = 1 - 3 * X2 + 2 * X3, Ab = 1 - 3 * Y2 + 2 * Y3;
-  const double Ba = X - 2 * X2 + X3, Bb = Y - 2 * Y2 + Y3;
-  const double Apa = -6 * X + 6 * X2, Apb = -6 * Y + 6 * Y2;
-  const double Bpa = 1 - 4 * X + 3 * X2, Bpb = 1 - 4 * Y + 3 * Y2;
+  // corner a (bit 0, s=+1) sits at distance X, corner b (bit 1, s=-1) at distance Y = 1-X.  With
+  // A(t) = 1-3t^2+2t^3, B(t) = t-2t^2+t^3 (grid.h:120-121) the two corners share everything:
+  //   A(Y) = X^2(3-2X) = 1-A(X),  B(X) = X Y^2,  B(Y) = Y X^2,  A'(X) = A'(Y) = -6XY,
+  //   B'(X) = Y(1-3X),  B'(Y) = X(3X-2)
+  const double Y = 1.0 - X;
+  const double X2 = X * X, Y2 = Y * Y;
+  const double Ab = X2 * (3.0 - 2.0 * X);
+  const double Aa = Y2 * (1.0 + 2.0 * X);
+  const double Ba = X * Y2, Bb = Y * X2;
+  const double Ap = -6.0 * X * Y;
+  const double Bpa = Y * (1.0 - 3.0 * X), Bpb = X * (3.0 * X - 2.0);
   const double ga = (fabs(fa) < 0.0000001) ? 0.0 : da * dx;  // grid.h:113-116
   const double gb = (fabs(fb) < 0.0000001) ? 0.0 : db * dx;
   value = (fa * Aa + ga * Ba) + (fb * Ab - gb * Bb);
-  der = ((fa * Apa + ga * Bpa) - (fb * Apb - gb * Bpb)) * inv_dx;
+  der = ((fa - fb) * Ap + ga * Bpa + gb * Bpb) * inv_dx;
 }
 
 typedef __attribute__((address_space(3))) const v2d lds_v2d;
@@ -403,28 +407,45 @@ typedef __attribute__((address_space(3))) const v2d lds_v2d;
 // grid's in_grid range simply contributes (0, 0) (gaussian_grid.h:128-135, grid.h:398-409).
 template <bool USE_LDS>
 __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict__ rec, lds_v2d *win,
-                                         long long w0, long long w1, double inv_dx, double x, double &v,
-                                         double &d) {
-  v = 0;
-  d = 0;
-  if (!(x >= g.bmin[0] && x <= g.bmax[0] && x >= g.min[0] && x < g.max[0] - g.dx[0])) return;
+                                         int w0, int w1, double inv_dx, double x, double &v, double &d) {
+  // Straight-line (predicated) evaluation so the compiler can interleave the independent lookups of
+  // a lane; the two rare cases -- an index within rounding of an integer, a cell outside the LDS
+  // window -- sit behind wave-uniform branches.
+  // in_bounds (gaussian_grid.h:490-499) and in_grid (grid.h:865-874) of a non-periodic 1-D grid
+  const bool in_range = (x >= g.bmin[0]) & (x <= g.bmax[0]) & (x >= g.min[0]) & (x < g.max[0] - g.dx[0]);
   const double q = (x - g.min[0]) * inv_dx;
-  long long idx = (long long)floor(q);
-  // floor(q) can differ from the reference's floor((x-min)/dx) only within rounding of an integer:
-  // there (rare, divergent) do the exact division
-  if (fabs(q - rint(q)) <= 1e-11 * fmax(1.0, q)) idx = (long long)floor((x - g.min[0]) / g.dx[0]);
-  if (idx > g.n[0] - 2) idx = g.n[0] - 2;
+  double fq = floor(q);
+  // floor(q) can differ from the reference's floor((x-min)/dx) only within rounding of an integer
+  const bool near = in_range & (fabs(q - rint(q)) <= 1e-11 * fmax(1.0, q));
+  if (__any(near)) {
+    if (near) fq = floor((x - g.min[0]) / g.dx[0]);
+  }
+  int idx = (int)fq;
+  idx = idx < 0 ? 0 : idx;
+  idx = idx > g.n[0] - 2 ? g.n[0] - 2 : idx;
   const double where = x - g.min[0] - idx * g.dx[0];
   const double X = where * inv_dx;
   v2d a, b;
-  if (USE_LDS && idx >= w0 && idx + 1 < w1) {
-    a = win[idx - w0];
-    b = win[idx - w0 + 1];
+  if (USE_LDS) {
+    const int li = idx - w0;
+    const bool inw = (li >= 0) & (idx + 1 < w1);
+    const int lc = inw ? li : 0;
+    a = win[lc];
+    b = win[lc + 1];
+    if (__any(in_range & !inw)) {
+      if (!inw) {
+        a = reinterpret_cast<const v2d *>(rec)[idx];
+        b = reinterpret_cast<const v2d *>(rec)[idx + 1];
+      }
+    }
   } else {
     a = reinterpret_cast<const v2d *>(rec)[idx];
     b = reinterpret_cast<const v2d *>(rec)[idx + 1];
   }
-  hermite_1d(a.x, a.y, b.x, b.y, X, g.dx[0], inv_dx, v, d);
+  double vv, dd;
+  hermite_1d(a.x, a.y, b.x, b.y, X, g.dx[0], inv_dx, vv, dd);
+  v = in_range ? vv : 0.0;
+  d = in_range ? dd : 0.0;
 }
 
 template <bool USE_LDS, int NT>
@@ -441,7 +462,7 @@ __global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *_
     __syncthreads();
   }
   lds_v2d *win = (lds_v2d *)(lds_all + 16);
-  const long long w1 = w0 + wn;
+  const int w1 = (int)w0 + wn;
   double e_acc = 0;
   const long long npair = n >> 1;
   const long long stride = (long long)gridDim.x * NT;
@@ -455,10 +476,10 @@ __global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *_
     if (has_b) {  // steady state: four independent lookups in flight per lane
       const v2d rb = __builtin_nontemporal_load(&r2[j]);
       double v0, v1, v2, v3, d0, d1, d2, d3;
-      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.x, v0, d0);
-      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.y, v1, d1);
-      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, rb.x, v2, d2);
-      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, rb.y, v3, d3);
+      pair_one<USE_LDS>(g, rec, win, (int)w0, w1, inv_dx, ra.x, v0, d0);
+      pair_one<USE_LDS>(g, rec, win, (int)w0, w1, inv_dx, ra.y, v1, d1);
+      pair_one<USE_LDS>(g, rec, win, (int)w0, w1, inv_dx, rb.x, v2, d2);
+      pair_one<USE_LDS>(g, rec, win, (int)w0, w1, inv_dx, rb.y, v3, d3);
       e_acc += v0;
       e_acc += v1;
       e_acc += v2;
@@ -472,8 +493,8 @@ __global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *_
       __builtin_nontemporal_store(ob, &f2[j]);
     } else {
       double v0, v1, d0, d1;
-      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.x, v0, d0);
-      pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, ra.y, v1, d1);
+      pair_one<USE_LDS>(g, rec, win, (int)w0, w1, inv_dx, ra.x, v0, d0);
+      pair_one<USE_LDS>(g, rec, win, (int)w0, w1, inv_dx, ra.y, v1, d1);
       e_acc += v0;
       e_acc += v1;
       v2d oa;
@@ -484,7 +505,7 @@ __global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *_
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     double v, d;
-    pair_one<USE_LDS>(g, rec, win, w0, w1, inv_dx, r[n - 1], v, d);
+    pair_one<USE_LDS>(g, rec, win, (int)w0, w1, inv_dx, r[n - 1], v, d);
     e_acc += v;
     force[n - 1] = 0.0 - d;
   }
