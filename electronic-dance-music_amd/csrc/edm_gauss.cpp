@@ -795,14 +795,18 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       plan.tile_bound = nh * per_hill;
     }
   }
+  const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
   if (!spec.ordered) {
     EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, hl, hh, plan, g->d_dirty, s));
-    EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
+    if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
   }
 
   // CV histogram (edm_bias.cpp:601-610): new hills log one 'h' line each (+1) and a 'u' line
   // per undo (-1); a flush logs 'b' (+1) for replayed hills only and 'v' (-1) for its undo
-  if (spec.hist_g && spec.hist_values) {
+  if (fused_post) {
+    EDM_HIP_TRY(launch_post_batch(q, g->rec, g->d_dirty, *spec.hist_g, spec.hist_values, nh, p_hx0, dres, p_flags,
+                                  spec.flush_mode, s));
+  } else if (spec.hist_g && spec.hist_values) {
     if (!spec.limited || !spec.flush_mode)
       EDM_HIP_TRY(launch_hist_add(*spec.hist_g, spec.hist_values, nh, p_hx0, dim, nullptr, nullptr, 1.0, s));
     if (spec.limited)

@@ -107,6 +107,13 @@ hipError_t launch_hill_gather(const Geom &g, const Tables &t, double *rec, const
 // gaussian_grid.h:571-630, executed iff *dirty_flag != 0; clears the flag
 hipError_t launch_duplicate_boundary(const Geom &g, double *rec, int *dirty_flag, hipStream_t s);
 
+// fused bookkeeping after a limited batch: boundary duplication + CV histogram (+1 per hill, or per
+// replayed hill of a flush; -1 per undo)
+struct LimitResult;
+hipError_t launch_post_batch(const Geom &g, double *rec, int *dirty_flag, const Geom &hist_geom, double *hist,
+                             long long nh, const double *hx0, const LimitResult *res_dev, const int *flags,
+                             int flush_mode, hipStream_t s);
+
 // limiter (edm_bias.cpp:444-526 for new hills, :313-380 for the overflow flush)
 #define EDM_TAIL_CAP 12288
 #define EDM_CHUNK 4096

@@ -729,29 +729,34 @@ __global__ void __launch_bounds__(BLOCK) k_sel_count(long long n, const double *
   }
 }
 
-// exclusive scan of the per-block counts by one block (counts -> offsets, total)
+// exclusive scan of the per-block counts by one block (counts -> offsets, total): 256 counts per
+// pass, wave prefix sums by shuffles + a 4-entry cross-wave fix-up, running carry between passes
 __global__ void __launch_bounds__(BLOCK) k_sel_scan(int nblocks, const int *__restrict__ counts,
                                                     long long *__restrict__ offsets, long long *__restrict__ total) {
-  __shared__ long long carry;
-  __shared__ int buf[BLOCK];
-  if (threadIdx.x == 0) carry = 0;
+  __shared__ long long wsum[BLOCK / 64];
+  __shared__ long long carry_sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_sh = 0;
   __syncthreads();
   for (int base = 0; base < nblocks; base += BLOCK) {
     const int i = base + threadIdx.x;
-    buf[threadIdx.x] = (i < nblocks) ? counts[i] : 0;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      long long c = carry;
-      const int lim = (nblocks - base < BLOCK) ? nblocks - base : BLOCK;
-      for (int j = 0; j < lim; j++) {
-        offsets[base + j] = c;
-        c += buf[j];
-      }
-      carry = c;
+    const long long c = (i < nblocks) ? counts[i] : 0;
+    long long inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
     }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    long long before = carry_sh;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    if (i < nblocks) offsets[i] = before + inc - c;
+    __syncthreads();
+    if (threadIdx.x == BLOCK - 1) carry_sh = before + inc;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *total = carry;
+  if (threadIdx.x == 0) *total = carry_sh;
 }
 
 __global__ void __launch_bounds__(BLOCK) k_sel_scatter(long long n, const double *__restrict__ ru, double thr,
@@ -1690,6 +1695,71 @@ hipError_t launch_hills_ordered(const Geom &g, const Tables &t, double *rec, con
     case 1: hipLaunchKernelGGL(k_hills_ordered<1>, dim3(1), dim3(ORD_BLOCK), 0, s, g, t, rec, h, op, tail, heights_out, added_out, result_dev, dp, dirty_flag); break;
     case 2: hipLaunchKernelGGL(k_hills_ordered<2>, dim3(1), dim3(ORD_BLOCK), 0, s, g, t, rec, h, op, tail, heights_out, added_out, result_dev, dp, dirty_flag); break;
     default: hipLaunchKernelGGL(k_hills_ordered<3>, dim3(1), dim3(ORD_BLOCK), 0, s, g, t, rec, h, op, tail, heights_out, added_out, result_dev, dp, dirty_flag); break;
+  }
+  return hipGetLastError();
+}
+
+// One launch for the bookkeeping that follows a limited hill batch: boundary duplication (K6, block 0)
+// and both histogram updates (K7, remaining blocks): +1 per hill (new hills) or per replayed hill
+// (flush), -1 per undo.
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_post_batch(Geom g, double *__restrict__ rec, DupPlan dp,
+                                                      int *__restrict__ dirty_flag, Geom hg,
+                                                      double *__restrict__ hist, long long nh,
+                                                      const double *__restrict__ hx0,
+                                                      const LimitResult *__restrict__ res,
+                                                      const int *__restrict__ flags, int flush_mode) {
+  if (blockIdx.x == 0) {
+    if (*dirty_flag != 0) {
+      duplicate_boundary_block(g, rec, dp);
+      __syncthreads();
+      if (threadIdx.x == 0) *dirty_flag = 0;
+    }
+    return;
+  }
+  if (res->error) return;
+  const long long k = res->k;
+  const long long stride = (long long)(gridDim.x - 1) * BLOCK;
+  for (long long i = (long long)(blockIdx.x - 1) * BLOCK + threadIdx.x; i < nh; i += stride) {
+    double wgt = flush_mode ? 0.0 : 1.0;
+    if (i >= k) {
+      const int fl = flags[i - k];
+      if (flush_mode && (fl & 1)) wgt += 1.0;
+      if (fl & 2) wgt -= 1.0;
+    }
+    if (wgt == 0.0) continue;
+    double xx[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) xx[d] = hx0[i * DIM + d];
+    if (!in_grid<DIM>(hg, xx)) continue;
+    long long idx[DIM];
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      double wr;
+      idx[d] = node_index(hg, d, xx[d], &wr);
+      if (idx[d] < 0 || idx[d] >= hg.n[d]) ok = false;
+    }
+    if (!ok) continue;
+    long long flat = idx[DIM - 1];
+#pragma unroll
+    for (int d = DIM - 1; d > 0; d--) flat = flat * hg.n[d - 1] + idx[d - 1];
+    atomicAdd(&hist[flat], wgt);
+  }
+}
+
+hipError_t launch_post_batch(const Geom &g, double *rec, int *dirty_flag, const Geom &hg, double *hist, long long nh,
+                             const double *hx0, const LimitResult *res_dev, const int *flags, int flush_mode,
+                             hipStream_t s) {
+  const DupPlan dp = make_dup_plan(g);
+  long long hb = (nh + BLOCK - 1) / BLOCK;
+  if (hb > 1024) hb = 1024;
+  if (hb < 1) hb = 1;
+  const unsigned blocks = (unsigned)hb + 1;
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL(k_post_batch<1>, dim3(blocks), dim3(BLOCK), 0, s, g, rec, dp, dirty_flag, hg, hist, nh, hx0, res_dev, flags, flush_mode); break;
+    case 2: hipLaunchKernelGGL(k_post_batch<2>, dim3(blocks), dim3(BLOCK), 0, s, g, rec, dp, dirty_flag, hg, hist, nh, hx0, res_dev, flags, flush_mode); break;
+    default: hipLaunchKernelGGL(k_post_batch<3>, dim3(blocks), dim3(BLOCK), 0, s, g, rec, dp, dirty_flag, hg, hist, nh, hx0, res_dev, flags, flush_mode); break;
   }
   return hipGetLastError();
 }
