@@ -400,6 +400,23 @@ __device__ __forceinline__ void hermite_1d(double fa, double da, double fb, doub
   der = ((fa - fb) * Ap + ga * Bpa + gb * Bpb) * inv_dx;
 }
 
+// The reference's own two-corner form (grid.h:110-123 with X = fabs(where/dx - x0)), used when the
+// scaled coordinate falls outside [0,1] by rounding: there fabs() mirrors the two corners
+// inconsistently and the shared-corner identities above do not describe what the reference computes.
+__device__ __forceinline__ void hermite_1d_mirrored(double fa, double da, double fb, double db, double Xs, double dx,
+                                                    double inv_dx, double &value, double &der) {
+  const double X = fabs(Xs), Y = fabs(Xs - 1.0);
+  const double X2 = X * X, X3 = X2 * X, Y2 = Y * Y, Y3 = Y2 * Y;
+  const double Aa = 1 - 3 * X2 + 2 * X3, Ab = 1 - 3 * Y2 + 2 * Y3;
+  const double Ba = X - 2 * X2 + X3, Bb = Y - 2 * Y2 + Y3;
+  const double Apa = -6 * X + 6 * X2, Apb = -6 * Y + 6 * Y2;
+  const double Bpa = 1 - 4 * X + 3 * X2, Bpb = 1 - 4 * Y + 3 * Y2;
+  const double ga = (fabs(fa) < 0.0000001) ? 0.0 : da * dx;
+  const double gb = (fabs(fb) < 0.0000001) ? 0.0 : db * dx;
+  value = (fa * Aa + ga * Ba) + (fb * Ab - gb * Bb);
+  der = ((fa * Apa + ga * Bpa) - (fb * Apb - gb * Bpb)) * inv_dx;
+}
+
 typedef __attribute__((address_space(3))) const v2d lds_v2d;
 
 // Fast-path precondition (checked by the launcher): 1-D, interpolating, grid and boundary both
@@ -444,6 +461,10 @@ __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict
   }
   double vv, dd;
   hermite_1d(a.x, a.y, b.x, b.y, X, g.dx[0], inv_dx, vv, dd);
+  const bool outside = in_range & ((X < 0.0) | (X > 1.0));  // `where` off by an ulp at a node
+  if (__any(outside)) {
+    if (outside) hermite_1d_mirrored(a.x, a.y, b.x, b.y, X, g.dx[0], inv_dx, vv, dd);
+  }
   v = in_range ? vv : 0.0;
   d = in_range ? dd : 0.0;
 }

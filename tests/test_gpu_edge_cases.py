@@ -1,0 +1,145 @@
+"""Edge cases of the hot path on the GPU, through the C ABI: empty and odd-sized batches, samples that sit
+exactly on grid nodes / boundaries (the K1 fast path's exact-index fallback), fully masked batches, hills
+that the boundary rejects, overflow-buffer exhaustion and call-order errors."""
+import numpy as np
+import pytest
+
+import edm_amd.hip as H
+import edm_amd.workloads as W
+from oracle import binding as B
+
+pytestmark = pytest.mark.gpu
+
+C1D = dict(lo=[0.0], hi=[2.8], sp=[0.00025], per=[0], sg=[0.025])
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    H.require_gpu()
+    yield
+
+
+def _pair(oracle_lib, c=C1D, nh=200):
+    g = H.Gauss.create(c["lo"], c["hi"], c["sp"], c["per"], 1, c["sg"])
+    o = B.Gauss.create(oracle_lib, c["lo"], c["hi"], c["sp"], c["per"], 1, c["sg"])
+    hx = np.zeros((nh, 3))
+    hx[:, 0] = W.pair_distances(nh, 5)
+    g.add_values(hx, 0.01)
+    for x in hx:
+        o.add_value(x[:1], 0.01)
+    return g, o
+
+
+def test_empty_and_tiny_batches(oracle_lib):
+    g, o = _pair(oracle_lib)
+    e, f = g.pair_forces(np.zeros(0))
+    assert e == 0.0 and f.size == 0
+    assert g.update_forces(np.zeros((0, 3)), np.zeros((0, 3))) == 0.0
+    assert g.add_values(np.zeros((0, 3)), 1.0).size == 0
+    for n in (1, 2, 3, 63, 64, 65, 1025):  # odd sizes exercise the tail of the vectorised kernel
+        r = W.pair_distances(n, 40 + n)
+        e, f = g.pair_forces(r)
+        ref = [o.get_value_deriv([x]) for x in r]
+        assert abs(e - sum(v for v, _ in ref)) <= 1e-10 * max(abs(e), 1e-30)
+        ref_f = np.array([-d[0] for _, d in ref])
+        # dV/dr is a difference of O(V/dx) terms: ~1e-12 relative-to-scale rounding noise is inherent
+        assert np.allclose(f, ref_f, rtol=1e-9, atol=1e-11 * np.abs(ref_f).max())
+
+
+def test_samples_on_nodes_and_boundaries(oracle_lib):
+    """x = k*dx exactly (and one ulp either side): the node index must equal the reference's
+    floor((x-min)/dx) bit for bit, in the fast pair kernel and in the generic kernel."""
+    g, o = _pair(oracle_lib)
+    og = o.grid
+    dx = float(og.dx[0])
+    ks = np.concatenate([np.arange(0, 11201, 37), [0, 1, 11198, 11199, 11200]]).astype(np.float64)
+    base = ks * dx
+    r = np.concatenate([base, np.nextafter(base, 10), np.nextafter(base, -10), [2.8, 2.8 - 1e-16, 0.0, -0.0, 2.8 + dx, -1e-300]])
+    idx = g.sample_index(r.reshape(-1, 1))
+    want = np.array([og.multi2one(og.get_index([x])) if (o.in_bounds([x]) and og.in_grid([x])) else -1 for x in r])
+    assert np.array_equal(idx, want)
+    e, f = g.pair_forces(r)
+    ref = [o.get_value_deriv([x]) for x in r]
+    ref_f = np.array([-d[0] for _, d in ref])
+    assert np.allclose(f, ref_f, rtol=1e-9, atol=1e-11 * np.abs(ref_f).max())
+    assert abs(e - sum(v for v, _ in ref)) <= 1e-10 * abs(e)
+    # big batch -> the LDS-window variant of the kernel; same node-aligned samples repeated
+    big = np.tile(r, (1 << 22) // r.size + 1)
+    e2, f2 = g.pair_forces(big)
+    assert np.allclose(f2[: r.size], ref_f, rtol=1e-9, atol=1e-11 * np.abs(ref_f).max())
+    assert np.array_equal(f2[: r.size], f2[r.size: 2 * r.size])
+
+
+def test_fully_masked_and_out_of_range():
+    g = H.Gauss.create(C1D["lo"], C1D["hi"], C1D["sp"], C1D["per"], 1, C1D["sg"])
+    g.add_values(np.array([[1.5, 0, 0]]), 1.0)
+    n = 1000
+    x = np.zeros((n, 3))
+    x[:, 0] = W.pair_distances(n, 3)
+    f = np.ones((n, 3))
+    e = g.update_forces(x, f, mask=np.zeros(n, dtype=np.int32), apply_mask=1)
+    assert e == 0.0 and np.array_equal(f, np.ones((n, 3)))
+    far = np.full(n, 7.5)  # outside boundary and grid: contributes (0, 0) (gaussian_grid.h:128-135)
+    e, fr = g.pair_forces(far)
+    assert e == 0.0 and not fr.any()
+    added = g.add_values(np.array([[7.5, 0, 0], [-0.1, 0, 0]]), 1.0)  # rejected by the boundary (:214-216)
+    assert not added.any()
+
+
+def _bias(tmp_path, tag, text):
+    cfg = str(tmp_path / (tag + ".edm"))
+    open(cfg, "w").write(text + "hills_filename %s/H_%s\nhistogram_filename %s/HIST_%s\n" % (tmp_path, tag, tmp_path, tag))
+    b = H.Bias(cfg)
+    b.setup(1.0, 1.0)
+    b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    return b
+
+
+BASE = "tempering 0\ndimension 1\nbox_low 0\nbox_high 2.8\nbias_spacing 0.001\nbias_sigma 0.05\n"
+
+
+def test_overflow_buffer_exhaustion_is_reported(tmp_path):
+    """More deferred hills than the 2048-slot overflow buffer holds: the reference aborts
+    (edm_bias.cpp:501-507); the C ABI returns EDM_HIP_ERR_OVERFLOW."""
+    b = _bias(tmp_path, "ovf", BASE + "hill_prefactor 1.0\nbias_per_step 0.0001\n")
+    b.set_hill_log(False)
+    n = 3000
+    r = W.pair_distances(n, 77).reshape(-1, 1)
+    with pytest.raises(H.EdmHipError) as ei:
+        b.add_hills(r, np.ones(n))
+    assert "overflow buffer is full" in str(ei.value)
+
+
+def test_call_order_errors(tmp_path):
+    b = _bias(tmp_path, "ord", BASE + "hill_prefactor 0.5\n")
+    with pytest.raises(H.EdmHipError):
+        b.add_hill([1.0], 0.5)  # before pre_add_hill (edm_bias.cpp:530-531)
+    b.pre_add_hill(4)
+    b.add_hill([1.0], 0.5)
+    b.post_add_hill()
+    assert b.get("cum_bias") > 0 and b.get("steps") == 1
+
+
+def test_skipped_round_when_buffer_not_drained(tmp_path, oracle_lib):
+    """Leftover buffered bias makes the whole next round of new hills be skipped (edm_bias.cpp:434-439)."""
+    text = BASE + "hill_prefactor 1.0\nbias_per_step 0.3\n"
+    b = _bias(tmp_path, "skip", text)
+    cfg_o = str(tmp_path / "skip_o.edm")
+    open(cfg_o, "w").write(text + "hills_filename %s/H_o\nhistogram_filename %s/HIST_o\n" % (tmp_path, tmp_path))
+    o = B.Bias(oracle_lib, cfg_o)
+    o.setup(1.0, 1.0)
+    o.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    for step in range(6):
+        r = W.pair_distances(5, 600 + step).reshape(-1, 1)
+        u = np.ones(5)
+        b.pre_add_hill(1)
+        o.pre_add_hill(1)
+        for x in r:
+            b.add_hill(x, 1.0)
+            o.add_hill(x, 1.0)
+        b.post_add_hill()
+        o.post_add_hill()
+        keys = ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added", "steps")
+        assert [b.get(k) for k in keys] == [o.get(k) for k in keys], step
+        assert abs(b.get("cum_bias") - o.get("cum_bias")) <= 1e-10 * o.get("cum_bias")
+    assert np.array_equal(b.hist.values, o.hist.values)
