@@ -25,7 +25,7 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 void HillWorkspace::release() {
-  heights.release(); hx.release(); hx0.release(); ht.release(); added.release(); partial.release(); scratch.release();
+  slots.release(); heights.release(); hx.release(); hx0.release(); ht.release(); added.release(); partial.release(); scratch.release();
   tail_h1.release(); tail_h2.release(); tail_a2.release(); tail_cum.release();
   hc.release(); tail_flags.release(); tile_flags.release(); tile_list.release(); result.release(); rb.release();
 }
@@ -736,8 +736,29 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hh.tail_h2 = p_h2;
   hh.res_dev = nullptr;
 
+  // Dense batches on small grids (the 1-D all-samples regime): fused path -- the gather runs first with
+  // the base heights and yields the per-hill integrals as a by-product; the limiter then only has to
+  // correct the hills it changed.
+  const long long ntiles_all = gather_tiles(q);
+  const bool fused = !spec.ordered && (nh >= 4096) && (ntiles_all < 1024);
+  GatherPlan fplan;
+  memset(&fplan, 0, sizeof(fplan));
+  if (fused) {
+    long long G = (2048 + ntiles_all - 1) / ntiles_all;
+    if (G > 64) G = 64;
+    if (G > nh / 256) G = nh / 256;
+    if (G < 1) G = 1;
+    fplan.groups = (int)G;
+    fplan.slots_per_hill = gather_slots_per_hill(q);
+    EDM_HIP_TRY(ws.partial.reserve((size_t)(G + 1) * (size_t)q.total * q.rec));
+    EDM_HIP_TRY(ws.slots.reserve((size_t)nh * fplan.slots_per_hill));
+    fplan.partial = ws.partial.p;
+    fplan.slots = ws.slots.p;
+  }
   const double *base_heights = spec.d_h;
-  if (spec.ordered) {
+  if (fused) {
+    EDM_HIP_TRY(launch_hill_gather_fused(q, tabs, hl, spec.d_h, spec.h_const, fplan, p_added, g->d_dirty, s));
+  } else if (spec.ordered) {
     if (nh > EDM_TAIL_CAP) {
       set_error("ordered (locally tempered) hill batches are limited to EDM_TAIL_CAP hills per step");
       return EDM_HIP_ERR_OVERFLOW;
@@ -772,7 +793,9 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   plan.tile_list = nullptr;
   plan.tile_bound = 0;
   const long long ntiles = gather_tiles(q);
-  if (nh >= 4096 && ntiles < 1024) {
+  if (fused) {
+    // planned above
+  } else if (nh >= 4096 && ntiles < 1024) {
     long long G = (2048 + ntiles - 1) / ntiles;
     if (G > 64) G = 64;
     if (G > nh / 256) G = nh / 256;
@@ -796,7 +819,10 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     }
   }
   const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
-  if (!spec.ordered) {
+  if (fused) {
+    EDM_HIP_TRY(launch_hill_gather_correct_and_apply(q, tabs, g->rec, hl, hh, fplan, spec.limited ? 1 : 0, g->d_dirty, s));
+    if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
+  } else if (!spec.ordered) {
     EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, hl, hh, plan, g->d_dirty, s));
     if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
   }

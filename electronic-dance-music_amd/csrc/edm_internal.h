@@ -49,7 +49,7 @@ struct DevBuf {
 
 // workspace of the hill path, shared by add_values / the controller
 struct HillWorkspace {
-  DevBuf<double> hx, hx0, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum, heights;
+  DevBuf<double> hx, hx0, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum, heights, slots;
   DevBuf<int> hc, tail_flags, tile_flags, tile_list;
   DevBuf<char> result;      // LimitResult
   DevBuf<char> rb;          // packed read-back region of small batches (one D2H instead of six)

@@ -94,11 +94,28 @@ hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList 
 
 struct GatherPlan {
   int groups;             // hill groups (partial buffers) -- 1 = accumulate in place
-  double *partial;        // [groups][total][rec] when groups > 1
+  double *partial;        // [groups (+1)][total][rec] when groups > 1 or in fused mode
   int *tile_flags;        // [ntiles] scratch when culling, else NULL
   int *tile_list;         // [ntiles + 1] (list + count at the end)
   long long tile_bound;   // launch bound for culled gathers
+  // fused mode (dense batches on small grids): the gather runs BEFORE the limiter with the base
+  // heights, writes per-group deltas and, as a by-product, the per-(hill, tile) pieces of each
+  // hill's integrated bias into `slots` [nh][slots_per_hill]; a correction pass then fixes up the
+  // (rare) hills the limiter changed.
+  double *slots;
+  int slots_per_hill;
 };
+// slots per hill needed by the fused gather for this geometry
+int gather_slots_per_hill(const Geom &g);
+// fused gather: partial[0..groups) += base-height contributions; added[i] = integrated bias of hill i
+hipError_t launch_hill_gather_fused(const Geom &g, const Tables &t, const HillList &h, const double *heights,
+                                    double h_const, const GatherPlan &plan, double *added, int *dirty_flag,
+                                    hipStream_t s);
+// correction: partial[groups] = sum over the limiter's tail hills of (tail_h1 - base, tail_h2) terms
+// (zero when the limiter changed nothing); then rec += partial[0] + ... + partial[groups] in order
+hipError_t launch_hill_gather_correct_and_apply(const Geom &g, const Tables &t, double *rec, const HillList &h,
+                                                const HillHeights &hh, const GatherPlan &plan, int with_correction,
+                                                int *dirty_flag, hipStream_t s);
 long long gather_tiles(const Geom &g);
 // applies the hills to the record array in list order; dirty_flag (device int) is set
 // when any boundary correction was non-zero (gaussian_grid.h:357-358)

@@ -1135,7 +1135,37 @@ __device__ __forceinline__ long long gather_tiles_dev(const Geom &g) {
   return t;
 }
 
+// slot of tile (by its per-dimension tile coordinates) among the tiles a hill centred at c overlaps
 template <int DIM>
+__device__ __forceinline__ int hill_tile_slot(const Geom &g, const int *c, const int *tile_coord) {
+  int slot = 0, mul = 1;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    const int T = Tile<DIM>::T[d];
+    const int nt = (g.n[d] + T - 1) / T;
+    const int m = g.msize[d];
+    int S = (2 * m) / T + 3;
+    if (S > nt) S = nt;
+    int sd;
+    if (g.periodic[d]) {
+      const int first = (int)((((long long)c[d] - m) % g.n[d] + g.n[d]) % g.n[d]);
+      sd = (tile_coord[d] - first / T + nt) % nt;
+    } else {
+      const int first = (c[d] - m > 0) ? c[d] - m : 0;
+      sd = tile_coord[d] - first / T;
+    }
+    if (sd < 0) sd = 0;
+    if (sd > S - 1) sd = S - 1;
+    slot += sd * mul;
+    mul *= S;
+  }
+  return slot;
+}
+
+// MODE 0: heights from (base | limiter tail), in place (groups == 1) or per-group partials
+// MODE 1: fused -- base heights only, always into partials, per-(hill, tile) integral pieces into slots
+// MODE 2: correction -- only the limiter's tail hills, heights (tail_h1 - base, tail_h2), into partial[groups]
+template <int DIM, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
                                                        HillHeights hh, GatherPlan plan, int use_list,
                                                        int *__restrict__ dirty_flag) {
@@ -1146,7 +1176,7 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
     tile = plan.tile_list[tile];
   }
   // tile origin and this thread's node
-  int t0[DIM], p[DIM];
+  int t0[DIM], p[DIM], tcoord[DIM];
   {
     long long rest = tile;
     int lrest = threadIdx.x;
@@ -1154,7 +1184,8 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
     for (int d = 0; d < DIM; d++) {
       const int T = Tile<DIM>::T[d];
       const int nt_d = (g.n[d] + T - 1) / T;
-      t0[d] = (int)(rest % nt_d) * T;
+      tcoord[d] = (int)(rest % nt_d);
+      t0[d] = tcoord[d] * T;
       rest /= nt_d;
       p[d] = t0[d] + (lrest % T);
       lrest /= T;
@@ -1181,13 +1212,21 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
     k_first_tail = hh.res_dev->k;
   }
   const int G = plan.groups;
-  const int grp = blockIdx.y;
+  const int grp = (MODE == 2) ? G : blockIdx.y;   // the correction owns the extra partial buffer
   const long long per = (h.nh + G - 1) / G;
-  const long long hbeg = per * grp;
-  const long long hend = (hbeg + per < h.nh) ? hbeg + per : h.nh;
+  long long hbeg = per * blockIdx.y;
+  long long hend = (hbeg + per < h.nh) ? hbeg + per : h.nh;
+  if (MODE == 2) {
+    hbeg = k_first_tail;
+    hend = h.nh;
+  }
+  const bool in_place = (MODE == 0) && (G == 1);
+  double vol = 1;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) vol *= g.dx[d];
 
   double acc[1 + DIM];
-  if (G == 1 && active) {
+  if (in_place && active) {
     // in-place: start from the stored record so the adds follow the reference's
     // sequence V0 + h0*t0 + h1*t1 + ... exactly
 #pragma unroll
@@ -1208,6 +1247,8 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
   __shared__ double s_t[BLOCK][2 * DIM];
   __shared__ double s_h1[BLOCK], s_h2[BLOCK];
   __shared__ int s_wcnt[BLOCK / 64];
+  __shared__ long long s_id[(MODE == 1) ? BLOCK : 1];
+  __shared__ double s_wpart[(MODE == 1) ? BLOCK / 64 : 1][(MODE == 1) ? BLOCK : 1];
   TermConst<DIM> tc;
   term_const<DIM>(g, tc);
   constexpr int ILP = 4;
@@ -1230,14 +1271,21 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
           if (images(g, d, c[d], t0[d], t1) == 0) take = false;
         }
         if (take) {
-          if (cur < k_first_tail) {
-            h1 = hh.h ? hh.h[cur] : hh.h_const;
+          const double hb = hh.h ? hh.h[cur] : hh.h_const;
+          if (MODE == 1) {
+            h1 = hb;
+            h2 = 0;
+          } else if (MODE == 2) {
+            h1 = hh.tail_h1[cur - k_first_tail] - hb;  // what the fused pass added too much
+            h2 = hh.tail_h2[cur - k_first_tail];
+          } else if (cur < k_first_tail) {
+            h1 = hb;
             h2 = 0;
           } else {
             h1 = hh.tail_h1[cur - k_first_tail];
             h2 = hh.tail_h2[cur - k_first_tail];
           }
-          if (h1 == 0 && h2 == 0) take = false;  // deferred to the overflow buffer: add_value is never called
+          if (h1 == 0 && h2 == 0) take = false;  // nothing to add (deferred hill / unchanged hill)
         }
       }
     }
@@ -1261,16 +1309,17 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
       }
       s_h1[pos] = h1;
       s_h2[pos] = h2;
+      if (MODE == 1) s_id[pos] = cur;
     }
     __syncthreads();
-    if (active) {
+    if (active || MODE == 1) {
       for (int q0 = 0; q0 < cnt; q0 += ILP) {
         double val[ILP], dval[ILP][DIM];
         int mult[ILP];
 #pragma unroll
         for (int q = 0; q < ILP; q++) {
           mult[q] = 0;
-          if (q0 + q < cnt) {
+          if (active && q0 + q < cnt) {
             int m = 1;
 #pragma unroll
             for (int d = 0; d < DIM; d++) m *= images(g, d, s_c[q0 + q][d], p[d], p[d]);
@@ -1299,16 +1348,38 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
             }
           }
         }
+        if (MODE == 1) {
+          // this tile's piece of each hill's integrated bias (gaussian_grid.h:349), fixed-order sums
+#pragma unroll
+          for (int q = 0; q < ILP; q++) {
+            double piece = 0;
+            if (mult[q] > 0) {
+              const double term = s_h1[q0 + q] * val[q] * vol;
+              for (int rep = 0; rep < mult[q]; rep++) piece += term;
+            }
+            piece = wave_sum(piece);
+            if (lane == 0 && q0 + q < cnt) s_wpart[wave][q0 + q] = piece;
+          }
+        }
+      }
+    }
+    if (MODE == 1) {
+      __syncthreads();
+      if ((int)threadIdx.x < cnt) {
+        double tot = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) tot += s_wpart[w][threadIdx.x];
+        plan.slots[s_id[threadIdx.x] * plan.slots_per_hill + hill_tile_slot<DIM>(g, s_c[threadIdx.x], tcoord)] = tot;
       }
     }
     __syncthreads();
   }
   if (active) {
-    double *dst = (G == 1) ? rec + flat * R : plan.partial + ((long long)grp * g.total + flat) * R;
+    double *dst = in_place ? rec + flat * R : plan.partial + ((long long)grp * g.total + flat) * R;
 #pragma unroll
     for (int j = 0; j <= DIM; j++) dst[j] = acc[j];
     if (any_corr) *dirty_flag = 1;
-  } else if (G > 1) {
+  } else if (!in_place) {
     // inactive nodes of a partial buffer must read as zero in the reduction
     bool in_grid_node = true;
 #pragma unroll
@@ -1327,7 +1398,9 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
 
 // rec[p] += partial[0][p] + partial[1][p] + ... in group (= hill list) order
 __global__ void __launch_bounds__(BLOCK) k_reduce_partials(Geom g, double *__restrict__ rec,
-                                                           const double *__restrict__ partial, int groups) {
+                                                           const double *__restrict__ partial, int groups,
+                                                           const LimitResult *__restrict__ res) {
+  if (res && res->error) return;  // limiter overflow: the batch is not applied
   const long long n = g.total * g.rec;
   const long long stride = (long long)gridDim.x * BLOCK;
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
@@ -1403,11 +1476,11 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
     use_list = 1;
     launch_tiles = plan.tile_bound < ntiles ? plan.tile_bound : ntiles;
   }
-  hipLaunchKernelGGL(k_hill_gather<DIM>, dim3((unsigned)launch_tiles, (unsigned)plan.groups), dim3(BLOCK), 0, s, g, t, rec, h,
-                     hh, plan, use_list, dirty_flag);
+  hipLaunchKernelGGL((k_hill_gather<DIM, 0>), dim3((unsigned)launch_tiles, (unsigned)plan.groups), dim3(BLOCK), 0, s, g, t,
+                     rec, h, hh, plan, use_list, dirty_flag);
   if (plan.groups > 1)
     hipLaunchKernelGGL(k_reduce_partials, dim3(blocks_for(g.total * g.rec)), dim3(BLOCK), 0, s, g, rec, plan.partial,
-                       plan.groups);
+                       plan.groups, hh.res_dev);
   return hipGetLastError();
 }
 
@@ -1419,6 +1492,77 @@ hipError_t launch_hill_gather(const Geom &g, const Tables &t, double *rec, const
     case 2: return gather_dim<2>(g, t, rec, h, hh, plan, dirty_flag, s);
     default: return gather_dim<3>(g, t, rec, h, hh, plan, dirty_flag, s);
   }
+}
+
+int gather_slots_per_hill(const Geom &g) {
+  static const int T1[3] = {256, 1, 1}, T2[3] = {16, 16, 1}, T3[3] = {8, 8, 4};
+  const int *T = g.dim == 1 ? T1 : g.dim == 2 ? T2 : T3;
+  int total = 1;
+  for (int d = 0; d < g.dim; d++) {
+    const int nt = (g.n[d] + T[d] - 1) / T[d];
+    int S = (2 * g.msize[d]) / T[d] + 3;
+    if (S > nt) S = nt;
+    total *= S;
+  }
+  return total;
+}
+
+// added[i] = slots[i][0] + slots[i][1] + ... (tile order: fixed)
+__global__ void __launch_bounds__(BLOCK) k_sum_slots(long long nh, int S, const double *__restrict__ slots,
+                                                     double *__restrict__ added) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < nh; i += stride) {
+    double a = 0;
+    for (int q = 0; q < S; q++) a += slots[i * S + q];
+    added[i] = a;
+  }
+}
+
+hipError_t launch_hill_gather_fused(const Geom &g, const Tables &t, const HillList &h, const double *heights,
+                                    double h_const, const GatherPlan &plan, double *added, int *dirty_flag,
+                                    hipStream_t s) {
+  if (h.nh <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(plan.slots, 0, sizeof(double) * (size_t)h.nh * plan.slots_per_hill, s);
+  if (e != hipSuccess) return e;
+  HillHeights hh;
+  hh.h = heights;
+  hh.h_const = h_const;
+  hh.k = h.nh;
+  hh.tail_h1 = nullptr;
+  hh.tail_h2 = nullptr;
+  hh.res_dev = nullptr;
+  const long long ntiles = gather_tiles(g);
+  const dim3 grid((unsigned)ntiles, (unsigned)plan.groups);
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL((k_hill_gather<1, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag); break;
+    case 2: hipLaunchKernelGGL((k_hill_gather<2, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag); break;
+    default: hipLaunchKernelGGL((k_hill_gather<3, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag); break;
+  }
+  hipLaunchKernelGGL(k_sum_slots, dim3(blocks_for(h.nh)), dim3(BLOCK), 0, s, h.nh, plan.slots_per_hill, plan.slots, added);
+  return hipGetLastError();
+}
+
+hipError_t launch_hill_gather_correct_and_apply(const Geom &g, const Tables &t, double *rec, const HillList &h,
+                                                const HillHeights &hh, const GatherPlan &plan, int with_correction,
+                                                int *dirty_flag, hipStream_t s) {
+  if (h.nh <= 0) return hipSuccess;
+  int groups = plan.groups;
+  if (with_correction) {
+    const size_t one = sizeof(double) * (size_t)g.total * g.rec;
+    hipError_t e = hipMemsetAsync(plan.partial + (size_t)plan.groups * g.total * g.rec, 0, one, s);
+    if (e != hipSuccess) return e;
+    const long long ntiles = gather_tiles(g);
+    const dim3 grid((unsigned)ntiles, 1);
+    switch (g.dim) {
+      case 1: hipLaunchKernelGGL((k_hill_gather<1, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag); break;
+      case 2: hipLaunchKernelGGL((k_hill_gather<2, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag); break;
+      default: hipLaunchKernelGGL((k_hill_gather<3, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag); break;
+    }
+    groups += 1;
+  }
+  hipLaunchKernelGGL(k_reduce_partials, dim3(blocks_for(g.total * g.rec)), dim3(BLOCK), 0, s, g, rec, plan.partial, groups,
+                     with_correction ? hh.res_dev : (const LimitResult *)nullptr);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

@@ -455,3 +455,49 @@ def test_initial_bias_and_2d_target_vs_oracle(oracle_lib, workdir):
     v, dv = b.gauss.download()
     close(v, og.values, rtol=1e-9, atol=1e-12 * np.abs(og.values).max(), what="grid")
     assert np.array_equal(b.hist.values, o.hist.values)
+
+
+def test_dense_batch_fused_path_vs_oracle(oracle_lib, workdir):
+    """Dense hill batches on a small grid take the fused path (gather first, integrals as a by-product,
+    limiter, correction gather).  Unlimited batch and a limited controller step that crosses the limit
+    inside the batch, both against the oracle's sequential add_value loop."""
+    c = dict(lo=[0.0], hi=[2.8], sp=[0.001], per=[0], sg=[0.05])
+    g, o = make_pair(c, oracle_lib)
+    n = 6000
+    hx = np.zeros((n, 3))
+    hx[:, 0] = W.pair_distances(n, 1500)
+    hh = 1e-4 * (1.0 + W.uniform(1501, n))
+    added = g.add_values(hx, hh)
+    ref = np.array([o.add_value(x[:1], float(h)) for x, h in zip(hx, hh)])
+    close(added, ref, rtol=1e-10, atol=1e-18, what="fused per-hill integrals")
+    v, dv = g.download()
+    og = o.grid
+    close(v, og.values, rtol=1e-9, atol=1e-12 * np.abs(og.values).max(), what="grid (fused)")
+    close(dv, og.derivs, rtol=1e-9, atol=1e-11 * np.abs(og.derivs).max(), what="derivs (fused)")
+    # limited: all-samples mode, the limit is crossed ~96% into the batch; the rest is deferred
+    # (320, 640, 960 buffered hills after the three steps: below the 2048-slot buffer)
+    text = ("tempering 0\nhill_prefactor 0.5\nbias_per_step 0.48\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+            "bias_spacing 0.001\nbias_sigma 0.05\n")
+    cfg = {}
+    for tag in ("gpu", "ora"):
+        cfg[tag] = str(workdir / (tag + ".edm"))
+        open(cfg[tag], "w").write(text + "hills_filename %s/H_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+    b = H.Bias(cfg["gpu"])
+    ob = B.Bias(oracle_lib, cfg["ora"])
+    for x in (b, ob):
+        x.setup(1.0, 1.0)
+        x.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    for step in range(3):
+        m = 8000
+        r = W.pair_distances(m, 1600 + step).reshape(-1, 1)
+        u = W.uniform(1700 + step, m)
+        b.add_hills(r, u)
+        ob.add_hills(np.ascontiguousarray(r), u)
+        close(b.get("cum_bias"), ob.get("cum_bias"), rtol=1e-10, what="cum_bias step %d" % step)
+        keys = ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added")
+        assert [b.get(k) for k in keys] == [ob.get(k) for k in keys], step
+    v, dv = b.gauss.download()
+    ogg = ob.gauss.grid
+    close(v, ogg.values, rtol=1e-9, atol=1e-12 * np.abs(ogg.values).max(), what="grid (fused + limiter)")
+    assert np.array_equal(b.hist.values, ob.hist.values)
+    assert ob.get("overflow_right") > 0
