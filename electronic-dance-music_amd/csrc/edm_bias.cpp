@@ -55,6 +55,7 @@ struct edm_hip_bias {
   // device scratch owned by the controller
   DevBuf<long long> sel;
   long long *h_count = nullptr, *d_count = nullptr;  // host-mapped pinned: the selection kernel writes the count here
+  DevBuf<long long> count_dev;                       // ... and here, for kernels consuming a deferred count
   DevBuf<int> sel_scratch;
   DevBuf<double> stage_x, stage_u, stage_h, tail_w;
   DevBuf<double> hx0;
@@ -229,7 +230,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   edm_hip_grid_destroy(b->hist);
   edm_hip_grid_destroy(b->target);
   if (b->hills_fp) fclose(b->hills_fp);
-  b->sel.release(); b->sel_scratch.release();
+  b->sel.release(); b->sel_scratch.release(); b->count_dev.release();
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
   delete b;
@@ -502,6 +503,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   const int use_thr = !(b->hill_density < 0);
   const double thr = b->hill_density / b->est_hill_count;   // :543
   long long nh = n;
+  long long deferred_bound = 0;
   const long long *d_sel = nullptr;
   if (use_thr || apply_mask >= 0) {
     if (use_thr && !d_ru) {
@@ -514,9 +516,27 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       EDM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_count), b->h_count, 0));
     }
     EDM_HIP_TRY(b->sel_scratch.reserve(select_scratch_ints(n)));
-    EDM_HIP_TRY(launch_select(n, d_ru, thr, use_thr, b->d_mask, apply_mask, b->sel.p, b->d_count, b->sel_scratch.p, s));
-    EDM_HIP_TRY(hipStreamSynchronize(s));
-    nh = *b->h_count;
+    EDM_HIP_TRY(b->count_dev.reserve(2));
+    EDM_HIP_TRY(launch_select(n, d_ru, thr, use_thr, b->d_mask, apply_mask, b->sel.p, b->d_count, b->sel_scratch.p, s,
+                              b->count_dev.p));
+    // Stochastic steps accept a few hundred of millions of samples: queue the rest of the step against a
+    // conservative bound instead of waiting for the count to reach the host (one sync per step saved);
+    // should the bound ever be too small the limiter reports it, nothing is applied and the step's hill
+    // path is redone below with the exact count.
+    long long bound = 0;
+    if (use_thr && !b->comm && !b->b_targeting && !local_tempering) {
+      const double expected = thr * (double)n;
+      bound = (long long)(4.0 * expected) + 128;
+      if (bound < 256) bound = 256;
+      if (bound > 4096 || bound >= n) bound = 0;
+    }
+    deferred_bound = bound;
+    if (!bound) {
+      EDM_HIP_TRY(hipStreamSynchronize(s));
+      nh = *b->h_count;
+    } else {
+      nh = bound;
+    }
     d_sel = b->sel.p;
   }
   if (b->comm) {
@@ -580,7 +600,13 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     spec.op.clamp = BIAS_CLAMP * b->bias_per_step;
   }
   ApplyOutcome oc;
+  if (deferred_bound) spec.d_nh = b->count_dev.p;
   int rc = apply_hills(b->bias, spec, &oc, false);
+  if (rc == EDM_APPLY_BOUND_EXCEEDED) {
+    spec.d_nh = nullptr;
+    spec.nh = *b->h_count;  // the stream has been synchronised: the exact count is on the host now
+    rc = apply_hills(b->bias, spec, &oc, false);
+  }
   if (rc) return rc;
   const LimitResult &res = oc.res;
   b->temp_hill_cum = res.cum_out;

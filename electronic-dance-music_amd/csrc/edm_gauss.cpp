@@ -725,6 +725,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hl.hc = ws.hc.p;
   hl.ht = ws.ht.p;
   hl.hx0 = p_hx0;
+  hl.nh_dev = spec.d_nh;
   const Tables tabs = g->tables();
   EDM_HIP_TRY(launch_hill_prep(q, hl, s));
 
@@ -740,7 +741,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   // the base heights and yields the per-hill integrals as a by-product; the limiter then only has to
   // correct the hills it changed.
   const long long ntiles_all = gather_tiles(q);
-  const bool fused = !spec.ordered && (nh >= 4096) && (ntiles_all < 1024);
+  const bool fused = !spec.ordered && !spec.d_nh && (nh >= 4096) && (ntiles_all < 1024);
   GatherPlan fplan;
   memset(&fplan, 0, sizeof(fplan));
   if (fused) {
@@ -778,7 +779,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   } else if (spec.limited) {
     LimitTail tail{ws.tail_h1.p, p_h2, p_a2, ws.tail_cum.p, p_flags};
     EDM_HIP_TRY(launch_limit(nh, p_added, spec.d_h, spec.h_const, spec.limit, spec.cum_in, spec.flush_mode, tail,
-                             dres, ws.scratch.p, s));
+                             dres, ws.scratch.p, s, spec.d_nh));
     hh.res_dev = dres;  // the gather reads k on the device: no host round trip here
   } else if (want_total) {
     EDM_HIP_TRY(launch_sum(nh, p_added, g->d_scalars + 1, ws.scratch.p, s));
@@ -788,6 +789,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   // when a large grid meets a short one
   GatherPlan plan;
   plan.groups = 1;
+  plan.adaptive = 0;
   plan.partial = nullptr;
   plan.tile_flags = nullptr;
   plan.tile_list = nullptr;
@@ -801,6 +803,20 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     if (G > nh / 256) G = nh / 256;
     if (G < 1) G = 1;
     plan.groups = (int)G;
+    if (G > 1) {
+      EDM_HIP_TRY(ws.partial.reserve((size_t)G * (size_t)q.total * q.rec));
+      plan.partial = ws.partial.p;
+    }
+  } else if (ntiles < 128) {
+    // a few hundred hills on a grid of a few dozen tiles (the stochastic 1-D step): the tile loop is a
+    // serial chain per node, so spread it over up to ~256 workgroups.  The split is a function of the
+    // true hill count alone (resolved on the device when the count is deferred).
+    long long G = (256 + ntiles - 1) / ntiles;
+    if (G > 16) G = 16;
+    if (G > nh / 128) G = nh / 128;
+    if (G < 1) G = 1;
+    plan.groups = (int)G;
+    plan.adaptive = 1;
     if (G > 1) {
       EDM_HIP_TRY(ws.partial.reserve((size_t)G * (size_t)q.total * q.rec));
       plan.partial = ws.partial.p;
@@ -860,34 +876,40 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   const double *st_added = reinterpret_cast<const double *>(stage + off_added);
   const double *st_pos = reinterpret_cast<const double *>(stage + off_pos);
   EDM_HIP_TRY(hipStreamSynchronize(s));
+  long long nh_act = nh;
   if (spec.limited) {
     res = *hres;
+    if (res.error == 2) {
+      if (out) out->res = res;
+      return EDM_APPLY_BOUND_EXCEEDED;  // deferred count above the launch bound: nothing was applied
+    }
     if (res.error) {
       set_error("The bias overflow buffer is full. Too many hills. Either increase & recompile, lower hill_density, or lower bias");
       return EDM_HIP_ERR_OVERFLOW;
     }
+    nh_act = res.nh;
   }
   if (out) {
     out->res = res;
     if (want_total && !spec.limited) out->total_added = g->h_scalars[1];
     if (base_heights && spec.limited) {
       const long long f0 = spec.fetch_all ? 0 : res.k;
-      if (nh - f0 > 0) {
-        out->heights.resize((size_t)(nh - f0));
-        EDM_HIP_TRY(hipMemcpy(out->heights.data(), base_heights + f0, sizeof(double) * (size_t)(nh - f0), hipMemcpyDeviceToHost));
+      if (nh_act - f0 > 0) {
+        out->heights.resize((size_t)(nh_act - f0));
+        EDM_HIP_TRY(hipMemcpy(out->heights.data(), base_heights + f0, sizeof(double) * (size_t)(nh_act - f0), hipMemcpyDeviceToHost));
       }
     }
     const long long k = res.k;
     const int ntail = spec.limited ? res.n_tail : 0;
     const long long first = spec.fetch_all ? 0 : k;
     out->first = first;
-    const long long need = nh - first;
+    const long long need = nh_act - first;
     if (small) {
       out->flags.assign(st_flags, st_flags + ntail);
       out->h2.assign(st_h2, st_h2 + ntail);
       out->a2.assign(st_a2, st_a2 + ntail);
-      out->pos.assign(st_pos + (size_t)first * dim, st_pos + (size_t)nh * dim);
-      out->added.assign(st_added + first, st_added + nh);
+      out->pos.assign(st_pos + (size_t)first * dim, st_pos + (size_t)nh_act * dim);
+      out->added.assign(st_added + first, st_added + nh_act);
     } else if (spec.limited || spec.fetch_all) {
       if (ntail > 0) {
         out->flags.resize((size_t)ntail);
@@ -943,7 +965,7 @@ int edm_hip_gauss_hill_integrals(const edm_hip_gauss *gc, long long n, const dou
   EDM_HIP_TRY(ws.hc.reserve((size_t)n * q.dim));
   HillList hl;
   hl.nh = n; hl.x = d_x; hl.x_stride = x_stride; hl.sel = nullptr;
-  hl.hx = ws.hx.p; hl.hc = ws.hc.p; hl.ht = ws.ht.p; hl.hx0 = nullptr;
+  hl.hx = ws.hx.p; hl.hc = ws.hc.p; hl.ht = ws.ht.p; hl.hx0 = nullptr; hl.nh_dev = nullptr;
   EDM_HIP_TRY(launch_hill_prep(q, hl, g->stream));
   EDM_HIP_TRY(launch_hill_integrals(q, g->tables(), hl, d_h, h_const, d_added, g->stream));
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));

@@ -105,6 +105,7 @@ struct edm_hip_gauss {
 
 // internal entry points shared between edm_gauss and edm_bias
 namespace edm {
+#define EDM_APPLY_BOUND_EXCEEDED 1000
 struct ApplySpec {
   long long nh = 0;
   const double *d_x = nullptr;     // sample positions
@@ -119,6 +120,9 @@ struct ApplySpec {
   const Geom *hist_g = nullptr;
   double *hist_values = nullptr;
   bool fetch_all = false;          // host wants position + bias_added of EVERY hill (HILLS log)
+  // deferred count: the batch is queued with `nh` as a launch bound while the true count still sits in
+  // device memory; apply_hills returns EDM_APPLY_BOUND_EXCEEDED (nothing applied) if the bound was too small
+  const long long *d_nh = nullptr;
   // heights that depend on the bias under construction (local tempering): strictly ordered kernel
   bool ordered = false;
   OrderedParams op;

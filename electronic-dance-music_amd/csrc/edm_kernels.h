@@ -61,9 +61,11 @@ hipError_t launch_hist_add(const Geom &g, double *values, long long n, const dou
 // order-preserving selection of accepted samples (edm_bias.cpp:543 and the mask
 // tests of :406): sel[j] = index of the j-th accepted sample, *count = how many.
 size_t select_scratch_ints(long long n);
+// count2 (may be NULL): a second place the count is written to (e.g. device memory for kernels that
+// consume a deferred count while `count` is host-mapped for the CPU)
 hipError_t launch_select(long long n, const double *runiform, double threshold, int use_threshold,
                          const int *mask, int apply_mask, long long *sel, long long *count,
-                         int *scratch, hipStream_t s);
+                         int *scratch, hipStream_t s, long long *count2 = nullptr);
 
 struct HillList {
   long long nh;
@@ -75,6 +77,9 @@ struct HillList {
   int *hc;                // centre node index (INT_MIN in hc[i*dim] = rejected) [nh][dim]
   double *ht;             // (t1, t3) of gaussian_grid.h:310,:312 per dim [nh][2*dim]
   double *hx0;            // original (un-remapped) position, compacted [nh][dim] (may be NULL)
+  // deferred count: when set, the true number of hills is min(*nh_dev, nh) and `nh` is only the launch
+  // bound -- lets a batch be queued before the selection count has travelled back to the host
+  const long long *nh_dev;
 };
 hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s);
 
@@ -94,6 +99,8 @@ hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList 
 
 struct GatherPlan {
   int groups;             // hill groups (partial buffers) -- 1 = accumulate in place
+  int adaptive;           // groups is an upper bound: the device uses min(groups, max(1, count / 128)), so a
+                          // batch queued with a deferred count is split exactly as if the count had been known
   double *partial;        // [groups (+1)][total][rec] when groups > 1 or in fused mode
   int *tile_flags;        // [ntiles] scratch when culling, else NULL
   int *tile_list;         // [ntiles + 1] (list + count at the end)
@@ -137,10 +144,11 @@ hipError_t launch_post_batch(const Geom &g, double *rec, int *dirty_flag, const 
 struct LimitResult {
   double cum_out;          // temp_hill_cum_ after the batch (flush: bias added by the flush)
   long long k;             // first hill handled by the ordered tail
+  long long nh;            // number of hills actually in the batch (deferred count resolved here)
   int n_tail;              // nh - k
   int stop;                // flush mode: tail-relative index where the flush stopped, or n_tail
   int n_deferred;          // new-hill mode: hills (whole or remainder) to append to the overflow buffer
-  int error;               // 1 = tail longer than EDM_TAIL_CAP
+  int error;               // 1 = tail longer than EDM_TAIL_CAP, 2 = deferred count exceeded the launch bound
 };
 // flags per tail hill: bit0 = applied (an 'h'/'b' hill was added), bit1 = undo hill
 // added too ('u'/'v'), bit2 = deferred to the overflow buffer
@@ -151,7 +159,8 @@ struct LimitTail {
 size_t limit_scratch_doubles(long long nh);
 hipError_t launch_limit(long long nh, const double *added, const double *heights, double h_const,
                         double limit, double cum_in, int flush_mode, const LimitTail &tail,
-                        LimitResult *result_dev, double *scratch, hipStream_t s);
+                        LimitResult *result_dev, double *scratch, hipStream_t s,
+                        const long long *nh_dev = nullptr);
 
 // histogram side of output_hill for the ordered tail: -1 for every hill whose undo was added
 // (flags bit1) and, when plus_for_applied, +1 for every hill that was applied (bit0), at its

@@ -31,6 +31,24 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// number of hills of a batch (resolves a deferred count)
+__device__ __forceinline__ long long hill_count(const HillList &h) {
+  long long n = h.nh;
+  if (h.nh_dev) {
+    const long long t = *h.nh_dev;
+    n = t < n ? t : n;
+  }
+  return n;
+}
+
+// hill groups of an adaptive gather plan (a function of the true hill count only)
+__device__ __host__ __forceinline__ int adaptive_groups(int cap, long long nh) {
+  long long G = nh / 128;
+  if (G > cap) G = cap;
+  if (G < 1) G = 1;
+  return (int)G;
+}
+
 // sum over the block, valid in thread 0
 __device__ __forceinline__ double block_sum(double v, double *lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -753,7 +771,8 @@ __global__ void __launch_bounds__(BLOCK) k_sel_count(long long n, const double *
 // exclusive scan of the per-block counts by one block (counts -> offsets, total): 256 counts per
 // pass, wave prefix sums by shuffles + a 4-entry cross-wave fix-up, running carry between passes
 __global__ void __launch_bounds__(BLOCK) k_sel_scan(int nblocks, const int *__restrict__ counts,
-                                                    long long *__restrict__ offsets, long long *__restrict__ total) {
+                                                    long long *__restrict__ offsets, long long *__restrict__ total,
+                                                    long long *__restrict__ total2) {
   __shared__ long long wsum[BLOCK / 64];
   __shared__ long long carry_sh;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -777,7 +796,10 @@ __global__ void __launch_bounds__(BLOCK) k_sel_scan(int nblocks, const int *__re
     if (threadIdx.x == BLOCK - 1) carry_sh = before + inc;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *total = carry_sh;
+  if (threadIdx.x == 0) {
+    *total = carry_sh;
+    if (total2) *total2 = carry_sh;
+  }
 }
 
 __global__ void __launch_bounds__(BLOCK) k_sel_scatter(long long n, const double *__restrict__ ru, double thr,
@@ -814,13 +836,19 @@ size_t select_scratch_ints(long long n) {
 }
 
 hipError_t launch_select(long long n, const double *ru, double thr, int use_thr, const int *mask, int apply_mask,
-                         long long *sel, long long *count, int *scratch, hipStream_t s) {
+                         long long *sel, long long *count, int *scratch, hipStream_t s, long long *count2) {
   const int nb = (int)((n + SEL_CHUNK - 1) / SEL_CHUNK);
-  if (nb == 0) return hipMemsetAsync(count, 0, sizeof(long long), s);
+  if (nb == 0) {
+    if (count2) {
+      hipError_t e = hipMemsetAsync(count2, 0, sizeof(long long), s);
+      if (e != hipSuccess) return e;
+    }
+    return hipMemsetAsync(count, 0, sizeof(long long), s);
+  }
   int *counts = scratch;
   long long *offsets = reinterpret_cast<long long *>(scratch + ((nb + 2) & ~1));
   hipLaunchKernelGGL(k_sel_count, dim3(nb), dim3(BLOCK), 0, s, n, ru, thr, use_thr, mask, apply_mask, counts);
-  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(BLOCK), 0, s, nb, counts, offsets, count);
+  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(BLOCK), 0, s, nb, counts, offsets, count, count2);
   hipLaunchKernelGGL(k_sel_scatter, dim3(nb), dim3(BLOCK), 0, s, n, ru, thr, use_thr, mask, apply_mask, offsets, sel);
   return hipGetLastError();
 }
@@ -832,7 +860,8 @@ hipError_t launch_select(long long n, const double *ru, double thr, int use_thr,
 template <int DIM>
 __global__ void __launch_bounds__(BLOCK) k_hill_prep(Geom g, HillList h) {
   const long long stride = (long long)gridDim.x * BLOCK;
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < h.nh; i += stride) {
+  const long long nh = hill_count(h);
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < nh; i += stride) {
     const long long src = h.sel ? h.sel[i] : i;
     double x[DIM];
 #pragma unroll
@@ -1008,17 +1037,23 @@ __device__ __forceinline__ bool pair_term(const Geom &g, const TermConst<DIM> &t
 // K3: per-hill integrated bias -- one wave per hill walks the reference's stencil
 // (gaussian_grid.h:227-281) and reduces h*(expo+corr)*vol in a fixed order.
 // ---------------------------------------------------------------------------
-template <int DIM>
+// TPH threads cooperate on one hill: 64 (a wave per hill, long lists) or 256 (a workgroup per hill:
+// four times shorter critical path for the few-hundred-hill batches of a stochastic hill step)
+template <int DIM, int TPH>
 __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, HillList h,
                                                           const double *__restrict__ heights, double h_const,
                                                           double *__restrict__ added) {
+  __shared__ double s_red[BLOCK / 64];
   const int lane = threadIdx.x & 63;
-  const long long hill = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-  if (hill >= h.nh) return;
+  const int lt = threadIdx.x % TPH;
+  const long long hill = (long long)blockIdx.x * (BLOCK / TPH) + (threadIdx.x / TPH);
+  const long long nh_eff = hill_count(h);
+  if (TPH == 64 && hill >= nh_eff) return;  // (a whole workgroup shares one hill when TPH == BLOCK)
+  const bool live = hill < nh_eff;
   TermConst<DIM> tc;
   term_const<DIM>(g, tc);
   double acc = 0;
-  const int c0 = h.hc[hill * DIM];
+  const int c0 = live ? h.hc[hill * DIM] : INT_MIN;
   if (c0 != INT_MIN) {
     int c[DIM];
     double hx[DIM], ht[2 * DIM];
@@ -1034,7 +1069,7 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
       total *= (2 * g.msize[d] + 1);
     }
     const double height = heights ? heights[hill] : h_const;
-    for (long long s = lane; s < total; s += 64) {
+    for (long long s = lt; s < total; s += TPH) {
       int p[DIM];
       long long rest = s;
       bool skip = false;
@@ -1069,17 +1104,36 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
     }
   }
   acc = wave_sum(acc);
-  if (lane == 0) added[hill] = acc;
+  if (TPH == 64) {
+    if (lane == 0) added[hill] = acc;
+  } else {
+    if (lane == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && live) {
+      double r = 0;
+      for (int w = 0; w < BLOCK / 64; w++) r += s_red[w];
+      added[hill] = r;
+    }
+  }
 }
 
 hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList &h, const double *heights,
                                  double h_const, double *added, hipStream_t s) {
   if (h.nh <= 0) return hipSuccess;
-  const long long nb = (h.nh + (BLOCK / 64) - 1) / (BLOCK / 64);
-  switch (g.dim) {
-    case 1: hipLaunchKernelGGL(k_hill_integrals<1>, dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
-    case 2: hipLaunchKernelGGL(k_hill_integrals<2>, dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
-    default: hipLaunchKernelGGL(k_hill_integrals<3>, dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+  if (h.nh <= 2048) {
+    const unsigned nb = (unsigned)h.nh;
+    switch (g.dim) {
+      case 1: hipLaunchKernelGGL((k_hill_integrals<1, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+      case 2: hipLaunchKernelGGL((k_hill_integrals<2, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+      default: hipLaunchKernelGGL((k_hill_integrals<3, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+    }
+  } else {
+    const long long nb = (h.nh + (BLOCK / 64) - 1) / (BLOCK / 64);
+    switch (g.dim) {
+      case 1: hipLaunchKernelGGL((k_hill_integrals<1, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+      case 2: hipLaunchKernelGGL((k_hill_integrals<2, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+      default: hipLaunchKernelGGL((k_hill_integrals<3, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+    }
   }
   return hipGetLastError();
 }
@@ -1208,17 +1262,21 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
   }
   long long k_first_tail = hh.k;
   if (hh.res_dev) {
-    if (hh.res_dev->error) return;  // limiter overflow: the host reports it, nothing is applied
+    if (hh.res_dev->error) return;  // limiter overflow / bound exceeded: the host handles it, nothing is applied
     k_first_tail = hh.res_dev->k;
+  } else if (h.nh_dev && k_first_tail > hill_count(h)) {
+    k_first_tail = hill_count(h);
   }
-  const int G = plan.groups;
+  const long long nh_eff = hill_count(h);
+  const int G = (MODE == 0 && plan.adaptive) ? adaptive_groups(plan.groups, nh_eff) : plan.groups;
+  if (MODE == 0 && plan.adaptive && (int)blockIdx.y >= G) return;
   const int grp = (MODE == 2) ? G : blockIdx.y;   // the correction owns the extra partial buffer
-  const long long per = (h.nh + G - 1) / G;
+  const long long per = (nh_eff + G - 1) / G;
   long long hbeg = per * blockIdx.y;
-  long long hend = (hbeg + per < h.nh) ? hbeg + per : h.nh;
+  long long hend = (hbeg + per < nh_eff) ? hbeg + per : nh_eff;
   if (MODE == 2) {
     hbeg = k_first_tail;
-    hend = h.nh;
+    hend = nh_eff;
   }
   const bool in_place = (MODE == 0) && (G == 1);
   double vol = 1;
@@ -1399,8 +1457,14 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
 // rec[p] += partial[0][p] + partial[1][p] + ... in group (= hill list) order
 __global__ void __launch_bounds__(BLOCK) k_reduce_partials(Geom g, double *__restrict__ rec,
                                                            const double *__restrict__ partial, int groups,
-                                                           const LimitResult *__restrict__ res) {
+                                                           const LimitResult *__restrict__ res, int adaptive,
+                                                           long long nh, const long long *__restrict__ nh_dev) {
   if (res && res->error) return;  // limiter overflow: the batch is not applied
+  if (adaptive) {
+    if (nh_dev && *nh_dev < nh) nh = *nh_dev;
+    groups = adaptive_groups(groups, nh);
+    if (groups == 1) return;      // the single group accumulated in place
+  }
   const long long n = g.total * g.rec;
   const long long stride = (long long)gridDim.x * BLOCK;
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
@@ -1414,7 +1478,7 @@ __global__ void __launch_bounds__(BLOCK) k_reduce_partials(Geom g, double *__res
 template <int DIM>
 __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *__restrict__ flags) {
   const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= h.nh) return;
+  if (i >= hill_count(h)) return;
   if (h.hc[i * DIM] == INT_MIN) return;
   int ntile[DIM], steps[DIM], c[DIM];
   long long combos = 1;
@@ -1480,7 +1544,7 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
                      rec, h, hh, plan, use_list, dirty_flag);
   if (plan.groups > 1)
     hipLaunchKernelGGL(k_reduce_partials, dim3(blocks_for(g.total * g.rec)), dim3(BLOCK), 0, s, g, rec, plan.partial,
-                       plan.groups, hh.res_dev);
+                       plan.groups, hh.res_dev, plan.adaptive, h.nh, h.nh_dev);
   return hipGetLastError();
 }
 
@@ -1561,7 +1625,7 @@ hipError_t launch_hill_gather_correct_and_apply(const Geom &g, const Tables &t, 
     groups += 1;
   }
   hipLaunchKernelGGL(k_reduce_partials, dim3(blocks_for(g.total * g.rec)), dim3(BLOCK), 0, s, g, rec, plan.partial, groups,
-                     with_correction ? hh.res_dev : (const LimitResult *)nullptr);
+                     with_correction ? hh.res_dev : (const LimitResult *)nullptr, 0, h.nh, (const long long *)nullptr);
   return hipGetLastError();
 }
 
@@ -1753,6 +1817,7 @@ __global__ void __launch_bounds__(ORD_BLOCK) k_hills_ordered(Geom g, Tables t, d
   if (threadIdx.x == 0) {
     res->cum_out = cum;
     res->k = 0;
+    res->nh = h.nh;
     res->n_tail = (int)h.nh;
     res->stop = (int)h.nh;
     res->n_deferred = n_def;
@@ -1884,6 +1949,7 @@ __global__ void __launch_bounds__(BLOCK) k_post_batch(Geom g, double *__restrict
   }
   if (res->error) return;
   const long long k = res->k;
+  if (res->nh < nh) nh = res->nh;  // deferred count
   const long long stride = (long long)(gridDim.x - 1) * BLOCK;
   for (long long i = (long long)(blockIdx.x - 1) * BLOCK + threadIdx.x; i < nh; i += stride) {
     double wgt = flush_mode ? 0.0 : 1.0;
@@ -1993,12 +2059,29 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(64) k_limit(long long nh, const double *__restrict__ added,
+__global__ void __launch_bounds__(64) k_limit(long long nh_bound, const double *__restrict__ added,
                                               const double *__restrict__ heights, double h_const, double limit,
                                               double cum_in, int flush_mode, LimitTail tail,
                                               LimitResult *__restrict__ res, long long nchunks,
                                               const double *__restrict__ chunk_sum,
-                                              const double *__restrict__ chunk_max) {
+                                              const double *__restrict__ chunk_max,
+                                              const long long *__restrict__ nh_dev) {
+  long long nh = nh_bound;
+  if (nh_dev) {
+    nh = *nh_dev;
+    if (nh > nh_bound) {  // the batch was queued with too small a bound: nothing is applied
+      if (threadIdx.x == 0) {
+        res->cum_out = cum_in;
+        res->k = 0;
+        res->nh = nh;
+        res->n_tail = 0;
+        res->stop = 0;
+        res->n_deferred = 0;
+        res->error = 2;
+      }
+      return;
+    }
+  }
   // One wave.  Every lane runs the same (uniform) walk; the hills of a 64-wide slab sit one per
   // lane in registers and are broadcast by v_readlane, so an iteration is a handful of dependent
   // fp64 instructions instead of an LDS round trip; lane j keeps the outcome of hill j and the
@@ -2032,6 +2115,7 @@ __global__ void __launch_bounds__(64) k_limit(long long nh, const double *__rest
     if (lane == 0) {
       res->cum_out = cum;
       res->k = k;
+      res->nh = nh;
       res->n_tail = 0;
       res->stop = 0;
       res->n_deferred = 0;
@@ -2127,6 +2211,7 @@ __global__ void __launch_bounds__(64) k_limit(long long nh, const double *__rest
   if (lane == 0) {
     res->cum_out = cum;
     res->k = k;
+    res->nh = nh;
     res->n_tail = (int)ntail;
     res->stop = stop;
     res->n_deferred = n_def;
@@ -2138,7 +2223,7 @@ size_t limit_scratch_doubles(long long nh) { return (size_t)(2 * ((nh + EDM_CHUN
 
 hipError_t launch_limit(long long nh, const double *added, const double *heights, double h_const, double limit,
                         double cum_in, int flush_mode, const LimitTail &tail, LimitResult *result_dev,
-                        double *scratch, hipStream_t s) {
+                        double *scratch, hipStream_t s, const long long *nh_dev) {
   long long nchunks = 0;
   double *csum = scratch, *cmax = scratch;
   if (!flush_mode && nh > EDM_CHUNK) {
@@ -2148,7 +2233,7 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
     hipLaunchKernelGGL(k_chunk_stats, dim3((unsigned)nchunks), dim3(BLOCK), 0, s, nh, added, csum, cmax);
   }
   hipLaunchKernelGGL(k_limit, dim3(1), dim3(64), 0, s, nh, added, heights, h_const, limit, cum_in, flush_mode, tail,
-                     result_dev, nchunks, csum, cmax);
+                     result_dev, nchunks, csum, cmax, nh_dev);
   return hipGetLastError();
 }
 
