@@ -56,6 +56,7 @@ struct edm_hip_bias {
   DevBuf<long long> sel;
   long long *h_count = nullptr, *d_count = nullptr;  // host-mapped pinned: the selection kernel writes the count here
   DevBuf<long long> count_dev;                       // ... and here, for kernels consuming a deferred count
+  DevBuf<int> sel_stage;                             // per-workgroup ordered lists of the chained selection
   DevBuf<int> sel_scratch;
   DevBuf<double> stage_x, stage_u, stage_h, tail_w;
   DevBuf<double> hx0;
@@ -230,7 +231,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   edm_hip_grid_destroy(b->hist);
   edm_hip_grid_destroy(b->target);
   if (b->hills_fp) fclose(b->hills_fp);
-  b->sel.release(); b->sel_scratch.release(); b->count_dev.release();
+  b->sel.release(); b->sel_scratch.release(); b->count_dev.release(); b->sel_stage.release();
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
   delete b;
@@ -504,6 +505,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   const double thr = b->hill_density / b->est_hill_count;   // :543
   long long nh = n;
   long long deferred_bound = 0;
+  SelectArgs sel_args;
   const long long *d_sel = nullptr;
   if (use_thr || apply_mask >= 0) {
     if (use_thr && !d_ru) {
@@ -517,9 +519,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     }
     EDM_HIP_TRY(b->sel_scratch.reserve(select_scratch_ints(n)));
     EDM_HIP_TRY(b->count_dev.reserve(2));
-    EDM_HIP_TRY(launch_select(n, d_ru, thr, use_thr, b->d_mask, apply_mask, b->sel.p, b->d_count, b->sel_scratch.p, s,
-                              b->count_dev.p));
-    // Stochastic steps accept a few hundred of millions of samples: queue the rest of the step against a
+    // Stochastic steps accept a few hundred of millions of samples: queue the whole step against a
     // conservative bound instead of waiting for the count to reach the host (one sync per step saved);
     // should the bound ever be too small the limiter reports it, nothing is applied and the step's hill
     // path is redone below with the exact count.
@@ -528,13 +528,30 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       const double expected = thr * (double)n;
       bound = (long long)(4.0 * expected) + 128;
       if (bound < 256) bound = 256;
-      if (bound > 4096 || bound >= n) bound = 0;
+      if (bound > 2048 || bound >= n) bound = 0;
     }
     deferred_bound = bound;
     if (!bound) {
+      EDM_HIP_TRY(launch_select(n, d_ru, thr, use_thr, b->d_mask, apply_mask, b->sel.p, b->d_count, b->sel_scratch.p, s,
+                                b->count_dev.p));
       EDM_HIP_TRY(hipStreamSynchronize(s));
       nh = *b->h_count;
     } else {
+      // selection is chained in front of the hill preparation inside apply_hills (one launch)
+      EDM_HIP_TRY(b->sel_stage.reserve(select_stage_ints(n)));
+      memset(&sel_args, 0, sizeof(sel_args));
+      sel_args.n = n;
+      sel_args.ru = d_ru;
+      sel_args.thr = thr;
+      sel_args.use_thr = use_thr;
+      sel_args.mask = b->d_mask;
+      sel_args.apply_mask = apply_mask;
+      sel_args.counts = b->sel_scratch.p;
+      sel_args.stage = b->sel_stage.p;
+      sel_args.sel = b->sel.p;
+      sel_args.count_host = b->d_count;
+      sel_args.count_dev = b->count_dev.p;
+      sel_args.ticket = b->bias->d_dirty + 1;
       nh = bound;
     }
     d_sel = b->sel.p;
@@ -578,6 +595,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   spec.flush_mode = 0;
   spec.limit = b->bias_per_step;
   spec.cum_in = b->temp_hill_cum;
+  if (use_thr && !b->comm) spec.expected_nh = thr * (double)n;
   spec.hist_g = &b->hist->g;
   spec.hist_values = b->hist->values;
   const bool log_all = b->hill_log && b->hills_fp;
@@ -600,11 +618,19 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     spec.op.clamp = BIAS_CLAMP * b->bias_per_step;
   }
   ApplyOutcome oc;
-  if (deferred_bound) spec.d_nh = b->count_dev.p;
+  if (deferred_bound) {
+    spec.d_nh = b->count_dev.p;
+    spec.sel_chain = &sel_args;
+  }
   int rc = apply_hills(b->bias, spec, &oc, false);
   if (rc == EDM_APPLY_BOUND_EXCEEDED) {
+    // (practically never) more hills than the bound: redo selection and the step with the exact count
     spec.d_nh = nullptr;
-    spec.nh = *b->h_count;  // the stream has been synchronised: the exact count is on the host now
+    spec.sel_chain = nullptr;
+    EDM_HIP_TRY(launch_select(n, d_ru, thr, use_thr, b->d_mask, apply_mask, b->sel.p, b->d_count, b->sel_scratch.p, s,
+                              b->count_dev.p));
+    EDM_HIP_TRY(hipStreamSynchronize(s));
+    spec.nh = *b->h_count;
     rc = apply_hills(b->bias, spec, &oc, false);
   }
   if (rc) return rc;

@@ -727,7 +727,10 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hl.hx0 = p_hx0;
   hl.nh_dev = spec.d_nh;
   const Tables tabs = g->tables();
-  EDM_HIP_TRY(launch_hill_prep(q, hl, s));
+  if (spec.sel_chain)
+    EDM_HIP_TRY(launch_select_prep(*spec.sel_chain, q, hl, s));  // selection + preparation in one launch
+  else
+    EDM_HIP_TRY(launch_hill_prep(q, hl, s));
 
   HillHeights hh;
   hh.h = spec.d_h;
@@ -757,6 +760,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     fplan.slots = ws.slots.p;
   }
   const double *base_heights = spec.d_h;
+  const bool chain_limit = spec.limited && !spec.ordered && !fused && hill_integrals_can_chain_limit(nh);
   if (fused) {
     EDM_HIP_TRY(launch_hill_gather_fused(q, tabs, hl, spec.d_h, spec.h_const, fplan, p_added, g->d_dirty, s));
   } else if (spec.ordered) {
@@ -771,11 +775,23 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     LimitTail tail{ws.tail_h1.p, p_h2, p_a2, ws.tail_cum.p, p_flags};
     EDM_HIP_TRY(launch_hills_ordered(q, tabs, g->rec, hl, op, tail, ws.heights.p, p_added, dres, g->d_dirty, s));
     base_heights = ws.heights.p;
+  } else if (chain_limit) {
+    // short batch: the limiter runs in the last integrals workgroup (one launch instead of two)
+    LimitArgs la;
+    memset(&la, 0, sizeof(la));
+    la.ticket = g->d_dirty + 2;
+    la.limit = spec.limit;
+    la.cum_in = spec.cum_in;
+    la.flush_mode = spec.flush_mode;
+    la.tail = LimitTail{ws.tail_h1.p, p_h2, p_a2, ws.tail_cum.p, p_flags};
+    la.res = dres;
+    EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s, &la));
+    hh.res_dev = dres;
   } else if (spec.limited || want_total) {
     EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s));
   }
-  if (spec.ordered) {
-    // everything was applied by the ordered kernel
+  if (spec.ordered || chain_limit) {
+    // everything was applied by the ordered kernel / the limiter was chained above
   } else if (spec.limited) {
     LimitTail tail{ws.tail_h1.p, p_h2, p_a2, ws.tail_cum.p, p_flags};
     EDM_HIP_TRY(launch_limit(nh, p_added, spec.d_h, spec.h_const, spec.limit, spec.cum_in, spec.flush_mode, tail,
@@ -813,6 +829,9 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     // true hill count alone (resolved on the device when the count is deferred).
     long long G = (256 + ntiles - 1) / ntiles;
     if (G > 16) G = 16;
+    // (the cap follows the EXPECTED batch size, which does not depend on how the batch was queued)
+    const double expected = spec.expected_nh >= 0 ? spec.expected_nh : (double)nh;
+    if (expected < 512) G = 1;
     if (G > nh / 128) G = nh / 128;
     if (G < 1) G = 1;
     plan.groups = (int)G;
@@ -835,17 +854,28 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     }
   }
   const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
+  bool chain_post = false;
   if (fused) {
     EDM_HIP_TRY(launch_hill_gather_correct_and_apply(q, tabs, g->rec, hl, hh, fplan, spec.limited ? 1 : 0, g->d_dirty, s));
     if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
   } else if (!spec.ordered) {
-    EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, hl, hh, plan, g->d_dirty, s));
+    // short limited batch applied in place: boundary duplication and histogram ride on the gather launch
+    chain_post = fused_post && plan.groups == 1 && hh.res_dev && nh <= 4096;
+    PostSpec ps;
+    ps.ticket = g->d_dirty + 3;
+    ps.hist_geom = spec.hist_g;
+    ps.hist = spec.hist_values;
+    ps.flags = p_flags;
+    ps.flush_mode = spec.flush_mode;
+    EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, hl, hh, plan, g->d_dirty, s, chain_post ? &ps : nullptr));
     if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
   }
 
   // CV histogram (edm_bias.cpp:601-610): new hills log one 'h' line each (+1) and a 'u' line
   // per undo (-1); a flush logs 'b' (+1) for replayed hills only and 'v' (-1) for its undo
-  if (fused_post) {
+  if (chain_post) {
+    // done by the gather's last workgroup
+  } else if (fused_post) {
     EDM_HIP_TRY(launch_post_batch(q, g->rec, g->d_dirty, *spec.hist_g, spec.hist_values, nh, p_hx0, dres, p_flags,
                                   spec.flush_mode, s));
   } else if (spec.hist_g && spec.hist_values) {

@@ -123,6 +123,9 @@ struct ApplySpec {
   // deferred count: the batch is queued with `nh` as a launch bound while the true count still sits in
   // device memory; apply_hills returns EDM_APPLY_BOUND_EXCEEDED (nothing applied) if the bound was too small
   const long long *d_nh = nullptr;
+  double expected_nh = -1;  // expected batch size when it is a random variable (stochastic selection); < 0: nh
+  // with a deferred count: selection chained in front of the hill preparation (one launch for both)
+  const SelectArgs *sel_chain = nullptr;
   // heights that depend on the bias under construction (local tempering): strictly ordered kernel
   bool ordered = false;
   OrderedParams op;

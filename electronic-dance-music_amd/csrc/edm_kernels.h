@@ -83,6 +83,26 @@ struct HillList {
 };
 hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s);
 
+// --- chained launches for short hill steps (see last_block_done in edm_kernels.hip) ---
+// selection + preparation in one launch; h.nh is the launch bound of the step, h.sel == a.sel
+struct SelectArgs {
+  long long n;
+  const double *ru;
+  double thr;
+  int use_thr;
+  const int *mask;
+  int apply_mask;
+  int *counts;            // [blocks] scratch (select_scratch_ints covers it)
+  int *stage;             // [select_stage_ints(n)] scratch
+  long long *sel;         // out: ordered accepted sample indices (first min(count, h.nh))
+  long long *count_host;  // out: count, host-mapped
+  long long *count_dev;   // out: count, device memory
+  int *ticket;            // zero-initialised device int, left at zero
+};
+size_t select_stage_ints(long long n);
+hipError_t launch_select_prep(const SelectArgs &a, const Geom &g, const HillList &h, hipStream_t s);
+struct LimitArgs;
+struct PostSpec;
 struct LimitResult;
 struct HillHeights {
   const double *h;        // per-hill base height or NULL
@@ -95,7 +115,7 @@ struct HillHeights {
 };
 // per-hill integrated bias for the BASE heights (the value add_value returns)
 hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList &h, const double *heights,
-                                 double h_const, double *added, hipStream_t s);
+                                 double h_const, double *added, hipStream_t s, const LimitArgs *chain = nullptr);
 
 struct GatherPlan {
   int groups;             // hill groups (partial buffers) -- 1 = accumulate in place
@@ -127,7 +147,8 @@ long long gather_tiles(const Geom &g);
 // applies the hills to the record array in list order; dirty_flag (device int) is set
 // when any boundary correction was non-zero (gaussian_grid.h:357-358)
 hipError_t launch_hill_gather(const Geom &g, const Tables &t, double *rec, const HillList &h,
-                              const HillHeights &hh, const GatherPlan &plan, int *dirty_flag, hipStream_t s);
+                              const HillHeights &hh, const GatherPlan &plan, int *dirty_flag, hipStream_t s,
+                              const PostSpec *chain = nullptr);
 // gaussian_grid.h:571-630, executed iff *dirty_flag != 0; clears the flag
 hipError_t launch_duplicate_boundary(const Geom &g, double *rec, int *dirty_flag, hipStream_t s);
 
@@ -161,6 +182,26 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
                         double limit, double cum_in, int flush_mode, const LimitTail &tail,
                         LimitResult *result_dev, double *scratch, hipStream_t s,
                         const long long *nh_dev = nullptr);
+
+// limiter chained onto the integrals kernel (h.nh <= 2048, no chunk skipping)
+struct LimitArgs {
+  int enabled;
+  int *ticket;
+  double limit, cum_in;
+  int flush_mode;
+  LimitTail tail;
+  LimitResult *res;
+};
+bool hill_integrals_can_chain_limit(long long nh);
+// boundary duplication + histogram chained onto the gather (plan.groups == 1, hh.res_dev and h.hx0 set)
+struct PostSpec {
+  int *ticket;
+  const Geom *hist_geom;
+  double *hist;
+  const int *flags;
+  int flush_mode;
+};
+
 
 // histogram side of output_hill for the ordered tail: -1 for every hill whose undo was added
 // (flags bit1) and, when plus_for_applied, +1 for every hill that was applied (bit0), at its

@@ -16,6 +16,7 @@
 #include "edm_kernels.h"
 
 #include <limits.h>
+#include <string.h>
 
 namespace edm {
 
@@ -858,39 +859,190 @@ hipError_t launch_select(long long n, const double *ru, double thr, int use_thr,
 // (gaussian_grid.h:206-224 and the temp1/temp3 terms of :310,:312)
 // ---------------------------------------------------------------------------
 template <int DIM>
+__device__ __forceinline__ void hill_prep_one(const Geom &g, const HillList &h, long long i, long long src) {
+  double x[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; d++) x[d] = h.x[src * h.x_stride + d];
+  if (h.hx0) {
+#pragma unroll
+    for (int d = 0; d < DIM; d++) h.hx0[i * DIM + d] = x[d];
+  }
+  remap<DIM>(g, x);
+  bool ok = true;
+#pragma unroll
+  for (int d = 0; d < DIM; d++)
+    if (!g.bper[d] && (x[d] < g.bmin[d] || x[d] > g.bmax[d])) ok = false;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    h.hx[i * DIM + d] = x[d];
+    h.hc[i * DIM + d] = ifloor((x[d] - g.min[d]) / g.dx[d]);
+    double t1 = 0, t3 = 0;
+    if (!g.bper[d]) {
+      const double sg = g.sigma[d];
+      t1 = exp(-((x[d] - g.bmin[d]) * (x[d] - g.bmin[d])) / (sg * sg));
+      t3 = exp(-((x[d] - g.bmax[d]) * (x[d] - g.bmax[d])) / (sg * sg));
+    }
+    h.ht[i * 2 * DIM + 2 * d] = t1;
+    h.ht[i * 2 * DIM + 2 * d + 1] = t3;
+  }
+  if (!ok) h.hc[i * DIM] = INT_MIN;
+}
+
+template <int DIM>
 __global__ void __launch_bounds__(BLOCK) k_hill_prep(Geom g, HillList h) {
   const long long stride = (long long)gridDim.x * BLOCK;
   const long long nh = hill_count(h);
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < nh; i += stride) {
-    const long long src = h.sel ? h.sel[i] : i;
-    double x[DIM];
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < nh; i += stride)
+    hill_prep_one<DIM>(g, h, i, h.sel ? h.sel[i] : i);
+}
+
+// ---------------------------------------------------------------------------
+// "Last workgroup done" chaining.  A short hill step is a chain of tiny dependent kernels, each
+// costing a launch; instead every workgroup of a stage publishes its results (agent-scope fence),
+// takes a ticket, and the workgroup that draws the last ticket runs the next (small, serial) stage
+// in the same launch.  The ticket is reset by that workgroup, so the counters stay zero between
+// launches.  Returns true (block-uniform) in the last workgroup, with the other workgroups' writes
+// visible.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool last_block_done(int *ticket, unsigned total_blocks) {
+  __shared__ int s_is_last;
+  // every thread's published stores (publish()) have reached the coherence point before the barrier
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = (unsigned)__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_is_last = (t == total_blocks - 1) ? 1 : 0;
+    if (s_is_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return s_is_last != 0;
+}
+// Data handed from the other workgroups to the last one travels through agent-scope (L2-coherent
+// across the XCDs) relaxed atomics: an agent-scope FENCE would write back the whole L2 of the XCD
+// (measured: ~35 us per stage on MI355X), these cost nothing extra.
+template <typename T>
+__device__ __forceinline__ void publish(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T acquire(const T *p) {
+  return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Selection + hill preparation in one launch (stochastic steps with a deferred count): every
+// workgroup compacts its SEL_CHUNK samples IN ORDER into its own stretch of `stage`, the last one
+// scans the per-workgroup counts, moves at most `h.nh` (the launch bound of the step) entries to the
+// dense ordered list and prepares those hills.
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, HillList h) {
+  __shared__ int s_w[BLOCK / 64];
+  __shared__ long long s_carry;
+  __shared__ int s_big[BLOCK];
+  __shared__ long long s_big_off[BLOCK];
+  __shared__ int s_nbig;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    const long long base = (long long)blockIdx.x * SEL_CHUNK + (long long)threadIdx.x * SEL_PER_THREAD;
+    bool fl[SEL_PER_THREAD];
+    int c = 0;
 #pragma unroll
-    for (int d = 0; d < DIM; d++) x[d] = h.x[src * h.x_stride + d];
-    if (h.hx0) {
-#pragma unroll
-      for (int d = 0; d < DIM; d++) h.hx0[i * DIM + d] = x[d];
+    for (int j = 0; j < SEL_PER_THREAD; j++) {
+      fl[j] = sel_flag(base + j, a.n, a.ru, a.thr, a.use_thr, a.mask, a.apply_mask);
+      c += fl[j] ? 1 : 0;
     }
-    remap<DIM>(g, x);
-    bool ok = true;
+    int inc = c;
 #pragma unroll
-    for (int d = 0; d < DIM; d++)
-      if (!g.bper[d] && (x[d] < g.bmin[d] || x[d] > g.bmax[d])) ok = false;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int before = 0, tot = 0;
 #pragma unroll
-    for (int d = 0; d < DIM; d++) {
-      h.hx[i * DIM + d] = x[d];
-      h.hc[i * DIM + d] = ifloor((x[d] - g.min[d]) / g.dx[d]);
-      double t1 = 0, t3 = 0;
-      if (!g.bper[d]) {
-        const double sg = g.sigma[d];
-        t1 = exp(-((x[d] - g.bmin[d]) * (x[d] - g.bmin[d])) / (sg * sg));
-        t3 = exp(-((x[d] - g.bmax[d]) * (x[d] - g.bmax[d])) / (sg * sg));
+    for (int w = 0; w < BLOCK / 64; w++) {
+      if (w < wave) before += s_w[w];
+      tot += s_w[w];
+    }
+    int pos = before + inc - c;
+    int *mine = a.stage + (long long)blockIdx.x * SEL_CHUNK;
+#pragma unroll
+    for (int j = 0; j < SEL_PER_THREAD; j++)
+      if (fl[j]) publish(&mine[pos++], (int)(threadIdx.x * SEL_PER_THREAD + j));
+    if (threadIdx.x == 0) publish(&a.counts[blockIdx.x], tot);
+  }
+  if (!last_block_done(a.ticket, gridDim.x)) return;
+
+  const int nblocks = (int)gridDim.x;
+  const long long bound = h.nh;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int bb = 0; bb < nblocks; bb += BLOCK) {
+    const int blk = bb + threadIdx.x;
+    const long long c = (blk < nblocks) ? acquire(&a.counts[blk]) : 0;
+    long long inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    __shared__ long long s_ws[BLOCK / 64];
+    if (lane == 63) s_ws[wave] = inc;
+    if (threadIdx.x == 0) s_nbig = 0;
+    __syncthreads();
+    long long off = s_carry;
+    for (int w = 0; w < wave; w++) off += s_ws[w];
+    off += inc - c;
+    if (c > 0 && off < bound) {
+      if (c <= 4) {
+        for (long long j = 0; j < c && off + j < bound; j++) {
+          const long long src = (long long)blk * SEL_CHUNK + acquire(&a.stage[(long long)blk * SEL_CHUNK + j]);
+          a.sel[off + j] = src;
+          hill_prep_one<DIM>(g, h, off + j, src);
+        }
+      } else {
+        const int q = atomicAdd(&s_nbig, 1);
+        s_big[q] = blk;
+        s_big_off[q] = off;
       }
-      h.ht[i * 2 * DIM + 2 * d] = t1;
-      h.ht[i * 2 * DIM + 2 * d + 1] = t3;
     }
-    if (!ok) h.hc[i * DIM] = INT_MIN;
+    __syncthreads();
+    // workgroups with many accepted samples: all threads share the copy
+    const int nbig = s_nbig;
+    for (int q = 0; q < nbig; q++) {
+      const int b2 = s_big[q];
+      const long long o2 = s_big_off[q];
+      const long long c2 = acquire(&a.counts[b2]);
+      for (long long j = threadIdx.x; j < c2 && o2 + j < bound; j += BLOCK) {
+        const long long src = (long long)b2 * SEL_CHUNK + acquire(&a.stage[(long long)b2 * SEL_CHUNK + j]);
+        a.sel[o2 + j] = src;
+        hill_prep_one<DIM>(g, h, o2 + j, src);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == BLOCK - 1) s_carry = off + c;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const long long total = s_carry;
+    *a.count_host = total;
+    *a.count_dev = total;
   }
 }
+
+size_t select_stage_ints(long long n) { return (size_t)((n + SEL_CHUNK - 1) / SEL_CHUNK) * SEL_CHUNK; }
+
+hipError_t launch_select_prep(const SelectArgs &a, const Geom &g, const HillList &h, hipStream_t s) {
+  const int nb = (int)((a.n + SEL_CHUNK - 1) / SEL_CHUNK);
+  if (nb <= 0) return hipErrorInvalidValue;
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL(k_select_prep<1>, dim3(nb), dim3(BLOCK), 0, s, a, g, h); break;
+    case 2: hipLaunchKernelGGL(k_select_prep<2>, dim3(nb), dim3(BLOCK), 0, s, a, g, h); break;
+    default: hipLaunchKernelGGL(k_select_prep<3>, dim3(nb), dim3(BLOCK), 0, s, a, g, h); break;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s) {
   if (h.nh <= 0) return hipSuccess;
   const int b = blocks_for(h.nh);
@@ -1039,10 +1191,18 @@ __device__ __forceinline__ bool pair_term(const Geom &g, const TermConst<DIM> &t
 // ---------------------------------------------------------------------------
 // TPH threads cooperate on one hill: 64 (a wave per hill, long lists) or 256 (a workgroup per hill:
 // four times shorter critical path for the few-hundred-hill batches of a stochastic hill step)
+template <bool COHERENT>
+__device__ __forceinline__ void limit_wave(long long nh_bound, const double *added, const double *heights,
+                                           double h_const, double limit, double cum_in, int flush_mode,
+                                           const LimitTail &tail, LimitResult *res, long long nchunks,
+                                           const double *chunk_sum, const double *chunk_max,
+                                           const long long *nh_dev);
+
+// `la` (TPH == BLOCK only): the ordered limiter is chained onto the last workgroup to finish
 template <int DIM, int TPH>
 __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, HillList h,
                                                           const double *__restrict__ heights, double h_const,
-                                                          double *__restrict__ added) {
+                                                          double *__restrict__ added, LimitArgs la) {
   __shared__ double s_red[BLOCK / 64];
   const int lane = threadIdx.x & 63;
   const int lt = threadIdx.x % TPH;
@@ -1112,27 +1272,42 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
     if (threadIdx.x == 0 && live) {
       double r = 0;
       for (int w = 0; w < BLOCK / 64; w++) r += s_red[w];
-      added[hill] = r;
+      if (la.enabled) publish(&added[hill], r); else added[hill] = r;
+    }
+    if (la.enabled) {
+      if (!last_block_done(la.ticket, gridDim.x)) return;
+      if (threadIdx.x < 64)
+        limit_wave<true>(h.nh, added, heights, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr,
+                   nullptr, h.nh_dev);
     }
   }
 }
 
+bool hill_integrals_can_chain_limit(long long nh) { return nh > 0 && nh <= 2048; }
+
 hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList &h, const double *heights,
-                                 double h_const, double *added, hipStream_t s) {
+                                 double h_const, double *added, hipStream_t s, const LimitArgs *chain) {
   if (h.nh <= 0) return hipSuccess;
+  LimitArgs la;
+  memset(&la, 0, sizeof(la));
+  if (chain) {
+    if (!hill_integrals_can_chain_limit(h.nh)) return hipErrorInvalidValue;
+    la = *chain;
+    la.enabled = 1;
+  }
   if (h.nh <= 2048) {
     const unsigned nb = (unsigned)h.nh;
     switch (g.dim) {
-      case 1: hipLaunchKernelGGL((k_hill_integrals<1, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
-      case 2: hipLaunchKernelGGL((k_hill_integrals<2, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
-      default: hipLaunchKernelGGL((k_hill_integrals<3, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+      case 1: hipLaunchKernelGGL((k_hill_integrals<1, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
+      case 2: hipLaunchKernelGGL((k_hill_integrals<2, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
+      default: hipLaunchKernelGGL((k_hill_integrals<3, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
     }
   } else {
     const long long nb = (h.nh + (BLOCK / 64) - 1) / (BLOCK / 64);
     switch (g.dim) {
-      case 1: hipLaunchKernelGGL((k_hill_integrals<1, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
-      case 2: hipLaunchKernelGGL((k_hill_integrals<2, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
-      default: hipLaunchKernelGGL((k_hill_integrals<3, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added); break;
+      case 1: hipLaunchKernelGGL((k_hill_integrals<1, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
+      case 2: hipLaunchKernelGGL((k_hill_integrals<2, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
+      default: hipLaunchKernelGGL((k_hill_integrals<3, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
     }
   }
   return hipGetLastError();
@@ -1219,10 +1394,30 @@ __device__ __forceinline__ int hill_tile_slot(const Geom &g, const int *c, const
 // MODE 0: heights from (base | limiter tail), in place (groups == 1) or per-group partials
 // MODE 1: fused -- base heights only, always into partials, per-(hill, tile) integral pieces into slots
 // MODE 2: correction -- only the limiter's tail hills, heights (tail_h1 - base, tail_h2), into partial[groups]
+struct DupPlan {
+  unsigned long long lo[3], hi[3];
+};
+__device__ __forceinline__ void duplicate_boundary_block(const Geom &g, double *__restrict__ rec, const DupPlan &dp);
+static DupPlan make_dup_plan(const Geom &g);
+template <int DIM>
+__device__ __forceinline__ void hist_batch(const Geom &hg, double *hist, long long nh, const double *hx0,
+                                           const LimitResult *res, const int *flags, int flush_mode, long long first,
+                                           long long stride);
+// bookkeeping chained onto the last gather workgroup (see last_block_done)
+struct PostArgs {
+  int enabled;
+  int *ticket;
+  DupPlan dp;
+  Geom hg;
+  double *hist;
+  const int *flags;
+  int flush_mode;
+};
+
 template <int DIM, int MODE>
-__global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
-                                                       HillHeights hh, GatherPlan plan, int use_list,
-                                                       int *__restrict__ dirty_flag) {
+__device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t, double *__restrict__ rec,
+                                                 const HillList &h, const HillHeights &hh, const GatherPlan &plan,
+                                                 int use_list, int *__restrict__ dirty_flag, int coherent) {
   constexpr int R = (DIM == 1) ? 2 : 4;
   long long tile = blockIdx.x;
   if (use_list) {
@@ -1434,9 +1629,17 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
   }
   if (active) {
     double *dst = in_place ? rec + flat * R : plan.partial + ((long long)grp * g.total + flat) * R;
+    if (coherent) {
+      // the chained boundary duplication (another workgroup) reads node values and the flag
+      publish(&dst[0], acc[0]);
 #pragma unroll
-    for (int j = 0; j <= DIM; j++) dst[j] = acc[j];
-    if (any_corr) *dirty_flag = 1;
+      for (int j = 1; j <= DIM; j++) dst[j] = acc[j];
+      if (any_corr) publish(dirty_flag, 1);
+    } else {
+#pragma unroll
+      for (int j = 0; j <= DIM; j++) dst[j] = acc[j];
+      if (any_corr) *dirty_flag = 1;
+    }
   } else if (!in_place) {
     // inactive nodes of a partial buffer must read as zero in the reduction
     bool in_grid_node = true;
@@ -1451,6 +1654,24 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
 #pragma unroll
       for (int j = 0; j <= DIM; j++) dst[j] = 0;
     }
+  }
+}
+
+template <int DIM, int MODE>
+__global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
+                                                       HillHeights hh, GatherPlan plan, int use_list,
+                                                       int *__restrict__ dirty_flag, PostArgs post) {
+  hill_gather_body<DIM, MODE>(g, t, rec, h, hh, plan, use_list, dirty_flag, (MODE == 0) ? post.enabled : 0);
+  if (MODE == 0 && post.enabled) {
+    // boundary duplication (K6) and the histogram updates (K7) by the last workgroup to finish
+    if (!last_block_done(post.ticket, gridDim.x * gridDim.y)) return;
+    if (acquire(dirty_flag) != 0) {
+      duplicate_boundary_block(g, rec, post.dp);
+      __syncthreads();
+      if (threadIdx.x == 0) *dirty_flag = 0;
+    }
+    if (hh.res_dev->error) return;
+    hist_batch<DIM>(post.hg, post.hist, h.nh, h.hx0, hh.res_dev, post.flags, post.flush_mode, threadIdx.x, BLOCK);
   }
 }
 
@@ -1525,7 +1746,19 @@ __global__ void __launch_bounds__(BLOCK) k_compact_tiles(long long ntiles, const
 
 template <int DIM>
 static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const HillList &h, const HillHeights &hh,
-                             const GatherPlan &plan, int *dirty_flag, hipStream_t s) {
+                             const GatherPlan &plan, int *dirty_flag, hipStream_t s, const PostSpec *chain) {
+  PostArgs post;
+  memset(&post, 0, sizeof(post));
+  if (chain) {
+    if (plan.groups != 1 || !hh.res_dev || !h.hx0) return hipErrorInvalidValue;
+    post.enabled = 1;
+    post.ticket = chain->ticket;
+    post.dp = make_dup_plan(g);
+    post.hg = *chain->hist_geom;
+    post.hist = chain->hist;
+    post.flags = chain->flags;
+    post.flush_mode = chain->flush_mode;
+  }
   const long long ntiles = gather_tiles(g);
   int use_list = 0;
   long long launch_tiles = ntiles;
@@ -1541,7 +1774,7 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
     launch_tiles = plan.tile_bound < ntiles ? plan.tile_bound : ntiles;
   }
   hipLaunchKernelGGL((k_hill_gather<DIM, 0>), dim3((unsigned)launch_tiles, (unsigned)plan.groups), dim3(BLOCK), 0, s, g, t,
-                     rec, h, hh, plan, use_list, dirty_flag);
+                     rec, h, hh, plan, use_list, dirty_flag, post);
   if (plan.groups > 1)
     hipLaunchKernelGGL(k_reduce_partials, dim3(blocks_for(g.total * g.rec)), dim3(BLOCK), 0, s, g, rec, plan.partial,
                        plan.groups, hh.res_dev, plan.adaptive, h.nh, h.nh_dev);
@@ -1549,12 +1782,12 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
 }
 
 hipError_t launch_hill_gather(const Geom &g, const Tables &t, double *rec, const HillList &h, const HillHeights &hh,
-                              const GatherPlan &plan, int *dirty_flag, hipStream_t s) {
-  if (h.nh <= 0) return hipSuccess;
+                              const GatherPlan &plan, int *dirty_flag, hipStream_t s, const PostSpec *chain) {
+  if (h.nh <= 0) return chain ? hipErrorInvalidValue : hipSuccess;
   switch (g.dim) {
-    case 1: return gather_dim<1>(g, t, rec, h, hh, plan, dirty_flag, s);
-    case 2: return gather_dim<2>(g, t, rec, h, hh, plan, dirty_flag, s);
-    default: return gather_dim<3>(g, t, rec, h, hh, plan, dirty_flag, s);
+    case 1: return gather_dim<1>(g, t, rec, h, hh, plan, dirty_flag, s, chain);
+    case 2: return gather_dim<2>(g, t, rec, h, hh, plan, dirty_flag, s, chain);
+    default: return gather_dim<3>(g, t, rec, h, hh, plan, dirty_flag, s, chain);
   }
 }
 
@@ -1597,10 +1830,12 @@ hipError_t launch_hill_gather_fused(const Geom &g, const Tables &t, const HillLi
   hh.res_dev = nullptr;
   const long long ntiles = gather_tiles(g);
   const dim3 grid((unsigned)ntiles, (unsigned)plan.groups);
+  PostArgs nopost;
+  memset(&nopost, 0, sizeof(nopost));
   switch (g.dim) {
-    case 1: hipLaunchKernelGGL((k_hill_gather<1, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag); break;
-    case 2: hipLaunchKernelGGL((k_hill_gather<2, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag); break;
-    default: hipLaunchKernelGGL((k_hill_gather<3, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag); break;
+    case 1: hipLaunchKernelGGL((k_hill_gather<1, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
+    case 2: hipLaunchKernelGGL((k_hill_gather<2, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
+    default: hipLaunchKernelGGL((k_hill_gather<3, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
   }
   hipLaunchKernelGGL(k_sum_slots, dim3(blocks_for(h.nh)), dim3(BLOCK), 0, s, h.nh, plan.slots_per_hill, plan.slots, added);
   return hipGetLastError();
@@ -1617,10 +1852,12 @@ hipError_t launch_hill_gather_correct_and_apply(const Geom &g, const Tables &t, 
     if (e != hipSuccess) return e;
     const long long ntiles = gather_tiles(g);
     const dim3 grid((unsigned)ntiles, 1);
+    PostArgs nopost;
+    memset(&nopost, 0, sizeof(nopost));
     switch (g.dim) {
-      case 1: hipLaunchKernelGGL((k_hill_gather<1, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag); break;
-      case 2: hipLaunchKernelGGL((k_hill_gather<2, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag); break;
-      default: hipLaunchKernelGGL((k_hill_gather<3, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag); break;
+      case 1: hipLaunchKernelGGL((k_hill_gather<1, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
+      case 2: hipLaunchKernelGGL((k_hill_gather<2, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
+      default: hipLaunchKernelGGL((k_hill_gather<3, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
     }
     groups += 1;
   }
@@ -1633,11 +1870,6 @@ hipError_t launch_hill_gather_correct_and_apply(const Geom &g, const Tables &t, 
 // Ordered (serial-dependence) hill application: one workgroup, hills strictly in sequence.
 // ---------------------------------------------------------------------------
 static constexpr int ORD_BLOCK = 1024;
-
-struct DupPlan {
-  unsigned long long lo[3], hi[3];
-};
-__device__ __forceinline__ void duplicate_boundary_block(const Geom &g, double *__restrict__ rec, const DupPlan &dp);
 
 template <int DIM>
 __global__ void __launch_bounds__(ORD_BLOCK) k_hills_ordered(Geom g, Tables t, double *__restrict__ rec, HillList h,
@@ -1885,7 +2117,7 @@ __device__ __forceinline__ void duplicate_boundary_block(const Geom &g, double *
   // inner nodes lie inside the boundary, non-trivial outer nodes outside it, so the
   // copies are independent of each other: read all, then write all
   double v = 0;
-  if (do_copy) v = rec[inner_flat * g.rec];
+  if (do_copy) v = acquire(&rec[inner_flat * g.rec]);  // (may have been published by another workgroup of this launch)
   __syncthreads();
   if (do_copy) rec[outer_flat * g.rec] = v;
 }
@@ -1948,10 +2180,17 @@ __global__ void __launch_bounds__(BLOCK) k_post_batch(Geom g, double *__restrict
     return;
   }
   if (res->error) return;
+  hist_batch<DIM>(hg, hist, nh, hx0, res, flags, flush_mode, (long long)(blockIdx.x - 1) * BLOCK + threadIdx.x,
+                  (long long)(gridDim.x - 1) * BLOCK);
+}
+
+template <int DIM>
+__device__ __forceinline__ void hist_batch(const Geom &hg, double *hist, long long nh, const double *hx0,
+                                           const LimitResult *res, const int *flags, int flush_mode, long long first,
+                                           long long stride) {
   const long long k = res->k;
   if (res->nh < nh) nh = res->nh;  // deferred count
-  const long long stride = (long long)(gridDim.x - 1) * BLOCK;
-  for (long long i = (long long)(blockIdx.x - 1) * BLOCK + threadIdx.x; i < nh; i += stride) {
+  for (long long i = first; i < nh; i += stride) {
     double wgt = flush_mode ? 0.0 : 1.0;
     if (i >= k) {
       const int fl = flags[i - k];
@@ -2059,13 +2298,14 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(64) k_limit(long long nh_bound, const double *__restrict__ added,
-                                              const double *__restrict__ heights, double h_const, double limit,
-                                              double cum_in, int flush_mode, LimitTail tail,
-                                              LimitResult *__restrict__ res, long long nchunks,
-                                              const double *__restrict__ chunk_sum,
-                                              const double *__restrict__ chunk_max,
-                                              const long long *__restrict__ nh_dev) {
+// (run by ONE wave: lanes 0..63 of a workgroup; COHERENT: `added` was published by other workgroups
+// of the same launch)
+template <bool COHERENT>
+__device__ __forceinline__ void limit_wave(long long nh_bound, const double *added, const double *heights,
+                                           double h_const, double limit, double cum_in, int flush_mode,
+                                           const LimitTail &tail, LimitResult *res, long long nchunks,
+                                           const double *chunk_sum, const double *chunk_max,
+                                           const long long *nh_dev) {
   long long nh = nh_bound;
   if (nh_dev) {
     nh = *nh_dev;
@@ -2132,7 +2372,7 @@ __global__ void __launch_bounds__(64) k_limit(long long nh_bound, const double *
   bool stopped = false;
   for (long long base = 0; base < ntail; base += 64) {
     const long long mine = k + base + lane;
-    const double a_l = (mine < nh) ? added[mine] : 0.0;
+    const double a_l = (mine < nh) ? (COHERENT ? acquire(&added[mine]) : added[mine]) : 0.0;
     const double h_l = (mine < nh) ? (heights ? heights[mine] : h_const) : 0.0;
     // add_value(pos, h) is linear in h: the undo hill's bias is h2 * (added / height)
     const double q_l = (h_l != 0.0) ? a_l / h_l : 0.0;
@@ -2217,6 +2457,17 @@ __global__ void __launch_bounds__(64) k_limit(long long nh_bound, const double *
     res->n_deferred = n_def;
     res->error = 0;
   }
+}
+
+__global__ void __launch_bounds__(64) k_limit(long long nh_bound, const double *__restrict__ added,
+                                              const double *__restrict__ heights, double h_const, double limit,
+                                              double cum_in, int flush_mode, LimitTail tail,
+                                              LimitResult *__restrict__ res, long long nchunks,
+                                              const double *__restrict__ chunk_sum,
+                                              const double *__restrict__ chunk_max,
+                                              const long long *__restrict__ nh_dev) {
+  limit_wave<false>(nh_bound, added, heights, h_const, limit, cum_in, flush_mode, tail, res, nchunks, chunk_sum,
+                    chunk_max, nh_dev);
 }
 
 size_t limit_scratch_doubles(long long nh) { return (size_t)(2 * ((nh + EDM_CHUNK - 1) / EDM_CHUNK) + 8); }
