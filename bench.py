@@ -170,9 +170,9 @@ def main():
     est = 2 * npairs  # fix_edm_pair makes up to two add_hill calls per pair (fix_edm_pair.cpp:230-237)
 
     def step():
-        e = b.pair_forces_device(d_r, d_f, npairs)
-        b.add_hills_device(d_r, npairs, 1, d_u, -1, est)
-        return e
+        # one hill-depositing fix edm_pair step: pre_add_hill(est), forces of all pairs, add_hill(r, u) for the
+        # staged samples, post_add_hill -- a single C-ABI call (edm_hip_bias_pair_step)
+        return b.pair_step_device(d_r, d_f, npairs, d_r, d_u, npairs, est)
 
     def barrier():
         H.synchronize()

@@ -710,6 +710,38 @@ int edm_hip_bias_add_hills(edm_hip_bias *b, long long n, const double *d_x, int 
   return do_post_add_hill(b);
 }
 
+int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, double *d_force, long long n_samples,
+                           const double *d_sample_r, const double *d_runiform, long long est_hill_count,
+                           double *energy) {
+  if (energy) *energy = 0;
+  if (!b->bias && !b->b_outofbounds) {
+    set_error("pair_step before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  if (b->dim != 1) {
+    set_error("pair_step: the pair-distance CV is 1-D (fix_edm_pair.cpp:52)");
+    return EDM_HIP_ERR_ARG;
+  }
+  // pre_add_hill first, as fix_edm_pair does (:174): a pending overflow flush is part of the bias the
+  // forces see
+  int rc = do_pre_add_hill(b, est_hill_count < 0 ? n_samples : est_hill_count);
+  if (rc) return rc;
+  if (b->b_outofbounds) {
+    if (n > 0) EDM_HIP_TRY(hipMemset(d_force, 0, sizeof(double) * (size_t)n));
+    return do_post_add_hill(b);
+  }
+  // forces (queued, not waited for), then the new hills behind them on the same stream: one host wait
+  int nblk = 0;
+  rc = pair_forces_enqueue(b->bias, n, d_r, d_force, &nblk);
+  if (rc) return rc;
+  rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
+  if (rc) return rc;
+  EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
+  const double e = pair_forces_finish(b->bias, nblk);
+  if (energy) *energy = e;
+  return do_post_add_hill(b);
+}
+
 int edm_hip_bias_pre_add_hill(edm_hip_bias *b, long long est_hill_count) {
   b->staged_x.clear();
   b->staged_u.clear();

@@ -419,7 +419,8 @@ static int gauss_alloc(edm_hip_gauss *g) {
   EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_partials), sizeof(double) * lookup_scratch_doubles(), hipHostMallocMapped));
   EDM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&g->d_partials), g->h_partials, 0));
   g->h_stage_bytes = (size_t)4096 * (sizeof(int) + sizeof(double) * (3 + 3)) + 1024;
-  EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_stage), g->h_stage_bytes, hipHostMallocDefault));
+  EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_stage), g->h_stage_bytes, hipHostMallocMapped));
+  EDM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&g->d_stage), g->h_stage, 0));
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_dirty), sizeof(int) * 4));
   EDM_HIP_TRY(hipMemset(g->d_dirty, 0, sizeof(int) * 4));
   return EDM_HIP_OK;
@@ -619,18 +620,12 @@ int edm_hip_gauss_update_forces(const edm_hip_gauss *g, long long n, const doubl
 int edm_hip_gauss_pair_forces(const edm_hip_gauss *g, long long n, const double *d_r, double *d_force,
                               double *energy) {
   if (energy) *energy = 0;
-  if (g->g.dim != 1) {
-    set_error("pair_forces: the pair-distance CV is 1-D (fix_edm_pair.cpp:52)");
-    return EDM_HIP_ERR_ARG;
-  }
-  if (n <= 0) return EDM_HIP_OK;
   int nblk = 0;
-  EDM_HIP_TRY(launch_pair_forces(g->g, g->rec, n, d_r, d_force, g->d_partials, nullptr, g->stream,
-                                 g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr, &nblk));
+  int rc = edm::pair_forces_enqueue(g, n, d_r, d_force, &nblk);
+  if (rc) return rc;
+  if (n <= 0) return EDM_HIP_OK;
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
-  double e = 0;
-  for (int i = 0; i < nblk; i++) e += g->h_partials[i];
-  profile_collect(g);
+  const double e = edm::pair_forces_finish(g, nblk);
   if (energy) *energy = e;
   return EDM_HIP_OK;
 }
@@ -658,6 +653,26 @@ int edm_hip_gauss_profile_read(edm_hip_gauss *g, double *kernel_ms_total, long l
 
 // ---- hill application pipeline --------------------------------------------------
 namespace edm {
+
+// K1 without the host wait: the launch is queued, the per-workgroup energy sums land in host-mapped
+// memory; pair_forces_finish() adds them up after the stream has been synchronised by the caller
+int pair_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_r, double *d_force, int *nblk) {
+  *nblk = 0;
+  if (g->g.dim != 1) {
+    set_error("pair_forces: the pair-distance CV is 1-D (fix_edm_pair.cpp:52)");
+    return EDM_HIP_ERR_ARG;
+  }
+  if (n <= 0) return EDM_HIP_OK;
+  EDM_HIP_TRY(launch_pair_forces(g->g, g->rec, n, d_r, d_force, g->d_partials, nullptr, g->stream,
+                                 g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr, nblk));
+  return EDM_HIP_OK;
+}
+double pair_forces_finish(const edm_hip_gauss *g, int nblk) {
+  double e = 0;
+  for (int i = 0; i < nblk; i++) e += g->h_partials[i];
+  if (nblk > 0) profile_collect(g);
+  return e;
+}
 
 static const long long SMALL_BATCH = 4096;  // read-back of a batch this small is one async burst
 
@@ -846,7 +861,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     long long per_hill = 1;
     for (int d = 0; d < q.dim; d++) per_hill *= (2 * q.msize[d]) / T[d] + 2;
     if (nh * per_hill < ntiles / 2) {
-      EDM_HIP_TRY(ws.tile_flags.reserve((size_t)ntiles));
+      EDM_HIP_TRY(ws.tile_flags.reserve_zeroed((size_t)ntiles));
       EDM_HIP_TRY(ws.tile_list.reserve((size_t)ntiles + 1));
       plan.tile_flags = ws.tile_flags.p;
       plan.tile_list = ws.tile_list.p;
@@ -855,6 +870,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   }
   const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
   bool chain_post = false;
+  bool rb_pushed = false;
   if (fused) {
     EDM_HIP_TRY(launch_hill_gather_correct_and_apply(q, tabs, g->rec, hl, hh, fplan, spec.limited ? 1 : 0, g->d_dirty, s));
     if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
@@ -867,6 +883,16 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     ps.hist = spec.hist_values;
     ps.flags = p_flags;
     ps.flush_mode = spec.flush_mode;
+    // ... and so does the read-back: the last workgroup copies the packed region into host-mapped memory
+    ps.rb_src = nullptr;
+    ps.rb_dst = nullptr;
+    ps.rb_bytes = 0;
+    if (chain_post && small && rb_bytes <= g->h_stage_bytes) {
+      ps.rb_src = ws.rb.p;
+      ps.rb_dst = g->d_stage;
+      ps.rb_bytes = (long long)rb_bytes;
+      rb_pushed = true;
+    }
     EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, hl, hh, plan, g->d_dirty, s, chain_post ? &ps : nullptr));
     if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
   }
@@ -893,7 +919,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   LimitResult *hres = reinterpret_cast<LimitResult *>(g->h_scalars + 8);
   char *stage = g->h_stage;
   if (small) {
-    EDM_HIP_TRY(hipMemcpyAsync(stage, ws.rb.p, rb_bytes, hipMemcpyDeviceToHost, s));
+    if (!rb_pushed) EDM_HIP_TRY(hipMemcpyAsync(stage, ws.rb.p, rb_bytes, hipMemcpyDeviceToHost, s));
     hres = reinterpret_cast<LimitResult *>(stage);
   } else if (spec.limited) {
     EDM_HIP_TRY(hipMemcpyAsync(hres, dres, sizeof(LimitResult), hipMemcpyDeviceToHost, s));

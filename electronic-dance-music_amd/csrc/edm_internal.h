@@ -40,6 +40,15 @@ struct DevBuf {
     cap = want;
     return hipSuccess;
   }
+  // as reserve(); a new allocation is zero-filled (contents are kept zero by its users)
+  hipError_t reserve_zeroed(size_t n) {
+    if (n <= cap) return hipSuccess;
+    hipError_t e = reserve(n);
+    if (e != hipSuccess) return e;
+    e = hipMemset(p, 0, cap * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipDeviceSynchronize();  // (rare: only when the buffer grows)
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -91,7 +100,8 @@ struct edm_hip_gauss {
   double *h_scalars = nullptr;           // pinned host mirror
   double *h_partials = nullptr;          // host-mapped pinned block partial sums (energy)
   double *d_partials = nullptr;          // device view of h_partials
-  char *h_stage = nullptr;               // pinned staging for batched result read-back
+  char *h_stage = nullptr;               // pinned (host-mapped) staging for batched result read-back
+  char *d_stage = nullptr;               // its device-side address
   size_t h_stage_bytes = 0;
   int *d_dirty = nullptr;
   // bench support: HIP events around the dominant lookup kernel
@@ -144,4 +154,6 @@ struct ApplyOutcome {
 // prep -> integrals -> (limiter) -> ordered gather -> boundary duplication.
 // Leaves per-hill `added` in g->ws.added and the tail arrays in g->ws.tail_*.
 int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool want_total);
+int pair_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_r, double *d_force, int *nblk);
+double pair_forces_finish(const edm_hip_gauss *g, int nblk);
 }  // namespace edm

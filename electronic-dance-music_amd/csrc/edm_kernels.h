@@ -200,6 +200,9 @@ struct PostSpec {
   double *hist;
   const int *flags;
   int flush_mode;
+  const char *rb_src;   // optional: rb_bytes (multiple of 8) copied to rb_dst (host-mapped) at the very end
+  char *rb_dst;
+  long long rb_bytes;
 };
 
 

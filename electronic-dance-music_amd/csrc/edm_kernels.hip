@@ -1229,38 +1229,53 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
       total *= (2 * g.msize[d] + 1);
     }
     const double height = heights ? heights[hill] : h_const;
-    for (long long s = lt; s < total; s += TPH) {
-      int p[DIM];
-      long long rest = s;
-      bool skip = false;
+    // ILP stencil points per trip (independent decode + exp chains overlap; a workgroup-per-hill launch
+    // has one wave per SIMD, so nothing else hides their latency); sums stay in stencil order.
+    // 32-bit decode: the stencil has < 2^31 points whenever it fits a grid at all.
+    constexpr int ILP = 4;
+    const unsigned utotal = (unsigned)total;
+    for (unsigned s0 = (unsigned)lt; s0 < utotal; s0 += ILP * TPH) {
+      double term[ILP];
 #pragma unroll
-      for (int d = 0; d < DIM; d++) {
-        const int w = 2 * g.msize[d] + 1;
-        int off;
-        if (d < DIM - 1) {
-          off = (int)(rest % w);
-          rest = (rest - off) / w;
-        } else {
-          off = (int)rest;
+      for (int u = 0; u < ILP; u++) {
+        term[u] = 0;
+        const unsigned s = s0 + (unsigned)(u * TPH);
+        if (s >= utotal) continue;
+        int p[DIM];
+        unsigned rest = s;
+        bool skip = false;
+#pragma unroll
+        for (int d = 0; d < DIM; d++) {
+          const unsigned w = (unsigned)(2 * g.msize[d] + 1);
+          int off;
+          if (d < DIM - 1) {
+            const unsigned qq = rest / w;
+            off = (int)(rest - qq * w);
+            rest = qq;
+          } else {
+            off = (int)rest;
+          }
+          int idx = off - g.msize[d] + c[d];
+          if (idx >= g.n[d]) {
+            if (g.periodic[d]) idx %= g.n[d]; else skip = true;
+          }
+          if (idx < 0) {
+            if (g.periodic[d]) idx += g.n[d]; else skip = true;
+            if (idx < 0) skip = true;  // reference: undefined (stencil wider than two grid lengths)
+          }
+          p[d] = idx;
         }
-        int idx = off - g.msize[d] + c[d];
-        if (idx >= g.n[d]) {
-          if (g.periodic[d]) idx %= g.n[d]; else skip = true;
-        }
-        if (idx < 0) {
-          if (g.periodic[d]) idx += g.n[d]; else skip = true;
-          if (idx < 0) skip = true;  // reference: undefined (stencil wider than two grid lengths)
-        }
-        p[d] = idx;
+        if (skip) continue;
+        NodeTerms<DIM> nt;
+        node_terms<DIM>(g, t, p, nt);
+        if (!nt.inside) continue;
+        double val, dval[DIM];
+        bool nz;
+        if (!pair_term<DIM>(g, tc, nt, hx, ht, val, dval, nz)) continue;
+        term[u] = height * val * vol;
       }
-      if (skip) continue;
-      NodeTerms<DIM> nt;
-      node_terms<DIM>(g, t, p, nt);
-      if (!nt.inside) continue;
-      double val, dval[DIM];
-      bool nz;
-      if (!pair_term<DIM>(g, tc, nt, hx, ht, val, dval, nz)) continue;
-      acc += height * val * vol;
+#pragma unroll
+      for (int u = 0; u < ILP; u++) acc += term[u];
     }
   }
   acc = wave_sum(acc);
@@ -1412,6 +1427,9 @@ struct PostArgs {
   double *hist;
   const int *flags;
   int flush_mode;
+  const char *rb_src;
+  char *rb_dst;
+  long long rb_bytes;
 };
 
 template <int DIM, int MODE>
@@ -1423,6 +1441,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   if (use_list) {
     if (tile >= plan.tile_list[gather_tiles_dev(g)]) return;
     tile = plan.tile_list[tile];
+    if (threadIdx.x == 0) plan.tile_flags[tile] = 0;  // (k_mark_tiles relies on an all-zero flag array)
   }
   // tile origin and this thread's node
   int t0[DIM], p[DIM], tcoord[DIM];
@@ -1455,14 +1474,19 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     node_terms<DIM>(g, t, p, nt);
     if (!nt.inside) active = false;
   }
+  // (limiter result and hill count in one round trip: the kernel is a chain of dependent loads)
   long long k_first_tail = hh.k;
+  long long nh_eff = h.nh;
   if (hh.res_dev) {
-    if (hh.res_dev->error) return;  // limiter overflow / bound exceeded: the host handles it, nothing is applied
-    k_first_tail = hh.res_dev->k;
-  } else if (h.nh_dev && k_first_tail > hill_count(h)) {
-    k_first_tail = hill_count(h);
+    const int err = hh.res_dev->error;
+    const long long kk = hh.res_dev->k, nn = hh.res_dev->nh;
+    if (err) return;  // limiter overflow / bound exceeded: the host handles it, nothing is applied
+    k_first_tail = kk;
+    if (nn < nh_eff) nh_eff = nn;
+  } else {
+    nh_eff = hill_count(h);
+    if (k_first_tail > nh_eff) k_first_tail = nh_eff;
   }
-  const long long nh_eff = hill_count(h);
   const int G = (MODE == 0 && plan.adaptive) ? adaptive_groups(plan.groups, nh_eff) : plan.groups;
   if (MODE == 0 && plan.adaptive && (int)blockIdx.y >= G) return;
   const int grp = (MODE == 2) ? G : blockIdx.y;   // the correction owns the extra partial buffer
@@ -1511,32 +1535,45 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     bool take = false;
     int c[DIM];
     double h1 = 0, h2 = 0;
+    double hx_r[DIM], ht_r[2 * DIM];
     if (cur < hend) {
-      c[0] = h.hc[cur * DIM];
+      // all of this hill's fields are requested together (one memory round trip)
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        c[d] = h.hc[cur * DIM + d];
+        hx_r[d] = h.hx[cur * DIM + d];
+        ht_r[2 * d] = h.ht[cur * 2 * DIM + 2 * d];
+        ht_r[2 * d + 1] = h.ht[cur * 2 * DIM + 2 * d + 1];
+      }
+      const double hb = hh.h ? hh.h[cur] : hh.h_const;
+      const bool in_tail = (MODE == 2) || (MODE == 0 && cur >= k_first_tail);
+      double th1 = 0, th2 = 0;
+      if (in_tail) {
+        th1 = hh.tail_h1[cur - k_first_tail];
+        th2 = hh.tail_h2[cur - k_first_tail];
+      }
       if (c[0] != INT_MIN) {
         take = true;
 #pragma unroll
         for (int d = 0; d < DIM; d++) {
-          if (d > 0) c[d] = h.hc[cur * DIM + d];
           const int T = Tile<DIM>::T[d];
           int t1 = t0[d] + T - 1;
           if (t1 > g.n[d] - 1) t1 = g.n[d] - 1;
           if (images(g, d, c[d], t0[d], t1) == 0) take = false;
         }
         if (take) {
-          const double hb = hh.h ? hh.h[cur] : hh.h_const;
           if (MODE == 1) {
             h1 = hb;
             h2 = 0;
           } else if (MODE == 2) {
-            h1 = hh.tail_h1[cur - k_first_tail] - hb;  // what the fused pass added too much
-            h2 = hh.tail_h2[cur - k_first_tail];
-          } else if (cur < k_first_tail) {
+            h1 = th1 - hb;  // what the fused pass added too much
+            h2 = th2;
+          } else if (!in_tail) {
             h1 = hb;
             h2 = 0;
           } else {
-            h1 = hh.tail_h1[cur - k_first_tail];
-            h2 = hh.tail_h2[cur - k_first_tail];
+            h1 = th1;
+            h2 = th2;
           }
           if (h1 == 0 && h2 == 0) take = false;  // nothing to add (deferred hill / unchanged hill)
         }
@@ -1556,9 +1593,9 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
 #pragma unroll
       for (int d = 0; d < DIM; d++) {
         s_c[pos][d] = c[d];
-        s_x[pos][d] = h.hx[cur * DIM + d];
-        s_t[pos][2 * d] = h.ht[cur * 2 * DIM + 2 * d];
-        s_t[pos][2 * d + 1] = h.ht[cur * 2 * DIM + 2 * d + 1];
+        s_x[pos][d] = hx_r[d];
+        s_t[pos][2 * d] = ht_r[2 * d];
+        s_t[pos][2 * d + 1] = ht_r[2 * d + 1];
       }
       s_h1[pos] = h1;
       s_h2[pos] = h2;
@@ -1670,8 +1707,15 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
       __syncthreads();
       if (threadIdx.x == 0) *dirty_flag = 0;
     }
-    if (hh.res_dev->error) return;
-    hist_batch<DIM>(post.hg, post.hist, h.nh, h.hx0, hh.res_dev, post.flags, post.flush_mode, threadIdx.x, BLOCK);
+    if (!hh.res_dev->error)
+      hist_batch<DIM>(post.hg, post.hist, h.nh, h.hx0, hh.res_dev, post.flags, post.flush_mode, threadIdx.x, BLOCK);
+    if (post.rb_dst) {
+      // read-back region (written by the earlier launches of the step) -> host-mapped memory
+      const long long words = post.rb_bytes / 8;
+      const long long *src = reinterpret_cast<const long long *>(post.rb_src);
+      long long *dst = reinterpret_cast<long long *>(post.rb_dst);
+      for (long long w = threadIdx.x; w < words; w += BLOCK) dst[w] = src[w];
+    }
   }
 }
 
@@ -1695,24 +1739,28 @@ __global__ void __launch_bounds__(BLOCK) k_reduce_partials(Geom g, double *__res
   }
 }
 
-// tile culling for large grids with few hills: mark tiles touched by any hill
+// tile culling for large grids with few hills: list the tiles touched by any hill.  One thread per
+// (hill, stencil-corner offset); a tile is appended by whoever flips its flag first (wave-aggregated
+// append), and the gather workgroup that later owns the tile clears the flag again, so `flags` is all
+// zero between batches and nothing has to be memset or compacted.
 template <int DIM>
-__global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *__restrict__ flags) {
-  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= hill_count(h)) return;
-  if (h.hc[i * DIM] == INT_MIN) return;
-  int ntile[DIM], steps[DIM], c[DIM];
+__global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *__restrict__ flags,
+                                                      int *__restrict__ list, long long ntiles) {
+  int ntile[DIM], steps[DIM];
   long long combos = 1;
 #pragma unroll
   for (int d = 0; d < DIM; d++) {
     const int T = Tile<DIM>::T[d];
     ntile[d] = (g.n[d] + T - 1) / T;
-    c[d] = h.hc[i * DIM + d];
     steps[d] = (2 * g.msize[d]) / T + 2;  // offsets -m, -m+T, ... plus the end point +m
     combos *= steps[d];
   }
-  for (long long q = 0; q < combos; q++) {
-    long long rest = q, tflat = 0, tstride = 1;
+  const long long id = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  const long long i = id / combos;
+  bool emit = false;
+  long long tflat = 0;
+  if (i < hill_count(h) && h.hc[i * DIM] != INT_MIN) {
+    long long rest = id - i * combos, tstride = 1;
     bool skip = false;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
@@ -1721,7 +1769,7 @@ __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *_
       rest /= steps[d];
       int off = -g.msize[d] + sidx * T;
       if (off > g.msize[d]) off = g.msize[d];
-      int idx = c[d] + off;
+      int idx = h.hc[i * DIM + d] + off;
       if (idx >= g.n[d]) {
         if (g.periodic[d]) idx %= g.n[d]; else skip = true;
       }
@@ -1732,16 +1780,25 @@ __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *_
       if (!skip) tflat += (long long)(idx / T) * tstride;
       tstride *= ntile[d];
     }
-    if (!skip) flags[tflat] = 1;
+    if (!skip) emit = (atomicExch(&flags[tflat], 1) == 0);
+  }
+  const unsigned long long bal = __ballot(emit);
+  if (bal) {
+    const int lane = threadIdx.x & 63;
+    const int leader = (int)__builtin_ctzll(bal);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&list[ntiles], (int)__popcll(bal));
+    base = __shfl(base, leader, 64);
+    if (emit) list[base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (int)tflat;
   }
 }
-__global__ void __launch_bounds__(BLOCK) k_compact_tiles(long long ntiles, const int *__restrict__ flags,
-                                                         int *__restrict__ list) {
-  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i < ntiles && flags[i]) {
-    const int pos = atomicAdd(&list[ntiles], 1);
-    list[pos] = (int)i;
+long long mark_tiles_threads(const Geom &g, long long nh) {
+  long long combos = 1;
+  for (int d = 0; d < g.dim; d++) {
+    const int T = (g.dim == 1) ? Tile<1>::T[d] : (g.dim == 2) ? Tile<2>::T[d] : Tile<3>::T[d];
+    combos *= (2 * g.msize[d]) / T + 2;
   }
+  return nh * combos;
 }
 
 template <int DIM>
@@ -1758,18 +1815,19 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
     post.hist = chain->hist;
     post.flags = chain->flags;
     post.flush_mode = chain->flush_mode;
+    post.rb_src = chain->rb_src;
+    post.rb_dst = chain->rb_dst;
+    post.rb_bytes = chain->rb_bytes;
   }
   const long long ntiles = gather_tiles(g);
   int use_list = 0;
   long long launch_tiles = ntiles;
   if (plan.tile_flags && plan.tile_list && plan.groups == 1) {
-    hipError_t e = hipMemsetAsync(plan.tile_flags, 0, sizeof(int) * (size_t)ntiles, s);
+    hipError_t e = hipMemsetAsync(plan.tile_list + ntiles, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(plan.tile_list + ntiles, 0, sizeof(int), s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_mark_tiles<DIM>, dim3((unsigned)((h.nh + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, g, h, plan.tile_flags);
-    hipLaunchKernelGGL(k_compact_tiles, dim3((unsigned)((ntiles + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, ntiles,
-                       plan.tile_flags, plan.tile_list);
+    const long long mt = mark_tiles_threads(g, h.nh);
+    hipLaunchKernelGGL(k_mark_tiles<DIM>, dim3((unsigned)((mt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, g, h, plan.tile_flags,
+                       plan.tile_list, ntiles);
     use_list = 1;
     launch_tiles = plan.tile_bound < ntiles ? plan.tile_bound : ntiles;
   }

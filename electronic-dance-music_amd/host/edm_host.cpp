@@ -573,6 +573,32 @@ void EDMBias::add_pair_hills(int n, const double* r, const double* runiform, int
   refresh();
 }
 
+double EDMBias::pair_step(int npairs, const double* r, double* force_r, int n_samples, const double* sample_r,
+                          const double* runiform, int est_hill_count) {
+  Stage& st = *st_;
+  const size_t pb = sizeof(double) * (size_t)(npairs > 0 ? npairs : 0);
+  const size_t sb = sizeof(double) * (size_t)(n_samples > 0 ? n_samples : 0);
+  if (npairs > 0) {
+    st.r.reserve(pb);
+    st.fr.reserve(pb);
+    check(edm_hip_memcpy_h2d(st.r.p, r, pb), "edm_bias.cpp:update_force");
+  }
+  if (n_samples > 0) {
+    st.x.reserve(sb);
+    st.u.reserve(sb);
+    check(edm_hip_memcpy_h2d(st.x.p, sample_r, sb), "edm_bias.cpp:add_hill");
+    check(edm_hip_memcpy_h2d(st.u.p, runiform, sb), "edm_bias.cpp:add_hill");
+  }
+  double energy = 0;
+  check(edm_hip_bias_pair_step(h_, npairs > 0 ? npairs : 0, (const double*)st.r.p, (double*)st.fr.p,
+                               n_samples > 0 ? n_samples : 0, (const double*)st.x.p, (const double*)st.u.p,
+                               est_hill_count, &energy),
+        "edm_bias.cpp:add_hill");
+  if (npairs > 0) check(edm_hip_memcpy_d2h(force_r, st.fr.p, pb), "edm_bias.cpp:update_force");
+  refresh();
+  return energy;
+}
+
 void EDMBias::pre_add_hill(int est_hill_count) { check(edm_hip_bias_pre_add_hill(h_, est_hill_count), "edm_bias.cpp:pre_add_hill"); }
 void EDMBias::add_hill(const double* position, double runiform) {
   check(edm_hip_bias_add_hill(h_, position, runiform), "edm_bias.cpp:add_hill");

@@ -138,10 +138,12 @@ void FixEDMPair::post_force(int /*vflag*/)
   const bool hill_step = (update->ntimestep % stride == 0);
 
   edm_energy = 0;
-  if (hill_step) bias->pre_add_hill(last_calls);  // flushes the overflow buffer before any force
 
   // pass 1: collect the pair records in neighbour-list order (filters of fix_edm_pair.cpp:181-202)
+  // and, on hill steps, stage the hill samples with their uniforms in the reference's call order
+  // (one add_hill per list entry, a second one iff j is owned, :230-237)
   pair_r.clear(); pair_del.clear(); pair_i.clear(); pair_j.clear();
+  hill_r.clear(); hill_u.clear();
   for (int ii = 0; ii < inum; ii++) {
     const int i = ilist[ii];
     const int itype = type[i];
@@ -166,16 +168,30 @@ void FixEDMPair::post_force(int /*vflag*/)
       pair_del.push_back(delx); pair_del.push_back(dely); pair_del.push_back(delz);
       pair_i.push_back(i);
       pair_j.push_back(j);
+      if (hill_step) {
+        hill_r.push_back(r);
+        hill_u.push_back(random->uniform());
+        if (newton_pair || j < nlocal) {
+          hill_r.push_back(r);
+          hill_u.push_back(random->uniform());
+        }
+      }
     }
   }
 
-  // one batched bias evaluation for all pairs of this rank
+  // one device round trip per step: the batched bias evaluation for all pairs of this rank and, on
+  // hill steps, pre_add_hill(last_calls) (overflow flush) before it and the hill cycle behind it
   const int npairs = (int) pair_r.size();
   pair_f.resize(pair_r.size());
-  edm_energy = bias->update_pair_forces(npairs, pair_r.data(), pair_f.data());
+  if (hill_step) {
+    const int ncalls = (int) hill_r.size();
+    edm_energy = bias->pair_step(npairs, pair_r.data(), pair_f.data(), ncalls, hill_r.data(), hill_u.data(), last_calls);
+    last_calls = ncalls;  // next step's estimate (fix_edm_pair.cpp:245)
+  } else {
+    edm_energy = bias->update_pair_forces(npairs, pair_r.data(), pair_f.data());
+  }
 
-  // pass 2: apply the pair forces and stage the hill samples, in the reference's order
-  int ncalls = 0;
+  // pass 2: apply the pair forces
   for (int k = 0; k < npairs; k++) {
     const int i = pair_i[k], j = pair_j[k];
     const double fr = pair_f[k];
@@ -188,19 +204,6 @@ void FixEDMPair::post_force(int /*vflag*/)
       f[j][1] -= del[1] * fr;
       f[j][2] -= del[2] * fr;
     }
-    if (hill_step) {
-      bias->add_hill(&pair_r[k], random->uniform());
-      ncalls++;
-      if (newton_pair || j < nlocal) {
-        bias->add_hill(&pair_r[k], random->uniform());
-        ncalls++;
-      }
-    }
-  }
-
-  if (hill_step) {
-    last_calls = ncalls;  // next step's estimate (fix_edm_pair.cpp:245)
-    bias->post_add_hill();
   }
   if (update->ntimestep % write_stride == 0) {
     bias->write_bias(bias_file);

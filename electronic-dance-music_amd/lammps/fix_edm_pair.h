@@ -46,6 +46,7 @@ class FixEDMPair : public Fix {
   int ipair, jpair;
   // per-step batch of pair records (host staging, reused across steps)
   std::vector<double> pair_r, pair_f, pair_del;
+  std::vector<double> hill_r, hill_u;  // staged add_hill(r, uniform) calls of a hill step, in call order
   std::vector<int> pair_i, pair_j;
 };
 

@@ -62,6 +62,11 @@ class EDMBias {
   double update_pair_forces(int npairs, const double* r, double* force_r) const;
   // one hill cycle over a flat distance array: pre_add_hill(est); add_hill(&r[i], runiform[i]); post
   void add_pair_hills(int n, const double* r, const double* runiform, int est_hill_count);
+  // one hill-depositing fix_edm_pair step in one call (one device round trip): pre_add_hill(est);
+  // force_r = update_pair_forces(npairs, r); add_hill(&sample_r[i], runiform[i]) for i < n_samples;
+  // post_add_hill().  Returns the bias energy of the pairs.
+  double pair_step(int npairs, const double* r, double* force_r, int n_samples, const double* sample_r,
+                   const double* runiform, int est_hill_count);
   // one rank per GPU: id is an ncclUniqueId made by make_comm_id() on rank 0 and broadcast by the
   // caller (MPI_Bcast in LAMMPS); must be called before subdivide
   // binds this process to GPU (rank % visible devices); call before constructing an EDMBias

@@ -192,6 +192,14 @@ int edm_hip_bias_pair_forces(edm_hip_bias *b, long long n, const double *d_r, do
  * means "use n" (add_hills semantics); fix_edm_pair passes its own estimate. */
 int edm_hip_bias_add_hills(edm_hip_bias *b, long long n, const double *d_x, int x_stride,
                            const double *d_runiform, int apply_mask, long long est_hill_count);
+/* One hill-depositing step of fix edm_pair (fix_edm_pair.cpp:174-246) in a single call:
+ * pre_add_hill(est_hill_count) (flushes the overflow buffer), the force evaluation of
+ * edm_hip_bias_pair_forces(n, d_r, d_force), add_hill(d_sample_r[i], d_runiform[i]) for the n_samples
+ * staged samples, post_add_hill.  Same results as the separate calls in that order; forces and hills
+ * are queued back to back and the host waits once. */
+int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, double *d_force,
+                           long long n_samples, const double *d_sample_r, const double *d_runiform,
+                           long long est_hill_count, double *energy);
 /* EDMBias::pre_add_hill / add_hill / post_add_hill (edm_bias.cpp:413-442, :528-563,
  * :565-583).  add_hill stages the sample (host values); the staged batch is
  * applied on the device, in call order, at post_add_hill. */

@@ -501,3 +501,45 @@ def test_dense_batch_fused_path_vs_oracle(oracle_lib, workdir):
     close(v, ogg.values, rtol=1e-9, atol=1e-12 * np.abs(ogg.values).max(), what="grid (fused + limiter)")
     assert np.array_equal(b.hist.values, ob.hist.values)
     assert ob.get("overflow_right") > 0
+
+
+def test_pair_step_equals_separate_calls(workdir):
+    """edm_hip_bias_pair_step (forces + hill cycle, one host wait) against the separate calls in the
+    order fix_edm_pair makes them: pre_add_hill, update_force over the pairs, add_hill per staged
+    sample, post_add_hill.  A small bias_per_step keeps the overflow buffer busy, so the flush inside
+    pre_add_hill precedes the force evaluation in both."""
+    text = ("tempering 0\nhill_prefactor 0.5\nhill_density 40\nbias_per_step 0.12\ndimension 1\nbox_low 0\n"
+            "box_high 2.8\nbias_spacing 0.001\nbias_sigma 0.05\n")
+    n = 6000
+    state = []
+    for tag in ("fused", "separate"):
+        cfg = str(workdir / (tag + ".edm"))
+        open(cfg, "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+        b = H.Bias(cfg)
+        b.setup(1.0, 1.0)
+        b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+        energies, forces = [], []
+        for step in range(6):
+            r = W.pair_distances(n, 300 + step)
+            u = W.uniform(350 + step, n)
+            d_r = H.DeviceArray.from_host(r)
+            d_u = H.DeviceArray.from_host(u)
+            d_f = H.DeviceArray.zeros((n,))
+            if tag == "fused":
+                e = b.pair_step_device(d_r, d_f, n, d_r, d_u, n, est=n)
+            else:
+                b.pre_add_hill(n)
+                e = b.pair_forces_device(d_r, d_f, n)
+                for i in range(n):
+                    b.add_hill([r[i]], u[i])
+                b.post_add_hill()
+            energies.append(e)
+            forces.append(d_f.to_host())
+        v, dv = b.gauss.download()
+        state.append((v, dv, b.hist.values, np.array(energies), np.array(forces), b.get("cum_bias"),
+                      b.get("overflow_right"), b.get("hills_added")))
+        del b
+    for a, c in zip(state[0], state[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(c))
+    assert state[0][0].max() > 0 and state[0][6] > 0   # hills were added and the overflow buffer was used
+    assert open(str(workdir / "HILLS_fused_0")).read() == open(str(workdir / "HILLS_separate_0")).read()
