@@ -1355,6 +1355,15 @@ __host__ __device__ inline int images(const Geom &g, int d, int c, int p0, int p
   const long long n = g.n[d], m = g.msize[d];
   long long lo = (long long)c - m, hi = (long long)c + m;
   if (!g.periodic[d]) return (lo <= p1 && hi >= p0) ? 1 : 0;
+  if (2 * m + 1 <= n && c >= 0 && c < n && p0 >= 0 && p1 < n) {
+    // the usual case (stencil narrower than the grid): only the images k = -1, 0, +1 can land on
+    // [p0, p1], so the count needs no 64-bit divisions (this sits in the gather's inner loop)
+    int cnt = 0;
+#pragma unroll
+    for (int k = -1; k <= 1; k++)
+      if (lo <= p1 + k * n && hi >= p0 + k * n) cnt++;
+    return cnt;
+  }
   if (lo < -n) lo = -n;
   const long long kmin = ceildiv(lo - p1, n), kmax = floordiv(hi - p0, n);
   return kmax >= kmin ? (int)(kmax - kmin + 1) : 0;
@@ -1513,6 +1522,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     for (int j = 0; j <= DIM; j++) acc[j] = 0;
   }
   bool any_corr = false;
+  bool touched = false;  // some hill reached this node (an untouched node of an in-place gather is not rewritten)
 
   // The hill list is walked in order, a chunk of BLOCK hills at a time: every thread tests ONE hill
   // of the chunk against this workgroup's tile (coalesced loads instead of a dependent scalar-load
@@ -1617,6 +1627,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
             if (m > 0 && pair_term<DIM>(g, tc, nt, s_x[q0 + q], s_t[q0 + q], val[q], dval[q], nz)) {
               mult[q] = m;
               any_corr |= nz;
+              touched = true;
             }
           }
         }
@@ -1664,7 +1675,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     }
     __syncthreads();
   }
-  if (active) {
+  if (active && (touched || !in_place)) {
     double *dst = in_place ? rec + flat * R : plan.partial + ((long long)grp * g.total + flat) * R;
     if (coherent) {
       // the chained boundary duplication (another workgroup) reads node values and the flag
@@ -1762,6 +1773,7 @@ __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *_
   if (i < hill_count(h) && h.hc[i * DIM] != INT_MIN) {
     long long rest = id - i * combos, tstride = 1;
     bool skip = false;
+    double dp2_min = 0;  // lower bound of dp2 (gaussian_grid.h:292) over the nodes of this tile
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
       const int T = Tile<DIM>::T[d];
@@ -1769,7 +1781,8 @@ __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *_
       rest /= steps[d];
       int off = -g.msize[d] + sidx * T;
       if (off > g.msize[d]) off = g.msize[d];
-      int idx = h.hc[i * DIM + d] + off;
+      const int unwrapped = h.hc[i * DIM + d] + off;
+      int idx = unwrapped;
       if (idx >= g.n[d]) {
         if (g.periodic[d]) idx %= g.n[d]; else skip = true;
       }
@@ -1777,10 +1790,27 @@ __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *_
         if (g.periodic[d]) idx += g.n[d]; else skip = true;
         if (idx < 0) skip = true;
       }
-      if (!skip) tflat += (long long)(idx / T) * tstride;
+      if (!skip) {
+        tflat += (long long)(idx / T) * tstride;
+        // the tile's node range, shifted back to the periodic image this offset belongs to
+        const int shift = unwrapped - idx;
+        const int n0 = (idx / T) * T + shift;
+        int n1 = (idx / T) * T + T - 1;
+        if (n1 > g.n[d] - 1) n1 = g.n[d] - 1;
+        n1 += shift;
+        const double xh = h.hx[i * DIM + d];
+        const double lo = g.min[d] + n0 * g.dx[d], hi = g.min[d] + n1 * g.dx[d];
+        double gap = 0;
+        if (xh < lo) gap = lo - xh;
+        if (xh > hi) gap = xh - hi;
+        gap /= g.sigma[d];
+        dp2_min += gap * gap;
+      }
       tstride *= ntile[d];
     }
-    if (!skip) emit = (atomicExch(&flags[tflat], 1) == 0);
+    // tiles of the stencil's bounding box that lie wholly outside the dp2 < 8 ball receive nothing
+    // (:294); the margin keeps the cut conservative against rounding in the per-node test
+    if (!skip && dp2_min < 8.0 * (1.0 + 1e-6)) emit = (atomicExch(&flags[tflat], 1) == 0);
   }
   const unsigned long long bal = __ballot(emit);
   if (bal) {

@@ -387,6 +387,25 @@ def test_c3d_full_size_properties(oracle_lib):
     # a sample sitting on a hill centre feels (almost) no force from that hill, and the energy is the peak
     E, der = g.get_value_deriv(hx[:1])
     assert E[0] >= 0.02 / (np.pi ** 1.5 * (0.25 * np.sqrt(2)) ** 3) * 0.99
+    # the culled tile-owned gather (ball test per tile) against the oracle: around isolated hills the
+    # big grid must carry exactly the one-hill bias of the equivalent 64^3 grid, inside the dp2 < 8
+    # ball, across its rim and in the stencil-box corners the tile cull drops
+    dist = np.abs(hx[:, None, :] - hx[None, :, :])
+    dist = np.sqrt((np.minimum(dist, 64.0 - dist) ** 2).sum(axis=2)) + 1e9 * np.eye(len(hx))
+    lonely = [i for i in range(len(hx)) if dist[i].min() > 6.5][:3]
+    assert len(lonely) == 3
+    for i in lonely:
+        o1 = B.Gauss.create(oracle_lib, [0.0] * 3, [8.0] * 3, c["spacing"], [1, 1, 1], 1, c["sigma"])
+        o1.add_value(np.mod(hx[i], 8.0), 0.02)
+        off = (W.uniform(500 + i, 900).reshape(300, 3) - 0.5) * 2 * 1.2   # the ball has radius 1.0, the stencil box +-1.375
+        pts = np.mod(hx[i] + off, 64.0)
+        Eg, Dg = g.get_value_deriv(pts)
+        ref = [o1.get_value_deriv(np.mod(p, 8.0)) for p in pts]
+        Er = np.array([r[0] for r in ref])
+        Dr = np.array([r[1] for r in ref])
+        assert (Er > 0).sum() > 50 and (Er == 0).sum() > 20
+        close(Eg, Er, rtol=1e-9, atol=1e-13 * Er.max(), what="3-D bias around a hill vs oracle")
+        close(Dg, Dr, rtol=1e-8, atol=1e-12 * np.abs(Dr).max(), what="3-D bias gradient around a hill vs oracle")
     g.add_values(hx, -0.02)
     E2, _ = g.get_value_deriv(x[:4096])
     assert np.abs(E2).max() < 1e-15, "hills followed by their negatives leave an empty grid"
