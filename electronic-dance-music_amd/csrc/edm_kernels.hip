@@ -1234,6 +1234,12 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
     // 32-bit decode: the stencil has < 2^31 points whenever it fits a grid at all.
     constexpr int ILP = 4;
     const unsigned utotal = (unsigned)total;
+    // the early distance test below works on un-wrapped offsets: valid while no stencil offset is
+    // further than half a period from the hill (else the reference's minimum image folds it back, :287-291)
+    bool ball_ok = true;
+#pragma unroll
+    for (int d = 0; d < DIM; d++)
+      if (g.periodic[d] && 2 * (g.msize[d] + 1) > g.n[d]) ball_ok = false;
     for (unsigned s0 = (unsigned)lt; s0 < utotal; s0 += ILP * TPH) {
       double term[ILP];
 #pragma unroll
@@ -1244,6 +1250,7 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
         int p[DIM];
         unsigned rest = s;
         bool skip = false;
+        double dp2_est = 0;
 #pragma unroll
         for (int d = 0; d < DIM; d++) {
           const unsigned w = (unsigned)(2 * g.msize[d] + 1);
@@ -1256,6 +1263,11 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
             off = (int)rest;
           }
           int idx = off - g.msize[d] + c[d];
+          {
+            // distance to this (un-wrapped) stencil point; most of the stencil box lies outside dp2 < 8
+            const double e = ((g.min[d] + idx * g.dx[d]) - hx[d]) * tc.inv_sigma[d];
+            dp2_est += e * e;
+          }
           if (idx >= g.n[d]) {
             if (g.periodic[d]) idx %= g.n[d]; else skip = true;
           }
@@ -1266,6 +1278,7 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
           p[d] = idx;
         }
         if (skip) continue;
+        if (ball_ok && dp2_est > 8.0 * (1.0 + 1e-6)) continue;  // conservative: the exact test is in pair_term (:294)
         NodeTerms<DIM> nt;
         node_terms<DIM>(g, t, p, nt);
         if (!nt.inside) continue;
