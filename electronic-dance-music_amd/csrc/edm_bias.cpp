@@ -61,6 +61,9 @@ struct edm_hip_bias {
   DevBuf<double> stage_x, stage_u, stage_h, tail_w;
   DevBuf<double> hx0;
   DevBuf<double> xchg_send, xchg_recv, xchg_all;
+  long long xchg_counts[EDM_MAX_RANKS], xchg_est[EDM_MAX_RANKS];  // last synchronous exchange: per-rank hills / est_hill_count
+  bool force_sync = false;      // redo of a deferred step whose launch bound proved too small
+  int debug_virtual_ranks = 0;  // tests: a one-rank communicator's packet is replicated, emulating that many ranks
   DevBuf<long long> xchg_cnt;
   // multi-GPU
   ncclComm_t comm = nullptr;
@@ -443,23 +446,28 @@ static int exchange_hills(edm_hip_bias *b, long long nh_local, const double *d_x
   hipStream_t s = b->bias->stream;
   const int N = b->nranks;
   const int dim = (int)b->dim;
-  EDM_HIP_TRY(b->xchg_cnt.reserve((size_t)N + 1));
-  long long *h_cnt = reinterpret_cast<long long *>(b->bias->h_scalars + 40);  // N <= 16 slots
-  if (N > 16) {
+  EDM_HIP_TRY(b->xchg_cnt.reserve((size_t)2 * N + 2));
+  long long *h_cnt = reinterpret_cast<long long *>(b->bias->h_scalars + 40);  // 2 * N <= 32 slots
+  if (N > EDM_MAX_RANKS) {
     set_error("exchange_hills: more than 16 ranks per node are not supported");
     return EDM_HIP_ERR_ARG;
   }
+  // (count, est_hill_count) of every rank: the height of an all-samples hill depends on its sender's
+  // estimate (edm_bias.cpp:552-556), which travels with the hill in the reference
   h_cnt[0] = nh_local;
-  EDM_HIP_TRY(hipMemcpyAsync(b->xchg_cnt.p + N, h_cnt, sizeof(long long), hipMemcpyHostToDevice, s));
-  if (ncclAllGather(b->xchg_cnt.p + N, b->xchg_cnt.p, 1, ncclInt64, b->comm, s) != ncclSuccess) {
+  h_cnt[1] = b->est_hill_count;
+  EDM_HIP_TRY(hipMemcpyAsync(b->xchg_cnt.p + 2 * N, h_cnt, 2 * sizeof(long long), hipMemcpyHostToDevice, s));
+  if (ncclAllGather(b->xchg_cnt.p + 2 * N, b->xchg_cnt.p, 2, ncclInt64, b->comm, s) != ncclSuccess) {
     set_error("ncclAllGather(hill counts) failed");
     return EDM_HIP_ERR_COMM;
   }
-  EDM_HIP_TRY(hipMemcpyAsync(h_cnt, b->xchg_cnt.p, sizeof(long long) * (size_t)N, hipMemcpyDeviceToHost, s));
+  EDM_HIP_TRY(hipMemcpyAsync(h_cnt, b->xchg_cnt.p, sizeof(long long) * (size_t)(2 * N), hipMemcpyDeviceToHost, s));
   EDM_HIP_TRY(hipStreamSynchronize(s));
-  long long counts[16], total = 0, maxc = 0;
+  long long counts[EDM_MAX_RANKS], total = 0, maxc = 0;
   for (int r = 0; r < N; r++) {
-    counts[r] = h_cnt[r];
+    counts[r] = h_cnt[2 * r];
+    b->xchg_counts[r] = counts[r];
+    b->xchg_est[r] = h_cnt[2 * r + 1];
     total += counts[r];
     if (counts[r] > maxc) maxc = counts[r];
   }
@@ -501,13 +509,90 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   }
   const bool local_tempering = (b->b_tempering && b->global_tempering < 0);  // :547
   hipStream_t s = b->bias->stream;
+  const double *const d_x_in = d_x;   // (the caller's arrays, for the synchronous redo of a deferred step)
+  const int x_stride_in = x_stride;
   const int use_thr = !(b->hill_density < 0);
   const double thr = b->hill_density / b->est_hill_count;   // :543
   long long nh = n;
   long long deferred_bound = 0;
   SelectArgs sel_args;
+  UnpackArgs unp_args;
   const long long *d_sel = nullptr;
-  if (use_thr || apply_mask >= 0) {
+  // Multi-GPU stochastic step without a host round trip: every rank packs its accepted samples into a
+  // fixed-size packet [count, positions...], ONE ncclAllGather concatenates the packets, one workgroup
+  // unpacks them into the rank-major global list, and the rest of the step runs against a launch bound
+  // exactly like the single-GPU deferred step.  Packet size and the decision to take this path depend
+  // on replicated state only (hill_density after the per-rank split, rank count), never on rank-local
+  // sample counts, so all ranks agree; an overflowing rank makes every rank fall back together.
+  bool packed_exchange = false;
+  long long pack_bound = 0;
+  int pack_ranks = b->nranks;
+  if (b->comm && use_thr && !b->b_targeting && !local_tempering && b->nranks <= EDM_MAX_RANKS && !b->force_sync) {
+    if (b->debug_virtual_ranks > 1 && b->nranks == 1) pack_ranks = b->debug_virtual_ranks;
+    pack_bound = (long long)(4.0 * b->hill_density) + 128;
+    if (pack_bound < 256) pack_bound = 256;
+    packed_exchange = (pack_bound * pack_ranks <= EDM_CHUNK);
+  }
+  if (packed_exchange) {
+    const int dim = (int)b->dim;
+    const long long packet = 1 + pack_bound * dim;
+    EDM_HIP_TRY(b->xchg_send.reserve((size_t)packet));
+    EDM_HIP_TRY(b->xchg_recv.reserve((size_t)packet * pack_ranks));
+    EDM_HIP_TRY(b->xchg_all.reserve((size_t)pack_bound * pack_ranks * dim));
+    EDM_HIP_TRY(b->count_dev.reserve(2));
+    if (!b->h_count) {
+      EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_count), 64, hipHostMallocMapped));
+      EDM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_count), b->h_count, 0));
+    }
+    if (n > 0) {
+      if (!d_ru) {
+        set_error("add_hills: hill_density set but no uniform random numbers given");
+        return EDM_HIP_ERR_ARG;
+      }
+      EDM_HIP_TRY(b->sel_scratch.reserve(select_scratch_ints(n)));
+      EDM_HIP_TRY(b->sel_stage.reserve(select_stage_ints(n)));
+      memset(&sel_args, 0, sizeof(sel_args));
+      sel_args.n = n;
+      sel_args.ru = d_ru;
+      sel_args.thr = thr;
+      sel_args.use_thr = use_thr;
+      sel_args.mask = b->d_mask;
+      sel_args.apply_mask = apply_mask;
+      sel_args.counts = b->sel_scratch.p;
+      sel_args.stage = b->sel_stage.p;
+      sel_args.count_host = b->d_count;
+      sel_args.count_dev = b->count_dev.p;
+      sel_args.ticket = b->bias->d_dirty + 1;
+      sel_args.pack = b->xchg_send.p;
+      HillList src;
+      memset(&src, 0, sizeof(src));
+      src.nh = pack_bound;
+      src.x = d_x;
+      src.x_stride = x_stride;
+      EDM_HIP_TRY(launch_select_prep(sel_args, b->bias->g, src, s));
+    } else {
+      EDM_HIP_TRY(hipMemsetAsync(b->xchg_send.p, 0, sizeof(double), s));  // an empty packet
+    }
+    if (ncclAllGather(b->xchg_send.p, b->xchg_recv.p, (size_t)packet, ncclDouble, b->comm, s) != ncclSuccess) {
+      set_error("ncclAllGather(hill packets) failed");
+      return EDM_HIP_ERR_COMM;
+    }
+    for (int r = 1; r < pack_ranks && b->nranks == 1; r++)   // (test hook: emulate more ranks with copies)
+      EDM_HIP_TRY(hipMemcpyAsync(b->xchg_recv.p + (size_t)r * packet, b->xchg_recv.p, sizeof(double) * (size_t)packet,
+                                 hipMemcpyDeviceToDevice, s));
+    memset(&unp_args, 0, sizeof(unp_args));
+    unp_args.recv = b->xchg_recv.p;
+    unp_args.nranks = pack_ranks;
+    unp_args.bound = pack_bound;
+    unp_args.packet = packet;
+    unp_args.all = b->xchg_all.p;
+    unp_args.count_dev = b->count_dev.p;
+    unp_args.count_host = b->d_count;
+    nh = pack_bound * pack_ranks;
+    deferred_bound = nh;
+    d_x = b->xchg_all.p;
+    x_stride = dim;
+  } else if (use_thr || apply_mask >= 0) {
     if (use_thr && !d_ru) {
       set_error("add_hills: hill_density set but no uniform random numbers given");
       return EDM_HIP_ERR_ARG;
@@ -524,7 +609,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     // should the bound ever be too small the limiter reports it, nothing is applied and the step's hill
     // path is redone below with the exact count.
     long long bound = 0;
-    if (use_thr && !b->comm && !b->b_targeting && !local_tempering) {
+    if (use_thr && !b->comm && !b->b_targeting && !local_tempering && !b->force_sync) {
       const double expected = thr * (double)n;
       bound = (long long)(4.0 * expected) + 128;
       if (bound < 256) bound = 256;
@@ -556,9 +641,11 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     }
     d_sel = b->sel.p;
   }
-  if (b->comm) {
+  bool rank_heights = false;
+  if (b->comm && !packed_exchange) {
     const double *d_all = nullptr;
     long long nh_all = 0;
+    rank_heights = (b->hill_density < 0);
     int rc = exchange_hills(b, nh, d_x, x_stride, d_sel, &nh_all, &d_all);
     if (rc) return rc;
     nh = nh_all;
@@ -582,6 +669,21 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     EDM_HIP_TRY(launch_target_heights(b->target->g, b->target->values, nh, d_x, x_stride, d_sel, b->temp_hill_prefactor,
                                       b->expected_target, divisor, BIAS_CLAMP * b->bias_per_step, b->stage_h.p, s));
     d_heights = b->stage_h.p;
+  } else if (rank_heights && !local_tempering) {
+    // all-samples hills carry the height their sender gave them: prefactor / that rank's estimate
+    RankHeights rh;
+    memset(&rh, 0, sizeof(rh));
+    rh.nranks = b->nranks;
+    long long run = 0;
+    for (int r = 0; r < b->nranks; r++) {
+      rh.offset[r] = run;
+      run += b->xchg_counts[r];
+      rh.height[r] = fmin(b->temp_hill_prefactor / (double)b->xchg_est[r], BIAS_CLAMP * b->bias_per_step);
+    }
+    rh.offset[b->nranks] = run;
+    EDM_HIP_TRY(b->stage_h.reserve((size_t)nh));
+    EDM_HIP_TRY(launch_rank_heights(rh, b->stage_h.p, s));
+    d_heights = b->stage_h.p;
   }
 
   ApplySpec spec;
@@ -596,6 +698,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   spec.limit = b->bias_per_step;
   spec.cum_in = b->temp_hill_cum;
   if (use_thr && !b->comm) spec.expected_nh = thr * (double)n;
+  if (packed_exchange) spec.expected_nh = b->hill_density * pack_ranks;
   spec.hist_g = &b->hist->g;
   spec.hist_values = b->hist->values;
   const bool log_all = b->hill_log && b->hills_fp;
@@ -620,18 +723,19 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   ApplyOutcome oc;
   if (deferred_bound) {
     spec.d_nh = b->count_dev.p;
-    spec.sel_chain = &sel_args;
+    if (packed_exchange)
+      spec.unpack_chain = &unp_args;
+    else
+      spec.sel_chain = &sel_args;
   }
   int rc = apply_hills(b->bias, spec, &oc, false);
   if (rc == EDM_APPLY_BOUND_EXCEEDED) {
-    // (practically never) more hills than the bound: redo selection and the step with the exact count
-    spec.d_nh = nullptr;
-    spec.sel_chain = nullptr;
-    EDM_HIP_TRY(launch_select(n, d_ru, thr, use_thr, b->d_mask, apply_mask, b->sel.p, b->d_count, b->sel_scratch.p, s,
-                              b->count_dev.p));
-    EDM_HIP_TRY(hipStreamSynchronize(s));
-    spec.nh = *b->h_count;
-    rc = apply_hills(b->bias, spec, &oc, false);
+    // (practically never) more hills than the launch bound -- on every rank alike, since the count is
+    // global: nothing was applied; redo the step's hill path the synchronous way with exact counts
+    b->force_sync = true;
+    rc = process_new_hills(b, n, d_x_in, x_stride_in, d_ru, apply_mask);
+    b->force_sync = false;
+    return rc;
   }
   if (rc) return rc;
   const LimitResult &res = oc.res;
@@ -677,17 +781,9 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
 static int do_post_add_hill(edm_hip_bias *b) {
   double step_bias = b->temp_hill_cum;
   if (b->comm) {
-    // one 8-byte all-reduce over xGMI replaces MPI_Allreduce(:925)
-    double *d = b->bias->d_scalars + 4;
-    hipStream_t s = b->bias->stream;
-    EDM_HIP_TRY(hipMemcpyAsync(d, &step_bias, sizeof(double), hipMemcpyHostToDevice, s));
-    if (ncclAllReduce(d, d, 1, ncclDouble, ncclSum, b->comm, s) != ncclSuccess) {
-      set_error("ncclAllReduce(temp_hill_cum) failed");
-      return EDM_HIP_ERR_COMM;
-    }
-    EDM_HIP_TRY(hipMemcpyAsync(b->bias->h_scalars + 4, d, sizeof(double), hipMemcpyDeviceToHost, s));
-    EDM_HIP_TRY(hipStreamSynchronize(s));
-    step_bias = b->bias->h_scalars[4];
+    // MPI_Allreduce(temp_hill_cum_) (:925): every rank replays the same global hill list, so the ranks'
+    // temp_hill_cum_ are identical by construction and their sum needs no collective
+    step_bias *= (double)b->nranks;
   }
   b->cum_bias += step_bias;
   b->temp_hill_cum = -1;
@@ -837,6 +933,7 @@ int edm_hip_bias_set(edm_hip_bias *b, const char *name, double value) {
   S("hill_density", b->hill_density, double)
   S("cum_bias", b->cum_bias, double)
   S("total_volume", b->total_volume, double)
+  S("debug_virtual_ranks", b->debug_virtual_ranks, int)
 #undef S
   set_error(std::string("unknown or read-only EDMBias member ") + name);
   return EDM_HIP_ERR_ARG;

@@ -413,7 +413,7 @@ static int gauss_alloc(edm_hip_gauss *g) {
   EDM_HIP_TRY(hipMemset(g->rec, 0, bytes));
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->scratch), sizeof(double) * lookup_scratch_doubles()));
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_scalars), sizeof(double) * 16));
-  EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_scalars), sizeof(double) * 64, hipHostMallocDefault));
+  EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_scalars), sizeof(double) * 128, hipHostMallocDefault));
   // block partial sums of the lookup kernels are written straight into host-mapped pinned memory
   // and added up on the host in index order: no reduction kernel, no copy
   EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_partials), sizeof(double) * lookup_scratch_doubles(), hipHostMallocMapped));
@@ -744,6 +744,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   const Tables tabs = g->tables();
   if (spec.sel_chain)
     EDM_HIP_TRY(launch_select_prep(*spec.sel_chain, q, hl, s));  // selection + preparation in one launch
+  else if (spec.unpack_chain)
+    EDM_HIP_TRY(launch_unpack_prep(*spec.unpack_chain, q, hl, s));  // exchange packets -> global prepared list
   else
     EDM_HIP_TRY(launch_hill_prep(q, hl, s));
 

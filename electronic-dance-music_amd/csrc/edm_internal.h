@@ -136,6 +136,8 @@ struct ApplySpec {
   double expected_nh = -1;  // expected batch size when it is a random variable (stochastic selection); < 0: nh
   // with a deferred count: selection chained in front of the hill preparation (one launch for both)
   const SelectArgs *sel_chain = nullptr;
+  // multi-GPU packed exchange: the hill list is unpacked from the gathered packets (replaces preparation)
+  const UnpackArgs *unpack_chain = nullptr;
   // heights that depend on the bias under construction (local tempering): strictly ordered kernel
   bool ordered = false;
   OrderedParams op;

@@ -98,7 +98,27 @@ struct SelectArgs {
   long long *count_host;  // out: count, host-mapped
   long long *count_dev;   // out: count, device memory
   int *ticket;            // zero-initialised device int, left at zero
+  double *pack;           // multi-GPU: instead of sel/prep, write this rank's exchange packet
+                          // [count, x_0 .. x_{bound-1}] (bound = h.nh, dim doubles per position)
 };
+// receive side of the packed exchange (see k_unpack_prep)
+#define EDM_MAX_RANKS 16
+struct UnpackArgs {
+  const double *recv;     // nranks packets of `packet` doubles
+  int nranks;
+  long long bound;        // per-rank capacity of a packet
+  long long packet;       // 1 + bound * dim
+  double *all;            // out: positions of the global list, stride dim
+  long long *count_dev;   // out: global count (poisoned when a rank overflowed its packet)
+  long long *count_host;
+};
+hipError_t launch_unpack_prep(const UnpackArgs &a, const Geom &g, const HillList &h, hipStream_t s);
+struct RankHeights {
+  int nranks;
+  long long offset[EDM_MAX_RANKS + 1];
+  double height[EDM_MAX_RANKS];
+};
+hipError_t launch_rank_heights(const RankHeights &rh, double *out, hipStream_t s);
 size_t select_stage_ints(long long n);
 hipError_t launch_select_prep(const SelectArgs &a, const Geom &g, const HillList &h, hipStream_t s);
 struct LimitArgs;

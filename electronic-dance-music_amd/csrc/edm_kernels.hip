@@ -859,10 +859,17 @@ hipError_t launch_select(long long n, const double *ru, double thr, int use_thr,
 // (gaussian_grid.h:206-224 and the temp1/temp3 terms of :310,:312)
 // ---------------------------------------------------------------------------
 template <int DIM>
+__device__ __forceinline__ void hill_prep_vals(const Geom &g, const HillList &h, long long i, double *x);
+template <int DIM>
 __device__ __forceinline__ void hill_prep_one(const Geom &g, const HillList &h, long long i, long long src) {
   double x[DIM];
 #pragma unroll
   for (int d = 0; d < DIM; d++) x[d] = h.x[src * h.x_stride + d];
+  hill_prep_vals<DIM>(g, h, i, x);
+}
+// (x holds the sample's CV on entry and is remapped in place)
+template <int DIM>
+__device__ __forceinline__ void hill_prep_vals(const Geom &g, const HillList &h, long long i, double *x) {
   if (h.hx0) {
 #pragma unroll
     for (int d = 0; d < DIM; d++) h.hx0[i * DIM + d] = x[d];
@@ -933,6 +940,19 @@ __device__ __forceinline__ T acquire(const T *p) {
 // workgroup compacts its SEL_CHUNK samples IN ORDER into its own stretch of `stage`, the last one
 // scans the per-workgroup counts, moves at most `h.nh` (the launch bound of the step) entries to the
 // dense ordered list and prepares those hills.
+// accepted sample `src` becomes hill i of this rank: prepared in place, or (multi-GPU) packed for the exchange
+template <int DIM>
+__device__ __forceinline__ void select_emit(const SelectArgs &a, const Geom &g, const HillList &h, long long i,
+                                            long long src) {
+  if (a.pack) {
+#pragma unroll
+    for (int d = 0; d < DIM; d++) a.pack[1 + i * DIM + d] = h.x[src * h.x_stride + d];
+  } else {
+    a.sel[i] = src;
+    hill_prep_one<DIM>(g, h, i, src);
+  }
+}
+
 template <int DIM>
 __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, HillList h) {
   __shared__ int s_w[BLOCK / 64];
@@ -997,8 +1017,7 @@ __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, Hil
       if (c <= 4) {
         for (long long j = 0; j < c && off + j < bound; j++) {
           const long long src = (long long)blk * SEL_CHUNK + acquire(&a.stage[(long long)blk * SEL_CHUNK + j]);
-          a.sel[off + j] = src;
-          hill_prep_one<DIM>(g, h, off + j, src);
+          select_emit<DIM>(a, g, h, off + j, src);
         }
       } else {
         const int q = atomicAdd(&s_nbig, 1);
@@ -1015,8 +1034,7 @@ __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, Hil
       const long long c2 = acquire(&a.counts[b2]);
       for (long long j = threadIdx.x; j < c2 && o2 + j < bound; j += BLOCK) {
         const long long src = (long long)b2 * SEL_CHUNK + acquire(&a.stage[(long long)b2 * SEL_CHUNK + j]);
-        a.sel[o2 + j] = src;
-        hill_prep_one<DIM>(g, h, o2 + j, src);
+        select_emit<DIM>(a, g, h, o2 + j, src);
       }
     }
     __syncthreads();
@@ -1027,6 +1045,7 @@ __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, Hil
     const long long total = s_carry;
     *a.count_host = total;
     *a.count_dev = total;
+    if (a.pack) a.pack[0] = (double)total;
   }
 }
 
@@ -1051,6 +1070,73 @@ hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s) {
     case 2: hipLaunchKernelGGL(k_hill_prep<2>, dim3(b), dim3(BLOCK), 0, s, g, h); break;
     default: hipLaunchKernelGGL(k_hill_prep<3>, dim3(b), dim3(BLOCK), 0, s, g, h); break;
   }
+  return hipGetLastError();
+}
+
+// Multi-GPU exchange, receive side: `recv` holds one fixed-size packet per rank, [count, x_0 .. x_{bound-1}]
+// (what k_select_prep packed and ncclAllGather concatenated).  One workgroup builds the rank-major global
+// hill list: positions into `all` (stride DIM), the prepared hill fields, and the global count (device +
+// host-mapped).  A rank that overflowed its packet poisons the count, which the limiter turns into
+// error 2 on every rank alike.
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_unpack_prep(UnpackArgs a, Geom g, HillList h) {
+  __shared__ long long s_off[EDM_MAX_RANKS + 1];
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) {
+    long long run = 0;
+    int bad = 0;
+    for (int r = 0; r < a.nranks; r++) {
+      const long long c = (long long)a.recv[(long long)r * a.packet];
+      s_off[r] = run;
+      if (c < 0 || c > a.bound) bad = 1;
+      run += (c < 0) ? 0 : (c > a.bound ? a.bound : c);
+    }
+    s_off[a.nranks] = run;
+    s_bad = bad;
+    const long long total = bad ? (long long)0x3fffffffffffffffLL : run;
+    *a.count_dev = total;
+    *a.count_host = total;
+  }
+  __syncthreads();
+  if (s_bad) return;
+  const long long total = s_off[a.nranks];
+  for (long long e = threadIdx.x; e < total; e += BLOCK) {
+    int r = 0;
+    while (r + 1 < a.nranks && e >= s_off[r + 1]) r++;
+    const long long i = e - s_off[r];
+    double x[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      x[d] = a.recv[(long long)r * a.packet + 1 + i * DIM + d];
+      a.all[e * DIM + d] = x[d];
+    }
+    hill_prep_vals<DIM>(g, h, e, x);
+  }
+}
+hipError_t launch_unpack_prep(const UnpackArgs &a, const Geom &g, const HillList &h, hipStream_t s) {
+  if (a.nranks < 1 || a.nranks > EDM_MAX_RANKS) return hipErrorInvalidValue;
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL(k_unpack_prep<1>, dim3(1), dim3(BLOCK), 0, s, a, g, h); break;
+    case 2: hipLaunchKernelGGL(k_unpack_prep<2>, dim3(1), dim3(BLOCK), 0, s, a, g, h); break;
+    default: hipLaunchKernelGGL(k_unpack_prep<3>, dim3(1), dim3(BLOCK), 0, s, a, g, h); break;
+  }
+  return hipGetLastError();
+}
+
+// per-hill heights of a rank-major hill list when the height depends on the rank of origin
+// (hill_density unset: prefactor / est_hill_count of the sending rank, edm_bias.cpp:552-556)
+__global__ void __launch_bounds__(BLOCK) k_rank_heights(RankHeights rh, double *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < rh.offset[rh.nranks]; i += stride) {
+    int r = 0;
+    while (r + 1 < rh.nranks && i >= rh.offset[r + 1]) r++;
+    out[i] = rh.height[r];
+  }
+}
+hipError_t launch_rank_heights(const RankHeights &rh, double *out, hipStream_t s) {
+  const long long n = rh.offset[rh.nranks];
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_rank_heights, dim3(blocks_for(n)), dim3(BLOCK), 0, s, rh, out);
   return hipGetLastError();
 }
 

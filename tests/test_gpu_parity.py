@@ -562,3 +562,37 @@ def test_pair_step_equals_separate_calls(workdir):
         assert np.array_equal(np.asarray(a), np.asarray(c))
     assert state[0][0].max() > 0 and state[0][6] > 0   # hills were added and the overflow buffer was used
     assert open(str(workdir / "HILLS_fused_0")).read() == open(str(workdir / "HILLS_separate_0")).read()
+
+
+def test_packed_exchange_virtual_ranks(workdir):
+    """The multi-GPU packed hill exchange (fixed-size packets, one all-gather, device-side unpack into the
+    rank-major list, deferred count) with a one-rank communicator whose packet is replicated three times
+    (test hook): must equal, bit for bit, a communicator-free run fed with the samples repeated three
+    times -- that IS the rank-major list three identical ranks would produce."""
+    text = ("tempering 0\nhill_prefactor 0.5\nhill_density 60\nbias_per_step 0.6\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+            "bias_spacing 0.001\nbias_sigma 0.05\n")
+    n, R = 40_000, 3
+    state = []
+    for tag in ("plain", "virtual"):
+        cfg = str(workdir / (tag + ".edm"))
+        open(cfg, "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+        b = H.Bias(cfg)
+        if tag == "virtual":
+            b.comm_init(H.comm_unique_id(), 1, 0)
+            b.set("debug_virtual_ranks", R)
+        b.setup(1.0, 1.0)
+        b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+        for step in range(5):
+            r = W.pair_distances(n, 700 + step).reshape(-1, 1)
+            u = W.uniform(750 + step, n)
+            if tag == "plain":
+                b.add_hills(np.tile(r, (R, 1)), np.tile(u, R), -1, est=2 * n)
+            else:
+                b.add_hills(r, u, -1, est=2 * n)
+        v, dv = b.gauss.download()
+        state.append((v, dv, b.hist.values, b.get("cum_bias"), b.get("overflow_right"), b.get("hills_added")))
+        del b
+    for a, c in zip(state[0], state[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(c))
+    assert state[0][0].max() > 0 and state[0][5] > 60
+    assert open(str(workdir / "HILLS_plain_0")).read() == open(str(workdir / "HILLS_virtual_0")).read()
