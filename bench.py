@@ -58,6 +58,24 @@ def pmc_traffic(kernel_prefix):
     return None
 
 
+def rocprof_avg_us(kernel_prefix):
+    """Average duration of a kernel in the newest committed rocprofv3 --kernel-trace capture of this
+    command (profiles/rNN_summary.json) -- printed beside the live figure so the two can be compared."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+    if not files:
+        return None
+    try:
+        kernels = json.load(open(files[-1])).get("kernels", [])
+    except Exception:  # noqa: BLE001
+        return None
+    for k in kernels:
+        if k["kernel"].startswith(kernel_prefix):
+            return k["avg_us"]
+    return None
+
+
 def make_bias(mod, tmpdir, tag, rank=0):
     cfg = os.path.join(tmpdir, "bench_%s_%d.edm" % (tag, rank))
     with open(cfg, "w") as fh:
@@ -234,7 +252,8 @@ def main():
         a2 = BYTES_PER_EVAL * n2 / (ms2 / l2 * 1e-3) / 1e9
         roof_w2 = dict(workload="W2: %d pair distances" % n2, bound="hbm", achieved=a2, peak=HBM_PEAK_GBS, unit="GB/s",
                        frac=a2 / HBM_PEAK_GBS, kernel_ms=ms2 / l2, kernel="k_pair_forces_fast<true> (LDS-staged window)",
-                       bytes_per_launch=BYTES_PER_EVAL * n2, traffic=pmc_traffic("edm::k_pair_forces_fast<true"))
+                       bytes_per_launch=BYTES_PER_EVAL * n2, traffic=pmc_traffic("edm::k_pair_forces_fast<true"),
+                       kernel_ms_rocprof=(rocprof_avg_us("edm::k_pair_forces_fast<true") or 0) / 1e3 or None)
 
     nd = None
     if args.nd and rank == 0:
@@ -305,6 +324,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("edm::k_pair_forces_fast<false"),
                 "kernel_us": k_ms / max(k_launches, 1) * 1e3,
+                "kernel_us_rocprof": rocprof_avg_us("edm::k_pair_forces_fast<false"),
                 "launches": k_launches,
                 "bytes_per_launch": BYTES_PER_EVAL * npairs,
             },

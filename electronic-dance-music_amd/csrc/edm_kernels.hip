@@ -15,8 +15,19 @@
 //   K8     block/wave reductions      fixed-order energy and bias sums
 #include "edm_kernels.h"
 
+#include <hip/hip_ext.h>
 #include <limits.h>
 #include <string.h>
+
+// launch with the kernel's own begin/end timestamps in (ev0, ev1) when profiling is on: hipEventRecord
+// brackets would add the dispatch latency (~3 us) to a 10 us kernel
+#define EDM_LAUNCH_TIMED(kernel, grid, block, lds, s, ev0, ev1, ...)                                   \
+  do {                                                                                                 \
+    if (ev0)                                                                                           \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, s, ev0, ev1, 0, __VA_ARGS__);                    \
+    else                                                                                               \
+      hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                                    \
+  } while (0)
 
 namespace edm {
 
@@ -320,19 +331,17 @@ static hipError_t lookup_dim(const Geom &g, const double *rec, LookupMode mode, 
   int blocks = (int)((a.n + BLOCK - 1) / BLOCK);
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
-  if (ev0) (void)hipEventRecord(ev0, s);
   switch (mode) {
     case LOOKUP_FORCES:
-      hipLaunchKernelGGL((k_lookup<DIM, LOOKUP_FORCES>), dim3(blocks), dim3(BLOCK), 0, s, g, rec, a, scratch);
+      EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_FORCES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch);
       break;
     case LOOKUP_VALUES:
-      hipLaunchKernelGGL((k_lookup<DIM, LOOKUP_VALUES>), dim3(blocks), dim3(BLOCK), 0, s, g, rec, a, scratch);
+      EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_VALUES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch);
       break;
     default:
-      hipLaunchKernelGGL((k_lookup<DIM, LOOKUP_INDEX>), dim3(blocks), dim3(BLOCK), 0, s, g, rec, a, scratch);
+      EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_INDEX>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch);
       break;
   }
-  if (ev1) (void)hipEventRecord(ev1, s);
   if (blocks_out) *blocks_out = blocks;
   if (energy_out)
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, s, scratch, (long long)blocks, energy_out);
@@ -582,29 +591,23 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
         attr_set = true;
       }
       blocks = n_cu;
-      if (ev0) (void)hipEventRecord(ev0, s);
-      hipLaunchKernelGGL((k_pair_forces_fast<true, FAST_BLOCK>), dim3(blocks), dim3(FAST_BLOCK), lds_bytes, s, g, rec, n, r, force,
-                         scratch, w0, wn, inv_dx);
-      if (ev1) (void)hipEventRecord(ev1, s);
+      EDM_LAUNCH_TIMED((k_pair_forces_fast<true, FAST_BLOCK>), dim3(blocks), dim3(FAST_BLOCK), lds_bytes, s, ev0, ev1, g, rec, n,
+                       r, force, scratch, w0, wn, inv_dx);
     } else {
       // short arrays: small workgroups spread over every CU (latency-bound regime)
       long long work = (n >> 1) + 1;
       blocks = (int)((work + BLOCK - 1) / BLOCK);
       if (blocks > 8 * n_cu) blocks = 8 * n_cu;
       if (blocks < 1) blocks = 1;
-      if (ev0) (void)hipEventRecord(ev0, s);
-      hipLaunchKernelGGL((k_pair_forces_fast<false, BLOCK>), dim3(blocks), dim3(BLOCK), 256, s, g, rec, n, r, force, scratch,
-                         0LL, 0, inv_dx);
-      if (ev1) (void)hipEventRecord(ev1, s);
+      EDM_LAUNCH_TIMED((k_pair_forces_fast<false, BLOCK>), dim3(blocks), dim3(BLOCK), 256, s, ev0, ev1, g, rec, n, r, force,
+                       scratch, 0LL, 0, inv_dx);
     }
   } else {
     long long work = (n >> 1) + 1;
     blocks = (int)((work + BLOCK - 1) / BLOCK);
     if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
-    if (ev0) (void)hipEventRecord(ev0, s);
-    hipLaunchKernelGGL(k_pair_forces, dim3(blocks), dim3(BLOCK), 0, s, g, rec, n, r, force, scratch);
-    if (ev1) (void)hipEventRecord(ev1, s);
+    EDM_LAUNCH_TIMED(k_pair_forces, dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, n, r, force, scratch);
   }
   if (blocks_out) *blocks_out = blocks;
   if (energy_out)
