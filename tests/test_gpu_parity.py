@@ -596,3 +596,24 @@ def test_packed_exchange_virtual_ranks(workdir):
         assert np.array_equal(np.asarray(a), np.asarray(c))
     assert state[0][0].max() > 0 and state[0][5] > 60
     assert open(str(workdir / "HILLS_plain_0")).read() == open(str(workdir / "HILLS_virtual_0")).read()
+
+
+def test_python_package_mirror_notebook(workdir):
+    """The reference's Python face (python/edm: EDMBias(input, T, kB), set_box, add_hill, get_force) on the
+    GPU path, driven exactly like the published notebook (python-example/EDM.ipynb): one hill at 0.25,
+    get_force(0.24) must return the notebook's printed numbers."""
+    import edm_amd.edm as E
+
+    k = GU.kats()
+    cfg = str(workdir / "nb2.edm")
+    open(cfg, "w").write(open(os.path.join(GU.FIXTURES, "notebook_input.edm")).read() + "\nhills_filename %s/H9\n" % workdir)
+    bias = E.EDMBias(cfg, 1.0, 1.0)
+    bias.set_box([0], [10], [0])
+    bias.add_hill([0.25])
+    e, f = bias.get_force([0.24])
+    close([e, f[0]], k["notebook"]["published"], rtol=1e-12, what="notebook KAT through the python package mirror")
+    close(bias.cum_bias, k["notebook"]["cum_bias"], rtol=1e-12, what="cum_bias")
+    bias.write_bias(str(workdir / "nb2.bias"))
+    bias.write_histogram()
+    bias.clear_histogram()
+    assert os.path.getsize(str(workdir / "nb2.bias")) > 1000
