@@ -701,6 +701,17 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   if (packed_exchange) spec.expected_nh = b->hill_density * pack_ranks;
   spec.hist_g = &b->hist->g;
   spec.hist_values = b->hist->values;
+  if (b->comm && !packed_exchange && b->debug_virtual_ranks <= 1) {
+    // dense batches on a small grid: this rank applies only its own slice of the global list, the ranks'
+    // delta grids are summed (apply_hills decides whether the batch qualifies)
+    spec.shard_comm = b->comm;
+    long long off = 0;
+    for (int r = 0; r < b->rank; r++) off += b->xchg_counts[r];
+    spec.shard_off = off;
+    spec.shard_cnt = b->xchg_counts[b->rank];
+  } else if (b->debug_virtual_ranks > 1 && !packed_exchange) {
+    spec.shard_virtual = b->debug_virtual_ranks;
+  }
   const bool log_all = b->hill_log && b->hills_fp;
   spec.fetch_all = log_all;
   if (local_tempering) {

@@ -13,6 +13,10 @@
 
 #include "edm_internal.h"
 
+#include <rccl/rccl.h>
+#include <utility>
+#include <vector>
+
 namespace edm {
 
 static thread_local std::string g_last_error;
@@ -756,6 +760,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hh.tail_h1 = ws.tail_h1.p;
   hh.tail_h2 = p_h2;
   hh.res_dev = nullptr;
+  hh.tail_shift = 0;
 
   // Dense batches on small grids (the 1-D all-samples regime): fused path -- the gather runs first with
   // the base heights and yields the per-hill integrals as a by-product; the limiter then only has to
@@ -778,7 +783,52 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   }
   const double *base_heights = spec.d_h;
   const bool chain_limit = spec.limited && !spec.ordered && !fused && hill_integrals_can_chain_limit(nh);
-  if (fused) {
+  // sharded (multi-GPU) variant of the fused path
+  const bool sharded = fused && (spec.shard_comm || spec.shard_virtual > 1);
+  std::vector<std::pair<long long, long long> > slices;
+  const size_t grid_doubles = (size_t)q.total * q.rec;
+  auto slice_of = [&](const std::pair<long long, long long> &sl) {
+    HillList own = hl;
+    own.nh = sl.second;
+    own.x = nullptr;
+    own.sel = nullptr;
+    own.hx = hl.hx + sl.first * dim;
+    own.hc = hl.hc + sl.first * dim;
+    own.ht = hl.ht + sl.first * 2 * dim;
+    own.hx0 = hl.hx0 ? hl.hx0 + sl.first * dim : nullptr;
+    return own;
+  };
+  if (sharded) {
+    if (spec.shard_comm) {
+      if (spec.shard_off < 0 || spec.shard_cnt < 0 || spec.shard_off + spec.shard_cnt > nh) {
+        set_error("apply_hills: shard outside the hill list");
+        return EDM_HIP_ERR_ARG;
+      }
+      slices.push_back(std::make_pair(spec.shard_off, spec.shard_cnt));
+    } else {
+      const long long R = spec.shard_virtual, per = (nh + R - 1) / R;
+      for (long long r = 0; r < R; r++) {
+        const long long o = r * per < nh ? r * per : nh;
+        const long long c = (o + per < nh ? o + per : nh) - o;
+        slices.push_back(std::make_pair(o, c));
+      }
+    }
+    EDM_HIP_TRY(ws.delta.reserve(grid_doubles));
+    EDM_HIP_TRY(hipMemsetAsync(ws.delta.p, 0, sizeof(double) * grid_doubles, s));
+    EDM_HIP_TRY(hipMemsetAsync(p_added, 0, sizeof(double) * (size_t)nh, s));
+    for (size_t k = 0; k < slices.size(); k++) {
+      const HillList own = slice_of(slices[k]);
+      if (own.nh <= 0) continue;
+      EDM_HIP_TRY(launch_hill_gather_fused(q, tabs, own, spec.d_h ? spec.d_h + slices[k].first : nullptr, spec.h_const, fplan,
+                                           p_added + slices[k].first, g->d_dirty, s));
+      EDM_HIP_TRY(launch_add_partials(q, ws.delta.p, fplan.partial, fplan.groups, nullptr, s));
+    }
+    if (spec.shard_comm &&
+        ncclAllReduce(p_added, p_added, (size_t)nh, ncclDouble, ncclSum, static_cast<ncclComm_t>(spec.shard_comm), s) != ncclSuccess) {
+      set_error("ncclAllReduce(hill integrals) failed");
+      return EDM_HIP_ERR_COMM;
+    }
+  } else if (fused) {
     EDM_HIP_TRY(launch_hill_gather_fused(q, tabs, hl, spec.d_h, spec.h_const, fplan, p_added, g->d_dirty, s));
   } else if (spec.ordered) {
     if (nh > EDM_TAIL_CAP) {
@@ -873,7 +923,31 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
   bool chain_post = false;
   bool rb_pushed = false;
-  if (fused) {
+  if (sharded) {
+    if (spec.limited) {
+      for (size_t k = 0; k < slices.size(); k++) {
+        const HillList own = slice_of(slices[k]);
+        HillHeights hs = hh;
+        hs.h = spec.d_h ? spec.d_h + slices[k].first : nullptr;
+        hs.tail_shift = slices[k].first;
+        EDM_HIP_TRY(launch_hill_gather_correction(q, tabs, own, hs, fplan, g->d_dirty, s));
+        EDM_HIP_TRY(launch_add_partials(q, ws.delta.p, fplan.partial + (size_t)fplan.groups * grid_doubles, 1, dres, s));
+      }
+    }
+    if (spec.shard_comm && ncclAllReduce(ws.delta.p, ws.delta.p, grid_doubles, ncclDouble, ncclSum,
+                                         static_cast<ncclComm_t>(spec.shard_comm), s) != ncclSuccess) {
+      set_error("ncclAllReduce(delta grid) failed");
+      return EDM_HIP_ERR_COMM;
+    }
+    EDM_HIP_TRY(launch_add_partials(q, g->rec, ws.delta.p, 1, spec.limited ? dres : nullptr, s));
+    // whether some hill of some rank had a boundary correction is not known locally: duplicate whenever
+    // the boundary is not periodic (idempotent on a consistent grid)
+    bool any_wall = false;
+    for (int d = 0; d < dim; d++)
+      if (!q.bper[d]) any_wall = true;
+    if (any_wall) EDM_HIP_TRY(hipMemsetAsync(g->d_dirty, 1, 1, s));
+    if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
+  } else if (fused) {
     EDM_HIP_TRY(launch_hill_gather_correct_and_apply(q, tabs, g->rec, hl, hh, fplan, spec.limited ? 1 : 0, g->d_dirty, s));
     if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
   } else if (!spec.ordered) {

@@ -58,7 +58,7 @@ struct DevBuf {
 
 // workspace of the hill path, shared by add_values / the controller
 struct HillWorkspace {
-  DevBuf<double> hx, hx0, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum, heights, slots;
+  DevBuf<double> hx, hx0, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum, heights, slots, delta;
   DevBuf<int> hc, tail_flags, tile_flags, tile_list;
   DevBuf<char> result;      // LimitResult
   DevBuf<char> rb;          // packed read-back region of small batches (one D2H instead of six)
@@ -138,6 +138,14 @@ struct ApplySpec {
   const SelectArgs *sel_chain = nullptr;
   // multi-GPU packed exchange: the hill list is unpacked from the gathered packets (replaces preparation)
   const UnpackArgs *unpack_chain = nullptr;
+  // sharded application of a dense batch on a replicated grid (multi-GPU): this rank gathers only its own
+  // slice [shard_off, shard_off + shard_cnt) of the global hill list into a delta grid; the per-hill
+  // integrals and the delta grid are summed over the ranks (ncclAllReduce) and every rank adds the same
+  // total.  shard_virtual > 1 (tests): the slices of that many ranks are processed one after the other
+  // in this process, with plain adds in place of the collectives.
+  void *shard_comm = nullptr;  // ncclComm_t
+  long long shard_off = 0, shard_cnt = 0;
+  int shard_virtual = 0;
   // heights that depend on the bias under construction (local tempering): strictly ordered kernel
   bool ordered = false;
   OrderedParams op;

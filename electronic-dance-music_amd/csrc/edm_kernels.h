@@ -132,6 +132,8 @@ struct HillHeights {
   const double *tail_h2;  // second add (the "undo" hill) or 0
   const LimitResult *res_dev;  // when set, k (and the error flag) are read from the limiter's
                                // device-side result: no host round trip between K4 and K5
+  long long tail_shift;   // the hill list is a slice of the list the limiter saw, starting at this global index
+                          // (sharded multi-GPU application); 0 otherwise
 };
 // per-hill integrated bias for the BASE heights (the value add_value returns)
 hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList &h, const double *heights,
@@ -169,6 +171,12 @@ long long gather_tiles(const Geom &g);
 hipError_t launch_hill_gather(const Geom &g, const Tables &t, double *rec, const HillList &h,
                               const HillHeights &hh, const GatherPlan &plan, int *dirty_flag, hipStream_t s,
                               const PostSpec *chain = nullptr);
+// pieces of launch_hill_gather_correct_and_apply for the sharded multi-GPU application: the correction pass
+// alone (writes partial buffer [plan.groups], zeroed first) and dst[i] += sum of `groups` partial buffers
+hipError_t launch_hill_gather_correction(const Geom &g, const Tables &t, const HillList &h, const HillHeights &hh,
+                                         const GatherPlan &plan, int *dirty_flag, hipStream_t s);
+hipError_t launch_add_partials(const Geom &g, double *dst, const double *partial, int groups,
+                               const LimitResult *res_dev, hipStream_t s);
 // gaussian_grid.h:571-630, executed iff *dirty_flag != 0; clears the flag
 hipError_t launch_duplicate_boundary(const Geom &g, double *rec, int *dirty_flag, hipStream_t s);
 

@@ -1592,8 +1592,8 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     const int err = hh.res_dev->error;
     const long long kk = hh.res_dev->k, nn = hh.res_dev->nh;
     if (err) return;  // limiter overflow / bound exceeded: the host handles it, nothing is applied
-    k_first_tail = kk;
-    if (nn < nh_eff) nh_eff = nn;
+    k_first_tail = kk - hh.tail_shift;  // (may be negative: the ordered tail began before this slice)
+    if (nn - hh.tail_shift < nh_eff) nh_eff = (nn - hh.tail_shift > 0) ? nn - hh.tail_shift : 0;
   } else {
     nh_eff = hill_count(h);
     if (k_first_tail > nh_eff) k_first_tail = nh_eff;
@@ -1605,7 +1605,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   long long hbeg = per * blockIdx.y;
   long long hend = (hbeg + per < nh_eff) ? hbeg + per : nh_eff;
   if (MODE == 2) {
-    hbeg = k_first_tail;
+    hbeg = (k_first_tail > 0) ? k_first_tail : 0;
     hend = nh_eff;
   }
   const bool in_place = (MODE == 0) && (G == 1);
@@ -2018,6 +2018,7 @@ hipError_t launch_hill_gather_fused(const Geom &g, const Tables &t, const HillLi
   hh.tail_h1 = nullptr;
   hh.tail_h2 = nullptr;
   hh.res_dev = nullptr;
+  hh.tail_shift = 0;
   const long long ntiles = gather_tiles(g);
   const dim3 grid((unsigned)ntiles, (unsigned)plan.groups);
   PostArgs nopost;
@@ -2053,6 +2054,31 @@ hipError_t launch_hill_gather_correct_and_apply(const Geom &g, const Tables &t, 
   }
   hipLaunchKernelGGL(k_reduce_partials, dim3(blocks_for(g.total * g.rec)), dim3(BLOCK), 0, s, g, rec, plan.partial, groups,
                      with_correction ? hh.res_dev : (const LimitResult *)nullptr, 0, h.nh, (const long long *)nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_hill_gather_correction(const Geom &g, const Tables &t, const HillList &h, const HillHeights &hh,
+                                         const GatherPlan &plan, int *dirty_flag, hipStream_t s) {
+  const size_t one = sizeof(double) * (size_t)g.total * g.rec;
+  hipError_t e = hipMemsetAsync(plan.partial + (size_t)plan.groups * g.total * g.rec, 0, one, s);
+  if (e != hipSuccess) return e;
+  if (h.nh <= 0) return hipSuccess;
+  const long long ntiles = gather_tiles(g);
+  const dim3 grid((unsigned)ntiles, 1);
+  PostArgs nopost;
+  memset(&nopost, 0, sizeof(nopost));
+  double *none = nullptr;
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL((k_hill_gather<1, 2>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
+    case 2: hipLaunchKernelGGL((k_hill_gather<2, 2>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
+    default: hipLaunchKernelGGL((k_hill_gather<3, 2>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_add_partials(const Geom &g, double *dst, const double *partial, int groups,
+                               const LimitResult *res_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(blocks_for(g.total * g.rec)), dim3(BLOCK), 0, s, g, dst, partial, groups,
+                     res_dev, 0, 0LL, (const long long *)nullptr);
   return hipGetLastError();
 }
 

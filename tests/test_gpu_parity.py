@@ -617,3 +617,42 @@ def test_python_package_mirror_notebook(workdir):
     bias.write_histogram()
     bias.clear_histogram()
     assert os.path.getsize(str(workdir / "nb2.bias")) > 1000
+
+
+@pytest.mark.parametrize("mode,n,limit", [("virtual3", 12000, 39.0), ("virtual3", 4500, 24.0), ("rccl1", 12000, 39.0)])
+def test_sharded_dense_application(mode, n, limit, workdir):
+    steps = 3 if n > 5000 else 1   # (the low limit fills most of the 2048-record overflow buffer in one step)
+    """Dense (all-samples) hill batches on the replicated 1-D grid, applied shard-wise: every rank gathers
+    only its own slice of the global list into a delta grid, integrals and delta grids are summed over the
+    ranks, the limiter runs on the global ordered list.  `virtual3`: three ranks' slices processed one
+    after the other in this process (test hook, exercises the slice offsets and the limiter tail that
+    starts inside a slice -- or, with the low limit, before the last slice); `rccl1`: a one-rank RCCL communicator (the real ncclAllReduce calls).
+    Both must agree with the unsharded controller to rounding: the sums are associated differently."""
+    text = ("tempering 0\nhill_prefactor 40\nbias_per_step %g\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+            "bias_spacing 0.001\nbias_sigma 0.05\n" % limit)
+    state = []
+    for tag in ("plain", mode):
+        cfg = str(workdir / (tag + ".edm"))
+        open(cfg, "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+        b = H.Bias(cfg)
+        if tag == "rccl1":
+            b.comm_init(H.comm_unique_id(), 1, 0)
+        if tag == "virtual3":
+            b.set("debug_virtual_ranks", 3)
+        b.setup(1.0, 1.0)
+        b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+        b.set_hill_log(False)
+        for step in range(steps):
+            r = W.pair_distances(n, 40 + step).reshape(-1, 1)
+            b.add_hills(r, W.uniform(45 + step, n), -1, est=n)
+        v, dv = b.gauss.download()
+        state.append((v, dv, b.hist.values, b.get("cum_bias"), b.get("overflow_left"), b.get("overflow_right"),
+                      b.get("hills_added"), b.get("b_skip_hill_add")))
+        del b
+    p, q = state
+    close(q[0], p[0], rtol=1e-12, atol=1e-14 * np.abs(p[0]).max(), what="grid values, sharded vs plain")
+    close(q[1], p[1], rtol=1e-11, atol=1e-12 * np.abs(p[1]).max(), what="grid derivatives, sharded vs plain")
+    assert np.array_equal(p[2], q[2]), "histogram"
+    close(q[3], p[3], rtol=1e-12, what="cum_bias")
+    assert p[4:] == q[4:], "limiter decisions (overflow buffer indices, hills added, skip flag)"
+    assert p[5] > 0 and p[0].max() > 0, "the limiter must have been active"
