@@ -126,6 +126,63 @@ def cpu_baseline(tmpdir, seconds=12.0):
                        % (evals // n, n, t_eval, done, t_hill))
 
 
+def all_samples_line(args, rank, world, dist, H, W, tmpdir):
+    """Strong scaling of the all-samples hill step: 1,048,576 hills per step in total, each rank
+    owns 1/N of the samples, computes their integrals and gathers them into its delta grid; integrals and
+    delta grids are all-reduced (RCCL) and every rank adds the same total to its replica."""
+    total = W.W1_PAIRS
+    n = total // world
+    cfg = os.path.join(tmpdir, "bench_all_%d.edm" % rank)
+    with open(cfg, "w") as fh:
+        fh.write(CFG.replace("hill_density 250\n", "").replace("hill_prefactor 0.5", "hill_prefactor 1e-3")
+                 + "bias_per_step 1e9\nhills_filename %s/HILLS_all\nhistogram_filename %s/HIST_all_%d\n" % (tmpdir, tmpdir, rank))
+    b = H.Bias(cfg)
+    if dist is not None:
+        ident = [H.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        b.comm_init(ident[0], world, rank)
+    b.setup(1.0, 1.0)
+    b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    b.set_hill_log(False)
+    r = W.pair_distances(total, 1)[rank * n:(rank + 1) * n]
+    d_r = H.DeviceArray.from_host(np.ascontiguousarray(r))
+
+    def barrier():
+        H.synchronize()
+        if dist is not None:
+            dist.barrier()
+            H.synchronize()
+
+    for _ in range(args.warmup):
+        b.add_hills_device(d_r, n, 1, None, -1, n)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        b.add_hills_device(d_r, n, 1, None, -1, n)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "hill adds/sec (1M-pair 1D CV, all-samples mode: every pair deposits a hill each step)",
+            "value": n * world / (elapsed / args.steps), "unit": "hill adds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "W1 all-samples: %d pair distances in total, C1D grid (11201 nodes, stencil 1131, McGDP "
+                                   "boundary), hill_density unset, bias_per_step not binding" % (n * world),
+                       "hills_per_gpu": n,
+                       "parallelism": "replicated grid, hills sharded, integrals + delta grid all-reduced, dp%d" % world},
+            "cum_bias": b.get("cum_bias")}))
+    del b
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +194,9 @@ def main():
                     help="skip the 38.8M-pair interpolation capture (W2 = BASELINE configs[2], the HBM-bound case)")
     ap.add_argument("--w2", action="store_true", help=argparse.SUPPRESS)  # kept for older command lines (now the default)
     ap.add_argument("--nd", action="store_true", help="also time the 2-D (2048^2) and 3-D (512^3) coordinate-CV kernels")
+    ap.add_argument("--all-samples", action="store_true",
+                    help="alternative line: STRONG scaling of the all-samples hill mode (hill_density unset; every one of "
+                         "1,048,576 pair distances deposits a hill each step; the samples are split over the GPUs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,6 +222,9 @@ def main():
     H.check(H.lib().edm_hip_set_device(local_rank))
     tmpdir = tempfile.mkdtemp(prefix="edm_bench_")
     npairs = args.pairs or W.W1_PAIRS
+
+    if args.all_samples:
+        return all_samples_line(args, rank, world, dist, H, W, tmpdir)
 
     b = H.Bias(make_bias(H, tmpdir, "gpu", rank))
     if dist is not None:
