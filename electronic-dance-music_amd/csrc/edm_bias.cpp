@@ -562,7 +562,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       sel_args.stage = b->sel_stage.p;
       sel_args.count_host = b->d_count;
       sel_args.count_dev = b->count_dev.p;
-      sel_args.ticket = b->bias->d_dirty + 1;
+      sel_args.ticket = b->bias->d_tickets;
       sel_args.pack = b->xchg_send.p;
       HillList src;
       memset(&src, 0, sizeof(src));
@@ -636,7 +636,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       sel_args.sel = b->sel.p;
       sel_args.count_host = b->d_count;
       sel_args.count_dev = b->count_dev.p;
-      sel_args.ticket = b->bias->d_dirty + 1;
+      sel_args.ticket = b->bias->d_tickets;
       nh = bound;
     }
     d_sel = b->sel.p;

@@ -427,6 +427,8 @@ static int gauss_alloc(edm_hip_gauss *g) {
   EDM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&g->d_stage), g->h_stage, 0));
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_dirty), sizeof(int) * 4));
   EDM_HIP_TRY(hipMemset(g->d_dirty, 0, sizeof(int) * 4));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_tickets), sizeof(int) * 3 * EDM_TICKET_INTS));
+  EDM_HIP_TRY(hipMemset(g->d_tickets, 0, sizeof(int) * 3 * EDM_TICKET_INTS));
   return EDM_HIP_OK;
 }
 
@@ -469,6 +471,7 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
   if (g->h_stage) (void)hipHostFree(g->h_stage);
   if (g->h_partials) (void)hipHostFree(g->h_partials);
   if (g->d_dirty) (void)hipFree(g->d_dirty);
+  if (g->d_tickets) (void)hipFree(g->d_tickets);
   if (g->ev0) (void)hipEventDestroy(g->ev0);
   if (g->ev1) (void)hipEventDestroy(g->ev1);
   g->ws.release();
@@ -846,7 +849,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     // short batch: the limiter runs in the last integrals workgroup (one launch instead of two)
     LimitArgs la;
     memset(&la, 0, sizeof(la));
-    la.ticket = g->d_dirty + 2;
+    la.ticket = g->d_tickets + 1 * EDM_TICKET_INTS;
     la.limit = spec.limit;
     la.cum_in = spec.cum_in;
     la.flush_mode = spec.flush_mode;
@@ -954,7 +957,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     // short limited batch applied in place: boundary duplication and histogram ride on the gather launch
     chain_post = fused_post && plan.groups == 1 && hh.res_dev && nh <= 4096;
     PostSpec ps;
-    ps.ticket = g->d_dirty + 3;
+    ps.ticket = g->d_tickets + 2 * EDM_TICKET_INTS;
     ps.hist_geom = spec.hist_g;
     ps.hist = spec.hist_values;
     ps.flags = p_flags;

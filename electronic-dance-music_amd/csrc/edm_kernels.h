@@ -84,6 +84,9 @@ struct HillList {
 hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s);
 
 // --- chained launches for short hill steps (see last_block_done in edm_kernels.hip) ---
+// a ticket = zero-initialised device ints: top counter + FAN sub-counters, one 128-byte line each
+#define EDM_TICKET_FAN 16
+#define EDM_TICKET_INTS (32 * (1 + EDM_TICKET_FAN))
 // selection + preparation in one launch; h.nh is the launch bound of the step, h.sel == a.sel
 struct SelectArgs {
   long long n;

@@ -914,15 +914,39 @@ __global__ void __launch_bounds__(BLOCK) k_hill_prep(Geom g, HillList h) {
 // launches.  Returns true (block-uniform) in the last workgroup, with the other workgroups' writes
 // visible.
 // ---------------------------------------------------------------------------
+// (A ticket is EDM_TICKET_INTS ints: a top counter and EDM_TICKET_FAN sub-counters, each on its own
+// 128-byte line.  Hundreds of workgroups incrementing ONE address serialise at ~12 ns per atomic -- 6 us
+// for the 512 workgroups of the selection kernel, measured -- so workgroups count on sub-counter
+// (id mod FAN) and only the last arrival of each sub-counter touches the top one.)
 __device__ __forceinline__ bool last_block_done(int *ticket, unsigned total_blocks) {
   __shared__ int s_is_last;
   // every thread's published stores (publish()) have reached the coherence point before the barrier
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = (unsigned)__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_is_last = (t == total_blocks - 1) ? 1 : 0;
-    if (s_is_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int last = 0;
+    if (total_blocks <= 2 * EDM_TICKET_FAN) {
+      const unsigned t = (unsigned)__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == total_blocks - 1) {
+        last = 1;
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      const unsigned id = blockIdx.x + gridDim.x * blockIdx.y;
+      const unsigned sub = id % EDM_TICKET_FAN;
+      const unsigned subtotal = total_blocks / EDM_TICKET_FAN + (sub < total_blocks % EDM_TICKET_FAN ? 1u : 0u);
+      int *mine = ticket + 32 * (1 + sub);
+      const unsigned t = (unsigned)__hip_atomic_fetch_add(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == subtotal - 1) {
+        __hip_atomic_store(mine, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t2 = (unsigned)__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t2 == EDM_TICKET_FAN - 1) {
+          last = 1;
+          __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    s_is_last = last;
   }
   __syncthreads();
   return s_is_last != 0;
@@ -996,13 +1020,24 @@ __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, Hil
   }
   if (!last_block_done(a.ticket, gridDim.x)) return;
 
+  // scan of the per-workgroup counts: every thread takes PERC consecutive workgroups and requests their
+  // counts together (one memory round trip per BLOCK * PERC workgroups; 512 workgroups = one pass)
   const int nblocks = (int)gridDim.x;
   const long long bound = h.nh;
+  constexpr int PERC_MAX = 8;
+  int PERC = (nblocks + BLOCK - 1) / BLOCK;
+  if (PERC > PERC_MAX) PERC = PERC_MAX;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
-  for (int bb = 0; bb < nblocks; bb += BLOCK) {
-    const int blk = bb + threadIdx.x;
-    const long long c = (blk < nblocks) ? acquire(&a.counts[blk]) : 0;
+  for (int bb = 0; bb < nblocks; bb += BLOCK * PERC) {
+    const int blk0 = bb + threadIdx.x * PERC;
+    int cj[PERC_MAX];
+    long long c = 0;
+#pragma unroll
+    for (int j = 0; j < PERC_MAX; j++) {
+      cj[j] = (j < PERC && blk0 + j < nblocks) ? acquire(&a.counts[blk0 + j]) : 0;
+      c += cj[j];
+    }
     long long inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1016,21 +1051,36 @@ __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, Hil
     long long off = s_carry;
     for (int w = 0; w < wave; w++) off += s_ws[w];
     off += inc - c;
-    if (c > 0 && off < bound) {
-      if (c <= 4) {
-        for (long long j = 0; j < c && off + j < bound; j++) {
-          const long long src = (long long)blk * SEL_CHUNK + acquire(&a.stage[(long long)blk * SEL_CHUNK + j]);
-          select_emit<DIM>(a, g, h, off + j, src);
+    const long long off_end = off + c;
+#pragma unroll
+    for (int j = 0; j < PERC_MAX; j++) {
+      const int cc = cj[j];
+      if (cc > 0 && off < bound) {
+        const int blk = blk0 + j;
+        if (cc <= 4) {
+          for (long long e = 0; e < cc && off + e < bound; e++) {
+            const long long src = (long long)blk * SEL_CHUNK + acquire(&a.stage[(long long)blk * SEL_CHUNK + e]);
+            select_emit<DIM>(a, g, h, off + e, src);
+          }
+        } else {
+          const int q = atomicAdd(&s_nbig, 1);
+          if (q < BLOCK) {
+            s_big[q] = blk;
+            s_big_off[q] = off;
+          } else {
+            // (more crowded workgroups in one pass than the shared list holds: copy them here)
+            for (long long e = 0; e < cc && off + e < bound; e++) {
+              const long long src = (long long)blk * SEL_CHUNK + acquire(&a.stage[(long long)blk * SEL_CHUNK + e]);
+              select_emit<DIM>(a, g, h, off + e, src);
+            }
+          }
         }
-      } else {
-        const int q = atomicAdd(&s_nbig, 1);
-        s_big[q] = blk;
-        s_big_off[q] = off;
       }
+      off += cc;
     }
     __syncthreads();
     // workgroups with many accepted samples: all threads share the copy
-    const int nbig = s_nbig;
+    const int nbig = s_nbig < BLOCK ? s_nbig : BLOCK;
     for (int q = 0; q < nbig; q++) {
       const int b2 = s_big[q];
       const long long o2 = s_big_off[q];
@@ -1041,7 +1091,7 @@ __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, Hil
       }
     }
     __syncthreads();
-    if (threadIdx.x == BLOCK - 1) s_carry = off + c;
+    if (threadIdx.x == BLOCK - 1) s_carry = off_end;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -1321,7 +1371,7 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
     // ILP stencil points per trip (independent decode + exp chains overlap; a workgroup-per-hill launch
     // has one wave per SIMD, so nothing else hides their latency); sums stay in stencil order.
     // 32-bit decode: the stencil has < 2^31 points whenever it fits a grid at all.
-    constexpr int ILP = 4;
+    constexpr int ILP = (DIM == 1) ? 8 : 4;  // (1-D: the whole 1131-point stencil in one trip of a 256-thread workgroup)
     const unsigned utotal = (unsigned)total;
     // the early distance test below works on un-wrapped offsets: valid while no stencil offset is
     // further than half a period from the hill (else the reference's minimum image folds it back, :287-291)
@@ -1543,11 +1593,17 @@ struct PostArgs {
   long long rb_bytes;
 };
 
-template <int DIM, int MODE>
+// PARTS (1 or 4): the workgroup has PARTS * BLOCK threads; thread (part, node) accumulates every PARTS-th
+// batch of the tile's hill list for its node and the parts are combined in LDS in a fixed order.  A
+// node's serial chain is its number of overlapping hills: on the 1-D grid (hills pile up where the pair
+// density is high, 40+ per tile at r ~ 2.7 against 10 at r ~ 1.3) this quarters the critical path.
+template <int DIM, int MODE, int PARTS>
 __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t, double *__restrict__ rec,
                                                  const HillList &h, const HillHeights &hh, const GatherPlan &plan,
                                                  int use_list, int *__restrict__ dirty_flag, int coherent) {
   constexpr int R = (DIM == 1) ? 2 : 4;
+  const int tnode = threadIdx.x % BLOCK;   // this thread's node within the tile
+  const int part = threadIdx.x / BLOCK;    // ... and its share of the hill batches
   long long tile = blockIdx.x;
   if (use_list) {
     if (tile >= plan.tile_list[gather_tiles_dev(g)]) return;
@@ -1558,7 +1614,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   int t0[DIM], p[DIM], tcoord[DIM];
   {
     long long rest = tile;
-    int lrest = threadIdx.x;
+    int lrest = tnode;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
       const int T = Tile<DIM>::T[d];
@@ -1614,7 +1670,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   for (int d = 0; d < DIM; d++) vol *= g.dx[d];
 
   double acc[1 + DIM];
-  if (in_place && active) {
+  if (in_place && active && part == 0) {
     // in-place: start from the stored record so the adds follow the reference's
     // sequence V0 + h0*t0 + h1*t1 + ... exactly
 #pragma unroll
@@ -1638,17 +1694,19 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   __shared__ int s_wcnt[BLOCK / 64];
   __shared__ long long s_id[(MODE == 1) ? BLOCK : 1];
   __shared__ double s_wpart[(MODE == 1) ? BLOCK / 64 : 1][(MODE == 1) ? BLOCK : 1];
+  __shared__ double s_pacc[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? BLOCK : 1][1 + DIM];
+  __shared__ int s_ptouch[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? BLOCK : 1];
   TermConst<DIM> tc;
   term_const<DIM>(g, tc);
   constexpr int ILP = 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long long base = hbeg; base < hend; base += BLOCK) {
-    const long long cur = base + threadIdx.x;
+    const long long cur = base + tnode;
     bool take = false;
     int c[DIM];
     double h1 = 0, h2 = 0;
     double hx_r[DIM], ht_r[2 * DIM];
-    if (cur < hend) {
+    if (cur < hend && part == 0) {   // (the chunk is staged by the first BLOCK threads)
       // all of this hill's fields are requested together (one memory round trip)
 #pragma unroll
       for (int d = 0; d < DIM; d++) {
@@ -1692,7 +1750,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       }
     }
     const unsigned long long bal = __ballot(take);
-    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    if (lane == 0 && part == 0) s_wcnt[wave] = __popcll(bal);
     __syncthreads();
     int pos = __popcll(bal & ((1ull << lane) - 1ull));
     int cnt = 0;
@@ -1715,7 +1773,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     }
     __syncthreads();
     if (active || MODE == 1) {
-      for (int q0 = 0; q0 < cnt; q0 += ILP) {
+      for (int q0 = part * ILP; q0 < cnt; q0 += PARTS * ILP) {
         double val[ILP], dval[ILP][DIM];
         int mult[ILP];
 #pragma unroll
@@ -1777,6 +1835,27 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     }
     __syncthreads();
   }
+  if (PARTS > 1) {
+    // parts 1.. hand their sums to part 0, which adds them in part order
+    if (part > 0) {
+#pragma unroll
+      for (int j = 0; j <= DIM; j++) s_pacc[part - 1][tnode][j] = acc[j];
+      s_ptouch[part - 1][tnode] = touched ? 1 : 0;
+    }
+    __syncthreads();
+    if (part > 0) {
+      if (any_corr && active) {
+        if (coherent) publish(dirty_flag, 1); else *dirty_flag = 1;
+      }
+      return;
+    }
+#pragma unroll
+    for (int q = 0; q < PARTS - 1; q++) {
+#pragma unroll
+      for (int j = 0; j <= DIM; j++) acc[j] += s_pacc[q][tnode][j];
+      touched |= (s_ptouch[q][tnode] != 0);
+    }
+  }
   if (active && (touched || !in_place)) {
     double *dst = in_place ? rec + flat * R : plan.partial + ((long long)grp * g.total + flat) * R;
     if (coherent) {
@@ -1807,11 +1886,11 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   }
 }
 
-template <int DIM, int MODE>
-__global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
-                                                       HillHeights hh, GatherPlan plan, int use_list,
-                                                       int *__restrict__ dirty_flag, PostArgs post) {
-  hill_gather_body<DIM, MODE>(g, t, rec, h, hh, plan, use_list, dirty_flag, (MODE == 0) ? post.enabled : 0);
+template <int DIM, int MODE, int PARTS>
+__global__ void __launch_bounds__(BLOCK * PARTS) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
+                                                               HillHeights hh, GatherPlan plan, int use_list,
+                                                               int *__restrict__ dirty_flag, PostArgs post) {
+  hill_gather_body<DIM, MODE, PARTS>(g, t, rec, h, hh, plan, use_list, dirty_flag, (MODE == 0) ? post.enabled : 0);
   if (MODE == 0 && post.enabled) {
     // boundary duplication (K6) and the histogram updates (K7) by the last workgroup to finish
     if (!last_block_done(post.ticket, gridDim.x * gridDim.y)) return;
@@ -1821,13 +1900,14 @@ __global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double 
       if (threadIdx.x == 0) *dirty_flag = 0;
     }
     if (!hh.res_dev->error)
-      hist_batch<DIM>(post.hg, post.hist, h.nh, h.hx0, hh.res_dev, post.flags, post.flush_mode, threadIdx.x, BLOCK);
+      hist_batch<DIM>(post.hg, post.hist, h.nh, h.hx0, hh.res_dev, post.flags, post.flush_mode, threadIdx.x,
+                      BLOCK * PARTS);
     if (post.rb_dst) {
       // read-back region (written by the earlier launches of the step) -> host-mapped memory
       const long long words = post.rb_bytes / 8;
       const long long *src = reinterpret_cast<const long long *>(post.rb_src);
       long long *dst = reinterpret_cast<long long *>(post.rb_dst);
-      for (long long w = threadIdx.x; w < words; w += BLOCK) dst[w] = src[w];
+      for (long long w = threadIdx.x; w < words; w += BLOCK * PARTS) dst[w] = src[w];
     }
   }
 }
@@ -1963,8 +2043,12 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
     use_list = 1;
     launch_tiles = plan.tile_bound < ntiles ? plan.tile_bound : ntiles;
   }
-  hipLaunchKernelGGL((k_hill_gather<DIM, 0>), dim3((unsigned)launch_tiles, (unsigned)plan.groups), dim3(BLOCK), 0, s, g, t,
-                     rec, h, hh, plan, use_list, dirty_flag, post);
+  if (DIM == 1 && !use_list)
+    hipLaunchKernelGGL((k_hill_gather<DIM, 0, (DIM == 1) ? 4 : 1>), dim3((unsigned)launch_tiles, (unsigned)plan.groups),
+                       dim3(BLOCK * 4), 0, s, g, t, rec, h, hh, plan, use_list, dirty_flag, post);
+  else
+    hipLaunchKernelGGL((k_hill_gather<DIM, 0, 1>), dim3((unsigned)launch_tiles, (unsigned)plan.groups), dim3(BLOCK), 0, s, g, t,
+                       rec, h, hh, plan, use_list, dirty_flag, post);
   if (plan.groups > 1)
     hipLaunchKernelGGL(k_reduce_partials, dim3(blocks_for(g.total * g.rec)), dim3(BLOCK), 0, s, g, rec, plan.partial,
                        plan.groups, hh.res_dev, plan.adaptive, h.nh, h.nh_dev);
@@ -2024,9 +2108,9 @@ hipError_t launch_hill_gather_fused(const Geom &g, const Tables &t, const HillLi
   PostArgs nopost;
   memset(&nopost, 0, sizeof(nopost));
   switch (g.dim) {
-    case 1: hipLaunchKernelGGL((k_hill_gather<1, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
-    case 2: hipLaunchKernelGGL((k_hill_gather<2, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
-    default: hipLaunchKernelGGL((k_hill_gather<3, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
+    case 1: hipLaunchKernelGGL((k_hill_gather<1, 1, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
+    case 2: hipLaunchKernelGGL((k_hill_gather<2, 1, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
+    default: hipLaunchKernelGGL((k_hill_gather<3, 1, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
   }
   hipLaunchKernelGGL(k_sum_slots, dim3(blocks_for(h.nh)), dim3(BLOCK), 0, s, h.nh, plan.slots_per_hill, plan.slots, added);
   return hipGetLastError();
@@ -2046,9 +2130,9 @@ hipError_t launch_hill_gather_correct_and_apply(const Geom &g, const Tables &t, 
     PostArgs nopost;
     memset(&nopost, 0, sizeof(nopost));
     switch (g.dim) {
-      case 1: hipLaunchKernelGGL((k_hill_gather<1, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
-      case 2: hipLaunchKernelGGL((k_hill_gather<2, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
-      default: hipLaunchKernelGGL((k_hill_gather<3, 2>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
+      case 1: hipLaunchKernelGGL((k_hill_gather<1, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
+      case 2: hipLaunchKernelGGL((k_hill_gather<2, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
+      default: hipLaunchKernelGGL((k_hill_gather<3, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
     }
     groups += 1;
   }
@@ -2069,9 +2153,9 @@ hipError_t launch_hill_gather_correction(const Geom &g, const Tables &t, const H
   memset(&nopost, 0, sizeof(nopost));
   double *none = nullptr;
   switch (g.dim) {
-    case 1: hipLaunchKernelGGL((k_hill_gather<1, 2>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
-    case 2: hipLaunchKernelGGL((k_hill_gather<2, 2>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
-    default: hipLaunchKernelGGL((k_hill_gather<3, 2>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
+    case 1: hipLaunchKernelGGL((k_hill_gather<1, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
+    case 2: hipLaunchKernelGGL((k_hill_gather<2, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
+    default: hipLaunchKernelGGL((k_hill_gather<3, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
   }
   return hipGetLastError();
 }
