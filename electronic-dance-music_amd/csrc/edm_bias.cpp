@@ -817,6 +817,31 @@ int edm_hip_bias_add_hills(edm_hip_bias *b, long long n, const double *d_x, int 
   return do_post_add_hill(b);
 }
 
+int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_stride, double *d_f, int f_stride,
+                      const double *d_runiform, int apply_mask, long long est_hill_count, double *energy) {
+  if (energy) *energy = 0;
+  if (!b->bias && !b->b_outofbounds) {
+    set_error("step before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  int nblk = 0;
+  if (!b->b_outofbounds) {   // update_forces (:279-280) -- queued, not waited for
+    int rc = update_forces_enqueue(b->bias, n, d_x, x_stride, d_f, f_stride, b->d_mask, apply_mask, &nblk);
+    if (rc) return rc;
+  }
+  // add_hills behind it on the same stream (:401-411): pre_add_hill, the samples, post_add_hill
+  int rc = do_pre_add_hill(b, est_hill_count < 0 ? n : est_hill_count);
+  if (rc) return rc;
+  if (!b->b_outofbounds) {
+    rc = process_new_hills(b, n, d_x, x_stride, d_runiform, apply_mask);
+    if (rc) return rc;
+    EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
+    const double e = pair_forces_finish(b->bias, nblk);
+    if (energy) *energy = e;
+  }
+  return do_post_add_hill(b);
+}
+
 int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, double *d_force, long long n_samples,
                            const double *d_sample_r, const double *d_runiform, long long est_hill_count,
                            double *energy) {

@@ -606,20 +606,12 @@ int edm_hip_gauss_sample_index(const edm_hip_gauss *g, long long n, const double
 int edm_hip_gauss_update_forces(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride, double *d_f,
                                 int f_stride, const int *d_mask, int apply_mask, double *energy) {
   if (energy) *energy = 0;
-  if (n <= 0) return EDM_HIP_OK;
-  if (apply_mask >= 0 && !d_mask) {
-    set_error("update_forces: apply_mask >= 0 needs a mask");
-    return EDM_HIP_ERR_ARG;
-  }
-  LookupArgs a{};
-  a.n = n; a.x = d_x; a.x_stride = x_stride; a.f = d_f; a.f_stride = f_stride; a.mask = d_mask; a.apply_mask = apply_mask;
   int nblk = 0;
-  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, a, g->d_partials, nullptr, g->stream,
-                            g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr, &nblk));
+  int rc = edm::update_forces_enqueue(g, n, d_x, x_stride, d_f, f_stride, d_mask, apply_mask, &nblk);
+  if (rc) return rc;
+  if (n <= 0) return EDM_HIP_OK;
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
-  double e = 0;
-  for (int i = 0; i < nblk; i++) e += g->h_partials[i];
-  profile_collect(g);
+  const double e = edm::pair_forces_finish(g, nblk);
   if (energy) *energy = e;
   return EDM_HIP_OK;
 }
@@ -672,6 +664,21 @@ int pair_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_r, 
   if (n <= 0) return EDM_HIP_OK;
   EDM_HIP_TRY(launch_pair_forces(g->g, g->rec, n, d_r, d_force, g->d_partials, nullptr, g->stream,
                                  g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr, nblk));
+  return EDM_HIP_OK;
+}
+// K2 (any dimension, strided rows, group mask) without the host wait; finish with pair_forces_finish()
+int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride, double *d_f, int f_stride,
+                          const int *d_mask, int apply_mask, int *nblk) {
+  *nblk = 0;
+  if (n <= 0) return EDM_HIP_OK;
+  if (apply_mask >= 0 && !d_mask) {
+    set_error("update_forces: apply_mask >= 0 needs a mask");
+    return EDM_HIP_ERR_ARG;
+  }
+  LookupArgs a{};
+  a.n = n; a.x = d_x; a.x_stride = x_stride; a.f = d_f; a.f_stride = f_stride; a.mask = d_mask; a.apply_mask = apply_mask;
+  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, a, g->d_partials, nullptr, g->stream,
+                            g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr, nblk));
   return EDM_HIP_OK;
 }
 double pair_forces_finish(const edm_hip_gauss *g, int nblk) {

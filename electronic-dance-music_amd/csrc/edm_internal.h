@@ -166,5 +166,7 @@ struct ApplyOutcome {
 // Leaves per-hill `added` in g->ws.added and the tail arrays in g->ws.tail_*.
 int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool want_total);
 int pair_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_r, double *d_force, int *nblk);
+int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride, double *d_f, int f_stride,
+                          const int *d_mask, int apply_mask, int *nblk);
 double pair_forces_finish(const edm_hip_gauss *g, int nblk);
 }  // namespace edm

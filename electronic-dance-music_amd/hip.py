@@ -84,6 +84,7 @@ _PROTOS = {
     "edm_hip_bias_update_forces": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, C.c_int, c_dp]),
     "edm_hip_bias_pair_forces": (C.c_int, [vp, C.c_longlong, vp, vp, c_dp]),
     "edm_hip_bias_add_hills": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, C.c_longlong]),
+    "edm_hip_bias_step": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pre_add_hill": (C.c_int, [vp, C.c_longlong]),
     "edm_hip_bias_add_hill": (C.c_int, [vp, c_dp, C.c_double]),
@@ -483,6 +484,13 @@ class Bias:
     def pair_forces_device(self, d_r, d_f, n):
         e = C.c_double(0)
         check(lib().edm_hip_bias_pair_forces(self.h, n, _ptr(d_r), _ptr(d_f), C.byref(e)))
+        return e.value
+
+    def step_device(self, d_x, x_stride, d_f, f_stride, n, d_u, apply_mask=-1, est=-1):
+        """update_forces + add_hills over the same samples (one hill-depositing fix edm step), one host wait"""
+        e = C.c_double(0)
+        check(lib().edm_hip_bias_step(self.h, n, _ptr(d_x), x_stride, _ptr(d_f), f_stride, _ptr(d_u), apply_mask, est,
+                                      C.byref(e)))
         return e.value
 
     def pair_step_device(self, d_r, d_f, n, d_sample_r, d_u, n_samples, est=-1):

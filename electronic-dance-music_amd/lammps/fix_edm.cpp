@@ -100,8 +100,6 @@ void FixEDM::min_setup(int vflag) { post_force(vflag); }
 void FixEDM::post_force(int /*vflag*/)
 {
   bias->set_mask(atom->mask);  // re-fetched every call: LAMMPS may reallocate atom->mask
-  edm_energy = bias->update_forces(atom->nlocal, atom->x, atom->f, groupbit);
-
   if (update->ntimestep % stride == 0) {
     if (random_cap < atom->nmax) {  // the bias is paid in uniform random numbers (fix_edm.cpp:145-151)
       free(random_numbers);
@@ -109,7 +107,10 @@ void FixEDM::post_force(int /*vflag*/)
       random_numbers = (double *) malloc(sizeof(double) * (size_t) (random_cap > 0 ? random_cap : 1));
     }
     for (int i = 0; i < atom->nlocal; i++) random_numbers[i] = random->uniform();
-    bias->add_hills(atom->nlocal, atom->x, random_numbers, groupbit);
+    // update_forces + add_hills in one call: positions and the group mask cross PCIe once, one device wait
+    edm_energy = bias->step(atom->nlocal, atom->x, atom->f, random_numbers, groupbit);
+  } else {
+    edm_energy = bias->update_forces(atom->nlocal, atom->x, atom->f, groupbit);
   }
 
   if (update->ntimestep % write_stride == 0) {

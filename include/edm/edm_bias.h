@@ -62,6 +62,9 @@ class EDMBias {
   double update_pair_forces(int npairs, const double* r, double* force_r) const;
   // one hill cycle over a flat distance array: pre_add_hill(est); add_hill(&r[i], runiform[i]); post
   void add_pair_hills(int n, const double* r, const double* runiform, int est_hill_count);
+  // one hill-depositing fix_edm step in one call: update_forces(nlocal, positions, forces, apply_mask) then
+  // add_hills(nlocal, positions, runiform, apply_mask); positions and mask cross PCIe once, one device wait
+  double step(int nlocal, const double* const* positions, double** forces, const double* runiform, int apply_mask);
   // one hill-depositing fix_edm_pair step in one call (one device round trip): pre_add_hill(est);
   // force_r = update_pair_forces(npairs, r); add_hill(&sample_r[i], runiform[i]) for i < n_samples;
   // post_add_hill().  Returns the bias energy of the pairs.

@@ -192,6 +192,12 @@ int edm_hip_bias_pair_forces(edm_hip_bias *b, long long n, const double *d_r, do
  * means "use n" (add_hills semantics); fix_edm_pair passes its own estimate. */
 int edm_hip_bias_add_hills(edm_hip_bias *b, long long n, const double *d_x, int x_stride,
                            const double *d_runiform, int apply_mask, long long est_hill_count);
+/* One hill-depositing step of fix edm (fix_edm.cpp:131-152) in a single call: EDMBias::update_forces
+ * (edm_bias.cpp:276-295) followed by EDMBias::add_hills (:401-411) over the same samples.  Same results as
+ * edm_hip_bias_update_forces + edm_hip_bias_add_hills; queued back to back, the host waits once. */
+int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_stride, double *d_f,
+                      int f_stride, const double *d_runiform, int apply_mask, long long est_hill_count,
+                      double *energy);
 /* One hill-depositing step of fix edm_pair (fix_edm_pair.cpp:174-246) in a single call:
  * pre_add_hill(est_hill_count) (flushes the overflow buffer), the force evaluation of
  * edm_hip_bias_pair_forces(n, d_r, d_force), add_hill(d_sample_r[i], d_runiform[i]) for the n_samples

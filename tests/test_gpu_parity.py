@@ -656,3 +656,43 @@ def test_sharded_dense_application(mode, n, limit, workdir):
     close(q[3], p[3], rtol=1e-12, what="cum_bias")
     assert p[4:] == q[4:], "limiter decisions (overflow buffer indices, hills added, skip flag)"
     assert p[5] > 0 and p[0].max() > 0, "the limiter must have been active"
+
+
+def test_step_equals_separate_calls(workdir):
+    """edm_hip_bias_step (update_forces + add_hills, one host wait) against the two separate calls, 2-D
+    coordinate CV with a group mask and an active limiter: bit-identical forces, energies, grid, histogram."""
+    text = ("tempering 0\nhill_prefactor 0.4\nhill_density 30\nbias_per_step 0.25\ndimension 2\nbox_low 0 0\n"
+            "box_high 8 8\nbias_spacing 0.05 0.05\nbias_sigma 0.2 0.2\n")
+    n = 5000
+    state = []
+    for tag in ("fused", "separate"):
+        cfg = str(workdir / (tag + ".edm"))
+        open(cfg, "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+        b = H.Bias(cfg)
+        b.setup(1.0, 1.0)
+        b.subdivide([0, 0], [8, 8], [0, 0], [8, 8], [1, 1], [0.3, 0.3])
+        energies, forces = [], []
+        for step in range(5):
+            x = W.uniform(800 + step, 3 * n).reshape(n, 3) * 8.0
+            u = W.uniform(850 + step, n)
+            mask = (W.splitmix64(870 + step, n) % np.uint64(4)).astype(np.int32)
+            d_x = H.DeviceArray.from_host(np.ascontiguousarray(x))
+            d_u = H.DeviceArray.from_host(u)
+            d_f = H.DeviceArray.zeros((n, 3))
+            b.set_mask(mask)
+            if tag == "fused":
+                e = b.step_device(d_x, 3, d_f, 3, n, d_u, apply_mask=1)
+            else:
+                e = H.C.c_double(0)
+                H.check(H.lib().edm_hip_bias_update_forces(b.h, n, d_x.ptr, 3, d_f.ptr, 3, 1, H.C.byref(e)))
+                e = e.value
+                b.add_hills_device(d_x, n, 3, d_u, 1, -1)
+            energies.append(e)
+            forces.append(d_f.to_host())
+        v, dv = b.gauss.download()
+        state.append((v, dv, b.hist.values, np.array(energies), np.array(forces), b.get("cum_bias"),
+                      b.get("overflow_right"), b.get("hills_added")))
+        del b
+    for a, c in zip(state[0], state[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(c))
+    assert state[0][0].max() > 0 and state[0][7] > 10 and np.abs(state[0][4]).max() > 0
