@@ -1945,7 +1945,10 @@ __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *_
   for (int d = 0; d < DIM; d++) {
     const int T = Tile<DIM>::T[d];
     ntile[d] = (g.n[d] + T - 1) / T;
-    steps[d] = (2 * g.msize[d]) / T + 2;  // offsets -m, -m+T, ... plus the end point +m
+    // sample nodes -m, -m+T, ... and the end point +m; a periodic dimension adds the four nodes next to the
+    // wrap seams (the samples are T apart in un-wrapped coordinates, so when n is not a multiple of T the
+    // partial last tile before a seam would fall between two of them)
+    steps[d] = (2 * g.msize[d]) / T + 2 + (g.periodic[d] ? 4 : 0);
     combos *= steps[d];
   }
   const long long id = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -1961,15 +1964,25 @@ __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *_
       const int T = Tile<DIM>::T[d];
       const int sidx = (int)(rest % steps[d]);
       rest /= steps[d];
-      int off = -g.msize[d] + sidx * T;
-      if (off > g.msize[d]) off = g.msize[d];
-      const int unwrapped = h.hc[i * DIM + d] + off;
+      const int nreg = (2 * g.msize[d]) / T + 2;
+      int unwrapped;
+      if (sidx < nreg) {
+        int off = -g.msize[d] + sidx * T;
+        if (off > g.msize[d]) off = g.msize[d];
+        unwrapped = h.hc[i * DIM + d] + off;
+      } else {
+        const int e = sidx - nreg;  // seam nodes -1 | 0 and n-1 | n
+        unwrapped = (e == 0) ? -1 : (e == 1) ? 0 : (e == 2) ? g.n[d] - 1 : g.n[d];
+        if (unwrapped < h.hc[i * DIM + d] - g.msize[d] || unwrapped > h.hc[i * DIM + d] + g.msize[d]) skip = true;
+      }
       int idx = unwrapped;
       if (idx >= g.n[d]) {
-        if (g.periodic[d]) idx %= g.n[d]; else skip = true;
+        // (non-periodic: a sample point past the end still stands for the last tile, whose leading nodes
+        //  the stencil reaches -- the samples are T apart and the centre node lies inside the grid)
+        if (g.periodic[d]) idx %= g.n[d]; else idx = unwrapped = g.n[d] - 1;
       }
       if (idx < 0) {
-        if (g.periodic[d]) idx += g.n[d]; else skip = true;
+        if (g.periodic[d]) idx += g.n[d]; else idx = unwrapped = 0;
         if (idx < 0) skip = true;
       }
       if (!skip) {
@@ -2008,7 +2021,7 @@ long long mark_tiles_threads(const Geom &g, long long nh) {
   long long combos = 1;
   for (int d = 0; d < g.dim; d++) {
     const int T = (g.dim == 1) ? Tile<1>::T[d] : (g.dim == 2) ? Tile<2>::T[d] : Tile<3>::T[d];
-    combos *= (2 * g.msize[d]) / T + 2;
+    combos *= (2 * g.msize[d]) / T + 2 + (g.periodic[d] ? 4 : 0);
   }
   return nh * combos;
 }
