@@ -28,7 +28,7 @@ def scenarios():
         (2, (120, 90), (5, 150)), (2, (900, 800), (4, 120)), (2, (640, 1000), (1500,)), (2, (48, 700), (60,)),
         (3, (40, 36, 28), (4, 40)), (3, (96, 96, 96), (3, 50)), (3, (24, 120, 200), (30,)),
     ]
-    for rep in range(2):
+    for rep in range(5):
         for dim, nodes, batches in plans:
             per = [int(rng.integers(0, 2)) for _ in range(dim)]
             dx = [float(rng.uniform(0.02, 0.3)) for _ in range(dim)]

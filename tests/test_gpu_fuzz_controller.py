@@ -1,0 +1,113 @@
+"""Randomised (seeded) parity sweep of the EDMBias controller against the CPU oracle: dimension, periodicity,
+tempering mode (none / global / local), stochastic vs all-samples selection, group masks, limiter pressure
+and sample counts are drawn so that the deferred-count chain, the synchronous path, the ordered
+(locally tempered) kernel, overflow flushes and skipped rounds all occur."""
+import os
+
+import numpy as np
+import pytest
+
+import edm_amd.hip as H
+from oracle import binding as B
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol, atol=0.0, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    bad = ~(np.abs(a - b) <= atol + rtol * np.abs(b))
+    assert not bad.any(), "%s: %d/%d differ, worst %g" % (what, bad.sum(), bad.size, np.abs(a - b).max())
+
+
+def scenarios():
+    rng = np.random.default_rng(777)
+    out = []
+    for k in range(24):
+        dim = int(rng.choice([1, 1, 2, 3]))
+        per = [int(rng.integers(0, 2)) for _ in range(dim)]
+        L = [float(rng.uniform(2.0, 6.0)) for _ in range(dim)]
+        nodes = {1: int(rng.integers(300, 3000)), 2: int(rng.integers(40, 160)), 3: int(rng.integers(16, 40))}[dim]
+        sp = [L[d] / nodes for d in range(dim)]
+        sg = [float(rng.uniform(1.5, 4.0)) * sp[d] for d in range(dim)]
+        mode = str(rng.choice(["plain", "plain", "global", "local"]))
+        if k % 5 == 4:
+            mode = str(rng.choice(["plain", "global"]))
+        stochastic = (k % 5 != 4)
+        n = int(rng.choice([300, 3000, 40000])) if stochastic else int(rng.choice([200, 1500]))
+        if mode == "local":
+            n = min(n, 3000)
+        density = float(rng.uniform(8, 120)) if stochastic else None
+        prefactor = float(rng.uniform(0.05, 0.6))
+        expected_total = prefactor            # (sum of accepted heights per step ~ prefactor in both selection modes)
+        limit = float(rng.uniform(0.3, 3.0)) * expected_total if rng.random() < 0.75 else None
+        cfg = "tempering %d\n" % (0 if mode == "plain" else 1)
+        if mode == "global":
+            cfg += "bias_factor %g\nglobal_tempering %g\n" % (rng.uniform(2, 12), rng.uniform(0.02, 0.5))
+        if mode == "local":
+            cfg += "bias_factor %g\nglobal_tempering -1\n" % rng.uniform(2, 12)
+        cfg += "hill_prefactor %.6g\n" % prefactor
+        if density:
+            cfg += "hill_density %.6g\n" % density
+        if limit:
+            cfg += "bias_per_step %.6g\n" % limit
+        cfg += "dimension %d\nbox_low %s\nbox_high %s\nbias_spacing %s\nbias_sigma %s\n" % (
+            dim, " ".join("0" for _ in range(dim)), " ".join("%.6g" % v for v in L),
+            " ".join("%.8g" % v for v in sp), " ".join("%.8g" % v for v in sg))
+        out.append(dict(name="%02d_%dd_%s_%s_n%d%s" % (k, dim, mode, "dens" if density else "all", n, "_lim" if limit else ""),
+                        cfg=cfg, dim=dim, per=per, L=L, n=n, steps=int(rng.integers(3, 6)), use_mask=bool(rng.random() < 0.4),
+                        seed=int(rng.integers(1, 1 << 30)), est_factor=float(rng.choice([1.0, 2.0]))))
+    return out
+
+
+@pytest.mark.parametrize("sc", scenarios(), ids=lambda s: s["name"])
+def test_random_controller_vs_oracle(sc, tmp_path):
+    lib = B.load("oracle")
+    dim = sc["dim"]
+    cfgs = {}
+    for tag in ("gpu", "ora"):
+        cfgs[tag] = str(tmp_path / (tag + ".edm"))
+        open(cfgs[tag], "w").write(sc["cfg"] + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (tmp_path, tag, tmp_path, tag))
+    b = H.Bias(cfgs["gpu"])
+    o = B.Bias(lib, cfgs["ora"])
+    lo, hi = [0.0] * dim, list(sc["L"])
+    skin = [0.0 if p else 0.25 for p in sc["per"]]
+    for x in (b, o):
+        x.setup(1.0, 1.0)
+        x.subdivide(lo, hi, lo, hi, sc["per"], skin)
+    rng = np.random.default_rng(sc["seed"])
+    n = sc["n"]
+    for step in range(sc["steps"]):
+        pos = np.zeros((n, 3))
+        pos[:, :dim] = rng.uniform(-0.03, 1.03, (n, dim)) * np.array(hi)
+        ru = rng.random(n)
+        mask = rng.integers(0, 4, n).astype(np.int32)
+        apply_mask = 2 if sc["use_mask"] else -1
+        f_g = np.zeros_like(pos)
+        f_o = np.zeros_like(pos)
+        for x in (b, o):
+            x.set_mask(mask)
+        e_g = b.update_forces(pos, f_g, apply_mask)
+        e_o = o.update_forces(pos, f_o, apply_mask)
+        close(e_g, e_o, rtol=1e-9, atol=1e-12, what="energy step %d" % step)
+        close(f_g, f_o, rtol=1e-8, atol=1e-10 * max(np.abs(f_o).max(), 1e-300), what="forces step %d" % step)
+        b.add_hills(pos, ru, apply_mask)
+        o.add_hills(pos, ru, apply_mask)
+        close(b.get("cum_bias"), o.get("cum_bias"), rtol=1e-9, what="cum_bias step %d" % step)
+        got = [int(b.get(k)) for k in ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added")]
+        want = [int(o.get(k)) for k in ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added")]
+        assert got == want, "limiter decisions step %d: %s vs %s" % (step, got, want)
+    v, dv = b.gauss.download()
+    og = o.gauss.grid
+    close(v, og.values, rtol=1e-8, atol=1e-12 * max(np.abs(og.values).max(), 1e-300), what="grid")
+    close(dv, og.derivs, rtol=1e-8, atol=1e-10 * max(np.abs(og.derivs).max(), 1e-300), what="derivs")
+    assert np.array_equal(b.hist.values, o.hist.values), "histogram counts are integers: exact"
+    hist_equal = np.array_equal(b.hist.values, o.hist.values)
+    del b
+    del o   # (both close their HILLS logs)
+    assert hist_equal
+    lg = open(str(tmp_path / "HILLS_gpu_0")).read().splitlines()
+    lo_ = open(str(tmp_path / "HILLS_ora_0")).read().splitlines()
+    assert len(lg) == len(lo_), "HILLS log length"
+    assert [ln.split()[:3] for ln in lg] == [ln.split()[:3] for ln in lo_], "HILLS event sequence"
