@@ -426,6 +426,45 @@ static void edm_bias_tests(const std::string& fx, const std::string& scratch) {
   REQUIRE(std::fabs(ep - e_all) < 1e-9 * std::fabs(e_all));
   REQUIRE(std::fabs(fr[300] - f1[0]) < 1e-9);
   bias.write_histogram();
+  // the single-call hill steps equal the separate calls: two identical biases, one driven by
+  // step() / pair_step(), the other by update_forces + add_hills / update_pair_forces + add_pair_hills
+  {
+    EDMBias a(cfg), b2(cfg);
+    EDMBias* both[2] = {&a, &b2};
+    for (int k = 0; k < 2; k++) {
+      both[k]->setup(1, 1);
+      both[k]->subdivide(low, high, low, high, p, skin);
+      both[k]->set_mask(mask.data());
+    }
+    std::vector<double> u(n), fa((size_t)n * 3, 0.0), fb((size_t)n * 3, 0.0);
+    std::vector<double*> fra(n), frb(n);
+    for (int i = 0; i < n; i++) {
+      u[i] = (i * 7919 % 1000) / 1000.0;
+      fra[i] = &fa[3 * (size_t)i];
+      frb[i] = &fb[3 * (size_t)i];
+    }
+    for (int step = 0; step < 3; step++) {
+      const double ea = a.step(n, x, fra.data(), u.data(), 2);
+      const double eb = b2.update_forces(n, x, frb.data(), 2);
+      b2.add_hills(n, x, u.data(), 2);
+      REQUIRE(ea == eb);
+    }
+    REQUIRE(fa == fb);
+    REQUIRE(a.cum_bias_ == b2.cum_bias_ && a.cum_bias_ > 0);
+    std::vector<double> pa(n), pb(n);
+    for (int step = 0; step < 3; step++) {
+      const double ea = a.pair_step(n, r.data(), pa.data(), n, r.data(), u.data(), n);
+      b2.pre_add_hill(n);   // (fix_edm_pair's order: the overflow flush precedes the forces)
+      const double eb = b2.update_pair_forces(n, r.data(), pb.data());
+      for (int i = 0; i < n; i++) b2.add_hill(&r[i], u[i]);
+      b2.post_add_hill();
+      REQUIRE(ea == eb);
+    }
+    REQUIRE(pa == pb);
+    REQUIRE(a.cum_bias_ == b2.cum_bias_);
+    const double probe[1] = {5.2};
+    REQUIRE(a.bias_->get_value(probe) == b2.bias_->get_value(probe));
+  }
   std::free(xblock); std::free(fblock); std::free(x); std::free(f);
   std::free(positions[0]); std::free(positions);
 }
