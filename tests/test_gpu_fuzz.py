@@ -34,7 +34,7 @@ def scenarios():
             dx = [float(rng.uniform(0.02, 0.3)) for _ in range(dim)]
             # periodic dimensions start at 0: the reference's duplicate_boundary looks up the node of the
             # boundary maximum, which for a periodic dimension wraps to  max - (max - min); when that rounds
-            # below min the index underflows to SIZE_MAX and its `while` loop (gaussian_grid.h:589-592) never
+            # below min the index underflows to SIZE_MAX and its `while` loop (gaussian_grid.h:585-587) never
             # ends -- reproduced with the real reference build, so such boxes cannot serve as oracle cases
             lo = [0.0 if per[d] else float(rng.uniform(-3, 3)) for d in range(dim)]
             hi = [lo[d] + dx[d] * nodes[d] for d in range(dim)]
