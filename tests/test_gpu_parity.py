@@ -696,3 +696,38 @@ def test_step_equals_separate_calls(workdir):
     for a, c in zip(state[0], state[1]):
         assert np.array_equal(np.asarray(a), np.asarray(c))
     assert state[0][0].max() > 0 and state[0][7] > 10 and np.abs(state[0][4]).max() > 0
+
+
+def test_large_selection_vs_oracle(oracle_lib, workdir):
+    """Stochastic selection over 8 M samples (3907 selection workgroups: the multi-pass branch of the chained
+    scan) against the oracle: same accepted hills in the same order -> same grid, histogram, counters."""
+    text = ("tempering 0\nhill_prefactor 0.5\nhill_density 300\nbias_per_step 0.4\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+            "bias_spacing 0.001\nbias_sigma 0.05\n")
+    cfgs = {}
+    for tag in ("gpu", "ora"):
+        cfgs[tag] = str(workdir / (tag + ".edm"))
+        open(cfgs[tag], "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+    b = H.Bias(cfgs["gpu"])
+    o = B.Bias(oracle_lib, cfgs["ora"])
+    for x in (b, o):
+        x.setup(1.0, 1.0)
+        x.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    n = 8_000_000
+    for step in range(2):
+        r = W.pair_distances(n, 60 + step)
+        u = W.uniform(65 + step, n)
+        pos = np.zeros((n, 3))
+        pos[:, 0] = r
+        o.add_hills(pos, u, -1)
+        del pos
+        d_r = H.DeviceArray.from_host(r)
+        d_u = H.DeviceArray.from_host(u)
+        b.add_hills_device(d_r, n, 1, d_u, -1, n)
+        close(b.get("cum_bias"), o.get("cum_bias"), rtol=1e-10, what="cum_bias")
+        for k in ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added"):
+            assert int(b.get(k)) == int(o.get(k)), k
+    v, dv = b.gauss.download()
+    og = o.gauss.grid
+    close(v, og.values, rtol=1e-9, atol=1e-13 * np.abs(og.values).max(), what="grid")
+    assert np.array_equal(b.hist.values, o.hist.values)
+    assert int(b.get("hills_added")) > 150
