@@ -921,8 +921,13 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     static const int T1[3] = {256, 1, 1}, T2[3] = {16, 16, 1}, T3[3] = {8, 8, 4};
     const int *T = q.dim == 1 ? T1 : q.dim == 2 ? T2 : T3;
     long long per_hill = 1;
-    for (int d = 0; d < q.dim; d++) per_hill *= (2 * q.msize[d]) / T[d] + 2 + (q.periodic[d] ? 2 : 0);  // (distinct tiles per hill)
-    if (nh * per_hill < ntiles / 2) {
+    // distinct tiles a hill can touch: 2m+1 nodes span at most 2m/T + 2 tiles, one more when a periodic seam
+    // cuts a partial tile (idle workgroups of an over-sized launch are not free: ~2 ns each)
+    for (int d = 0; d < q.dim; d++) per_hill *= (2 * q.msize[d]) / T[d] + 2 + ((q.periodic[d] && q.n[d] % T[d] != 0) ? 1 : 0);
+    bool narrow = true;  // (a stencil wider than a periodic dimension crosses more than one seam: no culling)
+    for (int d = 0; d < q.dim; d++)
+      if (q.periodic[d] && 2 * q.msize[d] + 1 > q.n[d]) narrow = false;
+    if (narrow && nh * per_hill < ntiles / 2) {
       EDM_HIP_TRY(ws.tile_flags.reserve_zeroed((size_t)ntiles));
       EDM_HIP_TRY(ws.tile_list.reserve((size_t)ntiles + 1));
       plan.tile_flags = ws.tile_flags.p;

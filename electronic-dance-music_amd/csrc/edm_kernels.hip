@@ -1339,13 +1339,16 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
 
 // `la` (TPH == BLOCK only): the ordered limiter is chained onto the last workgroup to finish
 template <int DIM, int TPH>
-__global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, HillList h,
-                                                          const double *__restrict__ heights, double h_const,
-                                                          double *__restrict__ added, LimitArgs la) {
-  __shared__ double s_red[BLOCK / 64];
+__global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(Geom g, Tables t, HillList h,
+                                                                                const double *__restrict__ heights,
+                                                                                double h_const,
+                                                                                double *__restrict__ added,
+                                                                                LimitArgs la) {
+  constexpr int NT = (TPH > BLOCK) ? TPH : BLOCK;  // workgroup size: 512 threads per hill for the 3-D stencil
+  __shared__ double s_red[NT / 64];
   const int lane = threadIdx.x & 63;
   const int lt = threadIdx.x % TPH;
-  const long long hill = (long long)blockIdx.x * (BLOCK / TPH) + (threadIdx.x / TPH);
+  const long long hill = (long long)blockIdx.x * (NT / TPH) + (threadIdx.x / TPH);
   const long long nh_eff = hill_count(h);
   if (TPH == 64 && hill >= nh_eff) return;  // (a whole workgroup shares one hill when TPH == BLOCK)
   const bool live = hill < nh_eff;
@@ -1438,7 +1441,7 @@ __global__ void __launch_bounds__(BLOCK) k_hill_integrals(Geom g, Tables t, Hill
     __syncthreads();
     if (threadIdx.x == 0 && live) {
       double r = 0;
-      for (int w = 0; w < BLOCK / 64; w++) r += s_red[w];
+      for (int w = 0; w < NT / 64; w++) r += s_red[w];
       if (la.enabled) publish(&added[hill], r); else added[hill] = r;
     }
     if (la.enabled) {
@@ -1467,7 +1470,7 @@ hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList 
     switch (g.dim) {
       case 1: hipLaunchKernelGGL((k_hill_integrals<1, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
       case 2: hipLaunchKernelGGL((k_hill_integrals<2, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
-      default: hipLaunchKernelGGL((k_hill_integrals<3, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
+      default: hipLaunchKernelGGL((k_hill_integrals<3, 2 * BLOCK>), dim3(nb), dim3(2 * BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
     }
   } else {
     const long long nb = (h.nh + (BLOCK / 64) - 1) / (BLOCK / 64);
@@ -1707,13 +1710,17 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     double h1 = 0, h2 = 0;
     double hx_r[DIM], ht_r[2 * DIM];
     if (cur < hend && part == 0) {   // (the chunk is staged by the first BLOCK threads)
-      // all of this hill's fields are requested together (one memory round trip)
+      // 1-D: all of this hill's fields are requested together (one memory round trip; a tile overlaps a
+      // good part of the hills).  2-D/3-D: a tile meets a few hills out of hundreds, so only the centre
+      // node is fetched for the test and the rest follows for the hills that pass.
 #pragma unroll
       for (int d = 0; d < DIM; d++) {
         c[d] = h.hc[cur * DIM + d];
-        hx_r[d] = h.hx[cur * DIM + d];
-        ht_r[2 * d] = h.ht[cur * 2 * DIM + 2 * d];
-        ht_r[2 * d + 1] = h.ht[cur * 2 * DIM + 2 * d + 1];
+        if (DIM == 1) {
+          hx_r[d] = h.hx[cur * DIM + d];
+          ht_r[2 * d] = h.ht[cur * 2 * DIM + 2 * d];
+          ht_r[2 * d + 1] = h.ht[cur * 2 * DIM + 2 * d + 1];
+        }
       }
       const double hb = hh.h ? hh.h[cur] : hh.h_const;
       const bool in_tail = (MODE == 2) || (MODE == 0 && cur >= k_first_tail);
@@ -1730,6 +1737,14 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
           int t1 = t0[d] + T - 1;
           if (t1 > g.n[d] - 1) t1 = g.n[d] - 1;
           if (images(g, d, c[d], t0[d], t1) == 0) take = false;
+        }
+        if (take && DIM > 1) {
+#pragma unroll
+          for (int d = 0; d < DIM; d++) {
+            hx_r[d] = h.hx[cur * DIM + d];
+            ht_r[2 * d] = h.ht[cur * 2 * DIM + 2 * d];
+            ht_r[2 * d + 1] = h.ht[cur * 2 * DIM + 2 * d + 1];
+          }
         }
         if (take) {
           if (MODE == 1) {
@@ -1947,8 +1962,8 @@ __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *_
     ntile[d] = (g.n[d] + T - 1) / T;
     // sample nodes -m, -m+T, ... and the end point +m; a periodic dimension adds the four nodes next to the
     // wrap seams (the samples are T apart in un-wrapped coordinates, so when n is not a multiple of T the
-    // partial last tile before a seam would fall between two of them)
-    steps[d] = (2 * g.msize[d]) / T + 2 + (g.periodic[d] ? 4 : 0);
+    // partial last tile before a seam would fall between two of them; not needed when T divides n)
+    steps[d] = (2 * g.msize[d]) / T + 2 + ((g.periodic[d] && g.n[d] % T != 0) ? 4 : 0);
     combos *= steps[d];
   }
   const long long id = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -2021,7 +2036,7 @@ long long mark_tiles_threads(const Geom &g, long long nh) {
   long long combos = 1;
   for (int d = 0; d < g.dim; d++) {
     const int T = (g.dim == 1) ? Tile<1>::T[d] : (g.dim == 2) ? Tile<2>::T[d] : Tile<3>::T[d];
-    combos *= (2 * g.msize[d]) / T + 2 + (g.periodic[d] ? 4 : 0);
+    combos *= (2 * g.msize[d]) / T + 2 + ((g.periodic[d] && g.n[d] % T != 0) ? 4 : 0);
   }
   return nh * combos;
 }
