@@ -482,6 +482,7 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
 
 // gaussian_grid.h:378-435.  libm erf/exp on the host: table bits equal the reference's.
 int edm_hip_gauss_set_boundary(edm_hip_gauss *g, const double *min, const double *max, const int *periodic) {
+  g->tiles_per_hill = 0;  // (cached bound: recomputed for the new geometry on demand)
   Geom &q = g->g;
   for (int d = 0; d < q.dim; d++) {
     q.bmin[d] = min[d];
@@ -689,6 +690,63 @@ double pair_forces_finish(const edm_hip_gauss *g, int nblk) {
 }
 
 static const long long SMALL_BATCH = 4096;  // read-back of a batch this small is one async burst
+
+// Upper bound on the tiles one hill can mark (k_mark_tiles keeps the tiles of the stencil's bounding box whose
+// nearest node lies inside the dp2 < 8 ball): the maximum, over every alignment of the hill's centre node
+// within its tile, of the tiles whose distance to the hill's CELL (the hill sits anywhere in it) passes the
+// same test.  The launch bound of a culled gather is this times the hill count -- idle workgroups of an
+// over-sized launch cost ~2 ns each, which is what a 3-D batch of 250 hills would otherwise mostly pay for.
+static long long tiles_per_hill_bound(const Geom &q) {
+  static const int T1[3] = {256, 1, 1}, T2[3] = {16, 16, 1}, T3[3] = {8, 8, 4};
+  const int *T = q.dim == 1 ? T1 : q.dim == 2 ? T2 : T3;
+  const int dim = q.dim;
+  // per dimension and alignment: for each candidate tile offset, the squared gap (in sigma units)
+  std::vector<std::vector<std::vector<double> > > gap2(dim);
+  for (int d = 0; d < dim; d++) {
+    const int m = q.msize[d];
+    gap2[d].resize(T[d]);
+    for (int a = 0; a < T[d]; a++) {  // centre node at offset a inside its tile (tile origin = -a)
+      const int first = (int)floor((double)(-m + a) / T[d]), last = (int)floor((double)(m + a) / T[d]);
+      for (int k = first; k <= last; k++) {
+        const double lo = (double)k * T[d] - a, hi = lo + T[d] - 1;  // tile node range relative to the centre node
+        double gap = 0;
+        if (lo > 1.0) gap = lo - 1.0;   // the hill lies in [0, 1) node units from its centre node
+        if (hi < 0.0) gap = 0.0 - hi;
+        gap *= q.dx[d] / q.sigma[d];
+        gap2[d][a].push_back(gap * gap);
+      }
+    }
+  }
+  long long best = 0;
+  const double cut = 8.0 * (1.0 + 1e-6);
+  for (int a0 = 0; a0 < T[0]; a0++)
+    for (int a1 = 0; a1 < (dim > 1 ? T[1] : 1); a1++)
+      for (int a2 = 0; a2 < (dim > 2 ? T[2] : 1); a2++) {
+        long long cnt = 0;
+        const std::vector<double> &g0 = gap2[0][a0];
+        for (size_t i = 0; i < g0.size(); i++) {
+          if (dim == 1) {
+            if (g0[i] < cut) cnt++;
+            continue;
+          }
+          const std::vector<double> &g1 = gap2[1][a1];
+          for (size_t j = 0; j < g1.size(); j++) {
+            if (dim == 2) {
+              if (g0[i] + g1[j] < cut) cnt++;
+              continue;
+            }
+            const std::vector<double> &g2v = gap2[2][a2];
+            for (size_t k = 0; k < g2v.size(); k++)
+              if (g0[i] + g1[j] + g2v[k] < cut) cnt++;
+          }
+        }
+        if (cnt > best) best = cnt;
+      }
+  // a periodic seam that cuts a partial tile splits one tile of the count in two, per such dimension
+  for (int d = 0; d < dim; d++)
+    if (q.periodic[d] && q.n[d] % T[d] != 0) best += best;  // (generous: rare geometry)
+  return best;
+}
 
 int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool want_total) {
   const Geom &q = g->g;
@@ -918,12 +976,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       plan.partial = ws.partial.p;
     }
   } else if (ntiles > 2048) {
-    static const int T1[3] = {256, 1, 1}, T2[3] = {16, 16, 1}, T3[3] = {8, 8, 4};
-    const int *T = q.dim == 1 ? T1 : q.dim == 2 ? T2 : T3;
-    long long per_hill = 1;
-    // distinct tiles a hill can touch: 2m+1 nodes span at most 2m/T + 2 tiles, one more when a periodic seam
-    // cuts a partial tile (idle workgroups of an over-sized launch are not free: ~2 ns each)
-    for (int d = 0; d < q.dim; d++) per_hill *= (2 * q.msize[d]) / T[d] + 2 + ((q.periodic[d] && q.n[d] % T[d] != 0) ? 1 : 0);
+    if (g->tiles_per_hill <= 0) g->tiles_per_hill = tiles_per_hill_bound(q);
+    long long per_hill = g->tiles_per_hill;
     bool narrow = true;  // (a stencil wider than a periodic dimension crosses more than one seam: no culling)
     for (int d = 0; d < q.dim; d++)
       if (q.periodic[d] && 2 * q.msize[d] + 1 > q.n[d]) narrow = false;

@@ -104,6 +104,7 @@ struct edm_hip_gauss {
   char *d_stage = nullptr;               // its device-side address
   size_t h_stage_bytes = 0;
   int *d_dirty = nullptr;
+  long long tiles_per_hill = 0;          // cached tiles_per_hill_bound() of the current geometry / boundary
   int *d_tickets = nullptr;              // three last-workgroup tickets (EDM_TICKET_INTS ints each), kept zero
   // bench support: HIP events around the dominant lookup kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -1603,16 +1603,12 @@ struct PostArgs {
 template <int DIM, int MODE, int PARTS>
 __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t, double *__restrict__ rec,
                                                  const HillList &h, const HillHeights &hh, const GatherPlan &plan,
-                                                 int use_list, int *__restrict__ dirty_flag, int coherent) {
+                                                 int use_list, int *__restrict__ dirty_flag, int coherent,
+                                                 long long tile) {
   constexpr int R = (DIM == 1) ? 2 : 4;
   const int tnode = threadIdx.x % BLOCK;   // this thread's node within the tile
   const int part = threadIdx.x / BLOCK;    // ... and its share of the hill batches
-  long long tile = blockIdx.x;
-  if (use_list) {
-    if (tile >= plan.tile_list[gather_tiles_dev(g)]) return;
-    tile = plan.tile_list[tile];
-    if (threadIdx.x == 0) plan.tile_flags[tile] = 0;  // (k_mark_tiles relies on an all-zero flag array)
-  }
+  if (use_list && threadIdx.x == 0) plan.tile_flags[tile] = 0;  // (k_mark_tiles relies on an all-zero flag array)
   // tile origin and this thread's node
   int t0[DIM], p[DIM], tcoord[DIM];
   {
@@ -1905,7 +1901,18 @@ template <int DIM, int MODE, int PARTS>
 __global__ void __launch_bounds__(BLOCK * PARTS) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
                                                                HillHeights hh, GatherPlan plan, int use_list,
                                                                int *__restrict__ dirty_flag, PostArgs post) {
-  hill_gather_body<DIM, MODE, PARTS>(g, t, rec, h, hh, plan, use_list, dirty_flag, (MODE == 0) ? post.enabled : 0);
+  if (use_list) {
+    // culled launch: the workgroups share the listed tiles (one each when the launch bound holds, which it
+    // does by construction -- the stride loop keeps the result right even if a bound were ever too small)
+    const long long count = plan.tile_list[gather_tiles_dev(g)];
+    for (long long i = blockIdx.x; i < count; i += gridDim.x) {
+      hill_gather_body<DIM, MODE, PARTS>(g, t, rec, h, hh, plan, 1, dirty_flag, (MODE == 0) ? post.enabled : 0,
+                                         plan.tile_list[i]);
+      __syncthreads();  // (the body's LDS staging is reused by the next tile)
+    }
+  } else {
+    hill_gather_body<DIM, MODE, PARTS>(g, t, rec, h, hh, plan, 0, dirty_flag, (MODE == 0) ? post.enabled : 0, blockIdx.x);
+  }
   if (MODE == 0 && post.enabled) {
     // boundary duplication (K6) and the histogram updates (K7) by the last workgroup to finish
     if (!last_block_done(post.ticket, gridDim.x * gridDim.y)) return;
