@@ -1223,7 +1223,9 @@ __device__ __forceinline__ void term_const(const Geom &g, TermConst<DIM> &tc) {
   }
 }
 
-template <int DIM>
+// PERB: every boundary dimension is periodic (no walls, no McGovern-De Pablo terms) -- known at compile time so
+// that the wall blends, table reads and their registers disappear; the arithmetic that remains is unchanged
+template <int DIM, bool PERB = false>
 __device__ __forceinline__ void node_terms(const Geom &g, const Tables &t, const int *p, NodeTerms<DIM> &nt) {
   nt.inside = true;
   double running = 1.0;
@@ -1234,7 +1236,7 @@ __device__ __forceinline__ void node_terms(const Geom &g, const Tables &t, const
     nt.t2[d] = nt.t4[d] = nt.t6[d] = nt.t7[d] = 0;
     nt.dden[d] = 0;
     double factor = sqrt(M_PI) * g.sigma[d];
-    if (!g.bper[d]) {
+    if (!PERB && !g.bper[d]) {
       factor = 1.0;
       if (xx < g.bmin[d] || xx > g.bmax[d]) {
         nt.inside = false;
@@ -1260,7 +1262,7 @@ __device__ __forceinline__ void node_terms(const Geom &g, const Tables &t, const
 // the node is outside the hill's support (dp2 >= 8).  Same formulas as gaussian_grid.h:284-355 with
 // every division replaced by a multiplication with a node- or launch-constant reciprocal (values
 // move by ~1e-16 relative; the accumulation ORDER over hills is untouched).
-template <int DIM>
+template <int DIM, bool PERB = false>
 __device__ __forceinline__ bool pair_term(const Geom &g, const TermConst<DIM> &tc, const NodeTerms<DIM> &nt,
                                           const double *hx, const double *ht, double &val, double *dval,
                                           bool &corr_nonzero) {
@@ -1299,7 +1301,7 @@ __device__ __forceinline__ bool pair_term(const Geom &g, const TermConst<DIM> &t
 #pragma unroll
   for (int d = 0; d < DIM; d++) {
     force[d] = 0;
-    if (!g.bper[d]) {
+    if (!PERB && !g.bper[d]) {
       const double t1 = ht[2 * d], t3 = ht[2 * d + 1];
       corr = (t1 - expo) * nt.t2[d] + (t3 - expo) * nt.t4[d];  // overwritten per dim (:316)
       const double t5 = -2 * dp[d] * tc.inv_sigma[d];
@@ -1315,7 +1317,7 @@ __device__ __forceinline__ bool pair_term(const Geom &g, const TermConst<DIM> &t
   val = expo + corr;
 #pragma unroll
   for (int d = 0; d < DIM; d++) {
-    if (g.bper[d])
+    if (PERB || g.bper[d])
       dval[d] = -(2 * dp[d] * tc.inv_sigma[d] * expo);
     else
       dval[d] = force[d];
@@ -1338,7 +1340,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            const long long *nh_dev);
 
 // `la` (TPH == BLOCK only): the ordered limiter is chained onto the last workgroup to finish
-template <int DIM, int TPH>
+template <int DIM, int TPH, bool PERB>
 __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(Geom g, Tables t, HillList h,
                                                                                 const double *__restrict__ heights,
                                                                                 double h_const,
@@ -1422,11 +1424,11 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
         if (skip) continue;
         if (ball_ok && dp2_est > 8.0 * (1.0 + 1e-6)) continue;  // conservative: the exact test is in pair_term (:294)
         NodeTerms<DIM> nt;
-        node_terms<DIM>(g, t, p, nt);
+        node_terms<DIM, PERB>(g, t, p, nt);
         if (!nt.inside) continue;
         double val, dval[DIM];
         bool nz;
-        if (!pair_term<DIM>(g, tc, nt, hx, ht, val, dval, nz)) continue;
+        if (!pair_term<DIM, PERB>(g, tc, nt, hx, ht, val, dval, nz)) continue;
         term[u] = height * val * vol;
       }
 #pragma unroll
@@ -1465,21 +1467,34 @@ hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList 
     la = *chain;
     la.enabled = 1;
   }
+  bool perb = true;
+  for (int d = 0; d < g.dim; d++)
+    if (!g.bper[d]) perb = false;
+#define EDM_INTEGRALS(D, TPHV, NTV, NB)                                                                            \
+  do {                                                                                                             \
+    if (perb)                                                                                                      \
+      hipLaunchKernelGGL((k_hill_integrals<D, TPHV, true>), dim3(NB), dim3(NTV), 0, s, g, t, h, heights, h_const,  \
+                         added, la);                                                                               \
+    else                                                                                                           \
+      hipLaunchKernelGGL((k_hill_integrals<D, TPHV, false>), dim3(NB), dim3(NTV), 0, s, g, t, h, heights, h_const, \
+                         added, la);                                                                               \
+  } while (0)
   if (h.nh <= 2048) {
     const unsigned nb = (unsigned)h.nh;
     switch (g.dim) {
-      case 1: hipLaunchKernelGGL((k_hill_integrals<1, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
-      case 2: hipLaunchKernelGGL((k_hill_integrals<2, BLOCK>), dim3(nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
-      default: hipLaunchKernelGGL((k_hill_integrals<3, 2 * BLOCK>), dim3(nb), dim3(2 * BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
+      case 1: EDM_INTEGRALS(1, BLOCK, BLOCK, nb); break;
+      case 2: EDM_INTEGRALS(2, BLOCK, BLOCK, nb); break;
+      default: EDM_INTEGRALS(3, 2 * BLOCK, 2 * BLOCK, nb); break;
     }
   } else {
-    const long long nb = (h.nh + (BLOCK / 64) - 1) / (BLOCK / 64);
+    const unsigned nb = (unsigned)((h.nh + (BLOCK / 64) - 1) / (BLOCK / 64));
     switch (g.dim) {
-      case 1: hipLaunchKernelGGL((k_hill_integrals<1, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
-      case 2: hipLaunchKernelGGL((k_hill_integrals<2, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
-      default: hipLaunchKernelGGL((k_hill_integrals<3, 64>), dim3((unsigned)nb), dim3(BLOCK), 0, s, g, t, h, heights, h_const, added, la); break;
+      case 1: EDM_INTEGRALS(1, 64, BLOCK, nb); break;
+      case 2: EDM_INTEGRALS(2, 64, BLOCK, nb); break;
+      default: EDM_INTEGRALS(3, 64, BLOCK, nb); break;
     }
   }
+#undef EDM_INTEGRALS
   return hipGetLastError();
 }
 
@@ -1600,7 +1615,7 @@ struct PostArgs {
 // batch of the tile's hill list for its node and the parts are combined in LDS in a fixed order.  A
 // node's serial chain is its number of overlapping hills: on the 1-D grid (hills pile up where the pair
 // density is high, 40+ per tile at r ~ 2.7 against 10 at r ~ 1.3) this quarters the critical path.
-template <int DIM, int MODE, int PARTS>
+template <int DIM, int MODE, int PARTS, bool PERB>
 __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t, double *__restrict__ rec,
                                                  const HillList &h, const HillHeights &hh, const GatherPlan &plan,
                                                  int use_list, int *__restrict__ dirty_flag, int coherent,
@@ -1637,7 +1652,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   }
   NodeTerms<DIM> nt;
   if (active) {
-    node_terms<DIM>(g, t, p, nt);
+    node_terms<DIM, PERB>(g, t, p, nt);
     if (!nt.inside) active = false;
   }
   // (limiter result and hill count in one round trip: the kernel is a chain of dependent loads)
@@ -1688,7 +1703,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   // -- accumulating strictly in list order: the sums are those of the sequential reference.
   __shared__ int s_c[BLOCK][DIM];
   __shared__ double s_x[BLOCK][DIM];
-  __shared__ double s_t[BLOCK][2 * DIM];
+  __shared__ double s_t[PERB ? 1 : BLOCK][2 * DIM];  // (hill-side wall exponentials: none without walls)
   __shared__ double s_h1[BLOCK], s_h2[BLOCK];
   __shared__ int s_wcnt[BLOCK / 64];
   __shared__ long long s_id[(MODE == 1) ? BLOCK : 1];
@@ -1697,7 +1712,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   __shared__ int s_ptouch[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? BLOCK : 1];
   TermConst<DIM> tc;
   term_const<DIM>(g, tc);
-  constexpr int ILP = 4;
+  constexpr int ILP = (DIM == 1) ? 4 : 2;  // (2-D/3-D tiles meet one to three hills of a sparse batch; fewer live registers, more workgroups per CU)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long long base = hbeg; base < hend; base += BLOCK) {
     const long long cur = base + tnode;
@@ -1714,8 +1729,10 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
         c[d] = h.hc[cur * DIM + d];
         if (DIM == 1) {
           hx_r[d] = h.hx[cur * DIM + d];
-          ht_r[2 * d] = h.ht[cur * 2 * DIM + 2 * d];
-          ht_r[2 * d + 1] = h.ht[cur * 2 * DIM + 2 * d + 1];
+          if (!PERB) {
+            ht_r[2 * d] = h.ht[cur * 2 * DIM + 2 * d];
+            ht_r[2 * d + 1] = h.ht[cur * 2 * DIM + 2 * d + 1];
+          }
         }
       }
       const double hb = hh.h ? hh.h[cur] : hh.h_const;
@@ -1738,8 +1755,10 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
 #pragma unroll
           for (int d = 0; d < DIM; d++) {
             hx_r[d] = h.hx[cur * DIM + d];
-            ht_r[2 * d] = h.ht[cur * 2 * DIM + 2 * d];
-            ht_r[2 * d + 1] = h.ht[cur * 2 * DIM + 2 * d + 1];
+            if (!PERB) {
+              ht_r[2 * d] = h.ht[cur * 2 * DIM + 2 * d];
+              ht_r[2 * d + 1] = h.ht[cur * 2 * DIM + 2 * d + 1];
+            }
           }
         }
         if (take) {
@@ -1775,8 +1794,10 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       for (int d = 0; d < DIM; d++) {
         s_c[pos][d] = c[d];
         s_x[pos][d] = hx_r[d];
-        s_t[pos][2 * d] = ht_r[2 * d];
-        s_t[pos][2 * d + 1] = ht_r[2 * d + 1];
+        if (!PERB) {
+          s_t[pos][2 * d] = ht_r[2 * d];
+          s_t[pos][2 * d + 1] = ht_r[2 * d + 1];
+        }
       }
       s_h1[pos] = h1;
       s_h2[pos] = h2;
@@ -1795,7 +1816,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
 #pragma unroll
             for (int d = 0; d < DIM; d++) m *= images(g, d, s_c[q0 + q][d], p[d], p[d]);
             bool nz = false;
-            if (m > 0 && pair_term<DIM>(g, tc, nt, s_x[q0 + q], s_t[q0 + q], val[q], dval[q], nz)) {
+            if (m > 0 && pair_term<DIM, PERB>(g, tc, nt, s_x[q0 + q], s_t[PERB ? 0 : q0 + q], val[q], dval[q], nz)) {
               mult[q] = m;
               any_corr |= nz;
               touched = true;
@@ -1897,7 +1918,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   }
 }
 
-template <int DIM, int MODE, int PARTS>
+template <int DIM, int MODE, int PARTS, bool PERB>
 __global__ void __launch_bounds__(BLOCK * PARTS) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
                                                                HillHeights hh, GatherPlan plan, int use_list,
                                                                int *__restrict__ dirty_flag, PostArgs post) {
@@ -1906,17 +1927,17 @@ __global__ void __launch_bounds__(BLOCK * PARTS) k_hill_gather(Geom g, Tables t,
     // does by construction -- the stride loop keeps the result right even if a bound were ever too small)
     const long long count = plan.tile_list[gather_tiles_dev(g)];
     for (long long i = blockIdx.x; i < count; i += gridDim.x) {
-      hill_gather_body<DIM, MODE, PARTS>(g, t, rec, h, hh, plan, 1, dirty_flag, (MODE == 0) ? post.enabled : 0,
+      hill_gather_body<DIM, MODE, PARTS, PERB>(g, t, rec, h, hh, plan, 1, dirty_flag, (MODE == 0) ? post.enabled : 0,
                                          plan.tile_list[i]);
       __syncthreads();  // (the body's LDS staging is reused by the next tile)
     }
   } else {
-    hill_gather_body<DIM, MODE, PARTS>(g, t, rec, h, hh, plan, 0, dirty_flag, (MODE == 0) ? post.enabled : 0, blockIdx.x);
+    hill_gather_body<DIM, MODE, PARTS, PERB>(g, t, rec, h, hh, plan, 0, dirty_flag, (MODE == 0) ? post.enabled : 0, blockIdx.x);
   }
   if (MODE == 0 && post.enabled) {
     // boundary duplication (K6) and the histogram updates (K7) by the last workgroup to finish
     if (!last_block_done(post.ticket, gridDim.x * gridDim.y)) return;
-    if (acquire(dirty_flag) != 0) {
+    if (!PERB && acquire(dirty_flag) != 0) {   // (no walls, no boundary corrections, nothing to duplicate)
       duplicate_boundary_block(g, rec, post.dp);
       __syncthreads();
       if (threadIdx.x == 0) *dirty_flag = 0;
@@ -2078,12 +2099,25 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
     use_list = 1;
     launch_tiles = plan.tile_bound < ntiles ? plan.tile_bound : ntiles;
   }
-  if (DIM == 1 && !use_list)
-    hipLaunchKernelGGL((k_hill_gather<DIM, 0, (DIM == 1) ? 4 : 1>), dim3((unsigned)launch_tiles, (unsigned)plan.groups),
-                       dim3(BLOCK * 4), 0, s, g, t, rec, h, hh, plan, use_list, dirty_flag, post);
-  else
-    hipLaunchKernelGGL((k_hill_gather<DIM, 0, 1>), dim3((unsigned)launch_tiles, (unsigned)plan.groups), dim3(BLOCK), 0, s, g, t,
-                       rec, h, hh, plan, use_list, dirty_flag, post);
+  bool perb = true;
+  for (int d = 0; d < DIM; d++)
+    if (!g.bper[d]) perb = false;
+  const dim3 grid((unsigned)launch_tiles, (unsigned)plan.groups);
+  if (DIM == 1 && !use_list) {
+    if (perb)
+      hipLaunchKernelGGL((k_hill_gather<DIM, 0, (DIM == 1) ? 4 : 1, true>), grid, dim3(BLOCK * 4), 0, s, g, t, rec, h, hh, plan,
+                         use_list, dirty_flag, post);
+    else
+      hipLaunchKernelGGL((k_hill_gather<DIM, 0, (DIM == 1) ? 4 : 1, false>), grid, dim3(BLOCK * 4), 0, s, g, t, rec, h, hh, plan,
+                         use_list, dirty_flag, post);
+  } else {
+    if (perb)
+      hipLaunchKernelGGL((k_hill_gather<DIM, 0, 1, true>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, use_list, dirty_flag,
+                         post);
+    else
+      hipLaunchKernelGGL((k_hill_gather<DIM, 0, 1, false>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, use_list, dirty_flag,
+                         post);
+  }
   if (plan.groups > 1)
     hipLaunchKernelGGL(k_reduce_partials, dim3(blocks_for(g.total * g.rec)), dim3(BLOCK), 0, s, g, rec, plan.partial,
                        plan.groups, hh.res_dev, plan.adaptive, h.nh, h.nh_dev);
@@ -2143,9 +2177,9 @@ hipError_t launch_hill_gather_fused(const Geom &g, const Tables &t, const HillLi
   PostArgs nopost;
   memset(&nopost, 0, sizeof(nopost));
   switch (g.dim) {
-    case 1: hipLaunchKernelGGL((k_hill_gather<1, 1, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
-    case 2: hipLaunchKernelGGL((k_hill_gather<2, 1, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
-    default: hipLaunchKernelGGL((k_hill_gather<3, 1, 1>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
+    case 1: hipLaunchKernelGGL((k_hill_gather<1, 1, 1, false>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
+    case 2: hipLaunchKernelGGL((k_hill_gather<2, 1, 1, false>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
+    default: hipLaunchKernelGGL((k_hill_gather<3, 1, 1, false>), grid, dim3(BLOCK), 0, s, g, t, (double *)nullptr, h, hh, plan, 0, dirty_flag, nopost); break;
   }
   hipLaunchKernelGGL(k_sum_slots, dim3(blocks_for(h.nh)), dim3(BLOCK), 0, s, h.nh, plan.slots_per_hill, plan.slots, added);
   return hipGetLastError();
@@ -2165,9 +2199,9 @@ hipError_t launch_hill_gather_correct_and_apply(const Geom &g, const Tables &t, 
     PostArgs nopost;
     memset(&nopost, 0, sizeof(nopost));
     switch (g.dim) {
-      case 1: hipLaunchKernelGGL((k_hill_gather<1, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
-      case 2: hipLaunchKernelGGL((k_hill_gather<2, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
-      default: hipLaunchKernelGGL((k_hill_gather<3, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
+      case 1: hipLaunchKernelGGL((k_hill_gather<1, 2, 1, false>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
+      case 2: hipLaunchKernelGGL((k_hill_gather<2, 2, 1, false>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
+      default: hipLaunchKernelGGL((k_hill_gather<3, 2, 1, false>), grid, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan, 0, dirty_flag, nopost); break;
     }
     groups += 1;
   }
@@ -2188,9 +2222,9 @@ hipError_t launch_hill_gather_correction(const Geom &g, const Tables &t, const H
   memset(&nopost, 0, sizeof(nopost));
   double *none = nullptr;
   switch (g.dim) {
-    case 1: hipLaunchKernelGGL((k_hill_gather<1, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
-    case 2: hipLaunchKernelGGL((k_hill_gather<2, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
-    default: hipLaunchKernelGGL((k_hill_gather<3, 2, 1>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
+    case 1: hipLaunchKernelGGL((k_hill_gather<1, 2, 1, false>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
+    case 2: hipLaunchKernelGGL((k_hill_gather<2, 2, 1, false>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
+    default: hipLaunchKernelGGL((k_hill_gather<3, 2, 1, false>), grid, dim3(BLOCK), 0, s, g, t, none, h, hh, plan, 0, dirty_flag, nopost); break;
   }
   return hipGetLastError();
 }
