@@ -359,7 +359,35 @@ def main():
             H.synchronize()
             t_h = (time.perf_counter() - t3) / reps
             gbs = per_atom * natoms / (ms / ln * 1e-3) / 1e9
-            nd[tag] = dict(atoms=natoms, lookup_kernel_us=ms / ln * 1e3, million_atom_evals_per_s=natoms / (ms / ln * 1e-3) / 1e6,
+            # one hill-depositing fix edm step on this grid (W3 / W4 of SURVEY 8d): update_forces over all atoms +
+            # add_hills (hill_density 250; W4: bias_per_step = 0.4 x the expected per-step sum, so the limiter and
+            # the overflow buffer work every step) through edm_hip_bias_step, atoms resident in HBM
+            cfgp = os.path.join(tmpdir, "bench_%s.edm" % tag)
+            with open(cfgp, "w") as fh:
+                fh.write("tempering 0\nhill_prefactor %g\nhill_density 250\n%sdimension %d\nbox_low %s\nbox_high %s\n"
+                         "bias_spacing %s\nbias_sigma %s\nhills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (
+                             0.02 if dim == 3 else 0.5, "bias_per_step 0.008\n" if dim == 3 else "", dim,
+                             " ".join("0" for _ in range(dim)), " ".join("64" for _ in range(dim)),
+                             " ".join("%.10g" % v for v in c["spacing"]), " ".join("%.10g" % v for v in c["sigma"]),
+                             tmpdir, tag, tmpdir, tag))
+            bb = H.Bias(cfgp)
+            bb.setup(1.0, 1.0)
+            bb.subdivide([0.0] * dim, [64.0] * dim, [0.0] * dim, [64.0] * dim, [1] * dim, [0.0] * dim)
+            bb.set_hill_log(False)
+            d_fs = H.DeviceArray.zeros((natoms, 3))
+            for _ in range(3):
+                bb.step_device(d_x, 3, d_fs, 3, natoms, d_uu, -1, natoms)
+            H.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(20):
+                bb.step_device(d_x, 3, d_fs, 3, natoms, d_uu, -1, natoms)
+            H.synchronize()
+            t_step = (time.perf_counter() - t4) / 20
+            hills_step = bb.get("hills_added") / 23.0
+            del bb
+            nd[tag] = dict(atoms=natoms, lookup_kernel_us=ms / ln * 1e3,
+                           step_ms=t_step * 1e3, step_million_atom_evals_per_s=natoms / t_step / 1e6,
+                           step_hills_added_avg=hills_step, million_atom_evals_per_s=natoms / (ms / ln * 1e-3) / 1e6,
                            algorithmic_bytes_per_atom=per_atom, achieved_GBs=gbs, frac_of_hbm_peak=gbs / HBM_PEAK_GBS,
                            lookup_kernel_us_bin_sorted_atoms=ms_s / ln_s * 1e3,
                            frac_of_hbm_peak_bin_sorted_atoms=per_atom * natoms / (ms_s / ln_s * 1e-3) / 1e9 / HBM_PEAK_GBS,

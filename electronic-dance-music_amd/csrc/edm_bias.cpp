@@ -62,6 +62,8 @@ struct edm_hip_bias {
   DevBuf<double> hx0;
   DevBuf<double> xchg_send, xchg_recv, xchg_all;
   long long xchg_counts[EDM_MAX_RANKS], xchg_est[EDM_MAX_RANKS];  // last synchronous exchange: per-rank hills / est_hill_count
+  double *h_flush = nullptr;   // pinned staging of the overflow records handed to a flush
+  size_t flush_cap = 0;
   bool force_sync = false;      // redo of a deferred step whose launch bound proved too small
   int debug_virtual_ranks = 0;  // tests: a one-rank communicator's packet is replicated, emulating that many ranks
   DevBuf<long long> xchg_cnt;
@@ -235,6 +237,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   edm_hip_grid_destroy(b->target);
   if (b->hills_fp) fclose(b->hills_fp);
   b->sel.release(); b->sel_scratch.release(); b->count_dev.release(); b->sel_stage.release();
+  if (b->h_flush) (void)hipHostFree(b->h_flush);
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
   delete b;
@@ -363,22 +366,27 @@ static int flush_overflow(edm_hip_bias *b, double max_bias, double *bias_added) 
     if (b->overflow_left == b->overflow_right) b->overflow_left = b->overflow_right = 0;
     return EDM_HIP_OK;
   }
-  std::vector<double> xs((size_t)n * b->dim), hs((size_t)n);
+  // positions and heights of the buffered hills: packed [x ... | h ...] in pinned memory, ONE H2D copy
+  const size_t nx = (size_t)n * b->dim, ntot = nx + (size_t)n;
+  if (b->flush_cap < ntot) {
+    if (b->h_flush) (void)hipHostFree(b->h_flush);
+    b->h_flush = nullptr;
+    b->flush_cap = ntot + ntot / 2 + 64;
+    EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_flush), sizeof(double) * b->flush_cap, hipHostMallocDefault));
+  }
   for (long long i = 0; i < n; i++) {
     const double *rec = &b->overflow[(b->overflow_left + (size_t)i) * w];
-    for (unsigned int d = 0; d < b->dim; d++) xs[(size_t)i * b->dim + d] = rec[d];
-    hs[(size_t)i] = rec[b->dim];
+    for (unsigned int d = 0; d < b->dim; d++) b->h_flush[(size_t)i * b->dim + d] = rec[d];
+    b->h_flush[nx + (size_t)i] = rec[b->dim];
   }
   hipStream_t s = b->bias->stream;
-  EDM_HIP_TRY(b->stage_x.reserve(xs.size()));
-  EDM_HIP_TRY(b->stage_h.reserve(hs.size()));
-  EDM_HIP_TRY(hipMemcpyAsync(b->stage_x.p, xs.data(), sizeof(double) * xs.size(), hipMemcpyHostToDevice, s));
-  EDM_HIP_TRY(hipMemcpyAsync(b->stage_h.p, hs.data(), sizeof(double) * hs.size(), hipMemcpyHostToDevice, s));
+  EDM_HIP_TRY(b->stage_x.reserve(ntot));
+  EDM_HIP_TRY(hipMemcpyAsync(b->stage_x.p, b->h_flush, sizeof(double) * ntot, hipMemcpyHostToDevice, s));
   ApplySpec spec;
   spec.nh = n;
   spec.d_x = b->stage_x.p;
   spec.x_stride = (int)b->dim;
-  spec.d_h = b->stage_h.p;
+  spec.d_h = b->stage_x.p + nx;
   spec.limited = true;
   spec.flush_mode = 1;
   spec.limit = max_bias;

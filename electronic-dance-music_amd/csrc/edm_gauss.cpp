@@ -944,6 +944,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   plan.partial = nullptr;
   plan.tile_flags = nullptr;
   plan.tile_list = nullptr;
+  plan.tile_parity = 0;
   plan.tile_bound = 0;
   const long long ntiles = gather_tiles(q);
   if (fused) {
@@ -981,12 +982,21 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     bool narrow = true;  // (a stencil wider than a periodic dimension crosses more than one seam: no culling)
     for (int d = 0; d < q.dim; d++)
       if (q.periodic[d] && 2 * q.msize[d] + 1 > q.n[d]) narrow = false;
-    if (narrow && nh * per_hill < ntiles / 2) {
+    // a batch queued against a launch bound (deferred count) is sized by its EXPECTED hill count: the
+    // workgroups of a culled gather stride over the tile list, so an optimistic launch stays correct
+    long long plan_nh = nh;
+    if (spec.d_nh && spec.expected_nh >= 0) {
+      const long long e = (long long)(1.5 * spec.expected_nh) + 64;
+      if (e < plan_nh) plan_nh = e;
+    }
+    if (narrow && plan_nh * per_hill < ntiles / 2) {
       EDM_HIP_TRY(ws.tile_flags.reserve_zeroed((size_t)ntiles));
-      EDM_HIP_TRY(ws.tile_list.reserve((size_t)ntiles + 1));
+      EDM_HIP_TRY(ws.tile_list.reserve_zeroed((size_t)ntiles + 2));
       plan.tile_flags = ws.tile_flags.p;
       plan.tile_list = ws.tile_list.p;
-      plan.tile_bound = nh * per_hill;
+      plan.tile_parity = ws.tile_parity;
+      ws.tile_parity ^= 1;
+      plan.tile_bound = plan_nh * per_hill;
     }
   }
   const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;

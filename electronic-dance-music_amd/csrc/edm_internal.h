@@ -60,6 +60,7 @@ struct DevBuf {
 struct HillWorkspace {
   DevBuf<double> hx, hx0, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum, heights, slots, delta;
   DevBuf<int> hc, tail_flags, tile_flags, tile_list;
+  int tile_parity = 0;      // which of tile_list's two counters the next culled gather uses
   DevBuf<char> result;      // LimitResult
   DevBuf<char> rb;          // packed read-back region of small batches (one D2H instead of six)
   void release();

@@ -148,7 +148,9 @@ struct GatherPlan {
                           // batch queued with a deferred count is split exactly as if the count had been known
   double *partial;        // [groups (+1)][total][rec] when groups > 1 or in fused mode
   int *tile_flags;        // [ntiles] scratch when culling, else NULL
-  int *tile_list;         // [ntiles + 1] (list + count at the end)
+  int *tile_list;         // [ntiles + 2]: list, then two counters used alternately (each k_mark_tiles launch
+                          // zeroes the counter of the NEXT batch, so no memset precedes it); kept zero in between
+  int tile_parity;        // which counter this batch uses
   long long tile_bound;   // launch bound for culled gathers
   // fused mode (dense batches on small grids): the gather runs BEFORE the limiter with the base
   // heights, writes per-group deltas and, as a by-product, the per-(hill, tile) pieces of each

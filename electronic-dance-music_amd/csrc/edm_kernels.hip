@@ -984,9 +984,6 @@ template <int DIM>
 __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, HillList h) {
   __shared__ int s_w[BLOCK / 64];
   __shared__ long long s_carry;
-  __shared__ int s_big[BLOCK];
-  __shared__ long long s_big_off[BLOCK];
-  __shared__ int s_nbig;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {
     const long long base = (long long)blockIdx.x * SEL_CHUNK + (long long)threadIdx.x * SEL_PER_THREAD;
@@ -1021,77 +1018,66 @@ __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, Hil
   if (!last_block_done(a.ticket, gridDim.x)) return;
 
   // scan of the per-workgroup counts: every thread takes PERC consecutive workgroups and requests their
-  // counts together (one memory round trip per BLOCK * PERC workgroups; 512 workgroups = one pass)
+  // counts together (one memory round trip per BLOCK * PERC workgroups; 512 workgroups = one pass), the
+  // exclusive offsets go to LDS, and the accepted samples of the pass are then dealt out evenly -- thread t
+  // takes output slots t, t + BLOCK, ... and finds each one's workgroup by bisection -- so a workgroup
+  // that accepted many samples costs no more than one that accepted one
   const int nblocks = (int)gridDim.x;
   const long long bound = h.nh;
   constexpr int PERC_MAX = 8;
   int PERC = (nblocks + BLOCK - 1) / BLOCK;
   if (PERC > PERC_MAX) PERC = PERC_MAX;
+  __shared__ int s_off[BLOCK * PERC_MAX + 1];
+  __shared__ int s_ws[BLOCK / 64];
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
   for (int bb = 0; bb < nblocks; bb += BLOCK * PERC) {
     const int blk0 = bb + threadIdx.x * PERC;
     int cj[PERC_MAX];
-    long long c = 0;
+    int c = 0;
 #pragma unroll
     for (int j = 0; j < PERC_MAX; j++) {
       cj[j] = (j < PERC && blk0 + j < nblocks) ? acquire(&a.counts[blk0 + j]) : 0;
       c += cj[j];
     }
-    long long inc = c;
+    int inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const long long up = __shfl_up(inc, o, 64);
+      const int up = __shfl_up(inc, o, 64);
       if (lane >= o) inc += up;
     }
-    __shared__ long long s_ws[BLOCK / 64];
     if (lane == 63) s_ws[wave] = inc;
-    if (threadIdx.x == 0) s_nbig = 0;
     __syncthreads();
-    long long off = s_carry;
-    for (int w = 0; w < wave; w++) off += s_ws[w];
-    off += inc - c;
-    const long long off_end = off + c;
+    int off = inc - c;
+    int pass_total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) {
+      if (w < wave) off += s_ws[w];
+      pass_total += s_ws[w];
+    }
 #pragma unroll
     for (int j = 0; j < PERC_MAX; j++) {
-      const int cc = cj[j];
-      if (cc > 0 && off < bound) {
-        const int blk = blk0 + j;
-        if (cc <= 4) {
-          for (long long e = 0; e < cc && off + e < bound; e++) {
-            const long long src = (long long)blk * SEL_CHUNK + acquire(&a.stage[(long long)blk * SEL_CHUNK + e]);
-            select_emit<DIM>(a, g, h, off + e, src);
-          }
-        } else {
-          const int q = atomicAdd(&s_nbig, 1);
-          if (q < BLOCK) {
-            s_big[q] = blk;
-            s_big_off[q] = off;
-          } else {
-            // (more crowded workgroups in one pass than the shared list holds: copy them here)
-            for (long long e = 0; e < cc && off + e < bound; e++) {
-              const long long src = (long long)blk * SEL_CHUNK + acquire(&a.stage[(long long)blk * SEL_CHUNK + e]);
-              select_emit<DIM>(a, g, h, off + e, src);
-            }
-          }
-        }
+      if (j < PERC) s_off[threadIdx.x * PERC + j] = off;
+      off += cj[j];
+    }
+    if (threadIdx.x == 0) s_off[BLOCK * PERC] = pass_total;
+    __syncthreads();
+    const long long carry = s_carry;
+    const int nloc = BLOCK * PERC;
+    for (int e = threadIdx.x; e < pass_total; e += BLOCK) {
+      if (carry + e >= bound) break;
+      // last k with s_off[k] <= e  (empty workgroups share their successor's offset and are skipped)
+      int lo = 0, hi = nloc;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_off[mid] <= e) lo = mid; else hi = mid;
       }
-      off += cc;
+      const long long blk = bb + lo;
+      const long long src = blk * SEL_CHUNK + acquire(&a.stage[blk * SEL_CHUNK + (e - s_off[lo])]);
+      select_emit<DIM>(a, g, h, carry + e, src);
     }
     __syncthreads();
-    // workgroups with many accepted samples: all threads share the copy
-    const int nbig = s_nbig < BLOCK ? s_nbig : BLOCK;
-    for (int q = 0; q < nbig; q++) {
-      const int b2 = s_big[q];
-      const long long o2 = s_big_off[q];
-      const long long c2 = acquire(&a.counts[b2]);
-      for (long long j = threadIdx.x; j < c2 && o2 + j < bound; j += BLOCK) {
-        const long long src = (long long)b2 * SEL_CHUNK + acquire(&a.stage[(long long)b2 * SEL_CHUNK + j]);
-        select_emit<DIM>(a, g, h, o2 + j, src);
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == BLOCK - 1) s_carry = off_end;
+    if (threadIdx.x == 0) s_carry = carry + pass_total;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -1925,7 +1911,7 @@ __global__ void __launch_bounds__(BLOCK * PARTS) k_hill_gather(Geom g, Tables t,
   if (use_list) {
     // culled launch: the workgroups share the listed tiles (one each when the launch bound holds, which it
     // does by construction -- the stride loop keeps the result right even if a bound were ever too small)
-    const long long count = plan.tile_list[gather_tiles_dev(g)];
+    const long long count = plan.tile_list[gather_tiles_dev(g) + plan.tile_parity];
     for (long long i = blockIdx.x; i < count; i += gridDim.x) {
       hill_gather_body<DIM, MODE, PARTS, PERB>(g, t, rec, h, hh, plan, 1, dirty_flag, (MODE == 0) ? post.enabled : 0,
                                          plan.tile_list[i]);
@@ -1981,7 +1967,9 @@ __global__ void __launch_bounds__(BLOCK) k_reduce_partials(Geom g, double *__res
 // zero between batches and nothing has to be memset or compacted.
 template <int DIM>
 __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *__restrict__ flags,
-                                                      int *__restrict__ list, long long ntiles) {
+                                                      int *__restrict__ list, long long ntiles, int parity) {
+  int *count = list + ntiles + parity;
+  if (blockIdx.x == 0 && threadIdx.x == 0) list[ntiles + (1 - parity)] = 0;  // the next batch's counter
   int ntile[DIM], steps[DIM];
   long long combos = 1;
 #pragma unroll
@@ -2055,7 +2043,7 @@ __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *_
     const int lane = threadIdx.x & 63;
     const int leader = (int)__builtin_ctzll(bal);
     int base = 0;
-    if (lane == leader) base = atomicAdd(&list[ntiles], (int)__popcll(bal));
+    if (lane == leader) base = atomicAdd(count, (int)__popcll(bal));
     base = __shfl(base, leader, 64);
     if (emit) list[base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (int)tflat;
   }
@@ -2091,11 +2079,9 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
   int use_list = 0;
   long long launch_tiles = ntiles;
   if (plan.tile_flags && plan.tile_list && plan.groups == 1) {
-    hipError_t e = hipMemsetAsync(plan.tile_list + ntiles, 0, sizeof(int), s);
-    if (e != hipSuccess) return e;
     const long long mt = mark_tiles_threads(g, h.nh);
     hipLaunchKernelGGL(k_mark_tiles<DIM>, dim3((unsigned)((mt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, g, h, plan.tile_flags,
-                       plan.tile_list, ntiles);
+                       plan.tile_list, ntiles, plan.tile_parity);
     use_list = 1;
     launch_tiles = plan.tile_bound < ntiles ? plan.tile_bound : ntiles;
   }
