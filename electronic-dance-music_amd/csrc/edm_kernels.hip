@@ -1578,6 +1578,7 @@ struct DupPlan {
   unsigned long long lo[3], hi[3];
 };
 __device__ __forceinline__ void duplicate_boundary_block(const Geom &g, double *__restrict__ rec, const DupPlan &dp);
+__device__ __forceinline__ void duplicate_boundary_wave(const Geom &g, double *__restrict__ rec, const DupPlan &dp, int lane);
 static DupPlan make_dup_plan(const Geom &g);
 template <int DIM>
 __device__ __forceinline__ void hist_batch(const Geom &hg, double *hist, long long nh, const double *hx0,
@@ -1923,20 +1924,38 @@ __global__ void __launch_bounds__(BLOCK * PARTS) k_hill_gather(Geom g, Tables t,
   if (MODE == 0 && post.enabled) {
     // boundary duplication (K6) and the histogram updates (K7) by the last workgroup to finish
     if (!last_block_done(post.ticket, gridDim.x * gridDim.y)) return;
-    if (!PERB && acquire(dirty_flag) != 0) {   // (no walls, no boundary corrections, nothing to duplicate)
-      duplicate_boundary_block(g, rec, post.dp);
-      __syncthreads();
-      if (threadIdx.x == 0) *dirty_flag = 0;
-    }
-    if (!hh.res_dev->error)
-      hist_batch<DIM>(post.hg, post.hist, h.nh, h.hx0, hh.res_dev, post.flags, post.flush_mode, threadIdx.x,
-                      BLOCK * PARTS);
-    if (post.rb_dst) {
-      // read-back region (written by the earlier launches of the step) -> host-mapped memory
-      const long long words = post.rb_bytes / 8;
+    // the three chores are independent: the waves of the workgroup split them (wave 0 the boundary copies --
+    // at most 4^DIM = 64, one per lane -- the lower half of the rest the histogram, the upper half the read-back)
+    constexpr int NW = BLOCK * PARTS / 64;
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    if (wv == 0) {
+      if (!PERB && acquire(dirty_flag) != 0) {   // (no walls, no boundary corrections, nothing to duplicate)
+        duplicate_boundary_wave(g, rec, post.dp, ln);
+        if (ln == 0) *dirty_flag = 0;
+      }
+    } else if (wv <= (NW - 1) / 2) {
+      const int nh_w = (NW - 1) / 2;   // waves 1 .. nh_w
+      if (!hh.res_dev->error)
+        hist_batch<DIM>(post.hg, post.hist, h.nh, h.hx0, hh.res_dev, post.flags, post.flush_mode, (wv - 1) * 64 + ln,
+                        nh_w * 64);
+    } else if (post.rb_dst) {
+      // read-back region (written by the earlier launches of the step) -> host-mapped memory; only the part
+      // the batch's true hill count fills: header + flags | h2 | added2 | added | positions (apply_hills' layout)
+      const int first = (NW - 1) / 2 + 1, nthr = (NW - first) * 64, me = (wv - first) * 64 + ln;
+      const long long nb = h.nh;                                  // the layout is sized by the launch bound
+      long long na = hh.res_dev->nh < nb ? hh.res_dev->nh : nb;   // ... the hills are fewer
+      if (hh.res_dev->error) na = 0;
+      const long long off_flags = 64, off_h2 = off_flags + ((4 * nb + 7) & ~7LL), off_a2 = off_h2 + 8 * nb,
+                      off_added = off_a2 + 8 * nb, off_pos = off_added + 8 * nb;
+      const long long seg_off[5] = {0, off_h2, off_a2, off_added, off_pos};
+      const long long seg_len[5] = {off_flags + ((4 * na + 7) & ~7LL), 8 * na, 8 * na, 8 * na, 8 * na * DIM};
       const long long *src = reinterpret_cast<const long long *>(post.rb_src);
       long long *dst = reinterpret_cast<long long *>(post.rb_dst);
-      for (long long w = threadIdx.x; w < words; w += BLOCK * PARTS) dst[w] = src[w];
+#pragma unroll
+      for (int sgm = 0; sgm < 5; sgm++) {
+        const long long w0 = seg_off[sgm] / 8, wn = seg_len[sgm] / 8;
+        for (long long w = me; w < wn; w += nthr) dst[w0 + w] = src[w0 + w];
+      }
     }
   }
 }
@@ -2418,10 +2437,12 @@ __global__ void __launch_bounds__(ORD_BLOCK) k_hills_ordered(Geom g, Tables t, d
 // last in-boundary node to its outward neighbour for the 4^dim index combinations.
 // ---------------------------------------------------------------------------
 // copies for the 4^dim index combinations; must be called by >= 64 threads of one workgroup
-__device__ __forceinline__ void duplicate_boundary_block(const Geom &g, double *__restrict__ rec, const DupPlan &dp) {
+// (c = this thread's combination index; BLOCK_SYNC: the callers are a whole workgroup, else one wave, whose
+//  lanes run the loads and the stores in lockstep)
+template <bool BLOCK_SYNC>
+__device__ __forceinline__ void duplicate_boundary_lanes(const Geom &g, double *__restrict__ rec, const DupPlan &dp, int c) {
   int combos = 1;
   for (int d = 0; d < g.dim; d++) combos *= 4;
-  const int c = threadIdx.x;
   bool do_copy = false;
   long long outer_flat = 0, inner_flat = 0;
   if (c < combos) {
@@ -2473,8 +2494,14 @@ __device__ __forceinline__ void duplicate_boundary_block(const Geom &g, double *
   // copies are independent of each other: read all, then write all
   double v = 0;
   if (do_copy) v = acquire(&rec[inner_flat * g.rec]);  // (may have been published by another workgroup of this launch)
-  __syncthreads();
+  if (BLOCK_SYNC) __syncthreads();
   if (do_copy) rec[outer_flat * g.rec] = v;
+}
+__device__ __forceinline__ void duplicate_boundary_block(const Geom &g, double *__restrict__ rec, const DupPlan &dp) {
+  duplicate_boundary_lanes<true>(g, rec, dp, threadIdx.x);
+}
+__device__ __forceinline__ void duplicate_boundary_wave(const Geom &g, double *__restrict__ rec, const DupPlan &dp, int lane) {
+  duplicate_boundary_lanes<false>(g, rec, dp, lane);
 }
 
 __global__ void k_duplicate_boundary(Geom g, double *__restrict__ rec, DupPlan dp, int *__restrict__ dirty_flag) {
