@@ -564,13 +564,24 @@ def test_pair_step_equals_separate_calls(workdir):
     assert open(str(workdir / "HILLS_fused_0")).read() == open(str(workdir / "HILLS_separate_0")).read()
 
 
-def test_packed_exchange_virtual_ranks(workdir):
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_packed_exchange_virtual_ranks(dim, workdir):
     """The multi-GPU packed hill exchange (fixed-size packets, one all-gather, device-side unpack into the
     rank-major list, deferred count) with a one-rank communicator whose packet is replicated three times
     (test hook): must equal, bit for bit, a communicator-free run fed with the samples repeated three
     times -- that IS the rank-major list three identical ranks would produce."""
-    text = ("tempering 0\nhill_prefactor 0.5\nhill_density 60\nbias_per_step 0.6\ndimension 1\nbox_low 0\nbox_high 2.8\n"
-            "bias_spacing 0.001\nbias_sigma 0.05\n")
+    if dim == 1:
+        text = ("tempering 0\nhill_prefactor 0.5\nhill_density 60\nbias_per_step 0.6\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+                "bias_spacing 0.001\nbias_sigma 0.05\n")
+        lo, hi, per, skin = [0], [2.8], [0], [0.3]
+    elif dim == 2:
+        text = ("tempering 0\nhill_prefactor 0.5\nhill_density 60\nbias_per_step 0.6\ndimension 2\nbox_low 0 0\nbox_high 8 8\n"
+                "bias_spacing 0.05 0.05\nbias_sigma 0.2 0.2\n")
+        lo, hi, per, skin = [0, 0], [8, 8], [1, 1], [0, 0]
+    else:
+        text = ("tempering 0\nhill_prefactor 0.5\nhill_density 60\nbias_per_step 0.6\ndimension 3\nbox_low 0 0 0\nbox_high 6 6 6\n"
+                "bias_spacing 0.1 0.1 0.1\nbias_sigma 0.25 0.25 0.25\n")
+        lo, hi, per, skin = [0] * 3, [6] * 3, [1, 0, 1], [0, 0.3, 0]
     n, R = 40_000, 3
     state = []
     for tag in ("plain", "virtual"):
@@ -581,9 +592,10 @@ def test_packed_exchange_virtual_ranks(workdir):
             b.comm_init(H.comm_unique_id(), 1, 0)
             b.set("debug_virtual_ranks", R)
         b.setup(1.0, 1.0)
-        b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+        b.subdivide(lo, hi, lo, hi, per, skin)
         for step in range(5):
-            r = W.pair_distances(n, 700 + step).reshape(-1, 1)
+            r = (W.pair_distances(n, 700 + step).reshape(-1, 1) if dim == 1 else
+                 W.uniform(700 + step, n * dim).reshape(n, dim) * np.array(hi))
             u = W.uniform(750 + step, n)
             if tag == "plain":
                 b.add_hills(np.tile(r, (R, 1)), np.tile(u, R), -1, est=2 * n)
@@ -594,7 +606,7 @@ def test_packed_exchange_virtual_ranks(workdir):
         del b
     for a, c in zip(state[0], state[1]):
         assert np.array_equal(np.asarray(a), np.asarray(c))
-    assert state[0][0].max() > 0 and state[0][5] > 60
+    assert state[0][0].max() > 0 and state[0][5] > 30
     assert open(str(workdir / "HILLS_plain_0")).read() == open(str(workdir / "HILLS_virtual_0")).read()
 
 
