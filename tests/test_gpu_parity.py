@@ -153,6 +153,10 @@ def test_controller_golden(case, workdir):
         h2, n2 = _grid_file_numbers(gold_bias)
         assert h1 == h2, "grid file header must be byte-identical"
         close(n1, n2, rtol=0, atol=1.01e-8, what="bias grid file body")
+        # (the body is printed with 8 decimals: a last-digit flip needs the device exp's ~1e-16 relative
+        #  difference from libm to straddle a rounding boundary -- possible in principle; on every fixture the
+        #  reference's tests and generator produced, the files are byte-identical)
+        assert open(str(workdir / "BIAS")).read() == open(gold_bias).read(), "written .grid file byte-identical to the reference's"
 
 
 def test_known_answers(workdir):
