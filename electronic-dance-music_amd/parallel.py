@@ -41,3 +41,36 @@ def replicated_totals(dist, value):
     t = torch.tensor([float(value)], dtype=torch.float64)
     dist.all_reduce(t)
     return float(t.item())
+
+
+def merge_packets(dist, local_positions, bound):
+    """The packed exchange of a stochastic step (csrc/edm_bias.cpp:process_new_hills, k_select_prep /
+    k_unpack_prep): every rank sends ONE fixed-size packet [count, x_0 .. x_{bound-1}] (bound positions of
+    `dim` doubles, unused slots undefined), the packets are all-gathered, and the rank-major global list is
+    cut out of them.  A rank whose count exceeds `bound` poisons the exchange: every rank returns None (and
+    falls back to merge_rank_major), because all ranks see the same counts."""
+    import torch
+
+    world = dist.get_world_size()
+    local = np.ascontiguousarray(local_positions, dtype=np.float64)
+    dim = local.shape[1]
+    packet = torch.zeros(1 + bound * dim, dtype=torch.float64)
+    packet[0] = float(local.shape[0])
+    k = min(local.shape[0], bound)
+    packet[1:1 + k * dim] = torch.from_numpy(local[:k].reshape(-1))
+    recv = [torch.zeros_like(packet) for _ in range(world)]
+    dist.all_gather(recv, packet)
+    counts = [int(p[0].item()) for p in recv]
+    if any(c > bound for c in counts):
+        return None, counts
+    merged = np.concatenate([recv[r][1:1 + counts[r] * dim].numpy().reshape(counts[r], dim) for r in range(world)], axis=0)
+    return merged, counts
+
+
+def allreduce_sum(dist, array):
+    """ncclAllReduce(sum) of a float64 array (per-hill integrals / delta grid of the sharded dense path)."""
+    import torch
+
+    t = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64).copy())
+    dist.all_reduce(t)
+    return t.numpy()
