@@ -472,8 +472,10 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
   if (g->h_partials) (void)hipHostFree(g->h_partials);
   if (g->d_dirty) (void)hipFree(g->d_dirty);
   if (g->d_tickets) (void)hipFree(g->d_tickets);
-  if (g->ev0) (void)hipEventDestroy(g->ev0);
-  if (g->ev1) (void)hipEventDestroy(g->ev1);
+  if (g->prof_ev) {
+    for (int i = 0; i < 2 * edm_hip_gauss::PROF_RING; i++) (void)hipEventDestroy(g->prof_ev[i]);
+    delete[] g->prof_ev;
+  }
   g->ws.release();
   if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
@@ -567,14 +569,26 @@ int edm_hip_gauss_device_buffer(edm_hip_gauss *g, double **d_records, int *doubl
   return EDM_HIP_OK;
 }
 
-static void profile_collect(const edm_hip_gauss *gc) {
+// event pair for the next timed launch (nullptrs when profiling is off or the ring is full)
+static void profile_slot(const edm_hip_gauss *gc, hipEvent_t *e0, hipEvent_t *e1) {
   edm_hip_gauss *g = const_cast<edm_hip_gauss *>(gc);
-  if (!g->profiling) return;
-  float ms = 0;
-  if (hipEventElapsedTime(&ms, g->ev0, g->ev1) == hipSuccess) {
-    g->prof_ms += ms;
-    g->prof_launches += 1;
+  *e0 = *e1 = nullptr;
+  if (!g->profiling || !g->prof_ev) return;
+  if ((g->prof_seen++ % g->profiling) != 0 || g->prof_pending >= edm_hip_gauss::PROF_RING) return;
+  *e0 = g->prof_ev[2 * g->prof_pending];
+  *e1 = g->prof_ev[2 * g->prof_pending + 1];
+  g->prof_pending++;
+}
+// sums the stamped launches (their kernels must have completed: call after a stream synchronisation)
+static void profile_drain(edm_hip_gauss *g) {
+  for (int i = 0; i < g->prof_pending; i++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g->prof_ev[2 * i], g->prof_ev[2 * i + 1]) == hipSuccess) {
+      g->prof_ms += ms;
+      g->prof_launches += 1;
+    }
   }
+  g->prof_pending = 0;
 }
 
 static int fetch_scalar(const edm_hip_gauss *g, int slot, double *out) {
@@ -631,15 +645,22 @@ int edm_hip_gauss_pair_forces(const edm_hip_gauss *g, long long n, const double 
 }
 
 int edm_hip_gauss_profile_enable(edm_hip_gauss *g, int enabled) {
-  if (enabled && !g->ev0) {
-    EDM_HIP_TRY(hipEventCreate(&g->ev0));
-    EDM_HIP_TRY(hipEventCreate(&g->ev1));
+  if (enabled && !g->prof_ev) {
+    g->prof_ev = new hipEvent_t[2 * edm_hip_gauss::PROF_RING];
+    for (int i = 0; i < 2 * edm_hip_gauss::PROF_RING; i++) EDM_HIP_TRY(hipEventCreate(&g->prof_ev[i]));
   }
-  g->profiling = enabled ? 1 : 0;
+  if (!enabled && g->profiling) {
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    profile_drain(g);
+  }
+  g->profiling = enabled > 0 ? enabled : 0;
+  g->prof_seen = 0;
   return EDM_HIP_OK;
 }
 
 int edm_hip_gauss_profile_read(edm_hip_gauss *g, double *kernel_ms_total, long long *launches, int reset) {
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  profile_drain(g);
   if (kernel_ms_total) *kernel_ms_total = g->prof_ms;
   if (launches) *launches = g->prof_launches;
   if (reset) {
@@ -663,8 +684,9 @@ int pair_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_r, 
     return EDM_HIP_ERR_ARG;
   }
   if (n <= 0) return EDM_HIP_OK;
-  EDM_HIP_TRY(launch_pair_forces(g->g, g->rec, n, d_r, d_force, g->d_partials, nullptr, g->stream,
-                                 g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr, nblk));
+  hipEvent_t e0, e1;
+  profile_slot(g, &e0, &e1);
+  EDM_HIP_TRY(launch_pair_forces(g->g, g->rec, n, d_r, d_force, g->d_partials, nullptr, g->stream, e0, e1, nblk));
   return EDM_HIP_OK;
 }
 // K2 (any dimension, strided rows, group mask) without the host wait; finish with pair_forces_finish()
@@ -678,14 +700,14 @@ int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x
   }
   LookupArgs a{};
   a.n = n; a.x = d_x; a.x_stride = x_stride; a.f = d_f; a.f_stride = f_stride; a.mask = d_mask; a.apply_mask = apply_mask;
-  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, a, g->d_partials, nullptr, g->stream,
-                            g->profiling ? g->ev0 : nullptr, g->profiling ? g->ev1 : nullptr, nblk));
+  hipEvent_t e0, e1;
+  profile_slot(g, &e0, &e1);
+  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, a, g->d_partials, nullptr, g->stream, e0, e1, nblk));
   return EDM_HIP_OK;
 }
 double pair_forces_finish(const edm_hip_gauss *g, int nblk) {
   double e = 0;
   for (int i = 0; i < nblk; i++) e += g->h_partials[i];
-  if (nblk > 0) profile_collect(g);
   return e;
 }
 

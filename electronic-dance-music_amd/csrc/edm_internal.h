@@ -108,8 +108,13 @@ struct edm_hip_gauss {
   long long tiles_per_hill = 0;          // cached tiles_per_hill_bound() of the current geometry / boundary
   int *d_tickets = nullptr;              // three last-workgroup tickets (EDM_TICKET_INTS ints each), kept zero
   // bench support: HIP events around the dominant lookup kernel
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int profiling = 0;
+  // (a ring of event pairs: the launches of a timed loop are stamped without any host-side read in between;
+  //  the elapsed times are summed up by profile_read, outside the loop)
+  static const int PROF_RING = 1024;
+  hipEvent_t *prof_ev = nullptr;         // 2 * PROF_RING events, created on first enable
+  int prof_pending = 0;                  // stamped launches not yet summed (<= PROF_RING; later ones go untimed)
+  int profiling = 0;                     // 0 = off, N > 0 = stamp every N-th launch of the lookup kernel
+  long long prof_seen = 0;               // lookup launches since profiling was enabled
   double prof_ms = 0;
   long long prof_launches = 0;
   edm::HillWorkspace ws;

@@ -143,9 +143,11 @@ int edm_hip_gauss_update_forces(const edm_hip_gauss *g, long long n, const doubl
 int edm_hip_gauss_pair_forces(const edm_hip_gauss *g, long long n, const double *d_r,
                               double *d_force, double *energy);
 
-/* measurement support (no reference counterpart): records HIP events on the handle's own
- * stream directly around the dominant lookup kernel of update_forces / pair_forces and
- * accumulates hipEventElapsedTime over the calls made while enabled. */
+/* measurement support (no reference counterpart): stamps the dominant lookup kernel of
+ * update_forces / pair_forces with HIP events on the handle's own stream (the dispatch's own begin/end
+ * timestamps) and sums hipEventElapsedTime over the stamped launches.  enabled = N > 0 stamps every
+ * N-th launch (a stamp costs the stream a few microseconds); the times are summed by profile_read,
+ * never inside the caller's timed loop. */
 int edm_hip_gauss_profile_enable(edm_hip_gauss *g, int enabled);
 int edm_hip_gauss_profile_read(edm_hip_gauss *g, double *kernel_ms_total, long long *launches, int reset);
 
