@@ -579,7 +579,8 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
     }
     const double inv_dx = 1.0 / g.dx[0];
     // LDS staging costs ~160 KB of L2 reads per workgroup: worth it only for long sample arrays
-    const bool use_lds = n >= (1LL << 22);
+    // (measured break-even ~1 M pairs: 2 M pairs 12.3 us staged vs 14.7 us from L2, 4 M pairs 20 vs 31 us)
+    const bool use_lds = n >= 1500000;
     if (use_lds) {
       int wn = g.n[0] < LDS_WINDOW_MAX ? g.n[0] : LDS_WINDOW_MAX;
       long long w0 = (long long)g.n[0] - wn;  // top-aligned: pair distances populate the upper range
@@ -597,7 +598,9 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
       // short arrays: small workgroups spread over every CU (latency-bound regime)
       long long work = (n >> 1) + 1;
       blocks = (int)((work + BLOCK - 1) / BLOCK);
-      if (blocks > 8 * n_cu) blocks = 8 * n_cu;
+      // (two workgroups per CU, each lane looping over groups of four pairs: measured faster than one
+      //  pass of eight workgroups per CU -- 52 vs 45 G evals/s at 1 M pairs -- fewer waves to launch and retire)
+      if (blocks > 2 * n_cu) blocks = 2 * n_cu;
       if (blocks < 1) blocks = 1;
       EDM_LAUNCH_TIMED((k_pair_forces_fast<false, BLOCK>), dim3(blocks), dim3(BLOCK), 256, s, ev0, ev1, g, rec, n, r, force,
                        scratch, 0LL, 0, inv_dx);
