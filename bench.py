@@ -126,6 +126,35 @@ def cpu_baseline(tmpdir, seconds=12.0):
                        % (evals // n, n, t_eval, done, t_hill))
 
 
+def cpu_baseline_all_cores(tmpdir, seconds=8.0):
+    """The reference's own scaling model on the host: one independent replica per core (MPI ranks each own a shard
+    of the samples).  Children are separate interpreters (this process has initialised the GPU) running the
+    single-core baseline concurrently; the rates add up."""
+    import subprocess
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))   # (a one-GPU slice of the host: 16 cores)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds),
+                               "--cpu-worker-dir", os.path.join(tmpdir, "w%d" % i)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(cores)]
+    ev = hl = 0.0
+    ok = 0
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=seconds * 6 + 60)
+            d = json.loads(out.strip().splitlines()[-1])
+            ev += d["value"]
+            hl += d["hill_adds_per_s"]
+            ok += 1
+        except Exception:  # noqa: BLE001
+            p.kill()
+    if ok == 0:
+        return None
+    return dict(value=ev, unit="million bias-force evals/s", cores=ok, hill_adds_per_s=hl,
+                sample="%d concurrent single-core replicas of the baseline above, %.0f s each" % (ok, seconds))
+
+
 def all_samples_measure(rank, world, dist, H, W, tmpdir, steps, warmup):
     """Strong scaling of the all-samples hill step: 1,048,576 hills per step in total, each rank
     owns 1/N of the samples, computes their integrals and gathers them into its delta grid; integrals and
@@ -201,10 +230,17 @@ def main():
                     help="skip the 38.8M-pair interpolation capture (W2 = BASELINE configs[2], the HBM-bound case)")
     ap.add_argument("--w2", action="store_true", help=argparse.SUPPRESS)  # kept for older command lines (now the default)
     ap.add_argument("--nd", action="store_true", help="also time the 2-D (2048^2) and 3-D (512^3) coordinate-CV kernels")
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # (child of cpu_baseline_all_cores)
+    ap.add_argument("--cpu-worker-dir", default="", help=argparse.SUPPRESS)
     ap.add_argument("--all-samples", action="store_true",
                     help="alternative line: STRONG scaling of the all-samples hill mode (hill_density unset; every one of "
                          "1,048,576 pair distances deposits a hill each step; the samples are split over the GPUs)")
     args = ap.parse_args()
+
+    if args.cpu_worker > 0:   # CPU only: never touches the GPU
+        os.makedirs(args.cpu_worker_dir, exist_ok=True)
+        print(json.dumps(cpu_baseline(args.cpu_worker_dir, args.cpu_worker)))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -459,6 +495,7 @@ def main():
             out["coordinate_cv"] = nd
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(tmpdir)
+            out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(tmpdir)
         elif world > 1:
             out["cpu_baseline"] = None
         print(json.dumps(out))
