@@ -1601,18 +1601,25 @@ struct PostArgs {
   long long rb_bytes;
 };
 
-// PARTS (1 or 4): the workgroup has PARTS * BLOCK threads; thread (part, node) accumulates every PARTS-th
-// batch of the tile's hill list for its node and the parts are combined in LDS in a fixed order.  A
-// node's serial chain is its number of overlapping hills: on the 1-D grid (hills pile up where the pair
-// density is high, 40+ per tile at r ~ 2.7 against 10 at r ~ 1.3) this quarters the critical path.
+// PARTS (1 or 4; 4 on the 1-D grid only): the tile is BLOCK / PARTS nodes wide and thread (part, node)
+// accumulates every PARTS-th batch of the tile's hill list for its node; the parts are combined in LDS in a
+// fixed order.  A node's serial chain is its number of overlapping hills, and a tile's work lands on ONE CU:
+// on the 1-D grid hills pile up where the pair density is high (40 per 256-node tile at r ~ 2.7 against 10 at
+// r ~ 1.3; timestamps: the dense tiles finished at 11.5 us, the sparse ones at 4), so 64-node tiles with four
+// hill-quarters each spread the same work over four times as many CUs.
+template <int DIM, int PARTS>
+__device__ __forceinline__ constexpr int tile_extent(int d) {
+  return (DIM == 1 && d == 0) ? BLOCK / PARTS : Tile<DIM>::T[d];
+}
 template <int DIM, int MODE, int PARTS, bool PERB>
 __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t, double *__restrict__ rec,
                                                  const HillList &h, const HillHeights &hh, const GatherPlan &plan,
                                                  int use_list, int *__restrict__ dirty_flag, int coherent,
                                                  long long tile) {
   constexpr int R = (DIM == 1) ? 2 : 4;
-  const int tnode = threadIdx.x % BLOCK;   // this thread's node within the tile
-  const int part = threadIdx.x / BLOCK;    // ... and its share of the hill batches
+  constexpr int NODES = BLOCK / PARTS;
+  const int tnode = threadIdx.x % NODES;   // this thread's node within the tile
+  const int part = threadIdx.x / NODES;    // ... and its share of the hill batches
   if (use_list && threadIdx.x == 0) plan.tile_flags[tile] = 0;  // (k_mark_tiles relies on an all-zero flag array)
   // tile origin and this thread's node
   int t0[DIM], p[DIM], tcoord[DIM];
@@ -1621,7 +1628,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     int lrest = tnode;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
-      const int T = Tile<DIM>::T[d];
+      const int T = tile_extent<DIM, PARTS>(d);
       const int nt_d = (g.n[d] + T - 1) / T;
       tcoord[d] = (int)(rest % nt_d);
       t0[d] = tcoord[d] * T;
@@ -1698,19 +1705,19 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   __shared__ int s_wcnt[BLOCK / 64];
   __shared__ long long s_id[(MODE == 1) ? BLOCK : 1];
   __shared__ double s_wpart[(MODE == 1) ? BLOCK / 64 : 1][(MODE == 1) ? BLOCK : 1];
-  __shared__ double s_pacc[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? BLOCK : 1][1 + DIM];
-  __shared__ int s_ptouch[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? BLOCK : 1];
+  __shared__ double s_pacc[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? NODES : 1][1 + DIM];
+  __shared__ int s_ptouch[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? NODES : 1];
   TermConst<DIM> tc;
   term_const<DIM>(g, tc);
   constexpr int ILP = (DIM == 1) ? 4 : 2;  // (2-D/3-D tiles meet one to three hills of a sparse batch; fewer live registers, more workgroups per CU)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long long base = hbeg; base < hend; base += BLOCK) {
-    const long long cur = base + tnode;
+    const long long cur = base + threadIdx.x;   // (every thread stages one hill of the chunk)
     bool take = false;
     int c[DIM];
     double h1 = 0, h2 = 0;
     double hx_r[DIM], ht_r[2 * DIM];
-    if (cur < hend && part == 0) {   // (the chunk is staged by the first BLOCK threads)
+    if (cur < hend) {
       // 1-D: all of this hill's fields are requested together (one memory round trip; a tile overlaps a
       // good part of the hills).  2-D/3-D: a tile meets a few hills out of hundreds, so only the centre
       // node is fetched for the test and the rest follows for the hills that pass.
@@ -1736,7 +1743,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
         take = true;
 #pragma unroll
         for (int d = 0; d < DIM; d++) {
-          const int T = Tile<DIM>::T[d];
+          const int T = tile_extent<DIM, PARTS>(d);
           int t1 = t0[d] + T - 1;
           if (t1 > g.n[d] - 1) t1 = g.n[d] - 1;
           if (images(g, d, c[d], t0[d], t1) == 0) take = false;
@@ -1770,7 +1777,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       }
     }
     const unsigned long long bal = __ballot(take);
-    if (lane == 0 && part == 0) s_wcnt[wave] = __popcll(bal);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
     __syncthreads();
     int pos = __popcll(bal & ((1ull << lane) - 1ull));
     int cnt = 0;
@@ -1909,7 +1916,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
 }
 
 template <int DIM, int MODE, int PARTS, bool PERB>
-__global__ void __launch_bounds__(BLOCK * PARTS) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
+__global__ void __launch_bounds__(BLOCK) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
                                                                HillHeights hh, GatherPlan plan, int use_list,
                                                                int *__restrict__ dirty_flag, PostArgs post) {
   if (use_list) {
@@ -1929,7 +1936,7 @@ __global__ void __launch_bounds__(BLOCK * PARTS) k_hill_gather(Geom g, Tables t,
     if (!last_block_done(post.ticket, gridDim.x * gridDim.y)) return;
     // the three chores are independent: the waves of the workgroup split them (wave 0 the boundary copies --
     // at most 4^DIM = 64, one per lane -- the lower half of the rest the histogram, the upper half the read-back)
-    constexpr int NW = BLOCK * PARTS / 64;
+    constexpr int NW = BLOCK / 64;
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
     if (wv == 0) {
       if (!PERB && acquire(dirty_flag) != 0) {   // (no walls, no boundary corrections, nothing to duplicate)
@@ -2112,11 +2119,13 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
     if (!g.bper[d]) perb = false;
   const dim3 grid((unsigned)launch_tiles, (unsigned)plan.groups);
   if (DIM == 1 && !use_list) {
+    // 1-D: 64-node tiles, four hill-quarters per node (see hill_gather_body)
+    const dim3 grid4((unsigned)((g.n[0] + BLOCK / 4 - 1) / (BLOCK / 4)), (unsigned)plan.groups);
     if (perb)
-      hipLaunchKernelGGL((k_hill_gather<DIM, 0, (DIM == 1) ? 4 : 1, true>), grid, dim3(BLOCK * 4), 0, s, g, t, rec, h, hh, plan,
+      hipLaunchKernelGGL((k_hill_gather<DIM, 0, (DIM == 1) ? 4 : 1, true>), grid4, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan,
                          use_list, dirty_flag, post);
     else
-      hipLaunchKernelGGL((k_hill_gather<DIM, 0, (DIM == 1) ? 4 : 1, false>), grid, dim3(BLOCK * 4), 0, s, g, t, rec, h, hh, plan,
+      hipLaunchKernelGGL((k_hill_gather<DIM, 0, (DIM == 1) ? 4 : 1, false>), grid4, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan,
                          use_list, dirty_flag, post);
   } else {
     if (perb)
