@@ -1053,7 +1053,19 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
   } else if (!spec.ordered) {
     // short limited batch applied in place: boundary duplication and histogram ride on the gather launch
-    chain_post = fused_post && plan.groups == 1 && hh.res_dev && nh <= 4096;
+    // A long list on a large 2-D/3-D grid: without culling every tile workgroup would scan every hill.  The
+    // in-place gather adds the hills of a node in list order, so the list can be applied as consecutive
+    // sub-batches, each short enough for the culled launch -- same sums, a fraction of the scanning.
+    long long sub = 0;
+    if (!spec.d_nh && plan.groups == 1 && !plan.tile_list && ntiles > 2048) {
+      if (g->tiles_per_hill <= 0) g->tiles_per_hill = tiles_per_hill_bound(q);
+      bool narrow = true;
+      for (int d = 0; d < q.dim; d++)
+        if (q.periodic[d] && 2 * q.msize[d] + 1 > q.n[d]) narrow = false;
+      const long long fit = (ntiles / 2 - 1) / g->tiles_per_hill;   // hills per culled launch
+      if (narrow && fit >= 256 && nh > fit) sub = fit;
+    }
+    chain_post = fused_post && plan.groups == 1 && hh.res_dev && nh <= 4096 && sub == 0;
     PostSpec ps;
     ps.ticket = g->d_tickets + 2 * EDM_TICKET_INTS;
     ps.hist_geom = spec.hist_g;
@@ -1070,7 +1082,34 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       ps.rb_bytes = (long long)rb_bytes;
       rb_pushed = true;
     }
-    EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, hl, hh, plan, g->d_dirty, s, chain_post ? &ps : nullptr));
+    if (sub > 0) {
+      EDM_HIP_TRY(ws.tile_flags.reserve_zeroed((size_t)ntiles));
+      EDM_HIP_TRY(ws.tile_list.reserve_zeroed((size_t)ntiles + 2));
+      for (long long off = 0; off < nh; off += sub) {
+        const long long cnt = (off + sub < nh) ? sub : nh - off;
+        HillList part = hl;
+        part.nh = cnt;
+        part.x = nullptr;
+        part.sel = nullptr;
+        part.hx = hl.hx + off * dim;
+        part.hc = hl.hc + off * dim;
+        part.ht = hl.ht + off * 2 * dim;
+        part.hx0 = hl.hx0 ? hl.hx0 + off * dim : nullptr;
+        HillHeights hp = hh;
+        hp.h = hh.h ? hh.h + off : nullptr;
+        if (!hh.res_dev) hp.k = cnt;   // (unlimited batch: every hill at its base height)
+        hp.tail_shift = off;
+        GatherPlan pp = plan;
+        pp.tile_flags = ws.tile_flags.p;
+        pp.tile_list = ws.tile_list.p;
+        pp.tile_parity = ws.tile_parity;
+        ws.tile_parity ^= 1;
+        pp.tile_bound = cnt * g->tiles_per_hill;
+        EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, part, hp, pp, g->d_dirty, s, nullptr));
+      }
+    } else {
+      EDM_HIP_TRY(launch_hill_gather(q, tabs, g->rec, hl, hh, plan, g->d_dirty, s, chain_post ? &ps : nullptr));
+    }
     if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
   }
 

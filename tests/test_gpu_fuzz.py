@@ -100,3 +100,24 @@ def test_random_geometry_vs_oracle(sc):
     assert np.array_equal(flat, refI), "node indices must be bit-exact"
     close(E, refE, rtol=1e-8, atol=1e-12 * max(np.abs(og.values).max(), 1e-300), what="interpolated value")
     close(der, refD, rtol=1e-8, atol=1e-10 * max(np.abs(refD).max(), 1e-300), what="interpolated gradient")
+
+
+def test_long_list_on_large_grid_sub_batches():
+    """3000 hills on a 1024^2 grid with a narrow stencil: too many for one culled launch, so the gather applies
+    them as consecutive culled sub-batches (in-place, list order preserved) -- whole grid against the oracle."""
+    lib = B.load("oracle")
+    sc = dict(lo=[0.0, 0.0], hi=[16.0, 16.0], sp=[1 / 64.0, 1 / 64.0], per=[1, 0], sg=[0.02, 0.025])
+    g = H.Gauss.create(sc["lo"], sc["hi"], sc["sp"], sc["per"], 1, sc["sg"])
+    o = B.Gauss.create(lib, sc["lo"], sc["hi"], sc["sp"], sc["per"], 1, sc["sg"])
+    rng = np.random.default_rng(5)
+    nh = 3000
+    hx = np.zeros((nh, 3))
+    hx[:, :2] = rng.uniform(-0.2, 16.2, (nh, 2))
+    hx[: nh // 3, :2] = 8.0 + rng.normal(0, 0.05, (nh // 3, 2))   # a cluster: many hills on the same nodes, in order
+    hh = rng.uniform(-0.2, 1.0, nh)
+    added = g.add_values(hx, hh)
+    ref = np.array([o.add_value(x[:2], float(h)) for x, h in zip(hx, hh)])
+    close(added, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max(), what="bias_added")
+    v, dv = g.download()
+    close(v, o.grid.values, rtol=1e-9, atol=1e-12 * np.abs(o.grid.values).max(), what="grid values")
+    close(dv, o.grid.derivs, rtol=1e-9, atol=1e-11 * np.abs(o.grid.derivs).max(), what="grid derivatives")

@@ -111,3 +111,37 @@ def test_random_controller_vs_oracle(sc, tmp_path):
     lo_ = open(str(tmp_path / "HILLS_ora_0")).read().splitlines()
     assert len(lg) == len(lo_), "HILLS log length"
     assert [ln.split()[:3] for ln in lg] == [ln.split()[:3] for ln in lo_], "HILLS event sequence"
+
+
+def test_all_samples_2d_large_grid_with_limiter(tmp_path):
+    """All-samples mode on a 1024^2 grid (hill_density unset: 3000 hills per step) with the limiter crossing
+    mid-batch: the long list goes through the culled sub-batches, the ordered tail through the limiter."""
+    lib = B.load("oracle")
+    cfg = ("tempering 0\nhill_prefactor 30\nbias_per_step 21\ndimension 2\nbox_low 0 0\nbox_high 16 16\n"
+           "bias_spacing 0.015625 0.015625\nbias_sigma 0.02 0.025\n")
+    cfgs = {}
+    for tag in ("gpu", "ora"):
+        cfgs[tag] = str(tmp_path / (tag + ".edm"))
+        open(cfgs[tag], "w").write(cfg + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (tmp_path, tag, tmp_path, tag))
+    b = H.Bias(cfgs["gpu"])
+    o = B.Bias(lib, cfgs["ora"])
+    for x in (b, o):
+        x.setup(1.0, 1.0)
+        x.subdivide([0, 0], [16, 16], [0, 0], [16, 16], [1, 1], [0, 0])
+    rng = np.random.default_rng(11)
+    n = 3000
+    for step in range(2):
+        pos = np.zeros((n, 3))
+        pos[:, :2] = rng.uniform(0, 16, (n, 2))
+        ru = rng.random(n)
+        b.add_hills(pos, ru, -1)
+        o.add_hills(pos, ru, -1)
+        close(b.get("cum_bias"), o.get("cum_bias"), rtol=1e-9, what="cum_bias")
+        got = [int(b.get(k)) for k in ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added")]
+        want = [int(o.get(k)) for k in ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added")]
+        assert got == want, (step, got, want)
+    assert int(o.get("overflow_right")) > 0, "the limiter must have deferred hills"
+    v, dv = b.gauss.download()
+    og = o.gauss.grid
+    close(v, og.values, rtol=1e-8, atol=1e-12 * np.abs(og.values).max(), what="grid")
+    assert np.array_equal(b.hist.values, o.hist.values)
