@@ -6,13 +6,16 @@
 // bit-exact and values differ from the CPU reference only through exp() ulps and
 // the documented reduction orders.
 //
-//   K1/K2  k_lookup / k_pair_forces   bias-grid interpolation, force update, energy sum
-//   K3     k_hill_integrals           per-hill integrated bias (value add_value returns)
-//   K4     k_chunk_stats/k_limit      ordered bias limiter (undo + overflow decisions)
-//   K5     k_hill_gather              tile-owned, ORDER-PRESERVING gather of hills onto nodes
-//   K6     k_duplicate_boundary       boundary value duplication
-//   K7     k_hist_add                 CV histogram
-//   K8     block/wave reductions      fixed-order energy and bias sums
+//   K1/K2  k_pair_forces_fast / k_lookup   bias-grid interpolation, force update, energy sum
+//   sel    k_select_prep (k_sel_*)         ordered selection of accepted samples (+ hill preparation,
+//                                          or the packet of the multi-GPU exchange; k_unpack_prep receives)
+//   K3     k_hill_integrals                per-hill integrated bias (value add_value returns)
+//   K4     limit_wave (k_limit)            ordered bias limiter (undo + overflow decisions)
+//   K5     k_hill_gather (+ k_mark_tiles)  tile-owned, ORDER-PRESERVING gather of hills onto nodes
+//   K6/K7  boundary duplication, CV histogram (chained onto K5, or k_post_batch)
+//   K8     block/wave reductions           fixed-order energy and bias sums
+// A short hill step is three launches: sel -> K3 (+K4) -> K5 (+K6, K7, read-back), each stage's small serial
+// tail run by the last workgroup to finish (last_block_done).
 #include "edm_kernels.h"
 
 #include <hip/hip_ext.h>
