@@ -325,6 +325,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same step with the acceptance uniforms drawn on the device (fast mode of the fixes' RNG: no array of
+    # uniforms is generated, uploaded or read); informational, not part of `value`
+    b.set_device_rng(True, 12345 + rank)
+    for _ in range(3):
+        b.pair_step_device(d_r, d_f, npairs, d_r, None, npairs, est)
+    barrier()
+    t_r = time.perf_counter()
+    for _ in range(args.steps):
+        b.pair_step_device(d_r, d_f, npairs, d_r, None, npairs, est)
+    barrier()
+    ms_step_device_rng = (time.perf_counter() - t_r) / args.steps * 1e3
+    b.set_device_rng(False, 0)
+
     # component rates (not part of `value`): force evaluation alone, all-samples hill adds
     reps = 20
     H.synchronize()
@@ -486,6 +499,7 @@ def main():
                 "bytes_per_launch": BYTES_PER_EVAL * npairs,
             },
             "evals_only_million_per_s": npairs / t_eval / 1e6,
+            "ms_per_step_device_rng": ms_step_device_rng,
             "energy_last_step": energy,
         }
         out.update(extra)

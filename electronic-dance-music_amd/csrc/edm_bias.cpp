@@ -64,6 +64,10 @@ struct edm_hip_bias {
   long long xchg_counts[EDM_MAX_RANKS], xchg_est[EDM_MAX_RANKS];  // last synchronous exchange: per-rank hills / est_hill_count
   double *h_flush = nullptr;   // pinned staging of the overflow records handed to a flush
   size_t flush_cap = 0;
+  // device uniforms (edm_hip_bias_set_device_rng): add_hill cycles given no uniform array draw from a
+  // counter-based stream keyed by (seed, cycle number, sample index)
+  bool device_rng = false;
+  unsigned long long rng_seed = 0, rng_cycle = 0;
   bool force_sync = false;      // redo of a deferred step whose launch bound proved too small
   int debug_virtual_ranks = 0;  // tests: a one-rank communicator's packet is replicated, emulating that many ranks
   DevBuf<long long> xchg_cnt;
@@ -521,6 +525,8 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   const int x_stride_in = x_stride;
   const int use_thr = !(b->hill_density < 0);
   const double thr = b->hill_density / b->est_hill_count;   // :543
+  // one stream per add_hill cycle (the same key for a synchronous redo of this cycle)
+  const unsigned long long rng = b->rng_seed + b->rng_cycle * 0x632BE59BD9B4E019ull;
   long long nh = n;
   long long deferred_bound = 0;
   SelectArgs sel_args;
@@ -553,7 +559,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       EDM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_count), b->h_count, 0));
     }
     if (n > 0) {
-      if (!d_ru) {
+      if (!d_ru && !b->device_rng) {
         set_error("add_hills: hill_density set but no uniform random numbers given");
         return EDM_HIP_ERR_ARG;
       }
@@ -562,6 +568,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       memset(&sel_args, 0, sizeof(sel_args));
       sel_args.n = n;
       sel_args.ru = d_ru;
+      sel_args.rng = rng;
       sel_args.thr = thr;
       sel_args.use_thr = use_thr;
       sel_args.mask = b->d_mask;
@@ -601,7 +608,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     d_x = b->xchg_all.p;
     x_stride = dim;
   } else if (use_thr || apply_mask >= 0) {
-    if (use_thr && !d_ru) {
+    if (use_thr && !d_ru && !b->device_rng) {
       set_error("add_hills: hill_density set but no uniform random numbers given");
       return EDM_HIP_ERR_ARG;
     }
@@ -626,7 +633,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     deferred_bound = bound;
     if (!bound) {
       EDM_HIP_TRY(launch_select(n, d_ru, thr, use_thr, b->d_mask, apply_mask, b->sel.p, b->d_count, b->sel_scratch.p, s,
-                                b->count_dev.p));
+                                b->count_dev.p, rng));
       EDM_HIP_TRY(hipStreamSynchronize(s));
       nh = *b->h_count;
     } else {
@@ -635,6 +642,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       memset(&sel_args, 0, sizeof(sel_args));
       sel_args.n = n;
       sel_args.ru = d_ru;
+      sel_args.rng = rng;
       sel_args.thr = thr;
       sel_args.use_thr = use_thr;
       sel_args.mask = b->d_mask;
@@ -808,6 +816,7 @@ static int do_post_add_hill(edm_hip_bias *b) {
   b->temp_hill_cum = -1;
   b->temp_hill_prefactor = -1;
   b->steps++;
+  b->rng_cycle++;
   if (b->hills_fp) fflush(b->hills_fp);
   return EDM_HIP_OK;
 }
@@ -991,6 +1000,13 @@ int edm_hip_bias_get_array(const edm_hip_bias *b, const char *name, double *out)
   if (strcmp(name, "max") == 0) v = &b->max;
   if (!v) return EDM_HIP_ERR_ARG;
   for (size_t i = 0; i < v->size(); i++) out[i] = (*v)[i];
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_set_device_rng(edm_hip_bias *b, int enabled, unsigned long long seed) {
+  b->device_rng = enabled != 0;
+  b->rng_seed = seed;
+  b->rng_cycle = 0;
   return EDM_HIP_OK;
 }
 

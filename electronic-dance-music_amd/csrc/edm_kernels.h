@@ -65,7 +65,7 @@ size_t select_scratch_ints(long long n);
 // consume a deferred count while `count` is host-mapped for the CPU)
 hipError_t launch_select(long long n, const double *runiform, double threshold, int use_threshold,
                          const int *mask, int apply_mask, long long *sel, long long *count,
-                         int *scratch, hipStream_t s, long long *count2 = nullptr);
+                         int *scratch, hipStream_t s, long long *count2 = nullptr, unsigned long long rng = 0);
 
 struct HillList {
   long long nh;
@@ -90,7 +90,8 @@ hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s);
 // selection + preparation in one launch; h.nh is the launch bound of the step, h.sel == a.sel
 struct SelectArgs {
   long long n;
-  const double *ru;
+  const double *ru;       // uniforms, or NULL: taken from the device stream `rng` (see device_uniform)
+  unsigned long long rng;
   double thr;
   int use_thr;
   const int *mask;

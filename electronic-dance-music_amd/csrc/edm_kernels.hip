@@ -751,22 +751,33 @@ hipError_t launch_hist_tail(const Geom &g, double *values, const LimitResult *re
 static constexpr int SEL_PER_THREAD = 8;
 static constexpr int SEL_CHUNK = BLOCK * SEL_PER_THREAD;
 
+// uniform number i (0-based) of the device stream `rng`: output i + 1 of SplitMix64 started at `rng`, top 53
+// bits -> [0, 1)  (edm_amd.workloads.uniform is the host twin)
+__device__ __forceinline__ double device_uniform(unsigned long long rng, long long i) {
+  unsigned long long z = rng + (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+// ru == NULL with use_thr: the uniforms come from the device stream `rng` (no array to generate, upload or read)
 __device__ __forceinline__ bool sel_flag(long long i, long long n, const double *__restrict__ ru, double thr,
-                                         int use_thr, const int *__restrict__ mask, int apply_mask) {
+                                         int use_thr, const int *__restrict__ mask, int apply_mask,
+                                         unsigned long long rng) {
   if (i >= n) return false;
   if (!(apply_mask < 0 || (apply_mask & mask[i]))) return false;
-  if (use_thr && !(ru[i] < thr)) return false;
+  if (use_thr && !((ru ? ru[i] : device_uniform(rng, i)) < thr)) return false;
   return true;
 }
 
 __global__ void __launch_bounds__(BLOCK) k_sel_count(long long n, const double *__restrict__ ru, double thr,
                                                      int use_thr, const int *__restrict__ mask, int apply_mask,
-                                                     int *__restrict__ counts) {
+                                                     int *__restrict__ counts, unsigned long long rng) {
   __shared__ int lds[BLOCK / 64];
   const long long base = (long long)blockIdx.x * SEL_CHUNK + (long long)threadIdx.x * SEL_PER_THREAD;
   int c = 0;
 #pragma unroll
-  for (int j = 0; j < SEL_PER_THREAD; j++) c += sel_flag(base + j, n, ru, thr, use_thr, mask, apply_mask) ? 1 : 0;
+  for (int j = 0; j < SEL_PER_THREAD; j++) c += sel_flag(base + j, n, ru, thr, use_thr, mask, apply_mask, rng) ? 1 : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
@@ -815,14 +826,14 @@ __global__ void __launch_bounds__(BLOCK) k_sel_scan(int nblocks, const int *__re
 __global__ void __launch_bounds__(BLOCK) k_sel_scatter(long long n, const double *__restrict__ ru, double thr,
                                                        int use_thr, const int *__restrict__ mask, int apply_mask,
                                                        const long long *__restrict__ offsets,
-                                                       long long *__restrict__ sel) {
+                                                       long long *__restrict__ sel, unsigned long long rng) {
   __shared__ int lds[BLOCK];
   const long long base = (long long)blockIdx.x * SEL_CHUNK + (long long)threadIdx.x * SEL_PER_THREAD;
   bool fl[SEL_PER_THREAD];
   int c = 0;
 #pragma unroll
   for (int j = 0; j < SEL_PER_THREAD; j++) {
-    fl[j] = sel_flag(base + j, n, ru, thr, use_thr, mask, apply_mask);
+    fl[j] = sel_flag(base + j, n, ru, thr, use_thr, mask, apply_mask, rng);
     c += fl[j] ? 1 : 0;
   }
   lds[threadIdx.x] = c;
@@ -846,7 +857,8 @@ size_t select_scratch_ints(long long n) {
 }
 
 hipError_t launch_select(long long n, const double *ru, double thr, int use_thr, const int *mask, int apply_mask,
-                         long long *sel, long long *count, int *scratch, hipStream_t s, long long *count2) {
+                         long long *sel, long long *count, int *scratch, hipStream_t s, long long *count2,
+                         unsigned long long rng) {
   const int nb = (int)((n + SEL_CHUNK - 1) / SEL_CHUNK);
   if (nb == 0) {
     if (count2) {
@@ -857,9 +869,9 @@ hipError_t launch_select(long long n, const double *ru, double thr, int use_thr,
   }
   int *counts = scratch;
   long long *offsets = reinterpret_cast<long long *>(scratch + ((nb + 2) & ~1));
-  hipLaunchKernelGGL(k_sel_count, dim3(nb), dim3(BLOCK), 0, s, n, ru, thr, use_thr, mask, apply_mask, counts);
+  hipLaunchKernelGGL(k_sel_count, dim3(nb), dim3(BLOCK), 0, s, n, ru, thr, use_thr, mask, apply_mask, counts, rng);
   hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(BLOCK), 0, s, nb, counts, offsets, count, count2);
-  hipLaunchKernelGGL(k_sel_scatter, dim3(nb), dim3(BLOCK), 0, s, n, ru, thr, use_thr, mask, apply_mask, offsets, sel);
+  hipLaunchKernelGGL(k_sel_scatter, dim3(nb), dim3(BLOCK), 0, s, n, ru, thr, use_thr, mask, apply_mask, offsets, sel, rng);
   return hipGetLastError();
 }
 
@@ -997,7 +1009,7 @@ __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, Hil
     int c = 0;
 #pragma unroll
     for (int j = 0; j < SEL_PER_THREAD; j++) {
-      fl[j] = sel_flag(base + j, a.n, a.ru, a.thr, a.use_thr, a.mask, a.apply_mask);
+      fl[j] = sel_flag(base + j, a.n, a.ru, a.thr, a.use_thr, a.mask, a.apply_mask, a.rng);
       c += fl[j] ? 1 : 0;
     }
     int inc = c;

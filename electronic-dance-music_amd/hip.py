@@ -84,6 +84,7 @@ _PROTOS = {
     "edm_hip_bias_update_forces": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, C.c_int, c_dp]),
     "edm_hip_bias_pair_forces": (C.c_int, [vp, C.c_longlong, vp, vp, c_dp]),
     "edm_hip_bias_add_hills": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, C.c_longlong]),
+    "edm_hip_bias_set_device_rng": (C.c_int, [vp, C.c_int, C.c_ulonglong]),
     "edm_hip_bias_step": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pre_add_hill": (C.c_int, [vp, C.c_longlong]),
@@ -485,6 +486,10 @@ class Bias:
         e = C.c_double(0)
         check(lib().edm_hip_bias_pair_forces(self.h, n, _ptr(d_r), _ptr(d_f), C.byref(e)))
         return e.value
+
+    def set_device_rng(self, enabled, seed):
+        """acceptance uniforms drawn on the device (fast mode): pass d_u = None afterwards"""
+        check(lib().edm_hip_bias_set_device_rng(self.h, int(enabled), int(seed)))
 
     def step_device(self, d_x, x_stride, d_f, f_stride, n, d_u, apply_mask=-1, est=-1):
         """update_forces + add_hills over the same samples (one hill-depositing fix edm step), one host wait"""

@@ -641,16 +641,20 @@ double EDMBias::pair_step(int npairs, const double* r, double* force_r, int n_sa
     st.x.reserve(sb);
     st.u.reserve(sb);
     check(edm_hip_memcpy_h2d(st.x.p, sample_r, sb), "edm_bias.cpp:add_hill");
-    check(edm_hip_memcpy_h2d(st.u.p, runiform, sb), "edm_bias.cpp:add_hill");
+    if (runiform) check(edm_hip_memcpy_h2d(st.u.p, runiform, sb), "edm_bias.cpp:add_hill");
   }
   double energy = 0;
   check(edm_hip_bias_pair_step(h_, npairs > 0 ? npairs : 0, (const double*)st.r.p, (double*)st.fr.p,
-                               n_samples > 0 ? n_samples : 0, (const double*)st.x.p, (const double*)st.u.p,
-                               est_hill_count, &energy),
+                               n_samples > 0 ? n_samples : 0, (const double*)st.x.p,
+                               runiform ? (const double*)st.u.p : NULL, est_hill_count, &energy),
         "edm_bias.cpp:add_hill");
   if (npairs > 0) check(edm_hip_memcpy_d2h(force_r, st.fr.p, pb), "edm_bias.cpp:update_force");
   refresh();
   return energy;
+}
+
+void EDMBias::set_device_rng(bool enabled, unsigned long long seed) {
+  check(edm_hip_bias_set_device_rng(h_, enabled ? 1 : 0, seed), "edm_bias.cpp:add_hill");
 }
 
 void EDMBias::pre_add_hill(int est_hill_count) { check(edm_hip_bias_pre_add_hill(h_, est_hill_count), "edm_bias.cpp:pre_add_hill"); }

@@ -50,6 +50,10 @@ FixEDM::FixEDM(LAMMPS *lmp, int narg, char **arg) : Fix(lmp, narg, arg), bias(NU
     MPI_Bcast(id, 128, MPI_CHAR, 0, world);
     bias->init_comm(id, size, me);
   }
+  // extension: "... seed device_rng" draws the acceptance uniforms on the GPU from a counter-based stream keyed
+  // by seed + rank (no RanMars calls, nothing to upload); without the keyword the reference's RNG order is kept
+  device_rng = (narg > 9 && strcmp(arg[9], "device_rng") == 0);
+  if (device_rng) bias->set_device_rng(true, (unsigned long long) seed + (unsigned long long) me);
   thermo_energy = 1;
   random = new RanMars(lmp, seed + me);
   edm_energy = 0;
@@ -106,9 +110,10 @@ void FixEDM::post_force(int /*vflag*/)
       random_cap = atom->nmax;
       random_numbers = (double *) malloc(sizeof(double) * (size_t) (random_cap > 0 ? random_cap : 1));
     }
-    for (int i = 0; i < atom->nlocal; i++) random_numbers[i] = random->uniform();
+    if (!device_rng)
+      for (int i = 0; i < atom->nlocal; i++) random_numbers[i] = random->uniform();
     // update_forces + add_hills in one call: positions and the group mask cross PCIe once, one device wait
-    edm_energy = bias->step(atom->nlocal, atom->x, atom->f, random_numbers, groupbit);
+    edm_energy = bias->step(atom->nlocal, atom->x, atom->f, device_rng ? NULL : random_numbers, groupbit);
   } else {
     edm_energy = bias->update_forces(atom->nlocal, atom->x, atom->f, groupbit);
   }

@@ -38,6 +38,7 @@ class FixEDM : public Fix {
   int random_cap;
   class RanMars *random;
   unsigned int seed;
+  bool device_rng;   // optional trailing keyword "device_rng": uniforms drawn on the GPU (fast mode, not RanMars)
   int nlevels_respa;
 };
 

@@ -63,6 +63,8 @@ FixEDMPair::FixEDMPair(LAMMPS *lmp, int narg, char **arg) : Fix(lmp, narg, arg),
     MPI_Bcast(id, 128, MPI_CHAR, 0, world);
     bias->init_comm(id, size, me);
   }
+  device_rng = (narg > 11 && strcmp(arg[11], "device_rng") == 0);
+  if (device_rng) bias->set_device_rng(true, (unsigned long long) seed + (unsigned long long) me);
   random = new RanMars(lmp, seed + me);
   edm_energy = 0;
   last_calls = 0;
@@ -170,10 +172,10 @@ void FixEDMPair::post_force(int /*vflag*/)
       pair_j.push_back(j);
       if (hill_step) {
         hill_r.push_back(r);
-        hill_u.push_back(random->uniform());
+        if (!device_rng) hill_u.push_back(random->uniform());
         if (newton_pair || j < nlocal) {
           hill_r.push_back(r);
-          hill_u.push_back(random->uniform());
+          if (!device_rng) hill_u.push_back(random->uniform());
         }
       }
     }
@@ -185,7 +187,8 @@ void FixEDMPair::post_force(int /*vflag*/)
   pair_f.resize(pair_r.size());
   if (hill_step) {
     const int ncalls = (int) hill_r.size();
-    edm_energy = bias->pair_step(npairs, pair_r.data(), pair_f.data(), ncalls, hill_r.data(), hill_u.data(), last_calls);
+    edm_energy = bias->pair_step(npairs, pair_r.data(), pair_f.data(), ncalls, hill_r.data(),
+                                 device_rng ? NULL : hill_u.data(), last_calls);
     last_calls = ncalls;  // next step's estimate (fix_edm_pair.cpp:245)
   } else {
     edm_energy = bias->update_pair_forces(npairs, pair_r.data(), pair_f.data());

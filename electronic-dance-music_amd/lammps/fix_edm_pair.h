@@ -41,6 +41,7 @@ class FixEDMPair : public Fix {
   class RanMars *random;
   class NeighList *list;  // half neighbor list
   unsigned int seed;
+  bool device_rng;   // optional trailing keyword "device_rng" (see fix_edm.h)
   int nlevels_respa;
   int last_calls;  // an estimate of the number of add_hill calls on this processor
   int ipair, jpair;

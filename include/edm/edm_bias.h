@@ -62,6 +62,9 @@ class EDMBias {
   double update_pair_forces(int npairs, const double* r, double* force_r) const;
   // one hill cycle over a flat distance array: pre_add_hill(est); add_hill(&r[i], runiform[i]); post
   void add_pair_hills(int n, const double* r, const double* runiform, int est_hill_count);
+  // fast mode of the random numbers: add_hills / step / pair_step called with runiform == NULL draw their
+  // uniforms from a counter-based stream on the device (see edm_hip_bias_set_device_rng); use seed + rank
+  void set_device_rng(bool enabled, unsigned long long seed);
   // one hill-depositing fix_edm step in one call: update_forces(nlocal, positions, forces, apply_mask) then
   // add_hills(nlocal, positions, runiform, apply_mask); positions and mask cross PCIe once, one device wait
   double step(int nlocal, const double* const* positions, double** forces, const double* runiform, int apply_mask);

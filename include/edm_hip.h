@@ -233,6 +233,12 @@ int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value);
 int edm_hip_bias_set(edm_hip_bias *b, const char *name, double value);
 /* bias_dx, bias_sigma, min, max (dim doubles) */
 int edm_hip_bias_get_array(const edm_hip_bias *b, const char *name, double *out);
+/* Fast mode of the fixes' random numbers (no reference counterpart): while enabled, an add_hill
+ * cycle that is given NO uniform array (d_runiform == NULL with hill_density set) draws
+ * u_i = SplitMix64(seed + cycle * 0x632BE59BD9B4E019, output i + 1) >> 11 * 2^-53 on the device for sample i
+ * of add_hill cycle number `cycle` (0, 1, ... since this call).  Nothing is generated on the host, uploaded or
+ * read from HBM.  The parity mode (the host's RanMars numbers passed in) stays the default. */
+int edm_hip_bias_set_device_rng(edm_hip_bias *b, int enabled, unsigned long long seed);
 /* 1 (default): write the per-rank HILLS log like the reference (edm_bias.cpp:586-599);
  * 0: skip the text log (the CV histogram is still updated). */
 int edm_hip_bias_set_hill_log(edm_hip_bias *b, int enabled);

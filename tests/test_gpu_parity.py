@@ -747,3 +747,37 @@ def test_large_selection_vs_oracle(oracle_lib, workdir):
     close(v, og.values, rtol=1e-9, atol=1e-13 * np.abs(og.values).max(), what="grid")
     assert np.array_equal(b.hist.values, o.hist.values)
     assert int(b.get("hills_added")) > 150
+
+
+def test_device_rng_equals_explicit_uniforms(workdir):
+    """Fast mode of the random numbers (edm_hip_bias_set_device_rng): the uniforms drawn on the device for
+    add_hill cycle c are output i + 1 of SplitMix64(seed + c * 0x632BE59BD9B4E019) -- feeding exactly those
+    numbers through the explicit-uniform path must give the same bias, bit for bit (both the chained
+    selection of large steps and the synchronous selection of small ones)."""
+    text = ("tempering 0\nhill_prefactor 0.5\nhill_density 80\nbias_per_step 0.3\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+            "bias_spacing 0.001\nbias_sigma 0.05\n")
+    seed, K, M = 20261004, 0x632BE59BD9B4E019, (1 << 64) - 1
+    sizes = [50_000, 300, 50_000, 2_000]
+    state = []
+    for tag in ("device", "explicit"):
+        cfg = str(workdir / (tag + ".edm"))
+        open(cfg, "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+        b = H.Bias(cfg)
+        b.setup(1.0, 1.0)
+        b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+        if tag == "device":
+            b.set_device_rng(True, seed)
+        for cycle, n in enumerate(sizes):
+            d_r = H.DeviceArray.from_host(W.pair_distances(n, 900 + cycle))
+            if tag == "device":
+                b.add_hills_device(d_r, n, 1, None, -1, n)
+            else:
+                d_u = H.DeviceArray.from_host(W.uniform((seed + cycle * K) & M, n))
+                b.add_hills_device(d_r, n, 1, d_u, -1, n)
+        v, dv = b.gauss.download()
+        state.append((v, dv, b.hist.values, b.get("cum_bias"), b.get("overflow_right"), b.get("hills_added")))
+        del b
+    for a, c in zip(state[0], state[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(c))
+    assert state[0][0].max() > 0
+    assert open(str(workdir / "HILLS_device_0")).read() == open(str(workdir / "HILLS_explicit_0")).read()
