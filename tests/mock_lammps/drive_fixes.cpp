@@ -65,8 +65,10 @@ int main(int argc, char **argv) {
   {
     char a0[] = "1", a1[] = "all", a2[] = "edm_pair", a3[] = "1.0", a5[] = "2", a6[] = "1000000", a8[] = "7", a9[] = "1", a10[] = "1";
     std::string bf = std::string(argv[3]) + ".pairbias";
-    char *args[] = {a0, a1, a2, a3, argv[1], a5, a6, &bf[0], a8, a9, a10};
-    FixEDMPair fix(&lmp, 11, args);
+    char kw[] = "device_rng";
+    const bool fast_rng = (argc > 4 && std::string(argv[4]) == "device_rng");
+    char *args[] = {a0, a1, a2, a3, argv[1], a5, a6, &bf[0], a8, a9, a10, kw};
+    FixEDMPair fix(&lmp, fast_rng ? 12 : 11, args);
     std::fprintf(out, "pair_mask %d\n", fix.setmask());
     fix.init();
     fix.init_list(0, &list);
@@ -85,8 +87,10 @@ int main(int argc, char **argv) {
   {
     char a0[] = "2", a1[] = "all", a2[] = "edm", a3[] = "1.0", a5[] = "2", a6[] = "1000000", a8[] = "11";
     std::string bf = std::string(argv[3]) + ".coordbias";
-    char *args[] = {a0, a1, a2, a3, argv[2], a5, a6, &bf[0], a8};
-    FixEDM fix(&lmp, 9, args);
+    char kw[] = "device_rng";
+    const bool fast_rng = (argc > 4 && std::string(argv[4]) == "device_rng");
+    char *args[] = {a0, a1, a2, a3, argv[2], a5, a6, &bf[0], a8, kw};
+    FixEDM fix(&lmp, fast_rng ? 10 : 9, args);
     std::fprintf(out, "coord_mask %d\n", fix.setmask());
     fix.init();
     for (int step = 0; step < 4; step++) {

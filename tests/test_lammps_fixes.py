@@ -150,3 +150,45 @@ def test_driven_fixes_agree_with_oracle(tmp_path, oracle_lib):
         assert abs(float(got[3]) - E) <= 1e-9 * max(abs(E), 1e-12), (step, got, E)
         assert abs(float(got[5]) - np.abs(f).sum()) <= 1e-8 * max(np.abs(f).sum(), 1e-12)
     assert float(coord_steps[-1][3]) > 0
+
+
+@pytest.mark.gpu
+def test_driven_fix_edm_device_rng_agrees_with_oracle(tmp_path, oracle_lib):
+    """`fix edm ... seed device_rng`: the acceptance uniforms are drawn on the GPU (stream seed + rank, one
+    sub-stream per hill step).  The oracle fed with the same SplitMix64 numbers must reproduce the fix's
+    energies and forces; fix edm_pair with the keyword must run and bias the system."""
+    from oracle import binding as B
+    import edm_amd.workloads as W
+
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "host")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", MOCK, "drive_fixes"], stdout=subprocess.DEVNULL)
+    cfgs = {}
+    for tag, text in (("pair", PAIR_CFG), ("coord", COORD_CFG), ("coord_o", COORD_CFG)):
+        cfgs[tag] = str(tmp_path / (tag + ".edm"))
+        open(cfgs[tag], "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (tmp_path, tag, tmp_path, tag))
+    out = str(tmp_path / "fixes.out")
+    res = subprocess.run([os.path.join(MOCK, "drive_fixes"), cfgs["pair"], cfgs["coord"], out, "device_rng"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln.split() for ln in open(out)]
+    pair_steps = [ln for ln in lines if ln[0] == "pair_step"]
+    coord_steps = [ln for ln in lines if ln[0] == "coord_step"]
+    assert float(pair_steps[-1][3]) > 0 and np.isfinite(float(pair_steps[-1][7]))
+    x = _positions()
+    n = len(x)
+    oc = B.Bias(oracle_lib, cfgs["coord_o"])
+    oc.setup(1.0, 1.0)
+    oc.subdivide([0] * 3, [8] * 3, [0] * 3, [8] * 3, [1, 1, 1], [0.3] * 3)
+    oc.set_mask(np.ones(n, dtype=np.int32))
+    seed, K, M = 11, 0x632BE59BD9B4E019, (1 << 64) - 1
+    cycle = 0
+    for step in range(4):
+        f = np.zeros((n, 3))
+        E = oc.update_forces(np.ascontiguousarray(x), f, 1)
+        if step % 2 == 0:
+            oc.add_hills(np.ascontiguousarray(x), W.uniform((seed + cycle * K) & M, n), 1)
+            cycle += 1
+        got = coord_steps[step]
+        assert abs(float(got[3]) - E) <= 1e-9 * max(abs(E), 1e-12), (step, got, E)
+        assert abs(float(got[5]) - np.abs(f).sum()) <= 1e-8 * max(np.abs(f).sum(), 1e-12)
+    assert float(coord_steps[-1][3]) > 0
