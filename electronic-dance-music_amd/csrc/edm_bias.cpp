@@ -68,6 +68,8 @@ struct edm_hip_bias {
   // counter-based stream keyed by (seed, cycle number, sample index)
   bool device_rng = false;
   unsigned long long rng_seed = 0, rng_cycle = 0;
+  DevBuf<double> vs_r;     // virtual add_hill samples of a device-resident neighbour list (2 per list entry)
+  DevBuf<int> vs_mask;
   bool force_sync = false;      // redo of a deferred step whose launch bound proved too small
   int debug_virtual_ranks = 0;  // tests: a one-rank communicator's packet is replicated, emulating that many ranks
   DevBuf<long long> xchg_cnt;
@@ -242,6 +244,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   if (b->hills_fp) fclose(b->hills_fp);
   b->sel.release(); b->sel_scratch.release(); b->count_dev.release(); b->sel_stage.release();
   if (b->h_flush) (void)hipHostFree(b->h_flush);
+  b->vs_r.release(); b->vs_mask.release();
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
   delete b;
@@ -889,6 +892,70 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
   const double e = pair_forces_finish(b->bias, nblk);
   if (energy) *energy = e;
   return do_post_add_hill(b);
+}
+
+int edm_hip_bias_pair_list_step(edm_hip_bias *b, long long npairs, const int *d_pair_i, const int *d_pair_j,
+                                const int *d_type, int itype, int jtype, int nlocal, long long nall, const double *d_x,
+                                double *d_fdelta, int hill_step, long long est_hill_count, double *energy,
+                                long long *ncalls) {
+  if (energy) *energy = 0;
+  if (ncalls) *ncalls = 0;
+  if (!b->bias && !b->b_outofbounds) {
+    set_error("pair_list_step before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  if (b->dim != 1) {
+    set_error("pair_list_step: the pair-distance CV is 1-D (fix_edm_pair.cpp:52)");
+    return EDM_HIP_ERR_ARG;
+  }
+  if (hill_step && !(b->hill_density < 0) && !b->device_rng) {
+    set_error("pair_list_step: hill steps draw their uniforms on the device -- call set_device_rng first");
+    return EDM_HIP_ERR_STATE;
+  }
+  if (nall > 0) EDM_HIP_TRY(hipMemsetAsync(d_fdelta, 0, sizeof(double) * 3 * (size_t)nall, b->bias ? b->bias->stream : 0));
+  int rc = EDM_HIP_OK;
+  if (hill_step) {
+    rc = do_pre_add_hill(b, est_hill_count);   // overflow flush before any force (fix_edm_pair.cpp:174)
+    if (rc) return rc;
+  }
+  if (b->b_outofbounds) return hill_step ? do_post_add_hill(b) : EDM_HIP_OK;
+  hipStream_t s = b->bias->stream;
+  PairListArgs a;
+  memset(&a, 0, sizeof(a));
+  a.npairs = npairs;
+  a.pair_i = d_pair_i;
+  a.pair_j = d_pair_j;
+  a.type = d_type;
+  a.itype = itype;
+  a.jtype = jtype;
+  a.nlocal = nlocal;
+  a.x = d_x;
+  a.fdelta = d_fdelta;
+  if (hill_step && npairs > 0) {
+    EDM_HIP_TRY(b->vs_r.reserve((size_t)2 * npairs));
+    EDM_HIP_TRY(b->vs_mask.reserve((size_t)2 * npairs));
+    a.vs_r = b->vs_r.p;
+    a.vs_mask = b->vs_mask.p;
+  }
+  int nblk = 0;
+  if (npairs > 0) EDM_HIP_TRY(launch_pairlist_forces(b->bias->g, b->bias->rec, a, b->bias->d_partials, s, &nblk));
+  if (hill_step) {
+    // add_hill(r, u) for the two virtual samples of every list entry, in list order; dead ones are masked out
+    const int *saved_mask = b->d_mask;
+    b->d_mask = b->vs_mask.p;
+    rc = process_new_hills(b, 2 * npairs, b->vs_r.p, 1, nullptr, 1);
+    b->d_mask = saved_mask;
+    if (rc) return rc;
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(s));
+  double e = 0, c = 0;
+  for (int k = 0; k < nblk; k++) {
+    e += b->bias->h_partials[k];
+    c += b->bias->h_partials[EDM_PAIRLIST_MAX_BLOCKS + k];
+  }
+  if (energy) *energy = e;
+  if (ncalls) *ncalls = (long long)c;
+  return hill_step ? do_post_add_hill(b) : EDM_HIP_OK;
 }
 
 int edm_hip_bias_pre_add_hill(edm_hip_bias *b, long long est_hill_count) {

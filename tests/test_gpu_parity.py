@@ -781,3 +781,95 @@ def test_device_rng_equals_explicit_uniforms(workdir):
         assert np.array_equal(np.asarray(a), np.asarray(c))
     assert state[0][0].max() > 0
     assert open(str(workdir / "HILLS_device_0")).read() == open(str(workdir / "HILLS_explicit_0")).read()
+
+
+def test_pair_list_step_vs_oracle(oracle_lib, workdir):
+    """fix edm_pair on a device-resident neighbour list (edm_hip_bias_pair_list_step): positions + flattened half
+    list in, pair distances / lookups / pair forces / hills on the GPU.  Against the oracle executing the
+    reference's per-pair loop with the same uniforms (device stream, sample index 2 * entry + slot): energies,
+    forces on owned and ghost atoms, add_hill call counts, limiter decisions, final grid and histogram.  Two atom
+    types with a type filter, ghost atoms (j >= nlocal: no force on j, one hill instead of two)."""
+    text = ("tempering 0\nhill_prefactor 0.3\nhill_density 25\nbias_per_step 0.2\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+            "bias_spacing 0.001\nbias_sigma 0.05\n")
+    cfgs = {}
+    for tag in ("gpu", "ora"):
+        cfgs[tag] = str(workdir / (tag + ".edm"))
+        open(cfgs[tag], "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+    b = H.Bias(cfgs["gpu"])
+    o = B.Bias(oracle_lib, cfgs["ora"])
+    for x in (b, o):
+        x.setup(1.0, 1.0)
+        x.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    seed, K, M = 4242, 0x632BE59BD9B4E019, (1 << 64) - 1
+    b.set_device_rng(True, seed)
+    rng = np.random.default_rng(3)
+    nall, nlocal = 700, 520
+    types = rng.integers(1, 3, nall).astype(np.int32)          # types 1 and 2; the fix pairs type 1 with type 2
+    itype, jtype = 1, 2
+    est = nall
+    cycle = 0
+    for step in range(5):
+        x = rng.uniform(0, 9.0, (nall, 3))
+        # half list in "neighbour-list order": for owned i, its neighbours j > i within the cutoff (owned or ghost)
+        pi, pj = [], []
+        for i in range(nlocal):
+            d2 = ((x[i + 1:] - x[i]) ** 2).sum(axis=1)
+            for j in (np.nonzero(d2 < 2.8 * 2.8)[0] + i + 1):
+                pi.append(i)
+                pj.append(int(j))
+        P = len(pi)
+        pi_a, pj_a = np.array(pi, dtype=np.int32), np.array(pj, dtype=np.int32)
+        d_fd = H.DeviceArray.zeros((nall, 3))
+        hill = step % 2 == 0
+        e, ncalls = b.pair_list_step_device(H.DeviceArray.from_host(pi_a), H.DeviceArray.from_host(pj_a), P,
+                                            H.DeviceArray.from_host(types), itype, jtype, nlocal, nall,
+                                            H.DeviceArray.from_host(x), d_fd, hill, est)
+        fd = d_fd.to_host()
+        # ---- oracle: the reference's loop ----
+        if hill:
+            o.pre_add_hill(est)
+        E, fref, calls = 0.0, np.zeros((nall, 3)), 0
+        u = W.uniform((seed + cycle * K) & M, 2 * P)
+        staged = []
+        for p, (i, j) in enumerate(zip(pi, pj)):
+            ti, tj = types[i], types[j]
+            if ti == itype:
+                ok = tj == jtype
+            elif ti == jtype:
+                ok = tj == itype
+            else:
+                ok = False
+            if not ok:
+                continue
+            dvec = x[i] - x[j]
+            r = np.sqrt((dvec ** 2).sum())
+            dvec = dvec * (1.0 / r)
+            ev, fv = o.update_force([r])
+            E += ev
+            fref[i] += dvec * fv[0]
+            if j < nlocal:
+                fref[j] -= dvec * fv[0]
+            if hill:
+                staged.append((r, u[2 * p]))
+                calls += 1
+                if j < nlocal:
+                    staged.append((r, u[2 * p + 1]))
+                    calls += 1
+        if hill:
+            for r, uu in staged:
+                o.add_hill([r], float(uu))
+            o.post_add_hill()
+            cycle += 1
+            assert ncalls == calls, (step, ncalls, calls)
+            est = calls
+            close(b.get("cum_bias"), o.get("cum_bias"), rtol=1e-9, what="cum_bias")
+            for k in ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added"):
+                assert int(b.get(k)) == int(o.get(k)), (step, k)
+        close(e, E, rtol=1e-9, atol=1e-13, what="energy step %d" % step)
+        close(fd, fref, rtol=1e-8, atol=1e-11 * max(np.abs(fref).max(), 1e-300), what="forces step %d" % step)
+        assert not fd[nlocal:].any(), "newton off: ghost atoms receive no force"
+    v, _ = b.gauss.download()
+    og = o.gauss.grid
+    close(v, og.values, rtol=1e-9, atol=1e-13 * np.abs(og.values).max(), what="grid")
+    assert np.array_equal(b.hist.values, o.hist.values)
+    assert og.values.max() > 0
