@@ -355,6 +355,12 @@ GaussGrid* make_gauss_grid(unsigned int dim, const double* min, const double* ma
 struct EDMBias::Stage {
   DevMem x, f, mask, u, r, fr;
   std::vector<double> pack_x, pack_f;
+  // device-resident neighbour list of pair_list_step
+  DevMem pl_i, pl_j, pl_type, pl_x, pl_f;
+  std::vector<int> pl_hi, pl_hj;
+  std::vector<double> pl_hx, pl_hf;
+  long long pl_npairs;
+  Stage() : pl_npairs(-1) {}
 };
 
 EDMBias::EDMBias(const std::string& input_filename)
@@ -650,6 +656,64 @@ double EDMBias::pair_step(int npairs, const double* r, double* force_r, int n_sa
         "edm_bias.cpp:add_hill");
   if (npairs > 0) check(edm_hip_memcpy_d2h(force_r, st.fr.p, pb), "edm_bias.cpp:update_force");
   refresh();
+  return energy;
+}
+
+double EDMBias::pair_list_step(int nlocal, int nall, const double* const* x, double** f, int inum, const int* ilist,
+                               const int* numneigh, int* const* firstneigh, int neighmask, const int* type, int itype,
+                               int jtype, bool list_changed, bool hill_step, int est_hill_count, int* ncalls) {
+  Stage& st = *st_;
+  if (ncalls) *ncalls = 0;
+  if (dim_ != 1) edm_error("pair_list_step needs a 1-D CV", "edm_bias.cpp:update_force");
+  if (list_changed || st.pl_npairs < 0) {
+    // flatten the half list in neighbour-list order (fix_edm_pair.cpp:177-186)
+    st.pl_hi.clear();
+    st.pl_hj.clear();
+    for (int ii = 0; ii < inum; ii++) {
+      const int i = ilist[ii];
+      const int* jlist = firstneigh[i];
+      for (int jj = 0; jj < numneigh[i]; jj++) {
+        st.pl_hi.push_back(i);
+        st.pl_hj.push_back(jlist[jj] & neighmask);
+      }
+    }
+    st.pl_npairs = (long long)st.pl_hi.size();
+    const size_t pb = sizeof(int) * (size_t)(st.pl_npairs > 0 ? st.pl_npairs : 1);
+    st.pl_i.reserve(pb);
+    st.pl_j.reserve(pb);
+    st.pl_type.reserve(sizeof(int) * (size_t)(nall > 0 ? nall : 1));
+    if (st.pl_npairs > 0) {
+      check(edm_hip_memcpy_h2d(st.pl_i.p, st.pl_hi.data(), sizeof(int) * (size_t)st.pl_npairs), "edm_bias.cpp:update_force");
+      check(edm_hip_memcpy_h2d(st.pl_j.p, st.pl_hj.data(), sizeof(int) * (size_t)st.pl_npairs), "edm_bias.cpp:update_force");
+    }
+    if (nall > 0) check(edm_hip_memcpy_h2d(st.pl_type.p, type, sizeof(int) * (size_t)nall), "edm_bias.cpp:update_force");
+  }
+  const size_t n3 = (size_t)3 * (size_t)(nall > 0 ? nall : 0);
+  if (n3 == 0) return 0.0;
+  st.pl_x.reserve(sizeof(double) * n3);
+  st.pl_f.reserve(sizeof(double) * n3);
+  // positions: LAMMPS rows are one contiguous [nall][3] block; pack otherwise
+  const long xs = row_stride(nall, x, 3);
+  const double* xsrc = x[0];
+  if (xs != 3) {
+    st.pl_hx.resize(n3);
+    for (int i = 0; i < nall; i++)
+      for (int d = 0; d < 3; d++) st.pl_hx[(size_t)3 * i + d] = x[i][d];
+    xsrc = st.pl_hx.data();
+  }
+  check(edm_hip_memcpy_h2d(st.pl_x.p, xsrc, sizeof(double) * n3), "edm_bias.cpp:update_force");
+  double energy = 0;
+  long long calls = 0;
+  check(edm_hip_bias_pair_list_step(h_, st.pl_npairs, (const int*)st.pl_i.p, (const int*)st.pl_j.p, (const int*)st.pl_type.p,
+                                    itype, jtype, nlocal, nall, (const double*)st.pl_x.p, (double*)st.pl_f.p,
+                                    hill_step ? 1 : 0, est_hill_count, &energy, &calls),
+        "edm_bias.cpp:add_hill");
+  st.pl_hf.resize(n3);
+  check(edm_hip_memcpy_d2h(st.pl_hf.data(), st.pl_f.p, sizeof(double) * n3), "edm_bias.cpp:update_force");
+  for (int i = 0; i < nall; i++)
+    for (int d = 0; d < 3; d++) f[i][d] += st.pl_hf[(size_t)3 * i + d];
+  if (ncalls) *ncalls = (int)calls;
+  if (hill_step) refresh();
   return energy;
 }
 

@@ -63,7 +63,12 @@ FixEDMPair::FixEDMPair(LAMMPS *lmp, int narg, char **arg) : Fix(lmp, narg, arg),
     MPI_Bcast(id, 128, MPI_CHAR, 0, world);
     bias->init_comm(id, size, me);
   }
-  device_rng = (narg > 11 && strcmp(arg[11], "device_rng") == 0);
+  // extensions: "... jtype device_rng" draws the acceptance uniforms on the GPU; "... jtype gpu_list" also keeps the
+  // neighbour list on the GPU: per step the positions go in and the bias forces come out (24 B per atom each way)
+  // instead of one distance and one force per PAIR
+  gpu_list = (narg > 11 && strcmp(arg[11], "gpu_list") == 0);
+  last_list_size = -1;
+  device_rng = gpu_list || (narg > 11 && strcmp(arg[11], "device_rng") == 0);
   if (device_rng) bias->set_device_rng(true, (unsigned long long) seed + (unsigned long long) me);
   random = new RanMars(lmp, seed + me);
   edm_energy = 0;
@@ -141,6 +146,27 @@ void FixEDMPair::post_force(int /*vflag*/)
 
   edm_energy = 0;
 
+  if (gpu_list) {
+    // the list is re-uploaded when LAMMPS rebuilt it (neighbor->ago == 0 on those steps; the mock and very old
+    // versions lack the field, so a changed total size or atom count also triggers it)
+    int total = 0;
+    for (int ii = 0; ii < inum; ii++) total += numneigh[ilist[ii]];
+    const int nall = atom->nlocal + atom->nghost;
+    const bool changed = (total != last_list_size) || list_rebuilt();
+    last_list_size = total;
+    int ncalls = 0;
+    edm_energy = bias->pair_list_step(nlocal, nall, x, f, inum, ilist, numneigh, firstneigh, NEIGHMASK, type, ipair, jpair,
+                                      changed, hill_step, last_calls, &ncalls);
+    if (hill_step) last_calls = ncalls;  // next step's estimate (fix_edm_pair.cpp:245)
+    if (update->ntimestep % write_stride == 0) {
+      bias->write_bias(bias_file);
+      bias->write_lammps_table(lammps_table_file);
+      bias->write_histogram();
+      bias->clear_histogram();
+    }
+    return;
+  }
+
   // pass 1: collect the pair records in neighbour-list order (filters of fix_edm_pair.cpp:181-202)
   // and, on hill steps, stage the hill samples with their uniforms in the reference's call order
   // (one add_hill per list entry, a second one iff j is owned, :230-237)
@@ -214,6 +240,15 @@ void FixEDMPair::post_force(int /*vflag*/)
     bias->write_histogram();
     bias->clear_histogram();
   }
+}
+
+bool FixEDMPair::list_rebuilt()
+{
+#ifdef EDM_LAMMPS_NO_NEIGHBOR_AGO
+  return true;    // no way to tell: upload every step
+#else
+  return neighbor->ago == 0;
+#endif
 }
 
 void FixEDMPair::post_force_respa(int vflag, int ilevel, int /*iloop*/)

@@ -28,6 +28,7 @@ class FixEDMPair : public Fix {
   void post_force_respa(int, int, int);
   void min_post_force(int);
   void init_list(int, class NeighList *);
+  bool list_rebuilt();
   double compute_scalar();
 
  private:
@@ -42,6 +43,8 @@ class FixEDMPair : public Fix {
   class NeighList *list;  // half neighbor list
   unsigned int seed;
   bool device_rng;   // optional trailing keyword "device_rng" (see fix_edm.h)
+  bool gpu_list;     // optional trailing keyword "gpu_list" (implies device_rng): neighbour list resident on the GPU
+  int last_list_size;  // total entries of the list last uploaded (re-upload when LAMMPS rebuilt it)
   int nlevels_respa;
   int last_calls;  // an estimate of the number of add_hill calls on this processor
   int ipair, jpair;

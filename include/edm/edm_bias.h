@@ -73,6 +73,14 @@ class EDMBias {
   // post_add_hill().  Returns the bias energy of the pairs.
   double pair_step(int npairs, const double* r, double* force_r, int n_samples, const double* sample_r,
                    const double* runiform, int est_hill_count);
+  // fix edm_pair with the neighbour list resident on the GPU (needs set_device_rng): LAMMPS' half list
+  // (ilist/numneigh/firstneigh, j masked with neighmask) is flattened and uploaded when list_changed, this
+  // step's positions x[nall][3] go in, the bias forces come back ADDED to f[nall][3] (i always, j iff
+  // j < nlocal), the return value is the bias energy.  hill_step: pre_add_hill(est_hill_count) first, then
+  // one add_hill per list entry of the right types and a second iff j is owned; *ncalls = calls made.
+  double pair_list_step(int nlocal, int nall, const double* const* x, double** f, int inum, const int* ilist,
+                        const int* numneigh, int* const* firstneigh, int neighmask, const int* type, int itype,
+                        int jtype, bool list_changed, bool hill_step, int est_hill_count, int* ncalls);
   // one rank per GPU: id is an ncclUniqueId made by make_comm_id() on rank 0 and broadcast by the
   // caller (MPI_Bcast in LAMMPS); must be called before subdivide
   // binds this process to GPU (rank % visible devices); call before constructing an EDMBias

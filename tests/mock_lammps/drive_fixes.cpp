@@ -41,7 +41,7 @@ int main(int argc, char **argv) {
       xb[3 * i + d] = box * ((s >> 11) * (1.0 / 9007199254740992.0));
     }
   }
-  atom.tag_enable = 1; atom.nlocal = n; atom.nmax = n; atom.x = xr.data(); atom.f = fr.data();
+  atom.tag_enable = 1; atom.nlocal = n; atom.nghost = 0; atom.nmax = n; atom.x = xr.data(); atom.f = fr.data();
   atom.type = type.data(); atom.mask = mask.data();
   upd.ntimestep = 0; upd.integrate_style = "verlet"; upd.integrate = &respa; respa.nlevels = 1;
   pair.cutforce = 2.5; frc.boltz = 1.0; frc.newton_pair = 0; frc.pair = &pair;
@@ -65,8 +65,9 @@ int main(int argc, char **argv) {
   {
     char a0[] = "1", a1[] = "all", a2[] = "edm_pair", a3[] = "1.0", a5[] = "2", a6[] = "1000000", a8[] = "7", a9[] = "1", a10[] = "1";
     std::string bf = std::string(argv[3]) + ".pairbias";
-    char kw[] = "device_rng";
-    const bool fast_rng = (argc > 4 && std::string(argv[4]) == "device_rng");
+    char kw[16];
+    std::snprintf(kw, sizeof kw, "%s", argc > 4 ? argv[4] : "");
+    const bool fast_rng = (argc > 4 && (std::string(argv[4]) == "device_rng" || std::string(argv[4]) == "gpu_list"));
     char *args[] = {a0, a1, a2, a3, argv[1], a5, a6, &bf[0], a8, a9, a10, kw};
     FixEDMPair fix(&lmp, fast_rng ? 12 : 11, args);
     std::fprintf(out, "pair_mask %d\n", fix.setmask());

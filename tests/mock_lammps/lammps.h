@@ -23,7 +23,7 @@ class Error {
 class Memory {};
 class Atom {
  public:
-  int tag_enable, nlocal, nmax;
+  int tag_enable, nlocal, nghost, nmax;
   double **x, **f;
   int *type, *mask;
 };
@@ -68,10 +68,11 @@ class NeighList {
 class Neighbor {
  public:
   double skin;
+  int ago;   // steps since the lists were last rebuilt
   NeighRequest **requests;
   int nrequest;
   void *last_requestor;
-  Neighbor() : skin(0.3), requests(NULL), nrequest(0), last_requestor(NULL) {}
+  Neighbor() : skin(0.3), ago(0), requests(NULL), nrequest(0), last_requestor(NULL) {}
   int request(void *who) {  // 2014-era API
     last_requestor = who;
     requests = (NeighRequest **) std::realloc(requests, sizeof(NeighRequest *) * (nrequest + 1));

@@ -192,3 +192,33 @@ def test_driven_fix_edm_device_rng_agrees_with_oracle(tmp_path, oracle_lib):
         assert abs(float(got[3]) - E) <= 1e-9 * max(abs(E), 1e-12), (step, got, E)
         assert abs(float(got[5]) - np.abs(f).sum()) <= 1e-8 * max(np.abs(f).sum(), 1e-12)
     assert float(coord_steps[-1][3]) > 0
+
+
+@pytest.mark.gpu
+def test_driven_fix_edm_pair_gpu_list_matches_host_list(tmp_path):
+    """`fix edm_pair ... gpu_list` (neighbour list resident on the GPU: positions in, forces out) against the same
+    fix walking the list on the host (`device_rng`): with every list entry live and owned, both feed the same
+    samples and uniforms in the same order, so energies and forces agree step by step (to the rounding of the
+    force atomics)."""
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "host")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", MOCK, "drive_fixes"], stdout=subprocess.DEVNULL)
+    runs = {}
+    for mode in ("device_rng", "gpu_list"):
+        d = tmp_path / mode
+        d.mkdir()
+        cfgs = {}
+        for tag, text in (("pair", PAIR_CFG), ("coord", COORD_CFG)):
+            cfgs[tag] = str(d / (tag + ".edm"))
+            open(cfgs[tag], "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (d, tag, d, tag))
+        out = str(d / "fixes.out")
+        res = subprocess.run([os.path.join(MOCK, "drive_fixes"), cfgs["pair"], cfgs["coord"], out, mode],
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        runs[mode] = [ln.split() for ln in open(out) if ln.startswith("pair_step")]
+    assert len(runs["gpu_list"]) == len(runs["device_rng"]) == 6
+    for a, b in zip(runs["gpu_list"], runs["device_rng"]):
+        ea, eb = float(a[3]), float(b[3])
+        assert abs(ea - eb) <= 1e-9 * max(abs(eb), 1e-12), (a, b)
+        assert abs(float(a[7]) - float(b[7])) <= 1e-8 * max(float(b[7]), 1e-12), (a, b)
+        assert abs(float(a[5])) <= 1e-9 * max(float(a[7]), 1e-12)   # pair forces cancel
+    assert float(runs["gpu_list"][-1][3]) > 0
