@@ -68,7 +68,12 @@ struct edm_hip_bias {
   // counter-based stream keyed by (seed, cycle number, sample index)
   bool device_rng = false;
   unsigned long long rng_seed = 0, rng_cycle = 0;
-  DevBuf<double> vs_r;     // virtual add_hill samples of a device-resident neighbour list (2 per list entry)
+  // device-resident neighbour list (edm_hip_bias_pair_list_upload / _step)
+  DevBuf<int> pl_i, pl_j, pl_type, pl_it_idx, pl_jt_idx;
+  DevBuf<long long> pl_it_off, pl_jt_off;
+  DevBuf<double> pl_force;
+  long long pl_npairs = -1, pl_nall = 0;
+  DevBuf<double> vs_r;     // virtual add_hill samples of the list (2 per entry)
   DevBuf<int> vs_mask;
   bool force_sync = false;      // redo of a deferred step whose launch bound proved too small
   int debug_virtual_ranks = 0;  // tests: a one-rank communicator's packet is replicated, emulating that many ranks
@@ -244,7 +249,8 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   if (b->hills_fp) fclose(b->hills_fp);
   b->sel.release(); b->sel_scratch.release(); b->count_dev.release(); b->sel_stage.release();
   if (b->h_flush) (void)hipHostFree(b->h_flush);
-  b->vs_r.release(); b->vs_mask.release();
+  b->vs_r.release(); b->vs_mask.release(); b->pl_i.release(); b->pl_j.release(); b->pl_type.release();
+  b->pl_it_idx.release(); b->pl_jt_idx.release(); b->pl_it_off.release(); b->pl_jt_off.release(); b->pl_force.release();
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
   delete b;
@@ -894,14 +900,65 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
   return do_post_add_hill(b);
 }
 
-int edm_hip_bias_pair_list_step(edm_hip_bias *b, long long npairs, const int *d_pair_i, const int *d_pair_j,
-                                const int *d_type, int itype, int jtype, int nlocal, long long nall, const double *d_x,
-                                double *d_fdelta, int hill_step, long long est_hill_count, double *energy,
-                                long long *ncalls) {
+int edm_hip_bias_pair_list_upload(edm_hip_bias *b, long long npairs, const int *h_pair_i, const int *h_pair_j,
+                                  long long nall, const int *h_type) {
+  if (npairs < 0 || nall < 0) return EDM_HIP_ERR_ARG;
+  for (long long p = 0; p < npairs; p++)
+    if (h_pair_i[p] < 0 || h_pair_i[p] >= nall || h_pair_j[p] < 0 || h_pair_j[p] >= nall) {
+      set_error("pair_list_upload: atom index outside [0, nall)");
+      return EDM_HIP_ERR_ARG;
+    }
+  // entry indices grouped by atom (as i, as j), each group in list order: stable counting sort
+  std::vector<long long> it_off((size_t)nall + 1, 0), jt_off((size_t)nall + 1, 0);
+  for (long long p = 0; p < npairs; p++) {
+    it_off[(size_t)h_pair_i[p] + 1]++;
+    jt_off[(size_t)h_pair_j[p] + 1]++;
+  }
+  for (long long a = 0; a < nall; a++) {
+    it_off[(size_t)a + 1] += it_off[(size_t)a];
+    jt_off[(size_t)a + 1] += jt_off[(size_t)a];
+  }
+  std::vector<int> it_idx((size_t)(npairs > 0 ? npairs : 1)), jt_idx((size_t)(npairs > 0 ? npairs : 1));
+  {
+    std::vector<long long> ci(it_off.begin(), it_off.end() - 1), cj(jt_off.begin(), jt_off.end() - 1);
+    for (long long p = 0; p < npairs; p++) {
+      it_idx[(size_t)ci[(size_t)h_pair_i[p]]++] = (int)p;
+      jt_idx[(size_t)cj[(size_t)h_pair_j[p]]++] = (int)p;
+    }
+  }
+  const size_t np1 = (size_t)(npairs > 0 ? npairs : 1), na1 = (size_t)(nall > 0 ? nall : 1);
+  EDM_HIP_TRY(b->pl_i.reserve(np1));
+  EDM_HIP_TRY(b->pl_j.reserve(np1));
+  EDM_HIP_TRY(b->pl_it_idx.reserve(np1));
+  EDM_HIP_TRY(b->pl_jt_idx.reserve(np1));
+  EDM_HIP_TRY(b->pl_type.reserve(na1));
+  EDM_HIP_TRY(b->pl_it_off.reserve(na1 + 1));
+  EDM_HIP_TRY(b->pl_jt_off.reserve(na1 + 1));
+  EDM_HIP_TRY(b->pl_force.reserve(3 * np1));
+  if (npairs > 0) {
+    EDM_HIP_TRY(hipMemcpy(b->pl_i.p, h_pair_i, sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice));
+    EDM_HIP_TRY(hipMemcpy(b->pl_j.p, h_pair_j, sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice));
+    EDM_HIP_TRY(hipMemcpy(b->pl_it_idx.p, it_idx.data(), sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice));
+    EDM_HIP_TRY(hipMemcpy(b->pl_jt_idx.p, jt_idx.data(), sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice));
+  }
+  if (nall > 0) EDM_HIP_TRY(hipMemcpy(b->pl_type.p, h_type, sizeof(int) * (size_t)nall, hipMemcpyHostToDevice));
+  EDM_HIP_TRY(hipMemcpy(b->pl_it_off.p, it_off.data(), sizeof(long long) * ((size_t)nall + 1), hipMemcpyHostToDevice));
+  EDM_HIP_TRY(hipMemcpy(b->pl_jt_off.p, jt_off.data(), sizeof(long long) * ((size_t)nall + 1), hipMemcpyHostToDevice));
+  b->pl_npairs = npairs;
+  b->pl_nall = nall;
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtype, const double *d_x, double *d_fdelta,
+                                int hill_step, long long est_hill_count, double *energy, long long *ncalls) {
   if (energy) *energy = 0;
   if (ncalls) *ncalls = 0;
   if (!b->bias && !b->b_outofbounds) {
     set_error("pair_list_step before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  if (b->pl_npairs < 0) {
+    set_error("pair_list_step before pair_list_upload");
     return EDM_HIP_ERR_STATE;
   }
   if (b->dim != 1) {
@@ -912,24 +969,33 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, long long npairs, const int *d_
     set_error("pair_list_step: hill steps draw their uniforms on the device -- call set_device_rng first");
     return EDM_HIP_ERR_STATE;
   }
-  if (nall > 0) EDM_HIP_TRY(hipMemsetAsync(d_fdelta, 0, sizeof(double) * 3 * (size_t)nall, b->bias ? b->bias->stream : 0));
+  const long long npairs = b->pl_npairs, nall = b->pl_nall;
   int rc = EDM_HIP_OK;
   if (hill_step) {
     rc = do_pre_add_hill(b, est_hill_count);   // overflow flush before any force (fix_edm_pair.cpp:174)
     if (rc) return rc;
   }
-  if (b->b_outofbounds) return hill_step ? do_post_add_hill(b) : EDM_HIP_OK;
+  if (b->b_outofbounds) {
+    if (nall > 0) EDM_HIP_TRY(hipMemset(d_fdelta, 0, sizeof(double) * 3 * (size_t)nall));
+    return hill_step ? do_post_add_hill(b) : EDM_HIP_OK;
+  }
   hipStream_t s = b->bias->stream;
   PairListArgs a;
   memset(&a, 0, sizeof(a));
   a.npairs = npairs;
-  a.pair_i = d_pair_i;
-  a.pair_j = d_pair_j;
-  a.type = d_type;
+  a.pair_i = b->pl_i.p;
+  a.pair_j = b->pl_j.p;
+  a.type = b->pl_type.p;
   a.itype = itype;
   a.jtype = jtype;
   a.nlocal = nlocal;
+  a.nall = (int)nall;
   a.x = d_x;
+  a.pair_force = b->pl_force.p;
+  a.it_off = b->pl_it_off.p;
+  a.jt_off = b->pl_jt_off.p;
+  a.it_idx = b->pl_it_idx.p;
+  a.jt_idx = b->pl_jt_idx.p;
   a.fdelta = d_fdelta;
   if (hill_step && npairs > 0) {
     EDM_HIP_TRY(b->vs_r.reserve((size_t)2 * npairs));
@@ -938,7 +1004,8 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, long long npairs, const int *d_
     a.vs_mask = b->vs_mask.p;
   }
   int nblk = 0;
-  if (npairs > 0) EDM_HIP_TRY(launch_pairlist_forces(b->bias->g, b->bias->rec, a, b->bias->d_partials, s, &nblk));
+  EDM_HIP_TRY(launch_pairlist_forces(b->bias->g, b->bias->rec, a, b->bias->d_partials, s, &nblk));
+  if (npairs <= 0) nblk = 0;
   if (hill_step) {
     // add_hill(r, u) for the two virtual samples of every list entry, in list order; dead ones are masked out
     const int *saved_mask = b->d_mask;

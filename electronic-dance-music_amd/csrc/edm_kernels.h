@@ -45,22 +45,28 @@ hipError_t launch_lookup(const Geom &g, const double *rec, LookupMode mode, cons
                          double *scratch, double *energy_out, hipStream_t s,
                          hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int *blocks_out = nullptr);
 // 1-D pair-distance form: force[i] = -dV/dr(r_i)
-// fix edm_pair on a device-resident neighbour list (fix_edm_pair.cpp:177-238 over flattened pair records): one
-// thread per list entry computes the pair distance from the positions, looks the bias up, accumulates the
-// pair force on both atoms (i always, j iff owned: newton off) and the energy, and -- on hill steps -- writes
-// the two virtual add_hill samples of the entry (the second one live iff j is owned) for the selection.
+// fix edm_pair on a device-resident neighbour list (fix_edm_pair.cpp:177-238 over flattened pair records).
+// Pass 1, one thread per list entry: pair distance from the positions, bias lookup, the entry's force vector
+// del * f_r into pair_force[entry] (zero when the types do not match), energy, and -- on hill steps -- the two
+// virtual add_hill samples of the entry (the second one live iff j is owned) for the selection.  Pass 2, 16 lanes
+// per atom: the atom's bias force = sum over its entries as i minus sum over its entries as j (owned atoms only:
+// newton off), both through index lists built when the list was uploaded, in a fixed order -- no atomics, the
+// forces are bit-reproducible.
 struct PairListArgs {
   long long npairs;
   const int *pair_i, *pair_j;   // list entries in neighbour-list order (j already masked with NEIGHMASK)
   const int *type;              // [nall] atom types; itype/jtype select the pairs (fix_edm_pair.cpp:181-202)
   int itype, jtype;
-  int nlocal;
+  int nlocal, nall;
   const double *x;              // [nall][3]
-  double *fdelta;               // [nall][3], zeroed by the caller: bias forces are ADDED here (fp64 atomics)
+  double *pair_force;           // [npairs][3] scratch
+  const long long *it_off, *jt_off;   // [nall + 1] CSR offsets of the entries with pair_i == a / pair_j == a
+  const int *it_idx, *jt_idx;         // [npairs] entry indices, each atom's run in list order
+  double *fdelta;               // out [nall][3]: bias force per atom (ghost atoms: zero)
   double *vs_r;                 // [2 * npairs] virtual-sample CVs, or NULL on steps without hills
   int *vs_mask;                 // [2 * npairs] 1 = live sample
 };
-// block_energy[0 .. blocks) and block_energy[EDM_PAIRLIST_MAX_BLOCKS .. +blocks): energy and add_hill-call partials
+// partials[0 .. blocks) and partials[EDM_PAIRLIST_MAX_BLOCKS .. +blocks): energy and add_hill-call partials
 #define EDM_PAIRLIST_MAX_BLOCKS 1024
 hipError_t launch_pairlist_forces(const Geom &g, const double *rec, const PairListArgs &a, double *partials,
                                   hipStream_t s, int *blocks_out);

@@ -395,74 +395,6 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces(Geom g, const double *__r
 }
 
 // ---------------------------------------------------------------------------
-// fix edm_pair over a device-resident neighbour list (see PairListArgs)
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_pairlist_forces(Geom g, const double *__restrict__ rec, PairListArgs a,
-                                                           double *__restrict__ partials) {
-  __shared__ double lds[BLOCK / 64];
-  double e_acc = 0, calls = 0;
-  const long long stride = (long long)gridDim.x * BLOCK;
-  for (long long p = (long long)blockIdx.x * BLOCK + threadIdx.x; p < a.npairs; p += stride) {
-    const int i = a.pair_i[p], j = a.pair_j[p];
-    // the type filter of fix_edm_pair.cpp:181-202: i of type ipair pairs with j of type jpair, and vice versa
-    const int ti = a.type[i], tj = a.type[j];
-    bool ok;
-    if (ti == a.itype) ok = (tj == a.jtype);
-    else if (ti == a.jtype) ok = (tj == a.itype);
-    else ok = false;
-    double r = 0;
-    if (ok) {
-      double delx = a.x[3 * (long long)i] - a.x[3 * (long long)j];
-      double dely = a.x[3 * (long long)i + 1] - a.x[3 * (long long)j + 1];
-      double delz = a.x[3 * (long long)i + 2] - a.x[3 * (long long)j + 2];
-      r = sqrt(delx * delx + dely * dely + delz * delz);
-      const double rinv = 1.0 / r;
-      delx *= rinv;
-      dely *= rinv;
-      delz *= rinv;
-      double v, d;
-      lookup_one<1>(g, rec, &r, v, &d);
-      const double fr = 0.0 - d;   // update_force on a zeroed accumulator (fix_edm_pair.cpp:215-217)
-      e_acc += v;
-      unsafeAtomicAdd(&a.fdelta[3 * (long long)i], delx * fr);
-      unsafeAtomicAdd(&a.fdelta[3 * (long long)i + 1], dely * fr);
-      unsafeAtomicAdd(&a.fdelta[3 * (long long)i + 2], delz * fr);
-      if (j < a.nlocal) {
-        unsafeAtomicAdd(&a.fdelta[3 * (long long)j], -(delx * fr));
-        unsafeAtomicAdd(&a.fdelta[3 * (long long)j + 1], -(dely * fr));
-        unsafeAtomicAdd(&a.fdelta[3 * (long long)j + 2], -(delz * fr));
-      }
-    }
-    if (a.vs_r) {
-      const bool second = ok && (j < a.nlocal);
-      a.vs_r[2 * p] = r;
-      a.vs_r[2 * p + 1] = r;
-      a.vs_mask[2 * p] = ok ? 1 : 0;
-      a.vs_mask[2 * p + 1] = second ? 1 : 0;
-      calls += (ok ? 1.0 : 0.0) + (second ? 1.0 : 0.0);
-    }
-  }
-  const double se = block_sum(e_acc, lds);
-  __syncthreads();
-  const double sc = block_sum(calls, lds);
-  if (threadIdx.x == 0) {
-    partials[blockIdx.x] = se;
-    partials[EDM_PAIRLIST_MAX_BLOCKS + blockIdx.x] = sc;
-  }
-}
-
-hipError_t launch_pairlist_forces(const Geom &g, const double *rec, const PairListArgs &a, double *partials,
-                                  hipStream_t s, int *blocks_out) {
-  if (g.dim != 1) return hipErrorInvalidValue;
-  long long nb = (a.npairs + BLOCK - 1) / BLOCK;
-  if (nb > EDM_PAIRLIST_MAX_BLOCKS) nb = EDM_PAIRLIST_MAX_BLOCKS;
-  if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_pairlist_forces, dim3((unsigned)nb), dim3(BLOCK), 0, s, g, rec, a, partials);
-  if (blocks_out) *blocks_out = (int)nb;
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
 // K1 fast path: 1-D, interpolating, non-periodic grid (the fix_edm_pair geometry).
 //  * the node records of a window [w0, w0+W) are staged ONCE per workgroup into LDS
 //    (up to 10224 nodes = 159.75 KiB of the CU's 160 KiB) by coalesced 16-B loads;
@@ -631,6 +563,116 @@ __global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *_
   }
   double s = block_sum(e_acc, red);
   if (threadIdx.x == 0) block_energy[blockIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------
+// fix edm_pair over a device-resident neighbour list (see PairListArgs)
+// ---------------------------------------------------------------------------
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK) k_pairlist_forces(Geom g, const double *__restrict__ rec, PairListArgs a,
+                                                           double *__restrict__ partials, double inv_dx) {
+  __shared__ double lds[BLOCK / 64];
+  double e_acc = 0, calls = 0;
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long p = (long long)blockIdx.x * BLOCK + threadIdx.x; p < a.npairs; p += stride) {
+    const int i = a.pair_i[p], j = a.pair_j[p];
+    // the type filter of fix_edm_pair.cpp:181-202: i of type ipair pairs with j of type jpair, and vice versa
+    const int ti = a.type[i], tj = a.type[j];
+    bool ok = false;
+    if (ti == a.itype) ok = (tj == a.jtype);
+    else if (ti == a.jtype) ok = (tj == a.itype);
+    double r = 0, fx = 0, fy = 0, fz = 0;
+    if (ok) {
+      double delx = a.x[3 * (long long)i] - a.x[3 * (long long)j];
+      double dely = a.x[3 * (long long)i + 1] - a.x[3 * (long long)j + 1];
+      double delz = a.x[3 * (long long)i + 2] - a.x[3 * (long long)j + 2];
+      r = sqrt(delx * delx + dely * dely + delz * delz);
+      const double rinv = 1.0 / r;
+      delx *= rinv;
+      dely *= rinv;
+      delz *= rinv;
+      double v, d;
+      if (FAST)
+        pair_one<false>(g, rec, nullptr, 0, 0, inv_dx, r, v, d);
+      else
+        lookup_one<1>(g, rec, &r, v, &d);
+      const double fr = 0.0 - d;   // update_force on a zeroed accumulator (fix_edm_pair.cpp:215-217)
+      e_acc += v;
+      fx = delx * fr;
+      fy = dely * fr;
+      fz = delz * fr;
+    }
+    a.pair_force[3 * p] = fx;
+    a.pair_force[3 * p + 1] = fy;
+    a.pair_force[3 * p + 2] = fz;
+    if (a.vs_r) {
+      const bool second = ok && (j < a.nlocal);
+      a.vs_r[2 * p] = r;
+      a.vs_r[2 * p + 1] = r;
+      a.vs_mask[2 * p] = ok ? 1 : 0;
+      a.vs_mask[2 * p + 1] = second ? 1 : 0;
+      calls += (ok ? 1.0 : 0.0) + (second ? 1.0 : 0.0);
+    }
+  }
+  const double se = block_sum(e_acc, lds);
+  __syncthreads();
+  const double sc = block_sum(calls, lds);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = se;
+    partials[EDM_PAIRLIST_MAX_BLOCKS + blockIdx.x] = sc;
+  }
+}
+
+// pass 2: 16 lanes per atom; f[a] = sum_{entries with i == a} pf - sum_{entries with j == a} pf (owned atoms)
+__global__ void __launch_bounds__(BLOCK) k_pairlist_reduce(PairListArgs a) {
+  const long long atom = ((long long)blockIdx.x * BLOCK + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  double fx = 0, fy = 0, fz = 0;
+  if (atom < a.nlocal) {   // (ghost atoms never appear as i and receive nothing as j: newton off)
+    for (long long q = a.it_off[atom] + sub; q < a.it_off[atom + 1]; q += 16) {
+      const long long e = a.it_idx[q];
+      fx += a.pair_force[3 * e];
+      fy += a.pair_force[3 * e + 1];
+      fz += a.pair_force[3 * e + 2];
+    }
+    for (long long q = a.jt_off[atom] + sub; q < a.jt_off[atom + 1]; q += 16) {
+      const long long e = a.jt_idx[q];
+      fx -= a.pair_force[3 * e];
+      fy -= a.pair_force[3 * e + 1];
+      fz -= a.pair_force[3 * e + 2];
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {   // fixed tree within the 16-lane group
+    fx += __shfl_xor(fx, o, 64);
+    fy += __shfl_xor(fy, o, 64);
+    fz += __shfl_xor(fz, o, 64);
+  }
+  if (sub == 0 && atom < a.nall) {
+    a.fdelta[3 * atom] = fx;
+    a.fdelta[3 * atom + 1] = fy;
+    a.fdelta[3 * atom + 2] = fz;
+  }
+}
+
+hipError_t launch_pairlist_forces(const Geom &g, const double *rec, const PairListArgs &a, double *partials,
+                                  hipStream_t s, int *blocks_out) {
+  if (g.dim != 1) return hipErrorInvalidValue;
+  long long nb = (a.npairs + BLOCK - 1) / BLOCK;
+  if (nb > EDM_PAIRLIST_MAX_BLOCKS) nb = EDM_PAIRLIST_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  const bool fast = (g.interp && !g.periodic[0] && !g.bper[0] && g.n[0] >= 2);
+  const double inv_dx = 1.0 / g.dx[0];
+  if (fast)
+    hipLaunchKernelGGL(k_pairlist_forces<true>, dim3((unsigned)nb), dim3(BLOCK), 0, s, g, rec, a, partials, inv_dx);
+  else
+    hipLaunchKernelGGL(k_pairlist_forces<false>, dim3((unsigned)nb), dim3(BLOCK), 0, s, g, rec, a, partials, inv_dx);
+  if (a.nall > 0) {
+    const long long threads = (long long)a.nall * 16;
+    hipLaunchKernelGGL(k_pairlist_reduce, dim3((unsigned)((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
+  }
+  if (blocks_out) *blocks_out = (int)nb;
+  return hipGetLastError();
 }
 
 hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, const double *r, double *force,

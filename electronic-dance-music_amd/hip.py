@@ -85,8 +85,9 @@ _PROTOS = {
     "edm_hip_bias_pair_forces": (C.c_int, [vp, C.c_longlong, vp, vp, c_dp]),
     "edm_hip_bias_add_hills": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, C.c_longlong]),
     "edm_hip_bias_set_device_rng": (C.c_int, [vp, C.c_int, C.c_ulonglong]),
-    "edm_hip_bias_pair_list_step": (C.c_int, [vp, C.c_longlong, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_longlong, vp, vp, C.c_int,
-                                              C.c_longlong, c_dp, C.POINTER(C.c_longlong)]),
+    "edm_hip_bias_pair_list_upload": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp]),
+    "edm_hip_bias_pair_list_step": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_longlong, c_dp,
+                                              C.POINTER(C.c_longlong)]),
     "edm_hip_bias_step": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pre_add_hill": (C.c_int, [vp, C.c_longlong]),
@@ -493,12 +494,18 @@ class Bias:
         """acceptance uniforms drawn on the device (fast mode): pass d_u = None afterwards"""
         check(lib().edm_hip_bias_set_device_rng(self.h, int(enabled), int(seed)))
 
-    def pair_list_step_device(self, d_pair_i, d_pair_j, npairs, d_type, itype, jtype, nlocal, nall, d_x, d_fdelta, hill_step, est):
-        """fix edm_pair over a device-resident neighbour list: returns (energy, add_hill calls of the step)"""
+    def pair_list_upload(self, pair_i, pair_j, types):
+        """flattened half list (host int32 arrays, neighbour-list order) + atom types -> device-resident list"""
+        pi = np.ascontiguousarray(pair_i, dtype=np.int32)
+        pj = np.ascontiguousarray(pair_j, dtype=np.int32)
+        ty = np.ascontiguousarray(types, dtype=np.int32)
+        check(lib().edm_hip_bias_pair_list_upload(self.h, len(pi), pi.ctypes.data, pj.ctypes.data, len(ty), ty.ctypes.data))
+
+    def pair_list_step_device(self, nlocal, itype, jtype, d_x, d_fdelta, hill_step, est):
+        """fix edm_pair over the uploaded list: returns (energy, add_hill calls of the step)"""
         e = C.c_double(0)
         nc = C.c_longlong(0)
-        check(lib().edm_hip_bias_pair_list_step(self.h, npairs, _ptr(d_pair_i), _ptr(d_pair_j), _ptr(d_type), itype, jtype,
-                                                nlocal, nall, _ptr(d_x), _ptr(d_fdelta), int(hill_step), est,
+        check(lib().edm_hip_bias_pair_list_step(self.h, nlocal, itype, jtype, _ptr(d_x), _ptr(d_fdelta), int(hill_step), est,
                                                 C.byref(e), C.byref(nc)))
         return e.value, nc.value
 

@@ -356,7 +356,7 @@ struct EDMBias::Stage {
   DevMem x, f, mask, u, r, fr;
   std::vector<double> pack_x, pack_f;
   // device-resident neighbour list of pair_list_step
-  DevMem pl_i, pl_j, pl_type, pl_x, pl_f;
+  DevMem pl_x, pl_f;
   std::vector<int> pl_hi, pl_hj;
   std::vector<double> pl_hx, pl_hf;
   long long pl_npairs;
@@ -678,15 +678,8 @@ double EDMBias::pair_list_step(int nlocal, int nall, const double* const* x, dou
       }
     }
     st.pl_npairs = (long long)st.pl_hi.size();
-    const size_t pb = sizeof(int) * (size_t)(st.pl_npairs > 0 ? st.pl_npairs : 1);
-    st.pl_i.reserve(pb);
-    st.pl_j.reserve(pb);
-    st.pl_type.reserve(sizeof(int) * (size_t)(nall > 0 ? nall : 1));
-    if (st.pl_npairs > 0) {
-      check(edm_hip_memcpy_h2d(st.pl_i.p, st.pl_hi.data(), sizeof(int) * (size_t)st.pl_npairs), "edm_bias.cpp:update_force");
-      check(edm_hip_memcpy_h2d(st.pl_j.p, st.pl_hj.data(), sizeof(int) * (size_t)st.pl_npairs), "edm_bias.cpp:update_force");
-    }
-    if (nall > 0) check(edm_hip_memcpy_h2d(st.pl_type.p, type, sizeof(int) * (size_t)nall), "edm_bias.cpp:update_force");
+    check(edm_hip_bias_pair_list_upload(h_, st.pl_npairs, st.pl_hi.data(), st.pl_hj.data(), nall, type),
+          "edm_bias.cpp:update_force");
   }
   const size_t n3 = (size_t)3 * (size_t)(nall > 0 ? nall : 0);
   if (n3 == 0) return 0.0;
@@ -704,8 +697,7 @@ double EDMBias::pair_list_step(int nlocal, int nall, const double* const* x, dou
   check(edm_hip_memcpy_h2d(st.pl_x.p, xsrc, sizeof(double) * n3), "edm_bias.cpp:update_force");
   double energy = 0;
   long long calls = 0;
-  check(edm_hip_bias_pair_list_step(h_, st.pl_npairs, (const int*)st.pl_i.p, (const int*)st.pl_j.p, (const int*)st.pl_type.p,
-                                    itype, jtype, nlocal, nall, (const double*)st.pl_x.p, (double*)st.pl_f.p,
+  check(edm_hip_bias_pair_list_step(h_, nlocal, itype, jtype, (const double*)st.pl_x.p, (double*)st.pl_f.p,
                                     hill_step ? 1 : 0, est_hill_count, &energy, &calls),
         "edm_bias.cpp:add_hill");
   st.pl_hf.resize(n3);

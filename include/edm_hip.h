@@ -200,19 +200,23 @@ int edm_hip_bias_add_hills(edm_hip_bias *b, long long n, const double *d_x, int 
 int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_stride, double *d_f,
                       int f_stride, const double *d_runiform, int apply_mask, long long est_hill_count,
                       double *energy);
-/* fix edm_pair on a device-resident neighbour list: the caller keeps the flattened half list on
- * the device -- pair_i/pair_j in neighbour-list order, j masked with NEIGHMASK; re-uploaded when LAMMPS rebuilds
- * the list -- and passes this step's positions; pair distances, bias lookups, pair forces (added into d_fdelta,
- * zeroed here; i always, j iff j < nlocal: newton off) and the energy are computed on the GPU.  On hill steps
+/* fix edm_pair on a device-resident neighbour list.
+ * edm_hip_bias_pair_list_upload: called when LAMMPS has rebuilt the list, with HOST arrays -- the half list
+ * flattened in neighbour-list order (pair_i/pair_j, j masked with NEIGHMASK) and the atom types [nall]; the library
+ * keeps them, plus per-atom index lists of the entries, on the device.
+ * edm_hip_bias_pair_list_step: this step's positions d_x [nall][3] in, the bias force per atom out in d_fdelta
+ * [nall][3] (i always, j iff j < nlocal: newton off; ghost atoms zero), energy returned.  Pair distances, lookups
+ * and the per-atom force sums (fixed order, no atomics: bit-reproducible) run on the GPU.  On hill steps
  * (hill_step != 0) pre_add_hill(est_hill_count) precedes the forces and every list entry passing the type filter
  * deposits add_hill(r, u) once, and a second time iff j is owned (fix_edm_pair.cpp:230-237), in list order, with
  * device uniforms (edm_hip_bias_set_device_rng; sample index 2 * entry + slot).  *ncalls returns the number of
  * add_hill calls of the step, the next hill step's est_hill_count (fix_edm_pair.cpp:245).  Per atom this moves
  * 24 B of positions in and 24 B of forces out instead of 16 B per PAIR. */
-int edm_hip_bias_pair_list_step(edm_hip_bias *b, long long npairs, const int *d_pair_i, const int *d_pair_j,
-                                const int *d_type, int itype, int jtype, int nlocal, long long nall,
-                                const double *d_x, double *d_fdelta, int hill_step, long long est_hill_count,
-                                double *energy, long long *ncalls);
+int edm_hip_bias_pair_list_upload(edm_hip_bias *b, long long npairs, const int *h_pair_i, const int *h_pair_j,
+                                  long long nall, const int *h_type);
+int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtype, const double *d_x,
+                                double *d_fdelta, int hill_step, long long est_hill_count, double *energy,
+                                long long *ncalls);
 /* One hill-depositing step of fix edm_pair (fix_edm_pair.cpp:174-246) in a single call:
  * pre_add_hill(est_hill_count) (flushes the overflow buffer), the force evaluation of
  * edm_hip_bias_pair_forces(n, d_r, d_force), add_hill(d_sample_r[i], d_runiform[i]) for the n_samples

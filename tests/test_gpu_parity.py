@@ -821,9 +821,8 @@ def test_pair_list_step_vs_oracle(oracle_lib, workdir):
         pi_a, pj_a = np.array(pi, dtype=np.int32), np.array(pj, dtype=np.int32)
         d_fd = H.DeviceArray.zeros((nall, 3))
         hill = step % 2 == 0
-        e, ncalls = b.pair_list_step_device(H.DeviceArray.from_host(pi_a), H.DeviceArray.from_host(pj_a), P,
-                                            H.DeviceArray.from_host(types), itype, jtype, nlocal, nall,
-                                            H.DeviceArray.from_host(x), d_fd, hill, est)
+        b.pair_list_upload(pi_a, pj_a, types)
+        e, ncalls = b.pair_list_step_device(nlocal, itype, jtype, H.DeviceArray.from_host(x), d_fd, hill, est)
         fd = d_fd.to_host()
         # ---- oracle: the reference's loop ----
         if hill:
