@@ -270,9 +270,12 @@ class Grid(_Geom):
         return cls(h.value)
 
     def __del__(self):
-        if getattr(self, "owned", False) and self.h:
-            lib().edm_hip_grid_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "owned", False) and self.h:
+                lib().edm_hip_grid_destroy(self.h)
+                self.h = None
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     @property
     def geometry(self):
@@ -317,9 +320,12 @@ class Gauss(_Geom):
         return cls(h.value)
 
     def __del__(self):
-        if getattr(self, "owned", False) and self.h:
-            lib().edm_hip_gauss_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "owned", False) and self.h:
+                lib().edm_hip_gauss_destroy(self.h)
+                self.h = None
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     @property
     def geometry(self):
@@ -456,9 +462,12 @@ class Bias:
         self._mask = None
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().edm_hip_bias_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().edm_hip_bias_destroy(self.h)
+                self.h = None
+        except Exception:  # noqa: BLE001  (interpreter shutdown: module globals may already be gone)
+            pass
 
     def setup(self, temperature, boltzmann):
         check(lib().edm_hip_bias_setup(self.h, temperature, boltzmann))
