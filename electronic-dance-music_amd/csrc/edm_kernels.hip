@@ -1965,15 +1965,37 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
         }
         if (MODE == 1) {
           // this tile's piece of each hill's integrated bias (gaussian_grid.h:349), fixed-order sums
+          double piece[ILP];
 #pragma unroll
           for (int q = 0; q < ILP; q++) {
-            double piece = 0;
+            piece[q] = 0;
             if (mult[q] > 0) {
               const double term = s_h1[q0 + q] * val[q] * vol;
-              for (int rep = 0; rep < mult[q]; rep++) piece += term;
+              for (int rep = 0; rep < mult[q]; rep++) piece[q] += term;
             }
-            piece = wave_sum(piece);
-            if (lane == 0 && q0 + q < cnt) s_wpart[wave][q0 + q] = piece;
+          }
+          if (ILP == 4) {
+            // four wave sums for the price of ~1.2: after the first two butterfly steps each 16-lane group
+            // carries ONE of the four hills (hill = 2 * (lane >= 32) + ((lane & 16) != 0)), the remaining four
+            // steps run on a single value -- 7 shuffles instead of 24, the same fixed order for every launch
+            const bool hi = (lane & 32) != 0, q16 = (lane & 16) != 0;
+            double k0 = hi ? piece[2] : piece[0], s0 = hi ? piece[0] : piece[2];
+            double k1 = hi ? piece[3] : piece[1], s1 = hi ? piece[1] : piece[3];
+            k0 += __shfl_xor(s0, 32, 64);
+            k1 += __shfl_xor(s1, 32, 64);
+            double c = q16 ? k1 : k0;
+            const double sd = q16 ? k0 : k1;
+            c += __shfl_xor(sd, 16, 64);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            const int mine = (hi ? 2 : 0) + (q16 ? 1 : 0);
+            if ((lane & 15) == 0 && q0 + mine < cnt) s_wpart[wave][q0 + mine] = c;
+          } else {
+#pragma unroll
+            for (int q = 0; q < ILP; q++) {
+              const double tot = wave_sum(piece[q]);
+              if (lane == 0 && q0 + q < cnt) s_wpart[wave][q0 + q] = tot;
+            }
           }
         }
       }
