@@ -1379,7 +1379,7 @@ __device__ __forceinline__ void node_terms(const Geom &g, const Tables &t, const
 template <int DIM, bool PERB = false>
 __device__ __forceinline__ bool pair_term(const Geom &g, const TermConst<DIM> &tc, const NodeTerms<DIM> &nt,
                                           const double *hx, const double *ht, double &val, double *dval,
-                                          bool &corr_nonzero) {
+                                          bool &corr_nonzero, bool interior = false) {
   double dp[DIM], raw[DIM];
   double dp2 = 0;
   bool edge = false;
@@ -1416,15 +1416,26 @@ __device__ __forceinline__ bool pair_term(const Geom &g, const TermConst<DIM> &t
   for (int d = 0; d < DIM; d++) {
     force[d] = 0;
     if (!PERB && !g.bper[d]) {
-      const double t1 = ht[2 * d], t3 = ht[2 * d + 1];
-      corr = (t1 - expo) * nt.t2[d] + (t3 - expo) * nt.t4[d];  // overwritten per dim (:316)
-      const double t5 = -2 * dp[d] * tc.inv_sigma[d];
-      double F = t5 * expo;
-      F += (t1 - expo) * nt.t6[d] - t5 * expo * nt.t2[d] + (t3 - expo) * nt.t7[d] - t5 * expo * nt.t4[d];
-      F = F * nt.dprod[d] - nt.dden[d] * (expo + corr);
-      F *= nt.inv_dprod2[d];
-      corr *= nt.inv_dprod[d];
-      force[d] = F;
+      if (interior) {
+        // no wall blend reaches this node (t2 = t4 = t6 = t7 = 0 for the whole wave): the general expressions
+        // below reduce to these, bit for bit (their extra terms are products with zero)
+        const double t5 = -2 * dp[d] * tc.inv_sigma[d];
+        double F = t5 * expo;
+        F = F * nt.dprod[d] - nt.dden[d] * expo;
+        F *= nt.inv_dprod2[d];
+        corr = 0;
+        force[d] = F;
+      } else {
+        const double t1 = ht[2 * d], t3 = ht[2 * d + 1];
+        corr = (t1 - expo) * nt.t2[d] + (t3 - expo) * nt.t4[d];  // overwritten per dim (:316)
+        const double t5 = -2 * dp[d] * tc.inv_sigma[d];
+        double F = t5 * expo;
+        F += (t1 - expo) * nt.t6[d] - t5 * expo * nt.t2[d] + (t3 - expo) * nt.t7[d] - t5 * expo * nt.t4[d];
+        F = F * nt.dprod[d] - nt.dden[d] * (expo + corr);
+        F *= nt.inv_dprod2[d];
+        corr *= nt.inv_dprod[d];
+        force[d] = F;
+      }
     }
   }
   expo *= nt.inv_dprod[DIM - 1];
@@ -1773,10 +1784,16 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     for (int d = DIM - 1; d > 0; d--) flat = flat * g.n[d - 1] + p[d - 1];
   }
   NodeTerms<DIM> nt;
+  bool node_interior = true;
   if (active) {
     node_terms<DIM, PERB>(g, t, p, nt);
     if (!nt.inside) active = false;
+#pragma unroll
+    for (int d = 0; d < DIM; d++)
+      if (!PERB && !g.bper[d] && (nt.t2[d] != 0 || nt.t4[d] != 0 || nt.t6[d] != 0 || nt.t7[d] != 0)) node_interior = false;
   }
+  // wave-uniform: away from the walls (95 % of the C1D nodes) the McGovern-De Pablo blends vanish
+  const bool interior = !PERB && __all(node_interior || !active);
   // (limiter result and hill count in one round trip: the kernel is a chain of dependent loads)
   long long k_first_tail = hh.k;
   long long nh_eff = h.nh;
@@ -1938,7 +1955,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
 #pragma unroll
             for (int d = 0; d < DIM; d++) m *= images(g, d, s_c[q0 + q][d], p[d], p[d]);
             bool nz = false;
-            if (m > 0 && pair_term<DIM, PERB>(g, tc, nt, s_x[q0 + q], s_t[PERB ? 0 : q0 + q], val[q], dval[q], nz)) {
+            if (m > 0 && pair_term<DIM, PERB>(g, tc, nt, s_x[q0 + q], s_t[PERB ? 0 : q0 + q], val[q], dval[q], nz, interior)) {
               mult[q] = m;
               any_corr |= nz;
               touched = true;
