@@ -2080,7 +2080,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
 }
 
 template <int DIM, int MODE, int PARTS, bool PERB>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == 1) ? 4 : 1, 8))) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == 1 && DIM == 1) ? 4 : 1, 8))) k_hill_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
                                                                HillHeights hh, GatherPlan plan, int use_list,
                                                                int *__restrict__ dirty_flag, PostArgs post) {
   if (use_list) {
