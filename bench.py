@@ -222,8 +222,8 @@ def all_samples_line(args, rank, world, dist, H, W, tmpdir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default W1 = 1,048,576)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-w2", action="store_true",
