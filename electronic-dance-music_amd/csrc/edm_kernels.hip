@@ -1851,7 +1851,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   __shared__ int s_ptouch[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? NODES : 1];
   TermConst<DIM> tc;
   term_const<DIM>(g, tc);
-  constexpr int ILP = (DIM == 1) ? 4 : 2;  // (2-D/3-D tiles meet one to three hills of a sparse batch; fewer live registers, more workgroups per CU)
+  constexpr int ILP = (DIM == 1) ? 4 : (DIM == 2) ? 2 : 1;  // (2-D/3-D tiles meet one to three hills of a sparse batch; fewer live registers -- 3-D: 128, four waves per SIMD -- more workgroups per CU)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long long base = hbeg; base < hend; base += BLOCK) {
     const long long cur = base + threadIdx.x;   // (every thread stages one hill of the chunk)
