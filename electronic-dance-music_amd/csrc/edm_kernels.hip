@@ -35,6 +35,7 @@
 namespace edm {
 
 static constexpr int BLOCK = 256;
+static constexpr int HIST_LDS_BINS = 2048;  // histograms up to this many bins are accumulated per workgroup in LDS
 static constexpr int MAX_BLOCKS = 2048;  // 256 CUs x 8 resident 256-thread blocks
 
 // ---------------------------------------------------------------------------
@@ -2738,8 +2739,24 @@ __global__ void __launch_bounds__(BLOCK) k_post_batch(Geom g, double *__restrict
     return;
   }
   if (res->error) return;
-  hist_batch<DIM>(hg, hist, nh, hx0, res, flags, flush_mode, (long long)(blockIdx.x - 1) * BLOCK + threadIdx.x,
-                  (long long)(gridDim.x - 1) * BLOCK);
+  // Small histograms (the 1-D CV has ~113 bins) are privatised: a million hills hammering a hundred global
+  // addresses took 1.1 ms of a 8.8 ms all-samples step; per-workgroup LDS counts (integer-valued, so the order
+  // of the adds is immaterial) cost one global atomic per touched bin and workgroup.
+  __shared__ double s_hist[HIST_LDS_BINS];
+  const bool priv = hg.total <= HIST_LDS_BINS;
+  if (priv) {
+    for (int k = threadIdx.x; k < (int)hg.total; k += BLOCK) s_hist[k] = 0.0;
+    __syncthreads();
+  }
+  hist_batch<DIM>(hg, priv ? s_hist : hist, nh, hx0, res, flags, flush_mode,
+                  (long long)(blockIdx.x - 1) * BLOCK + threadIdx.x, (long long)(gridDim.x - 1) * BLOCK);
+  if (priv) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < (int)hg.total; k += BLOCK) {
+      const double c = s_hist[k];
+      if (c != 0.0) atomicAdd(&hist[k], c);
+    }
+  }
 }
 
 template <int DIM>
