@@ -1852,6 +1852,11 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   __shared__ int s_ptouch[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? NODES : 1];
   TermConst<DIM> tc;
   term_const<DIM>(g, tc);
+  // launch-uniform: no dimension whose stencil can reach a node through more than one periodic image
+  bool single_image = true;
+#pragma unroll
+  for (int d = 0; d < DIM; d++)
+    if (g.periodic[d] && 2 * g.msize[d] + 1 > g.n[d]) single_image = false;
   constexpr int ILP = (DIM == 1) ? 4 : (DIM == 2) ? 2 : 1;  // (2-D/3-D tiles meet one to three hills of a sparse batch; fewer live registers -- 3-D: 128, four waves per SIMD -- more workgroups per CU)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long long base = hbeg; base < hend; base += BLOCK) {
@@ -1967,13 +1972,16 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
         for (int q = 0; q < ILP; q++) {
           if (mult[q] > 0) {
             const double a1 = s_h1[q0 + q], a2 = s_h2[q0 + q];
-            for (int rep = 0; rep < mult[q]; rep++) {
+            // (a stencil that wraps a small periodic grid more than once hits a node `mult` times: repeated adds,
+            //  as the reference's loop makes them; everywhere else mult is 1 and the loops below are one add)
+            const int reps = single_image ? 1 : mult[q];
+            for (int rep = 0; rep < reps; rep++) {
               acc[0] += a1 * val[q];
 #pragma unroll
               for (int d = 0; d < DIM; d++) acc[1 + d] += a1 * dval[q][d];
             }
             if (a2 != 0) {
-              for (int rep = 0; rep < mult[q]; rep++) {
+              for (int rep = 0; rep < reps; rep++) {
                 acc[0] += a2 * val[q];
 #pragma unroll
                 for (int d = 0; d < DIM; d++) acc[1 + d] += a2 * dval[q][d];
@@ -1989,7 +1997,8 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
             piece[q] = 0;
             if (mult[q] > 0) {
               const double term = s_h1[q0 + q] * val[q] * vol;
-              for (int rep = 0; rep < mult[q]; rep++) piece[q] += term;
+              const int reps = single_image ? 1 : mult[q];
+              for (int rep = 0; rep < reps; rep++) piece[q] += term;
             }
           }
           if (ILP == 4) {
