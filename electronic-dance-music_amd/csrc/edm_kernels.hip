@@ -461,11 +461,18 @@ __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict
   // a lane; the two rare cases -- an index within rounding of an integer, a cell outside the LDS
   // window -- sit behind wave-uniform branches.
   // in_bounds (gaussian_grid.h:490-499) and in_grid (grid.h:865-874) of a non-periodic 1-D grid
-  const bool in_range = (x >= g.bmin[0]) & (x <= g.bmax[0]) & (x >= g.min[0]) & (x < g.max[0] - g.dx[0]);
+  // (the four comparisons folded into two launch-uniform bounds: x >= max(bmin, min) and
+  //  x < min(nextafter(bmax), max - dx) -- the closed upper end of the boundary becomes an open one)
+  const double lo_ok = fmax(g.bmin[0], g.min[0]);
+  const double hi_open = fmin(nextafter(g.bmax[0], 1.0e308), g.max[0] - g.dx[0]);
+  const bool in_range = (x >= lo_ok) & (x < hi_open);
   const double q = (x - g.min[0]) * inv_dx;
   double fq = floor(q);
-  // floor(q) can differ from the reference's floor((x-min)/dx) only within rounding of an integer
-  const bool near = in_range & (fabs(q - rint(q)) <= 1e-11 * fmax(1.0, q));
+  // floor(q) can differ from the reference's floor((x-min)/dx) only within rounding of an integer: the guard
+  // is |q - nearest integer| <= 1e-11 * max(1, q), tested here against its launch-uniform upper bound
+  const double eps = 1e-11 * fmax(1.0, (double)g.n[0]);
+  const double frac = q - fq;
+  const bool near = in_range & ((frac <= eps) | (frac >= 1.0 - eps));
   if (__any(near)) {
     if (near) fq = floor((x - g.min[0]) / g.dx[0]);
   }
