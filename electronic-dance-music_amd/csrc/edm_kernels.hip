@@ -528,13 +528,20 @@ __global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *_
   const long long stride = (long long)gridDim.x * NT;
   const v2d *r2 = reinterpret_cast<const v2d *>(r);
   v2d *f2 = reinterpret_cast<v2d *>(force);
-  // two independent 16-B loads in flight per lane per iteration (64 B of HBM traffic per lane)
-  for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < npair; i += 2 * stride) {
+  // two independent 16-B loads per lane per iteration, requested ONE ITERATION AHEAD: the next pairs travel
+  // while the current four lookups are evaluated (the loop is latency-bound at four waves per SIMD)
+  const long long i0 = (long long)blockIdx.x * NT + threadIdx.x;
+  v2d ra = {0.0, 0.0}, rb = {0.0, 0.0};
+  if (i0 < npair) ra = __builtin_nontemporal_load(&r2[i0]);
+  if (i0 + stride < npair) rb = __builtin_nontemporal_load(&r2[i0 + stride]);
+  for (long long i = i0; i < npair; i += 2 * stride) {
     const long long j = i + stride;
     const bool has_b = j < npair;
-    const v2d ra = __builtin_nontemporal_load(&r2[i]);
+    const long long in = i + 2 * stride, jn = in + stride;
+    v2d na = {0.0, 0.0}, nb = {0.0, 0.0};
+    if (in < npair) na = __builtin_nontemporal_load(&r2[in]);
+    if (jn < npair) nb = __builtin_nontemporal_load(&r2[jn]);
     if (has_b) {  // steady state: four independent lookups in flight per lane
-      const v2d rb = __builtin_nontemporal_load(&r2[j]);
       double v0, v1, v2, v3, d0, d1, d2, d3;
       pair_one<USE_LDS>(g, rec, win, (int)w0, w1, inv_dx, ra.x, v0, d0);
       pair_one<USE_LDS>(g, rec, win, (int)w0, w1, inv_dx, ra.y, v1, d1);
@@ -562,6 +569,8 @@ __global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *_
       oa.y = 0.0 - d1;
       __builtin_nontemporal_store(oa, &f2[i]);
     }
+    ra = na;
+    rb = nb;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     double v, d;
