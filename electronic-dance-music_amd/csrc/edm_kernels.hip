@@ -432,6 +432,25 @@ __device__ __forceinline__ void hermite_1d(double fa, double da, double fb, doub
   der = ((fa - fb) * Ap + ga * Bpa + gb * Bpb) * inv_dx;
 }
 
+// The same cubic in monomial form, from the corner values and the SCALED corner slopes g = d * dx (zero where
+// |f| < 1e-7, grid.h:113-116): p(X) = fa + X (ga + X (c2 + X c3)), c2 = 3 (fb - fa) - 2 ga - gb,
+// c3 = 2 (fa - fb) + ga + gb.  14 fp64 operations instead of 25 -- K1 is bound by fp64 issue, not by HBM -- and
+// the same polynomial to ~1e-16 of the largest coefficient (the reference's own form cancels as much).
+__device__ __forceinline__ void hermite_1d_horner(double fa, double ga, double fb, double gb, double X, double inv_dx,
+                                                  double &value, double &der) {
+#pragma clang fp contract(fast)
+  const double df = fb - fa;
+  const double gs = ga + gb;
+  const double c3 = gs - 2.0 * df;
+  const double c2 = 3.0 * df - (gs + ga);
+  value = fa + X * (ga + X * (c2 + X * c3));
+  der = (ga + X * (2.0 * c2 + X * (3.0 * c3))) * inv_dx;
+}
+// scaled slope of a node record as the interpolation uses it
+__device__ __forceinline__ double scaled_slope(double f, double d, double dx) {
+  return (fabs(f) < 0.0000001) ? 0.0 : d * dx;
+}
+
 // The reference's own two-corner form (grid.h:110-123 with X = fabs(where/dx - x0)), used when the
 // scaled coordinate falls outside [0,1] by rounding: there fabs() mirrors the two corners
 // inconsistently and the shared-corner identities above do not describe what the reference computes.
@@ -481,6 +500,7 @@ __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict
   idx = idx > g.n[0] - 2 ? g.n[0] - 2 : idx;
   const double where = x - g.min[0] - idx * g.dx[0];
   const double X = where * inv_dx;
+  // corner records as (f, g = scaled slope): the LDS window was staged in that form, global records are converted
   v2d a, b;
   if (USE_LDS) {
     const int li = idx - w0;
@@ -492,17 +512,24 @@ __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict
       if (!inw) {
         a = reinterpret_cast<const v2d *>(rec)[idx];
         b = reinterpret_cast<const v2d *>(rec)[idx + 1];
+        a.y = scaled_slope(a.x, a.y, g.dx[0]);
+        b.y = scaled_slope(b.x, b.y, g.dx[0]);
       }
     }
   } else {
     a = reinterpret_cast<const v2d *>(rec)[idx];
     b = reinterpret_cast<const v2d *>(rec)[idx + 1];
+    a.y = scaled_slope(a.x, a.y, g.dx[0]);
+    b.y = scaled_slope(b.x, b.y, g.dx[0]);
   }
   double vv, dd;
-  hermite_1d(a.x, a.y, b.x, b.y, X, g.dx[0], inv_dx, vv, dd);
+  hermite_1d_horner(a.x, a.y, b.x, b.y, X, inv_dx, vv, dd);
   const bool outside = in_range & ((X < 0.0) | (X > 1.0));  // `where` off by an ulp at a node
   if (__any(outside)) {
-    if (outside) hermite_1d_mirrored(a.x, a.y, b.x, b.y, X, g.dx[0], inv_dx, vv, dd);
+    if (outside) {   // (the reference's fabs() mirroring: its own form, from the original records)
+      const v2d ra = reinterpret_cast<const v2d *>(rec)[idx], rb = reinterpret_cast<const v2d *>(rec)[idx + 1];
+      hermite_1d_mirrored(ra.x, ra.y, rb.x, rb.y, X, g.dx[0], inv_dx, vv, dd);
+    }
   }
   v = in_range ? vv : 0.0;
   d = in_range ? dd : 0.0;
@@ -517,8 +544,14 @@ __global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *_
   extern __shared__ double2 lds_all[];
   double *red = reinterpret_cast<double *>(lds_all);  // first 256 B: reduction scratch
   if (USE_LDS) {
+    // the window is staged as (f, scaled slope): the |f| < 1e-7 test and the product with dx are paid once per
+    // node here instead of once per sample
     const double2 *src = reinterpret_cast<const double2 *>(rec) + w0;
-    for (int i = threadIdx.x; i < wn; i += NT) lds_all[16 + i] = src[i];
+    for (int i = threadIdx.x; i < wn; i += NT) {
+      double2 t = src[i];
+      t.y = scaled_slope(t.x, t.y, g.dx[0]);
+      lds_all[16 + i] = t;
+    }
     __syncthreads();
   }
   lds_v2d *win = (lds_v2d *)(lds_all + 16);
