@@ -498,7 +498,9 @@ __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict
   int idx = (int)fq;
   idx = idx < 0 ? 0 : idx;
   idx = idx > g.n[0] - 2 ? g.n[0] - 2 : idx;
-  const double where = x - g.min[0] - idx * g.dx[0];
+  // (for a sample in range fq IS the index -- the clamps only keep the addresses of masked lanes legal -- so the
+  //  int -> double conversion of the reference's idx * dx is not needed)
+  const double where = x - g.min[0] - fq * g.dx[0];
   const double X = where * inv_dx;
   // corner records as (f, g = scaled slope): the LDS window was staged in that form, global records are converted
   v2d a, b;
