@@ -473,6 +473,9 @@ typedef __attribute__((address_space(3))) const v2d lds_v2d;
 // Fast-path precondition (checked by the launcher): 1-D, interpolating, grid and boundary both
 // non-periodic, so remap() is the identity and a sample outside [bmin,bmax] or outside the
 // grid's in_grid range simply contributes (0, 0) (gaussian_grid.h:128-135, grid.h:398-409).
+// "some lane of the wave": straight from the lane mask (the library's __any materialises the predicate in a VGPR)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 template <bool USE_LDS>
 __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict__ rec, lds_v2d *win,
                                          int w0, int w1, double inv_dx, double x, double &v, double &d) {
@@ -492,7 +495,7 @@ __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict
   const double eps = 1e-11 * fmax(1.0, (double)g.n[0]);
   const double frac = q - fq;
   const bool near = in_range & ((frac <= eps) | (frac >= 1.0 - eps));
-  if (__any(near)) {
+  if (wave_any(near)) {
     if (near) fq = floor((x - g.min[0]) / g.dx[0]);
   }
   int idx = (int)fq;
@@ -506,11 +509,11 @@ __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict
   v2d a, b;
   if (USE_LDS) {
     const int li = idx - w0;
-    const bool inw = (li >= 0) & (idx + 1 < w1);
+    const bool inw = (unsigned)li < (unsigned)(w1 - w0 - 1);   // 0 <= li and idx + 1 < w1, in one comparison
     const int lc = inw ? li : 0;
     a = win[lc];
     b = win[lc + 1];
-    if (__any(in_range & !inw)) {
+    if (wave_any(in_range & !inw)) {
       if (!inw) {
         a = reinterpret_cast<const v2d *>(rec)[idx];
         b = reinterpret_cast<const v2d *>(rec)[idx + 1];
@@ -527,7 +530,7 @@ __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict
   double vv, dd;
   hermite_1d_horner(a.x, a.y, b.x, b.y, X, inv_dx, vv, dd);
   const bool outside = in_range & ((X < 0.0) | (X > 1.0));  // `where` off by an ulp at a node
-  if (__any(outside)) {
+  if (wave_any(outside)) {
     if (outside) {   // (the reference's fabs() mirroring: its own form, from the original records)
       const v2d ra = reinterpret_cast<const v2d *>(rec)[idx], rb = reinterpret_cast<const v2d *>(rec)[idx + 1];
       hermite_1d_mirrored(ra.x, ra.y, rb.x, rb.y, X, g.dx[0], inv_dx, vv, dd);
