@@ -19,6 +19,7 @@ Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
   cpu_baseline -- the CPU oracle (or the real reference build when present) timed on a
                   bounded sample of the same workload on the host cores
 """
+import ctypes as C
 import argparse
 import json
 import os
@@ -74,6 +75,33 @@ def rocprof_avg_us(kernel_prefix):
         if k["kernel"].startswith(kernel_prefix):
             return k["avg_us"]
     return None
+
+
+def copy_probe(H, src, dst, nbytes, reps=50):
+    """Context for the roofline fractions: the runtime's own device-to-device copy (hipMemcpyAsync, a blit kernel)
+    moving the SAME traffic as one launch of the lookup kernel (nbytes read + nbytes written), timed with HIP
+    events around `reps` back-to-back copies.  Returns microseconds per copy, or None."""
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        ev = [C.c_void_p(), C.c_void_p()]
+        for e in ev:
+            if hip.hipEventCreate(C.byref(e)) != 0:
+                return None
+        H.synchronize()
+        for _ in range(3):
+            hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 3, None)
+        hip.hipEventRecord(ev[0], None)
+        for _ in range(reps):
+            hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 3, None)
+        hip.hipEventRecord(ev[1], None)
+        hip.hipEventSynchronize(ev[1])
+        ms = C.c_float(0)
+        rc = hip.hipEventElapsedTime(C.byref(ms), ev[0], ev[1])
+        for e in ev:
+            hip.hipEventDestroy(e)
+        return ms.value / reps * 1e3 if rc == 0 else None
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def make_bias(mod, tmpdir, tag, rank=0):
@@ -374,6 +402,7 @@ def main():
         except Exception as exc:  # noqa: BLE001  (scipy missing: skip the extra)
             lj = dict(skipped=repr(exc))
 
+    copy_us = copy_probe(H, d_r.ptr, d_f.ptr, 8 * npairs) if rank == 0 else None
     # component rates (not part of `value`): force evaluation alone, all-samples hill adds
     reps = 20
     H.synchronize()
@@ -414,7 +443,9 @@ def main():
         ms2, l2 = g.profile_read(reset=True)
         g.profile_enable(False)
         a2 = BYTES_PER_EVAL * n2 / (ms2 / l2 * 1e-3) / 1e9
+        cp2 = copy_probe(H, d_r2.ptr, d_f2.ptr, 8 * n2, reps=10)
         roof_w2 = dict(workload="W2: %d pair distances" % n2, bound="hbm", achieved=a2, peak=HBM_PEAK_GBS, unit="GB/s",
+                       device_copy_same_traffic_us=cp2,
                        frac=a2 / HBM_PEAK_GBS, kernel_ms=ms2 / l2, kernel="k_pair_forces_fast<true> (LDS-staged window)",
                        bytes_per_launch=BYTES_PER_EVAL * n2, traffic=pmc_traffic("edm::k_pair_forces_fast<true"),
                        kernel_ms_rocprof=(rocprof_avg_us("edm::k_pair_forces_fast<true") or 0) / 1e3 or None)
@@ -533,6 +564,9 @@ def main():
                 "launches": k_launches,
                 "timed_every": TIMED_EVERY,
                 "bytes_per_launch": BYTES_PER_EVAL * npairs,
+                # hipMemcpyAsync device-to-device of the same 8 B in + 8 B out per pair, for scale: at this size a
+                # launch is latency-bound whatever it computes
+                "device_copy_same_traffic_us": copy_us,
             },
             "evals_only_million_per_s": npairs / t_eval / 1e6,
             "ms_per_step_device_rng": ms_step_device_rng,
