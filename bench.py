@@ -73,7 +73,7 @@ def rocprof_avg_us(kernel_prefix):
         return None
     for k in kernels:
         if k["kernel"].startswith(kernel_prefix):
-            return k["avg_us"]
+            return k.get("avg_us_timed_region", k["avg_us"])
     return None
 
 
@@ -529,7 +529,11 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         total_pairs = npairs * world
-        achieved = BYTES_PER_EVAL * npairs / (k_ms / max(k_launches, 1) * 1e-3) / 1e9
+        # the force kernel rides in one launch with the step's selection (k_pair_forces_select): per pair 8 B distance
+        # in + 8 B force out, per sample 8 B acceptance uniform in (the sample distances are read for accepted
+        # samples only)
+        step_bytes = BYTES_PER_EVAL * npairs + 8 * npairs
+        achieved = step_bytes / (k_ms / max(k_launches, 1) * 1e-3) / 1e9
         out = {
             "metric": "million bias-force evals/sec (1M-pair 1D CV, force eval + hill step per step)",
             "value": total_pairs / (elapsed / args.steps) / 1e6,
@@ -552,18 +556,19 @@ def main():
                 "parallelism": "replicated bias grid, samples sharded, dp%d" % world,
             },
             "roofline": {
-                "kernel": "k_pair_forces_fast<false,256>",
+                "kernel": "k_pair_forces_select (K1 = k_pair_forces_fast<false,256> body + the step's selection/preparation, one launch)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("edm::k_pair_forces_fast<false"),
+                "traffic": pmc_traffic("edm::k_pair_forces_select"),
                 "kernel_us": k_ms / max(k_launches, 1) * 1e3,
-                "kernel_us_rocprof": rocprof_avg_us("edm::k_pair_forces_fast<false"),
+                "kernel_us_rocprof": rocprof_avg_us("edm::k_pair_forces_select"),
                 "launches": k_launches,
                 "timed_every": TIMED_EVERY,
-                "bytes_per_launch": BYTES_PER_EVAL * npairs,
+                "bytes_per_launch": step_bytes,
+                "bytes_per_launch_note": "16 B per pair (K1) + 8 B per sample (acceptance uniforms of the selection)",
                 # hipMemcpyAsync device-to-device of the same 8 B in + 8 B out per pair, for scale: at this size a
                 # launch is latency-bound whatever it computes
                 "device_copy_same_traffic_us": copy_us,

@@ -76,6 +76,7 @@ struct edm_hip_bias {
   DevBuf<double> vs_r;     // virtual add_hill samples of the list (2 per entry)
   DevBuf<int> vs_mask;
   bool force_sync = false;      // redo of a deferred step whose launch bound proved too small
+  PendingForces pending;        // pair forces of a fused step waiting for the launch of the step's selection
   int debug_virtual_ranks = 0;  // tests: a one-rank communicator's packet is replicated, emulating that many ranks
   DevBuf<long long> xchg_cnt;
   // multi-GPU
@@ -593,8 +594,11 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       src.nh = pack_bound;
       src.x = d_x;
       src.x_stride = x_stride;
-      EDM_HIP_TRY(launch_select_prep(sel_args, b->bias->g, src, s));
+      int rcs = select_prep_enqueue(b->bias, sel_args, src, &b->pending);
+      if (rcs) return rcs;
     } else {
+      int rcp = pending_forces_flush(b->bias, &b->pending);
+      if (rcp) return rcp;
       EDM_HIP_TRY(hipMemsetAsync(b->xchg_send.p, 0, sizeof(double), s));  // an empty packet
     }
     if (ncclAllGather(b->xchg_send.p, b->xchg_recv.p, (size_t)packet, ncclDouble, b->comm, s) != ncclSuccess) {
@@ -641,6 +645,8 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     }
     deferred_bound = bound;
     if (!bound) {
+      int rcp = pending_forces_flush(b->bias, &b->pending);
+      if (rcp) return rcp;
       EDM_HIP_TRY(launch_select(n, d_ru, thr, use_thr, b->d_mask, apply_mask, b->sel.p, b->d_count, b->sel_scratch.p, s,
                                 b->count_dev.p, rng));
       EDM_HIP_TRY(hipStreamSynchronize(s));
@@ -665,6 +671,10 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       nh = bound;
     }
     d_sel = b->sel.p;
+  }
+  if (!deferred_bound) {   // (no chained selection ahead: the pair forces of a fused step go first)
+    int rcp = pending_forces_flush(b->bias, &b->pending);
+    if (rcp) return rcp;
   }
   bool rank_heights = false;
   if (b->comm && !packed_exchange) {
@@ -761,8 +771,10 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     spec.d_nh = b->count_dev.p;
     if (packed_exchange)
       spec.unpack_chain = &unp_args;
-    else
+    else {
       spec.sel_chain = &sel_args;
+      spec.forces = &b->pending;
+    }
   }
   int rc = apply_hills(b->bias, spec, &oc, false);
   if (rc == EDM_APPLY_BOUND_EXCEEDED) {
@@ -889,13 +901,20 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
     return do_post_add_hill(b);
   }
   // forces (queued, not waited for), then the new hills behind them on the same stream: one host wait
-  int nblk = 0;
-  rc = pair_forces_enqueue(b->bias, n, d_r, d_force, &nblk);
-  if (rc) return rc;
+  // (where the step's selection runs as a chained launch, the force kernel rides in that launch)
+  b->pending = PendingForces();
+  if (n > 0) {
+    b->pending.active = true;
+    b->pending.n = n;
+    b->pending.d_r = d_r;
+    b->pending.d_force = d_force;
+  }
   rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
+  int rcf = pending_forces_flush(b->bias, &b->pending);  // (no hills this step: nothing has touched the grid)
   if (rc) return rc;
+  if (rcf) return rcf;
   EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
-  const double e = pair_forces_finish(b->bias, nblk);
+  const double e = pair_forces_finish(b->bias, b->pending.nblk);
   if (energy) *energy = e;
   return do_post_add_hill(b);
 }

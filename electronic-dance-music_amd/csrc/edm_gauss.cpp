@@ -705,6 +705,25 @@ int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x
   EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, a, g->d_partials, nullptr, g->stream, e0, e1, nblk));
   return EDM_HIP_OK;
 }
+int pending_forces_flush(const edm_hip_gauss *g, PendingForces *pf) {
+  if (!pf || !pf->active) return EDM_HIP_OK;
+  pf->active = false;
+  return pair_forces_enqueue(g, pf->n, pf->d_r, pf->d_force, &pf->nblk);
+}
+int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a, const HillList &h, PendingForces *pf) {
+  if (pf && pf->active && pair_forces_select_fusable(g->g, pf->n, a.n)) {
+    hipEvent_t e0, e1;
+    profile_slot(g, &e0, &e1);
+    pf->active = false;
+    EDM_HIP_TRY(launch_pair_forces_select(a, g->g, h, g->rec, pf->n, pf->d_r, pf->d_force, g->d_partials, g->stream, e0, e1,
+                                          &pf->nblk));
+    return EDM_HIP_OK;
+  }
+  int rc = pending_forces_flush(g, pf);
+  if (rc) return rc;
+  EDM_HIP_TRY(launch_select_prep(a, g->g, h, g->stream));
+  return EDM_HIP_OK;
+}
 double pair_forces_finish(const edm_hip_gauss *g, int nblk) {
   double e = 0;
   for (int i = 0; i < nblk; i++) e += g->h_partials[i];
@@ -836,9 +855,11 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hl.hx0 = p_hx0;
   hl.nh_dev = spec.d_nh;
   const Tables tabs = g->tables();
-  if (spec.sel_chain)
-    EDM_HIP_TRY(launch_select_prep(*spec.sel_chain, q, hl, s));  // selection + preparation in one launch
-  else if (spec.unpack_chain)
+  if (spec.sel_chain) {
+    // selection + preparation in one launch (and the step's pair forces with them, when they are pending)
+    int rc = select_prep_enqueue(g, *spec.sel_chain, hl, spec.forces);
+    if (rc) return rc;
+  } else if (spec.unpack_chain)
     EDM_HIP_TRY(launch_unpack_prep(*spec.unpack_chain, q, hl, s));  // exchange packets -> global prepared list
   else
     EDM_HIP_TRY(launch_hill_prep(q, hl, s));

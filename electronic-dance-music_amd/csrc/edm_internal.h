@@ -124,6 +124,16 @@ struct edm_hip_gauss {
 // internal entry points shared between edm_gauss and edm_bias
 namespace edm {
 #define EDM_APPLY_BOUND_EXCEEDED 1000
+// pair forces of a fused step (edm_hip_bias_pair_step) not launched yet: they ride in the launch of the step's
+// selection when that is possible (launch_pair_forces_select), else they are queued on their own BEFORE anything
+// of the step that writes the bias grid
+struct PendingForces {
+  bool active = false;
+  long long n = 0;
+  const double *d_r = nullptr;
+  double *d_force = nullptr;
+  int nblk = 0;              // K1 workgroups launched (partial energy sums to add up)
+};
 struct ApplySpec {
   long long nh = 0;
   const double *d_x = nullptr;     // sample positions
@@ -144,6 +154,7 @@ struct ApplySpec {
   double expected_nh = -1;  // expected batch size when it is a random variable (stochastic selection); < 0: nh
   // with a deferred count: selection chained in front of the hill preparation (one launch for both)
   const SelectArgs *sel_chain = nullptr;
+  PendingForces *forces = nullptr;   // launched together with sel_chain where possible
   // multi-GPU packed exchange: the hill list is unpacked from the gathered packets (replaces preparation)
   const UnpackArgs *unpack_chain = nullptr;
   // sharded application of a dense batch on a replicated grid (multi-GPU): this rank gathers only its own
@@ -176,4 +187,8 @@ int pair_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_r, 
 int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride, double *d_f, int f_stride,
                           const int *d_mask, int apply_mask, int *nblk);
 double pair_forces_finish(const edm_hip_gauss *g, int nblk);
+// queues pending forces on their own (no-op when none are pending)
+int pending_forces_flush(const edm_hip_gauss *g, PendingForces *pf);
+// selection (+ preparation / packing) of a step, in one launch with the pending forces where possible
+int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a, const HillList &h, PendingForces *pf);
 }  // namespace edm

@@ -150,6 +150,11 @@ struct RankHeights {
 hipError_t launch_rank_heights(const RankHeights &rh, double *out, hipStream_t s);
 size_t select_stage_ints(long long n);
 hipError_t launch_select_prep(const SelectArgs &a, const Geom &g, const HillList &h, hipStream_t s);
+// K1 and the selection (+ preparation) of a fix edm_pair hill step as ONE launch (short pair arrays only)
+bool pair_forces_select_fusable(const Geom &g, long long n_pairs, long long n_samples);
+hipError_t launch_pair_forces_select(const SelectArgs &a, const Geom &g, const HillList &h, const double *rec, long long n,
+                                     const double *r, double *force, double *scratch, hipStream_t s, hipEvent_t ev0,
+                                     hipEvent_t ev1, int *blocks_out);
 struct LimitArgs;
 struct PostSpec;
 struct LimitResult;

@@ -540,13 +540,12 @@ __device__ __forceinline__ void pair_one(const Geom &g, const double *__restrict
   d = in_range ? dd : 0.0;
 }
 
+// (body of K1 for workgroup `bid` of `nb`: shared by the plain launch and by the launch fused with the selection)
 template <bool USE_LDS, int NT>
-__global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *__restrict__ rec, long long n,
-                                                                 const double *__restrict__ r,
-                                                                 double *__restrict__ force,
-                                                                 double *__restrict__ block_energy, long long w0,
-                                                                 int wn, double inv_dx) {
-  extern __shared__ double2 lds_all[];
+__device__ __forceinline__ void pair_forces_fast_body(const Geom &g, const double *__restrict__ rec, long long n,
+                                                      const double *__restrict__ r, double *__restrict__ force,
+                                                      double *__restrict__ block_energy, long long w0, int wn,
+                                                      double inv_dx, double2 *lds_all, unsigned bid, unsigned nb) {
   double *red = reinterpret_cast<double *>(lds_all);  // first 256 B: reduction scratch
   if (USE_LDS) {
     // the window is staged as (f, scaled slope): the |f| < 1e-7 test and the product with dx are paid once per
@@ -563,12 +562,12 @@ __global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *_
   const int w1 = (int)w0 + wn;
   double e_acc = 0;
   const long long npair = n >> 1;
-  const long long stride = (long long)gridDim.x * NT;
+  const long long stride = (long long)nb * NT;
   const v2d *r2 = reinterpret_cast<const v2d *>(r);
   v2d *f2 = reinterpret_cast<v2d *>(force);
   // two independent 16-B loads per lane per iteration, requested ONE ITERATION AHEAD: the next pairs travel
   // while the current four lookups are evaluated (the loop is latency-bound at four waves per SIMD)
-  const long long i0 = (long long)blockIdx.x * NT + threadIdx.x;
+  const long long i0 = (long long)bid * NT + threadIdx.x;
   v2d ra = {0.0, 0.0}, rb = {0.0, 0.0};
   if (i0 < npair) ra = __builtin_nontemporal_load(&r2[i0]);
   if (i0 + stride < npair) rb = __builtin_nontemporal_load(&r2[i0 + stride]);
@@ -610,14 +609,24 @@ __global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *_
     ra = na;
     rb = nb;
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+  if ((n & 1) && bid == 0 && threadIdx.x == 0) {
     double v, d;
     pair_one<USE_LDS>(g, rec, win, (int)w0, w1, inv_dx, r[n - 1], v, d);
     e_acc += v;
     force[n - 1] = 0.0 - d;
   }
   double s = block_sum(e_acc, red);
-  if (threadIdx.x == 0) block_energy[blockIdx.x] = s;
+  if (threadIdx.x == 0) block_energy[bid] = s;
+}
+
+template <bool USE_LDS, int NT>
+__global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *__restrict__ rec, long long n,
+                                                                 const double *__restrict__ r,
+                                                                 double *__restrict__ force,
+                                                                 double *__restrict__ block_energy, long long w0,
+                                                                 int wn, double inv_dx) {
+  extern __shared__ double2 lds_all[];
+  pair_forces_fast_body<USE_LDS, NT>(g, rec, n, r, force, block_energy, w0, wn, inv_dx, lds_all, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -730,25 +739,44 @@ hipError_t launch_pairlist_forces(const Geom &g, const double *rec, const PairLi
   return hipGetLastError();
 }
 
+static int cu_count() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  return n_cu;
+}
+// geometry served by the specialised K1 (the pair-distance CV: 1-D, interpolating, nothing periodic)
+static bool pair_fast_path(const Geom &g) {
+  return g.dim == 1 && g.interp && !g.periodic[0] && !g.bper[0] && g.n[0] >= 2;
+}
+// LDS staging costs ~160 KB of L2 reads per workgroup: worth it only for long sample arrays
+// (measured break-even ~1 M pairs: 2 M pairs 12.3 us staged vs 14.7 us from L2, 4 M pairs 20 vs 31 us)
+static constexpr long long PAIR_LDS_THRESHOLD = 1500000;
+// short arrays: two workgroups per CU, each lane looping over groups of four pairs (measured faster than one
+// pass of eight workgroups per CU -- 52 vs 45 G evals/s at 1 M pairs -- fewer waves to launch and retire)
+static int pair_short_blocks(long long n) {
+  const long long work = (n >> 1) + 1;
+  long long blocks = (work + BLOCK - 1) / BLOCK;
+  if (blocks > 2 * cu_count()) blocks = 2 * cu_count();
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
 hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, const double *r, double *force,
                               double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
                               int *blocks_out) {
   int blocks;
-  const bool fast = (g.dim == 1 && g.interp && !g.periodic[0] && !g.bper[0] && g.n[0] >= 2);
+  const bool fast = pair_fast_path(g);
   if (fast) {
-    static int n_cu = 0;
     static bool attr_set = false;
-    if (n_cu == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-        n_cu = prop.multiProcessorCount;
-      if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = cu_count();
     const double inv_dx = 1.0 / g.dx[0];
-    // LDS staging costs ~160 KB of L2 reads per workgroup: worth it only for long sample arrays
-    // (measured break-even ~1 M pairs: 2 M pairs 12.3 us staged vs 14.7 us from L2, 4 M pairs 20 vs 31 us)
-    const bool use_lds = n >= 1500000;
+    const bool use_lds = n >= PAIR_LDS_THRESHOLD;
     if (use_lds) {
       int wn = g.n[0] < LDS_WINDOW_MAX ? g.n[0] : LDS_WINDOW_MAX;
       long long w0 = (long long)g.n[0] - wn;  // top-aligned: pair distances populate the upper range
@@ -764,12 +792,7 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
                        r, force, scratch, w0, wn, inv_dx);
     } else {
       // short arrays: small workgroups spread over every CU (latency-bound regime)
-      long long work = (n >> 1) + 1;
-      blocks = (int)((work + BLOCK - 1) / BLOCK);
-      // (two workgroups per CU, each lane looping over groups of four pairs: measured faster than one
-      //  pass of eight workgroups per CU -- 52 vs 45 G evals/s at 1 M pairs -- fewer waves to launch and retire)
-      if (blocks > 2 * n_cu) blocks = 2 * n_cu;
-      if (blocks < 1) blocks = 1;
+      blocks = pair_short_blocks(n);
       EDM_LAUNCH_TIMED((k_pair_forces_fast<false, BLOCK>), dim3(blocks), dim3(BLOCK), 256, s, ev0, ev1, g, rec, n, r, force,
                        scratch, 0LL, 0, inv_dx);
     }
@@ -1101,7 +1124,7 @@ __global__ void __launch_bounds__(BLOCK) k_hill_prep(Geom g, HillList h) {
 // 128-byte line.  Hundreds of workgroups incrementing ONE address serialise at ~12 ns per atomic -- 6 us
 // for the 512 workgroups of the selection kernel, measured -- so workgroups count on sub-counter
 // (id mod FAN) and only the last arrival of each sub-counter touches the top one.)
-__device__ __forceinline__ bool last_block_done(int *ticket, unsigned total_blocks) {
+__device__ __forceinline__ bool last_block_done(int *ticket, unsigned total_blocks, unsigned id) {
   __shared__ int s_is_last;
   // every thread's published stores (publish()) have reached the coherence point before the barrier
   __builtin_amdgcn_s_waitcnt(0);
@@ -1115,7 +1138,6 @@ __device__ __forceinline__ bool last_block_done(int *ticket, unsigned total_bloc
         __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
-      const unsigned id = blockIdx.x + gridDim.x * blockIdx.y;
       const unsigned sub = id % EDM_TICKET_FAN;
       const unsigned subtotal = total_blocks / EDM_TICKET_FAN + (sub < total_blocks % EDM_TICKET_FAN ? 1u : 0u);
       int *mine = ticket + 32 * (1 + sub);
@@ -1133,6 +1155,9 @@ __device__ __forceinline__ bool last_block_done(int *ticket, unsigned total_bloc
   }
   __syncthreads();
   return s_is_last != 0;
+}
+__device__ __forceinline__ bool last_block_done(int *ticket, unsigned total_blocks) {
+  return last_block_done(ticket, total_blocks, blockIdx.x + gridDim.x * blockIdx.y);
 }
 // Data handed from the other workgroups to the last one travels through agent-scope (L2-coherent
 // across the XCDs) relaxed atomics: an agent-scope FENCE would write back the whole L2 of the XCD
@@ -1164,12 +1189,13 @@ __device__ __forceinline__ void select_emit(const SelectArgs &a, const Geom &g, 
 }
 
 template <int DIM>
-__global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, HillList h) {
+__device__ __forceinline__ void select_prep_body(const SelectArgs &a, const Geom &g, const HillList &h, unsigned bid,
+                                                 unsigned nblk) {
   __shared__ int s_w[BLOCK / 64];
   __shared__ long long s_carry;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {
-    const long long base = (long long)blockIdx.x * SEL_CHUNK + (long long)threadIdx.x * SEL_PER_THREAD;
+    const long long base = (long long)bid * SEL_CHUNK + (long long)threadIdx.x * SEL_PER_THREAD;
     bool fl[SEL_PER_THREAD];
     int c = 0;
 #pragma unroll
@@ -1192,20 +1218,20 @@ __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, Hil
       tot += s_w[w];
     }
     int pos = before + inc - c;
-    int *mine = a.stage + (long long)blockIdx.x * SEL_CHUNK;
+    int *mine = a.stage + (long long)bid * SEL_CHUNK;
 #pragma unroll
     for (int j = 0; j < SEL_PER_THREAD; j++)
       if (fl[j]) publish(&mine[pos++], (int)(threadIdx.x * SEL_PER_THREAD + j));
-    if (threadIdx.x == 0) publish(&a.counts[blockIdx.x], tot);
+    if (threadIdx.x == 0) publish(&a.counts[bid], tot);
   }
-  if (!last_block_done(a.ticket, gridDim.x)) return;
+  if (!last_block_done(a.ticket, nblk, bid)) return;
 
   // scan of the per-workgroup counts: every thread takes PERC consecutive workgroups and requests their
   // counts together (one memory round trip per BLOCK * PERC workgroups; 512 workgroups = one pass), the
   // exclusive offsets go to LDS, and the accepted samples of the pass are then dealt out evenly -- thread t
   // takes output slots t, t + BLOCK, ... and finds each one's workgroup by bisection -- so a workgroup
   // that accepted many samples costs no more than one that accepted one
-  const int nblocks = (int)gridDim.x;
+  const int nblocks = (int)nblk;
   const long long bound = h.nh;
   constexpr int PERC_MAX = 8;
   int PERC = (nblocks + BLOCK - 1) / BLOCK;
@@ -1271,6 +1297,33 @@ __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, Hil
   }
 }
 
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, HillList h) {
+  select_prep_body<DIM>(a, g, h, blockIdx.x, gridDim.x);
+}
+
+// One launch for the two independent streaming passes of a fix edm_pair hill step: workgroups [0, nsel) run the
+// selection (+ hill preparation in the last of them), the rest evaluate the pair forces (K1, arrays read from
+// L2).  Neither touches what the other reads or writes; the selection's serial tail hides behind the lookups.
+// (The selection workgroups come first: they are dispatched first and their ticket ids stay 0 .. nsel-1.)
+struct PairForcesArgs {
+  const double *rec;
+  long long n;
+  const double *r;
+  double *force;
+  double *block_energy;
+  double inv_dx;
+  unsigned nsel, nk1;
+};
+__global__ void __launch_bounds__(BLOCK) k_pair_forces_select(SelectArgs a, Geom g, HillList h, PairForcesArgs f) {
+  extern __shared__ double2 lds_all[];
+  if (blockIdx.x >= f.nk1)
+    select_prep_body<1>(a, g, h, blockIdx.x - f.nk1, f.nsel);
+  else
+    pair_forces_fast_body<false, BLOCK>(g, f.rec, f.n, f.r, f.force, f.block_energy, 0LL, 0, f.inv_dx, lds_all,
+                                        blockIdx.x, f.nk1);
+}
+
 size_t select_stage_ints(long long n) { return (size_t)((n + SEL_CHUNK - 1) / SEL_CHUNK) * SEL_CHUNK; }
 
 hipError_t launch_select_prep(const SelectArgs &a, const Geom &g, const HillList &h, hipStream_t s) {
@@ -1281,6 +1334,27 @@ hipError_t launch_select_prep(const SelectArgs &a, const Geom &g, const HillList
     case 2: hipLaunchKernelGGL(k_select_prep<2>, dim3(nb), dim3(BLOCK), 0, s, a, g, h); break;
     default: hipLaunchKernelGGL(k_select_prep<3>, dim3(nb), dim3(BLOCK), 0, s, a, g, h); break;
   }
+  return hipGetLastError();
+}
+
+bool pair_forces_select_fusable(const Geom &g, long long n_pairs, long long n_samples) {
+  return pair_fast_path(g) && n_pairs > 0 && n_pairs < PAIR_LDS_THRESHOLD && n_samples > 0;
+}
+hipError_t launch_pair_forces_select(const SelectArgs &a, const Geom &g, const HillList &h, const double *rec, long long n,
+                                     const double *r, double *force, double *scratch, hipStream_t s, hipEvent_t ev0,
+                                     hipEvent_t ev1, int *blocks_out) {
+  if (!pair_forces_select_fusable(g, n, a.n)) return hipErrorInvalidValue;
+  PairForcesArgs f;
+  f.rec = rec;
+  f.n = n;
+  f.r = r;
+  f.force = force;
+  f.block_energy = scratch;
+  f.inv_dx = 1.0 / g.dx[0];
+  f.nsel = (unsigned)((a.n + SEL_CHUNK - 1) / SEL_CHUNK);
+  f.nk1 = (unsigned)pair_short_blocks(n);
+  EDM_LAUNCH_TIMED(k_pair_forces_select, dim3(f.nsel + f.nk1), dim3(BLOCK), 256, s, ev0, ev1, a, g, h, f);
+  if (blocks_out) *blocks_out = (int)f.nk1;
   return hipGetLastError();
 }
 

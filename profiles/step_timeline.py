@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].split("(")[0].replace("void ", "")[-44:] for r in rows]
 idx = [i for i, n in enumerate(names) if "pair_forces" in n]
-which = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
+which = int(sys.argv[2]) if len(sys.argv) > 2 else 30   # (a step of bench.py's timed region: --warmup 5 --steps 50)
 i0, i1 = idx[which], idx[which + 1]
 t0 = int(rows[i0]["Start_Timestamp"])
 busy = 0.0

@@ -526,35 +526,46 @@ def test_dense_batch_fused_path_vs_oracle(oracle_lib, workdir):
     assert ob.get("overflow_right") > 0
 
 
-def test_pair_step_equals_separate_calls(workdir):
+@pytest.mark.parametrize("mode", ["fused_launch", "odd_n_other_samples", "count_not_deferred", "all_samples", "communicator"])
+def test_pair_step_equals_separate_calls(mode, workdir):
     """edm_hip_bias_pair_step (forces + hill cycle, one host wait) against the separate calls in the
     order fix_edm_pair makes them: pre_add_hill, update_force over the pairs, add_hill per staged
     sample, post_add_hill.  A small bias_per_step keeps the overflow buffer busy, so the flush inside
-    pre_add_hill precedes the force evaluation in both."""
-    text = ("tempering 0\nhill_prefactor 0.5\nhill_density 40\nbias_per_step 0.12\ndimension 1\nbox_low 0\n"
+    pre_add_hill precedes the force evaluation in both.  The modes walk the ways the force kernel is queued:
+    in one launch with the step's selection (short pair arrays, deferred hill count), on its own ahead of a
+    synchronous selection (expected count above the deferred bound), ahead of an all-samples batch, and in the
+    packing launch of the multi-GPU exchange (one-rank communicator)."""
+    density = {"count_not_deferred": "hill_density 900\n", "all_samples": ""}.get(mode, "hill_density 40\n")
+    per_step = "bias_per_step 0.12\n" if mode != "all_samples" else "bias_per_step 0.004\n"
+    text = ("tempering 0\nhill_prefactor 0.5\n" + density + per_step + "dimension 1\nbox_low 0\n"
             "box_high 2.8\nbias_spacing 0.001\nbias_sigma 0.05\n")
-    n = 6000
+    n = 6001 if mode == "odd_n_other_samples" else 6000
+    ns = 4000 if mode == "odd_n_other_samples" else (700 if mode == "all_samples" else n)
     state = []
     for tag in ("fused", "separate"):
         cfg = str(workdir / (tag + ".edm"))
         open(cfg, "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
         b = H.Bias(cfg)
+        if mode == "communicator":
+            b.comm_init(H.comm_unique_id(), 1, 0)
         b.setup(1.0, 1.0)
         b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
         energies, forces = [], []
         for step in range(6):
             r = W.pair_distances(n, 300 + step)
-            u = W.uniform(350 + step, n)
+            rs = r if ns == n else W.pair_distances(ns, 400 + step)
+            u = W.uniform(350 + step, ns)
             d_r = H.DeviceArray.from_host(r)
+            d_s = d_r if ns == n else H.DeviceArray.from_host(rs)
             d_u = H.DeviceArray.from_host(u)
             d_f = H.DeviceArray.zeros((n,))
             if tag == "fused":
-                e = b.pair_step_device(d_r, d_f, n, d_r, d_u, n, est=n)
+                e = b.pair_step_device(d_r, d_f, n, d_s, d_u, ns, est=ns)
             else:
-                b.pre_add_hill(n)
+                b.pre_add_hill(ns)
                 e = b.pair_forces_device(d_r, d_f, n)
-                for i in range(n):
-                    b.add_hill([r[i]], u[i])
+                for i in range(ns):
+                    b.add_hill([rs[i]], u[i])
                 b.post_add_hill()
             energies.append(e)
             forces.append(d_f.to_host())
@@ -565,6 +576,7 @@ def test_pair_step_equals_separate_calls(workdir):
     for a, c in zip(state[0], state[1]):
         assert np.array_equal(np.asarray(a), np.asarray(c))
     assert state[0][0].max() > 0 and state[0][6] > 0   # hills were added and the overflow buffer was used
+    assert np.abs(state[0][4][-1]).max() > 0           # the last step's forces saw a non-zero bias
     assert open(str(workdir / "HILLS_fused_0")).read() == open(str(workdir / "HILLS_separate_0")).read()
 
 
