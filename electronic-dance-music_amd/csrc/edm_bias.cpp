@@ -63,6 +63,7 @@ struct edm_hip_bias {
   DevBuf<double> xchg_send, xchg_recv, xchg_all;
   long long xchg_counts[EDM_MAX_RANKS], xchg_est[EDM_MAX_RANKS];  // last synchronous exchange: per-rank hills / est_hill_count
   double *h_flush = nullptr;   // pinned staging of the overflow records handed to a flush
+  double *d_flush = nullptr;   // its device-side address (host-mapped: read by launch_fetch_words)
   size_t flush_cap = 0;
   // device uniforms (edm_hip_bias_set_device_rng): add_hill cycles given no uniform array draw from a
   // counter-based stream keyed by (seed, cycle number, sample index)
@@ -386,7 +387,8 @@ static int flush_overflow(edm_hip_bias *b, double max_bias, double *bias_added) 
     if (b->h_flush) (void)hipHostFree(b->h_flush);
     b->h_flush = nullptr;
     b->flush_cap = ntot + ntot / 2 + 64;
-    EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_flush), sizeof(double) * b->flush_cap, hipHostMallocDefault));
+    EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_flush), sizeof(double) * b->flush_cap, hipHostMallocMapped));
+    EDM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_flush), b->h_flush, 0));
   }
   for (long long i = 0; i < n; i++) {
     const double *rec = &b->overflow[(b->overflow_left + (size_t)i) * w];
@@ -395,7 +397,7 @@ static int flush_overflow(edm_hip_bias *b, double max_bias, double *bias_added) 
   }
   hipStream_t s = b->bias->stream;
   EDM_HIP_TRY(b->stage_x.reserve(ntot));
-  EDM_HIP_TRY(hipMemcpyAsync(b->stage_x.p, b->h_flush, sizeof(double) * ntot, hipMemcpyHostToDevice, s));
+  EDM_HIP_TRY(launch_fetch_words(b->stage_x.p, b->d_flush, (long long)ntot, s));
   ApplySpec spec;
   spec.nh = n;
   spec.d_x = b->stage_x.p;
@@ -408,6 +410,7 @@ static int flush_overflow(edm_hip_bias *b, double max_bias, double *bias_added) 
   spec.hist_g = &b->hist->g;
   spec.hist_values = b->hist->values;
   spec.fetch_all = true;
+  spec.fetch_heights = false;   // (the heights came from the host's own overflow records)
   ApplyOutcome oc;
   int rc = apply_hills(b->bias, spec, &oc, false);
   if (rc) return rc;
@@ -871,9 +874,10 @@ int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_str
   int rc = do_pre_add_hill(b, est_hill_count < 0 ? n : est_hill_count);
   if (rc) return rc;
   if (!b->b_outofbounds) {
+    b->bias->wait_polled = false;
     rc = process_new_hills(b, n, d_x, x_stride, d_runiform, apply_mask);
     if (rc) return rc;
-    EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
+    if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
     const double e = pair_forces_finish(b->bias, nblk);
     if (energy) *energy = e;
   }
@@ -903,6 +907,7 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
   // forces (queued, not waited for), then the new hills behind them on the same stream: one host wait
   // (where the step's selection runs as a chained launch, the force kernel rides in that launch)
   b->pending = PendingForces();
+  b->bias->wait_polled = false;
   if (n > 0) {
     b->pending.active = true;
     b->pending.n = n;
@@ -913,7 +918,9 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
   int rcf = pending_forces_flush(b->bias, &b->pending);  // (no hills this step: nothing has touched the grid)
   if (rc) return rc;
   if (rcf) return rcf;
-  EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
+  // (a polled hill batch has shown the stream's last kernel past its read-back: the force kernel, earlier on the
+  //  stream, is complete and its partial sums are in host memory)
+  if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
   const double e = pair_forces_finish(b->bias, b->pending.nblk);
   if (energy) *energy = e;
   return do_post_add_hill(b);
@@ -1023,6 +1030,7 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     a.vs_mask = b->vs_mask.p;
   }
   int nblk = 0;
+  b->bias->wait_polled = false;
   EDM_HIP_TRY(launch_pairlist_forces(b->bias->g, b->bias->rec, a, b->bias->d_partials, s, &nblk));
   if (npairs <= 0) nblk = 0;
   if (hill_step) {
@@ -1033,7 +1041,8 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     b->d_mask = saved_mask;
     if (rc) return rc;
   }
-  EDM_HIP_TRY(hipStreamSynchronize(s));
+  // (a polled hill batch has shown the stream past the force passes queued ahead of it)
+  if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(s));
   double e = 0, c = 0;
   for (int k = 0; k < nblk; k++) {
     e += b->bias->h_partials[k];

@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
 #include <limits>
 
 #include "edm_internal.h"
@@ -425,6 +427,7 @@ static int gauss_alloc(edm_hip_gauss *g) {
   g->h_stage_bytes = (size_t)4096 * (sizeof(int) + sizeof(double) * (3 + 3)) + 1024;
   EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_stage), g->h_stage_bytes, hipHostMallocMapped));
   EDM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&g->d_stage), g->h_stage, 0));
+  memset(g->h_stage, 0, g->h_stage_bytes);   // (the last 128 B hold the polled completion words, see apply_hills)
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_dirty), sizeof(int) * 4));
   EDM_HIP_TRY(hipMemset(g->d_dirty, 0, sizeof(int) * 4));
   EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_tickets), sizeof(int) * 3 * EDM_TICKET_INTS));
@@ -730,6 +733,16 @@ double pair_forces_finish(const edm_hip_gauss *g, int nblk) {
   return e;
 }
 
+// Completion of a short hill batch is seen by polling two words its last kernel writes behind the read-back
+// region (EDM_HIP_POLL=0 in the environment: always wait for the stream instead)
+static bool poll_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("EDM_HIP_POLL");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
+}
 static const long long SMALL_BATCH = 4096;  // read-back of a batch this small is one async burst
 
 // Upper bound on the tiles one hill can mark (k_mark_tiles keeps the tiles of the stencil's bounding box whose
@@ -1045,6 +1058,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
   bool chain_post = false;
   bool rb_pushed = false;
+  bool polled = false;   // completion seen through the read-back flag words instead of the stream wait
   if (sharded) {
     if (spec.limited) {
       for (size_t k = 0; k < slices.size(); k++) {
@@ -1097,11 +1111,18 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     ps.rb_src = nullptr;
     ps.rb_dst = nullptr;
     ps.rb_bytes = 0;
-    if (chain_post && small && rb_bytes <= g->h_stage_bytes) {
+    ps.done_flag = nullptr;
+    ps.done_seq = 0;
+    if (chain_post && small && rb_bytes + 128 <= g->h_stage_bytes) {
       ps.rb_src = ws.rb.p;
       ps.rb_dst = g->d_stage;
       ps.rb_bytes = (long long)rb_bytes;
       rb_pushed = true;
+      if (sub <= 0 && poll_enabled()) {
+        ps.done_flag = reinterpret_cast<unsigned long long *>(g->d_stage + g->h_stage_bytes - 128);
+        ps.done_seq = ++g->done_seq;
+        polled = true;
+      }
     }
     if (sub > 0) {
       EDM_HIP_TRY(ws.tile_flags.reserve_zeroed((size_t)ntiles));
@@ -1168,7 +1189,27 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   const double *st_a2 = reinterpret_cast<const double *>(stage + off_a2);
   const double *st_added = reinterpret_cast<const double *>(stage + off_added);
   const double *st_pos = reinterpret_cast<const double *>(stage + off_pos);
-  EDM_HIP_TRY(hipStreamSynchronize(s));
+  g->wait_polled = false;
+  if (polled) {
+    // the gather's read-back waves flag their part of the host-mapped region: poll the two words instead of
+    // waiting for the kernel's completion signal (bounded; falls back to the stream wait)
+    volatile unsigned long long *w = reinterpret_cast<volatile unsigned long long *>(g->h_stage + g->h_stage_bytes - 128);
+    const unsigned long long want = g->done_seq;
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+    bool seen = false;
+    for (unsigned spin = 0;; spin++) {
+      if (w[0] == want && w[8] == want) { seen = true; break; }
+      __builtin_ia32_pause();
+      if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (seen)
+      g->wait_polled = true;
+    else
+      EDM_HIP_TRY(hipStreamSynchronize(s));
+  } else {
+    EDM_HIP_TRY(hipStreamSynchronize(s));
+  }
   long long nh_act = nh;
   if (spec.limited) {
     res = *hres;
@@ -1185,7 +1226,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   if (out) {
     out->res = res;
     if (want_total && !spec.limited) out->total_added = g->h_scalars[1];
-    if (base_heights && spec.limited) {
+    if (base_heights && spec.limited && spec.fetch_heights) {
       const long long f0 = spec.fetch_all ? 0 : res.k;
       if (nh_act - f0 > 0) {
         out->heights.resize((size_t)(nh_act - f0));

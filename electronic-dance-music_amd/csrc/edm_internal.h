@@ -104,6 +104,9 @@ struct edm_hip_gauss {
   char *h_stage = nullptr;               // pinned (host-mapped) staging for batched result read-back
   char *d_stage = nullptr;               // its device-side address
   size_t h_stage_bytes = 0;
+  unsigned long long done_seq = 0;       // sequence number of the last polled read-back (see PostSpec::done_flag)
+  bool wait_polled = false;              // the last apply_hills saw its results through the polled words: the
+                                         // stream was NOT synchronised (its last kernel may still be retiring)
   int *d_dirty = nullptr;
   long long tiles_per_hill = 0;          // cached tiles_per_hill_bound() of the current geometry / boundary
   int *d_tickets = nullptr;              // three last-workgroup tickets (EDM_TICKET_INTS ints each), kept zero
@@ -148,6 +151,7 @@ struct ApplySpec {
   const Geom *hist_g = nullptr;
   double *hist_values = nullptr;
   bool fetch_all = false;          // host wants position + bias_added of EVERY hill (HILLS log)
+  bool fetch_heights = true;       // with d_h: copy the per-hill base heights back (a flush already has them)
   // deferred count: the batch is queued with `nh` as a launch bound while the true count still sits in
   // device memory; apply_hills returns EDM_APPLY_BOUND_EXCEEDED (nothing applied) if the bound was too small
   const long long *d_nh = nullptr;

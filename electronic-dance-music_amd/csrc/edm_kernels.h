@@ -149,6 +149,8 @@ struct RankHeights {
 };
 hipError_t launch_rank_heights(const RankHeights &rh, double *out, hipStream_t s);
 size_t select_stage_ints(long long n);
+// dst[0..n) = src_mapped[0..n) where src_mapped is the device address of host-mapped pinned memory
+hipError_t launch_fetch_words(double *dst, const double *src_mapped, long long n, hipStream_t s);
 hipError_t launch_select_prep(const SelectArgs &a, const Geom &g, const HillList &h, hipStream_t s);
 // K1 and the selection (+ preparation) of a fix edm_pair hill step as ONE launch (short pair arrays only)
 bool pair_forces_select_fusable(const Geom &g, long long n_pairs, long long n_samples);
@@ -267,6 +269,10 @@ struct PostSpec {
   const char *rb_src;   // optional: rb_bytes (multiple of 8) copied to rb_dst (host-mapped) at the very end
   char *rb_dst;
   long long rb_bytes;
+  // optional (host-mapped, two words 64 B apart): each read-back wave stores done_seq here once its part of the
+  // region has landed -- the host polls the words instead of waiting for the kernel's completion signal
+  unsigned long long *done_flag;
+  unsigned long long done_seq;
 };
 
 

@@ -830,6 +830,20 @@ __global__ void __launch_bounds__(BLOCK) k_unpack(Geom g, const double *__restri
       for (int d = 0; d < g.dim; d++) derivs[i * g.dim + d] = rec[i * g.rec + 1 + d];
   }
 }
+// small host -> device upload as a KERNEL reading host-mapped memory: stays on the compute queue (an async copy
+// queued behind a kernel that is still retiring waits on a cross-engine signal, measured +12 us per step)
+__global__ void __launch_bounds__(BLOCK) k_fetch_words(double *__restrict__ dst, const double *__restrict__ src_mapped,
+                                                       long long n) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) dst[i] = src_mapped[i];
+}
+hipError_t launch_fetch_words(double *dst, const double *src_mapped, long long n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  long long b = (n + BLOCK - 1) / BLOCK;
+  if (b > 64) b = 64;
+  hipLaunchKernelGGL(k_fetch_words, dim3((unsigned)b), dim3(BLOCK), 0, s, dst, src_mapped, n);
+  return hipGetLastError();
+}
 static int blocks_for(long long n) {
   long long b = (n + BLOCK - 1) / BLOCK;
   if (b > MAX_BLOCKS) b = MAX_BLOCKS;
@@ -1864,6 +1878,8 @@ struct PostArgs {
   const char *rb_src;
   char *rb_dst;
   long long rb_bytes;
+  unsigned long long *done_flag;
+  unsigned long long done_seq;
 };
 
 // PARTS (1 or 4; 4 on the 1-D grid only): the tile is BLOCK / PARTS nodes wide and thread (part, node)
@@ -2266,7 +2282,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MOD
 #pragma unroll
       for (int sgm = 0; sgm < 5; sgm++) {
         const long long w0 = seg_off[sgm] / 8, wn = seg_len[sgm] / 8;
-        for (long long w = me; w < wn; w += nthr) dst[w0 + w] = src[w0 + w];
+        // (system-scope stores: written through to host memory now, not at the end-of-kernel write-back)
+        for (long long w = me; w < wn; w += nthr)
+          __hip_atomic_store(&dst[w0 + w], src[w0 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (post.done_flag) {
+        // this wave's stores into the host-mapped region have been acknowledged; the flag word follows them
+        // on the same path (posted writes of one requester stay in order)
+        __builtin_amdgcn_s_waitcnt(0);
+        if (ln == 0)
+          __hip_atomic_store(post.done_flag + 8 * (wv - first), post.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
@@ -2405,6 +2430,8 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
     post.rb_src = chain->rb_src;
     post.rb_dst = chain->rb_dst;
     post.rb_bytes = chain->rb_bytes;
+    post.done_flag = chain->done_flag;
+    post.done_seq = chain->done_seq;
   }
   const long long ntiles = gather_tiles(g);
   int use_list = 0;
