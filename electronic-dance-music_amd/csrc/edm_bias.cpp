@@ -1105,10 +1105,16 @@ int edm_hip_bias_write_histogram(const edm_hip_bias *b, int serial_format) {
 }
 int edm_hip_bias_clear_histogram(edm_hip_bias *b) {
   if (!b->hist) return EDM_HIP_ERR_STATE;
+  // (the histogram is updated by kernels on the bias stream, which may still be running behind a polled batch)
+  if (b->bias) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
   return edm_hip_grid_clear(b->hist);
 }
 edm_hip_gauss *edm_hip_bias_gauss(edm_hip_bias *b) { return b->bias; }
-edm_hip_grid *edm_hip_bias_histogram(edm_hip_bias *b) { return b->hist; }
+edm_hip_grid *edm_hip_bias_histogram(edm_hip_bias *b) {
+  // the handle has a stream of its own: hand it out only once the updates queued on the bias stream are done
+  if (b->bias && b->hist) (void)hipStreamSynchronize(b->bias->stream);
+  return b->hist;
+}
 
 int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
 #define G(n, expr) if (strcmp(name, n) == 0) { *value = (double)(expr); return EDM_HIP_OK; }

@@ -905,6 +905,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     fplan.partial = ws.partial.p;
     fplan.slots = ws.slots.p;
   }
+  bool rb_pushed = false;   // the packed read-back region is copied to host-mapped memory by a kernel of the chain
+  bool polled = false;      // ... and flagged there: the host polls the flag instead of waiting for the stream
   const double *base_heights = spec.d_h;
   const bool chain_limit = spec.limited && !spec.ordered && !fused && hill_integrals_can_chain_limit(nh);
   // sharded (multi-GPU) variant of the fused path
@@ -976,6 +978,19 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     la.flush_mode = spec.flush_mode;
     la.tail = LimitTail{ws.tail_h1.p, p_h2, p_a2, ws.tail_cum.p, p_flags};
     la.res = dres;
+    if (small && rb_bytes + 128 <= g->h_stage_bytes) {
+      // ... and so does the read-back: everything the host reads is final once the limiter has run, so the
+      // same workgroup copies the packed region into host-mapped memory and flags it; the host polls the flag
+      // (see below) and the gather runs on behind the host's back
+      la.rb_src = ws.rb.p;
+      la.rb_dst = g->d_stage;
+      rb_pushed = true;
+      if (poll_enabled()) {
+        la.done_flag = reinterpret_cast<unsigned long long *>(g->d_stage + g->h_stage_bytes - 128);
+        la.done_seq = ++g->done_seq;
+        polled = true;
+      }
+    }
     EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s, &la));
     hh.res_dev = dres;
   } else if (spec.limited || want_total) {
@@ -1057,8 +1072,6 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   }
   const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
   bool chain_post = false;
-  bool rb_pushed = false;
-  bool polled = false;   // completion seen through the read-back flag words instead of the stream wait
   if (sharded) {
     if (spec.limited) {
       for (size_t k = 0; k < slices.size(); k++) {
@@ -1111,18 +1124,11 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     ps.rb_src = nullptr;
     ps.rb_dst = nullptr;
     ps.rb_bytes = 0;
-    ps.done_flag = nullptr;
-    ps.done_seq = 0;
-    if (chain_post && small && rb_bytes + 128 <= g->h_stage_bytes) {
+    if (!rb_pushed && chain_post && small && rb_bytes + 128 <= g->h_stage_bytes) {
       ps.rb_src = ws.rb.p;
       ps.rb_dst = g->d_stage;
       ps.rb_bytes = (long long)rb_bytes;
       rb_pushed = true;
-      if (sub <= 0 && poll_enabled()) {
-        ps.done_flag = reinterpret_cast<unsigned long long *>(g->d_stage + g->h_stage_bytes - 128);
-        ps.done_seq = ++g->done_seq;
-        polled = true;
-      }
     }
     if (sub > 0) {
       EDM_HIP_TRY(ws.tile_flags.reserve_zeroed((size_t)ntiles));
@@ -1191,14 +1197,14 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   const double *st_pos = reinterpret_cast<const double *>(stage + off_pos);
   g->wait_polled = false;
   if (polled) {
-    // the gather's read-back waves flag their part of the host-mapped region: poll the two words instead of
-    // waiting for the kernel's completion signal (bounded; falls back to the stream wait)
+    // the limiter's workgroup flags the host-mapped region once it is complete: poll the word instead of waiting
+    // for the stream's completion signal (bounded; falls back to the stream wait)
     volatile unsigned long long *w = reinterpret_cast<volatile unsigned long long *>(g->h_stage + g->h_stage_bytes - 128);
     const unsigned long long want = g->done_seq;
     const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
     bool seen = false;
     for (unsigned spin = 0;; spin++) {
-      if (w[0] == want && w[8] == want) { seen = true; break; }
+      if (w[0] == want) { seen = true; break; }
       __builtin_ia32_pause();
       if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
     }

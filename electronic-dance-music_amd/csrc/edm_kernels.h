@@ -257,6 +257,15 @@ struct LimitArgs {
   int flush_mode;
   LimitTail tail;
   LimitResult *res;
+  // optional: once the limiter has run, the packed read-back region of the batch (apply_hills' layout: header +
+  // flags | h2 | added2 | added | positions, sized by the launch bound) is complete -- nothing the host reads is
+  // written by the gather -- and the last workgroup copies the part the true hill count fills to rb_dst
+  // (host-mapped) and then stores done_seq to *done_flag: the host polls that word and returns while the gather
+  // still runs (every later call is ordered behind it on the stream)
+  const char *rb_src;
+  char *rb_dst;
+  unsigned long long *done_flag;
+  unsigned long long done_seq;
 };
 bool hill_integrals_can_chain_limit(long long nh);
 // boundary duplication + histogram chained onto the gather (plan.groups == 1, hh.res_dev and h.hx0 set)
@@ -269,10 +278,6 @@ struct PostSpec {
   const char *rb_src;   // optional: rb_bytes (multiple of 8) copied to rb_dst (host-mapped) at the very end
   char *rb_dst;
   long long rb_bytes;
-  // optional (host-mapped, two words 64 B apart): each read-back wave stores done_seq here once its part of the
-  // region has landed -- the host polls the words instead of waiting for the kernel's completion signal
-  unsigned long long *done_flag;
-  unsigned long long done_seq;
 };
 
 

@@ -1600,6 +1600,27 @@ __device__ __forceinline__ bool pair_term(const Geom &g, const TermConst<DIM> &t
 // ---------------------------------------------------------------------------
 // TPH threads cooperate on one hill: 64 (a wave per hill, long lists) or 256 (a workgroup per hill:
 // four times shorter critical path for the few-hundred-hill batches of a stochastic hill step)
+// Packed read-back region of a short limited batch (apply_hills' layout, sized by the launch bound nb) -> host-mapped
+// memory; only the part the batch's true hill count na fills.  System-scope stores: written through to host
+// memory now (plain stores would sit in L2 until the end-of-kernel write-back); agent-scope loads: the region
+// was filled by other workgroups and launches.
+template <int DIM>
+__device__ __forceinline__ void readback_copy(const char *rb_src, char *rb_dst, long long nb, long long na, int me,
+                                              int nthr) {
+  const long long off_flags = 64, off_h2 = off_flags + ((4 * nb + 7) & ~7LL), off_a2 = off_h2 + 8 * nb,
+                  off_added = off_a2 + 8 * nb, off_pos = off_added + 8 * nb;
+  const long long seg_off[5] = {0, off_h2, off_a2, off_added, off_pos};
+  const long long seg_len[5] = {off_flags + ((4 * na + 7) & ~7LL), 8 * na, 8 * na, 8 * na, 8 * na * DIM};
+  const long long *src = reinterpret_cast<const long long *>(rb_src);
+  long long *dst = reinterpret_cast<long long *>(rb_dst);
+#pragma unroll
+  for (int sgm = 0; sgm < 5; sgm++) {
+    const long long w0 = seg_off[sgm] / 8, wn = seg_len[sgm] / 8;
+    for (long long w = me; w < wn; w += nthr)
+      __hip_atomic_store(&dst[w0 + w], acquire(&src[w0 + w]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 template <bool COHERENT>
 __device__ __forceinline__ void limit_wave(long long nh_bound, const double *added, const double *heights,
                                            double h_const, double limit, double cum_in, int flush_mode,
@@ -1719,6 +1740,18 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
       if (threadIdx.x < 64)
         limit_wave<true>(h.nh, added, heights, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr,
                    nullptr, h.nh_dev);
+      if (la.rb_dst) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();   // the limiter's result and tail arrays, written by wave 0
+        const long long nb = h.nh;                                            // the layout is sized by the launch bound
+        long long na = acquire(&la.res->nh) < nb ? acquire(&la.res->nh) : nb;   // ... the hills are fewer
+        if (acquire(&la.res->error)) na = 0;
+        readback_copy<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x, NT);
+        __builtin_amdgcn_s_waitcnt(0);   // every wave's stores into the host-mapped region have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0 && la.done_flag)
+          __hip_atomic_store(la.done_flag, la.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -1878,8 +1911,6 @@ struct PostArgs {
   const char *rb_src;
   char *rb_dst;
   long long rb_bytes;
-  unsigned long long *done_flag;
-  unsigned long long done_seq;
 };
 
 // PARTS (1 or 4; 4 on the 1-D grid only): the tile is BLOCK / PARTS nodes wide and thread (part, node)
@@ -2273,26 +2304,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MOD
       const long long nb = h.nh;                                  // the layout is sized by the launch bound
       long long na = hh.res_dev->nh < nb ? hh.res_dev->nh : nb;   // ... the hills are fewer
       if (hh.res_dev->error) na = 0;
-      const long long off_flags = 64, off_h2 = off_flags + ((4 * nb + 7) & ~7LL), off_a2 = off_h2 + 8 * nb,
-                      off_added = off_a2 + 8 * nb, off_pos = off_added + 8 * nb;
-      const long long seg_off[5] = {0, off_h2, off_a2, off_added, off_pos};
-      const long long seg_len[5] = {off_flags + ((4 * na + 7) & ~7LL), 8 * na, 8 * na, 8 * na, 8 * na * DIM};
-      const long long *src = reinterpret_cast<const long long *>(post.rb_src);
-      long long *dst = reinterpret_cast<long long *>(post.rb_dst);
-#pragma unroll
-      for (int sgm = 0; sgm < 5; sgm++) {
-        const long long w0 = seg_off[sgm] / 8, wn = seg_len[sgm] / 8;
-        // (system-scope stores: written through to host memory now, not at the end-of-kernel write-back)
-        for (long long w = me; w < wn; w += nthr)
-          __hip_atomic_store(&dst[w0 + w], src[w0 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      if (post.done_flag) {
-        // this wave's stores into the host-mapped region have been acknowledged; the flag word follows them
-        // on the same path (posted writes of one requester stay in order)
-        __builtin_amdgcn_s_waitcnt(0);
-        if (ln == 0)
-          __hip_atomic_store(post.done_flag + 8 * (wv - first), post.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+      readback_copy<DIM>(post.rb_src, post.rb_dst, nb, na, me, nthr);
     }
   }
 }
@@ -2430,8 +2442,6 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
     post.rb_src = chain->rb_src;
     post.rb_dst = chain->rb_dst;
     post.rb_bytes = chain->rb_bytes;
-    post.done_flag = chain->done_flag;
-    post.done_seq = chain->done_seq;
   }
   const long long ntiles = gather_tiles(g);
   int use_list = 0;
