@@ -1594,12 +1594,6 @@ __device__ __forceinline__ bool pair_term(const Geom &g, const TermConst<DIM> &t
   return true;
 }
 
-// ---------------------------------------------------------------------------
-// K3: per-hill integrated bias -- one wave per hill walks the reference's stencil
-// (gaussian_grid.h:227-281) and reduces h*(expo+corr)*vol in a fixed order.
-// ---------------------------------------------------------------------------
-// TPH threads cooperate on one hill: 64 (a wave per hill, long lists) or 256 (a workgroup per hill:
-// four times shorter critical path for the few-hundred-hill batches of a stochastic hill step)
 // Packed read-back region of a short limited batch (apply_hills' layout, sized by the launch bound nb) -> host-mapped
 // memory; only the part the batch's true hill count na fills.  System-scope stores: written through to host
 // memory now (plain stores would sit in L2 until the end-of-kernel write-back); agent-scope loads: the region
@@ -1621,6 +1615,12 @@ __device__ __forceinline__ void readback_copy(const char *rb_src, char *rb_dst, 
   }
 }
 
+// ---------------------------------------------------------------------------
+// K3: per-hill integrated bias -- one wave per hill walks the reference's stencil
+// (gaussian_grid.h:227-281) and reduces h*(expo+corr)*vol in a fixed order.
+// ---------------------------------------------------------------------------
+// TPH threads cooperate on one hill: 64 (a wave per hill, long lists) or 256 (a workgroup per hill:
+// four times shorter critical path for the few-hundred-hill batches of a stochastic hill step)
 template <bool COHERENT>
 __device__ __forceinline__ void limit_wave(long long nh_bound, const double *added, const double *heights,
                                            double h_const, double limit, double cum_in, int flush_mode,
