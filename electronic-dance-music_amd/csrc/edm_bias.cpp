@@ -395,14 +395,14 @@ static int flush_overflow(edm_hip_bias *b, double max_bias, double *bias_added) 
     for (unsigned int d = 0; d < b->dim; d++) b->h_flush[(size_t)i * b->dim + d] = rec[d];
     b->h_flush[nx + (size_t)i] = rec[b->dim];
   }
-  hipStream_t s = b->bias->stream;
   EDM_HIP_TRY(b->stage_x.reserve(ntot));
-  EDM_HIP_TRY(launch_fetch_words(b->stage_x.p, b->d_flush, (long long)ntot, s));
+  // (no upload: the preparation kernel reads positions and heights straight from the host-mapped array)
   ApplySpec spec;
   spec.nh = n;
-  spec.d_x = b->stage_x.p;
+  spec.d_x = b->d_flush;
   spec.x_stride = (int)b->dim;
   spec.d_h = b->stage_x.p + nx;
+  spec.h_fetch_src = b->d_flush + nx;
   spec.limited = true;
   spec.flush_mode = 1;
   spec.limit = max_bias;

@@ -875,7 +875,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   } else if (spec.unpack_chain)
     EDM_HIP_TRY(launch_unpack_prep(*spec.unpack_chain, q, hl, s));  // exchange packets -> global prepared list
   else
-    EDM_HIP_TRY(launch_hill_prep(q, hl, s));
+    EDM_HIP_TRY(launch_hill_prep(q, hl, s, spec.h_fetch_src, spec.h_fetch_src ? const_cast<double *>(spec.d_h) : nullptr));
 
   HillHeights hh;
   hh.h = spec.d_h;

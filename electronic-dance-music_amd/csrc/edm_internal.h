@@ -152,6 +152,8 @@ struct ApplySpec {
   double *hist_values = nullptr;
   bool fetch_all = false;          // host wants position + bias_added of EVERY hill (HILLS log)
   bool fetch_heights = true;       // with d_h: copy the per-hill base heights back (a flush already has them)
+  // optional: d_h is filled by the preparation kernel from this host-mapped array (nh doubles)
+  const double *h_fetch_src = nullptr;
   // deferred count: the batch is queued with `nh` as a launch bound while the true count still sits in
   // device memory; apply_hills returns EDM_APPLY_BOUND_EXCEEDED (nothing applied) if the bound was too small
   const long long *d_nh = nullptr;

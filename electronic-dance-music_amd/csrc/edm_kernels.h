@@ -106,7 +106,8 @@ struct HillList {
   // bound -- lets a batch be queued before the selection count has travelled back to the host
   const long long *nh_dev;
 };
-hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s);
+hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s, const double *fetch_src = nullptr,
+                            double *fetch_dst = nullptr);
 
 // --- chained launches for short hill steps (see last_block_done in edm_kernels.hip) ---
 // a ticket = zero-initialised device ints: top counter + FAN sub-counters, one 128-byte line each
@@ -149,8 +150,6 @@ struct RankHeights {
 };
 hipError_t launch_rank_heights(const RankHeights &rh, double *out, hipStream_t s);
 size_t select_stage_ints(long long n);
-// dst[0..n) = src_mapped[0..n) where src_mapped is the device address of host-mapped pinned memory
-hipError_t launch_fetch_words(double *dst, const double *src_mapped, long long n, hipStream_t s);
 hipError_t launch_select_prep(const SelectArgs &a, const Geom &g, const HillList &h, hipStream_t s);
 // K1 and the selection (+ preparation) of a fix edm_pair hill step as ONE launch (short pair arrays only)
 bool pair_forces_select_fusable(const Geom &g, long long n_pairs, long long n_samples);

@@ -830,20 +830,6 @@ __global__ void __launch_bounds__(BLOCK) k_unpack(Geom g, const double *__restri
       for (int d = 0; d < g.dim; d++) derivs[i * g.dim + d] = rec[i * g.rec + 1 + d];
   }
 }
-// small host -> device upload as a KERNEL reading host-mapped memory: stays on the compute queue (an async copy
-// queued behind a kernel that is still retiring waits on a cross-engine signal, measured +12 us per step)
-__global__ void __launch_bounds__(BLOCK) k_fetch_words(double *__restrict__ dst, const double *__restrict__ src_mapped,
-                                                       long long n) {
-  const long long stride = (long long)gridDim.x * BLOCK;
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) dst[i] = src_mapped[i];
-}
-hipError_t launch_fetch_words(double *dst, const double *src_mapped, long long n, hipStream_t s) {
-  if (n <= 0) return hipSuccess;
-  long long b = (n + BLOCK - 1) / BLOCK;
-  if (b > 64) b = 64;
-  hipLaunchKernelGGL(k_fetch_words, dim3((unsigned)b), dim3(BLOCK), 0, s, dst, src_mapped, n);
-  return hipGetLastError();
-}
 static int blocks_for(long long n) {
   long long b = (n + BLOCK - 1) / BLOCK;
   if (b > MAX_BLOCKS) b = MAX_BLOCKS;
@@ -1119,11 +1105,16 @@ __device__ __forceinline__ void hill_prep_vals(const Geom &g, const HillList &h,
 }
 
 template <int DIM>
-__global__ void __launch_bounds__(BLOCK) k_hill_prep(Geom g, HillList h) {
+// (fetch_src/fetch_dst, optional: the per-hill heights of an overflow flush sit in host-mapped memory next to the
+//  positions; this kernel brings them over while it prepares the hills -- no separate upload)
+__global__ void __launch_bounds__(BLOCK) k_hill_prep(Geom g, HillList h, const double *__restrict__ fetch_src,
+                                                     double *__restrict__ fetch_dst) {
   const long long stride = (long long)gridDim.x * BLOCK;
   const long long nh = hill_count(h);
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < nh; i += stride)
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < nh; i += stride) {
+    if (fetch_dst) fetch_dst[i] = fetch_src[i];
     hill_prep_one<DIM>(g, h, i, h.sel ? h.sel[i] : i);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1372,13 +1363,13 @@ hipError_t launch_pair_forces_select(const SelectArgs &a, const Geom &g, const H
   return hipGetLastError();
 }
 
-hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s) {
+hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s, const double *fetch_src, double *fetch_dst) {
   if (h.nh <= 0) return hipSuccess;
   const int b = blocks_for(h.nh);
   switch (g.dim) {
-    case 1: hipLaunchKernelGGL(k_hill_prep<1>, dim3(b), dim3(BLOCK), 0, s, g, h); break;
-    case 2: hipLaunchKernelGGL(k_hill_prep<2>, dim3(b), dim3(BLOCK), 0, s, g, h); break;
-    default: hipLaunchKernelGGL(k_hill_prep<3>, dim3(b), dim3(BLOCK), 0, s, g, h); break;
+    case 1: hipLaunchKernelGGL(k_hill_prep<1>, dim3(b), dim3(BLOCK), 0, s, g, h, fetch_src, fetch_dst); break;
+    case 2: hipLaunchKernelGGL(k_hill_prep<2>, dim3(b), dim3(BLOCK), 0, s, g, h, fetch_src, fetch_dst); break;
+    default: hipLaunchKernelGGL(k_hill_prep<3>, dim3(b), dim3(BLOCK), 0, s, g, h, fetch_src, fetch_dst); break;
   }
   return hipGetLastError();
 }
