@@ -1,0 +1,77 @@
+"""Child process of test_polled_completion_equals_stream_wait: one scripted run of hill-depositing steps with
+calls that read the bias right behind them; prints a digest of everything a caller can observe.
+The parent runs it twice -- EDM_HIP_POLL unset (results polled from host-mapped memory, the call returns while the
+grid update still executes) and EDM_HIP_POLL=0 (every batch waits for its stream) -- and compares the digests."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import edm_amd.hip as H  # noqa: E402
+import edm_amd.workloads as W  # noqa: E402
+
+
+def main(workdir):
+    H.require_gpu()
+    dig = hashlib.sha256()
+
+    def feed(*arrays):
+        for a in arrays:
+            dig.update(np.ascontiguousarray(np.asarray(a, dtype=np.float64)).tobytes())
+
+    # 1-D pair CV with walls (boundary duplication chained behind the gather), limiter and overflow buffer busy
+    cfg = os.path.join(workdir, "p1.edm")
+    open(cfg, "w").write("tempering 0\nhill_prefactor 0.5\nhill_density 40\nbias_per_step 0.12\ndimension 1\nbox_low 0\n"
+                         "box_high 2.8\nbias_spacing 0.001\nbias_sigma 0.05\nhills_filename %s/HILLS_p1\n"
+                         "histogram_filename %s/HIST_p1\n" % (workdir, workdir))
+    b = H.Bias(cfg)
+    b.setup(1.0, 1.0)
+    b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    n = 6000
+    probe = np.linspace(0.9, 2.75, 57).reshape(-1, 1)
+    for step in range(8):
+        r = W.pair_distances(n, 900 + step)
+        d_r = H.DeviceArray.from_host(r)
+        d_u = H.DeviceArray.from_host(W.uniform(950 + step, n))
+        d_f = H.DeviceArray.zeros((n,))
+        e = b.pair_step_device(d_r, d_f, n, d_r, d_u, n, est=n)
+        # straight behind the step: lookups, the force array, and (every other step) the histogram
+        v, dv = b.gauss.get_value_deriv(probe)
+        feed([e], v, dv, d_f.to_host())
+        if step % 2:
+            feed(b.hist.values)
+        if step == 5:
+            b.clear_histogram()
+    b.write_bias(os.path.join(workdir, "BIAS_p1"))
+    gv, gd = b.gauss.download()
+    feed(gv, gd, b.hist.values, [b.get("cum_bias"), b.get("overflow_right"), b.get("hills_added")])
+    dig.update(open(os.path.join(workdir, "BIAS_p1"), "rb").read())
+    dig.update(open(os.path.join(workdir, "HILLS_p1_0"), "rb").read())
+    del b
+
+    # 2-D periodic coordinate CV through edm_hip_bias_step (flush + new hills every step)
+    cfg = os.path.join(workdir, "p2.edm")
+    open(cfg, "w").write("tempering 0\nhill_prefactor 0.5\nhill_density 60\nbias_per_step 0.2\ndimension 2\nbox_low 0 0\n"
+                         "box_high 8 8\nbias_spacing 0.05 0.05\nbias_sigma 0.2 0.2\nhills_filename %s/HILLS_p2\n"
+                         "histogram_filename %s/HIST_p2\n" % (workdir, workdir))
+    b = H.Bias(cfg)
+    b.setup(1.0, 1.0)
+    b.subdivide([0, 0], [8, 8], [0, 0], [8, 8], [1, 1], [0, 0])
+    na = 20000
+    for step in range(5):
+        x = W.uniform(1200 + step, 3 * na).reshape(na, 3) * 8.0
+        d_x = H.DeviceArray.from_host(x)
+        d_u = H.DeviceArray.from_host(W.uniform(1300 + step, na))
+        d_f = H.DeviceArray.zeros((na, 3))
+        e = b.step_device(d_x, 3, d_f, 3, na, d_u, -1, na)
+        feed([e], d_f.to_host())
+    gv, gd = b.gauss.download()
+    feed(gv, gd, b.hist.values, [b.get("cum_bias"), b.get("overflow_right"), b.get("hills_added")])
+    del b
+    print("DIGEST", dig.hexdigest())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -884,3 +884,28 @@ def test_pair_list_step_vs_oracle(oracle_lib, workdir):
     close(v, og.values, rtol=1e-9, atol=1e-13 * np.abs(og.values).max(), what="grid")
     assert np.array_equal(b.hist.values, o.hist.values)
     assert og.values.max() > 0
+
+
+def test_polled_completion_equals_stream_wait(workdir):
+    """Short hill batches hand their results to the host through host-mapped memory flagged by the limiter's
+    workgroup, and the call returns while the gather still runs.  Everything a caller can
+    observe straight behind such a call -- energies, forces, lookups, the histogram, written files, the final
+    grid -- must be identical, byte for byte, to a run with EDM_HIP_POLL=0 (every batch waits for its stream)."""
+    import subprocess
+    import sys
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "poll_worker.py")
+    digests = []
+    for tag, val in (("polled", None), ("waited", "0")):
+        d = workdir / tag
+        d.mkdir()
+        env = dict(os.environ)
+        env.pop("EDM_HIP_POLL", None)
+        if val is not None:
+            env["EDM_HIP_POLL"] = val
+        res = subprocess.run([sys.executable, worker, str(d)], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("DIGEST ")]
+        assert lines, res.stdout[-2000:]
+        digests.append(lines[-1])
+    assert digests[0] == digests[1]
