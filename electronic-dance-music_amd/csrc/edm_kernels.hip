@@ -1598,11 +1598,35 @@ __device__ __forceinline__ void readback_copy(const char *rb_src, char *rb_dst, 
   const long long seg_len[5] = {off_flags + ((4 * na + 7) & ~7LL), 8 * na, 8 * na, 8 * na, 8 * na * DIM};
   const long long *src = reinterpret_cast<const long long *>(rb_src);
   long long *dst = reinterpret_cast<long long *>(rb_dst);
+  long long longest = 0;
 #pragma unroll
-  for (int sgm = 0; sgm < 5; sgm++) {
-    const long long w0 = seg_off[sgm] / 8, wn = seg_len[sgm] / 8;
-    for (long long w = me; w < wn; w += nthr)
-      __hip_atomic_store(&dst[w0 + w], acquire(&src[w0 + w]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int sgm = 0; sgm < 5; sgm++) longest = seg_len[sgm] > longest ? seg_len[sgm] : longest;
+  // one word of every segment per round: the five loads travel together, then the five stores (a load -> store
+  // pair per segment in turn made the copy a chain of five memory round trips)
+  for (long long w = me; w < longest / 8; w += nthr) {
+    long long v[5];
+#pragma unroll
+    for (int sgm = 0; sgm < 5; sgm++) v[sgm] = (w < seg_len[sgm] / 8) ? acquire(&src[seg_off[sgm] / 8 + w]) : 0;
+#pragma unroll
+    for (int sgm = 0; sgm < 5; sgm++)
+      if (w < seg_len[sgm] / 8)
+        __hip_atomic_store(&dst[seg_off[sgm] / 8 + w], v[sgm], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// the limiter-independent part of the same region: per-hill bias and original positions of hills [0, na)
+template <int DIM>
+__device__ __forceinline__ void readback_copy_hills(const char *rb_src, char *rb_dst, long long nb, long long na, int me,
+                                                    int nthr) {
+  const long long off_flags = 64, off_h2 = off_flags + ((4 * nb + 7) & ~7LL), off_a2 = off_h2 + 8 * nb,
+                  off_added = off_a2 + 8 * nb, off_pos = off_added + 8 * nb;
+  const long long *src = reinterpret_cast<const long long *>(rb_src);
+  long long *dst = reinterpret_cast<long long *>(rb_dst);
+  for (long long w = me; w < na * DIM; w += nthr) {
+    const bool has_a = w < na;
+    const long long va = has_a ? acquire(&src[off_added / 8 + w]) : 0;
+    const long long vp = acquire(&src[off_pos / 8 + w]);
+    if (has_a) __hip_atomic_store(&dst[off_added / 8 + w], va, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&dst[off_pos / 8 + w], vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1617,7 +1641,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            double h_const, double limit, double cum_in, int flush_mode,
                                            const LimitTail &tail, LimitResult *res, long long nchunks,
                                            const double *chunk_sum, const double *chunk_max,
-                                           const long long *nh_dev);
+                                           const long long *nh_dev, long long mirror = 0);
 
 // `la` (TPH == BLOCK only): the ordered limiter is chained onto the last workgroup to finish
 template <int DIM, int TPH, bool PERB>
@@ -1728,16 +1752,20 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
     }
     if (la.enabled) {
       if (!last_block_done(la.ticket, gridDim.x)) return;
-      if (threadIdx.x < 64)
+      // wave 0 walks the limiter; with a read-back region (la.rb_dst) it stores its outputs to the device region and
+      // to its host-mapped copy alike, while the other waves copy what does not depend on the limiter -- per-hill
+      // bias and positions, by the true hill count -- so nothing is left to read back once the limiter is done
+      const long long mirror = la.rb_dst ? (long long)(la.rb_dst - la.rb_src) : 0;
+      if (threadIdx.x < 64) {
         limit_wave<true>(h.nh, added, heights, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr,
-                   nullptr, h.nh_dev);
+                   nullptr, h.nh_dev, mirror);
+      } else if (la.rb_dst) {
+        const long long nb = h.nh;   // the layout is sized by the launch bound
+        long long na = h.nh_dev ? *h.nh_dev : nb;
+        if (na > nb) na = 0;         // (bound exceeded: the limiter reports it, nothing is read)
+        readback_copy_hills<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x - 64, NT - 64);
+      }
       if (la.rb_dst) {
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();   // the limiter's result and tail arrays, written by wave 0
-        const long long nb = h.nh;                                            // the layout is sized by the launch bound
-        long long na = acquire(&la.res->nh) < nb ? acquire(&la.res->nh) : nb;   // ... the hills are fewer
-        if (acquire(&la.res->error)) na = 0;
-        readback_copy<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x, NT);
         __builtin_amdgcn_s_waitcnt(0);   // every wave's stores into the host-mapped region have been acknowledged
         __syncthreads();
         if (threadIdx.x == 0 && la.done_flag)
@@ -3045,20 +3073,41 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            double h_const, double limit, double cum_in, int flush_mode,
                                            const LimitTail &tail, LimitResult *res, long long nchunks,
                                            const double *chunk_sum, const double *chunk_max,
-                                           const long long *nh_dev) {
+                                           const long long *nh_dev, long long mirror) {
+  // `mirror` != 0: the result and the tail's flags / h2 / added2 live in the packed read-back region, whose copy in
+  // host-mapped memory sits `mirror` bytes away -- they are stored to both as they are produced (see LimitArgs)
+  auto put_f64 = [mirror](double *p, double v) {
+    *p = v;
+    if (mirror)
+      __hip_atomic_store(reinterpret_cast<double *>(reinterpret_cast<char *>(p) + mirror), v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  auto put_i32 = [mirror](int *p, int v) {
+    *p = v;
+    if (mirror)
+      __hip_atomic_store(reinterpret_cast<int *>(reinterpret_cast<char *>(p) + mirror), v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  auto put_i64 = [mirror](long long *p, long long v) {
+    *p = v;
+    if (mirror)
+      __hip_atomic_store(reinterpret_cast<long long *>(reinterpret_cast<char *>(p) + mirror), v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  auto put_result = [&](double cum_out, long long k_, long long nh_, int n_tail, int stop_, int n_def_, int error) {
+    put_f64(&res->cum_out, cum_out);
+    put_i64(&res->k, k_);
+    put_i64(&res->nh, nh_);
+    put_i32(&res->n_tail, n_tail);
+    put_i32(&res->stop, stop_);
+    put_i32(&res->n_deferred, n_def_);
+    put_i32(&res->error, error);
+  };
   long long nh = nh_bound;
   if (nh_dev) {
     nh = *nh_dev;
     if (nh > nh_bound) {  // the batch was queued with too small a bound: nothing is applied
-      if (threadIdx.x == 0) {
-        res->cum_out = cum_in;
-        res->k = 0;
-        res->nh = nh;
-        res->n_tail = 0;
-        res->stop = 0;
-        res->n_deferred = 0;
-        res->error = 2;
-      }
+      if (threadIdx.x == 0) put_result(cum_in, 0, nh, 0, 0, 0, 2);
       return;
     }
   }
@@ -3092,15 +3141,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
   }
   const long long ntail = nh - k;
   if (ntail > EDM_TAIL_CAP) {
-    if (lane == 0) {
-      res->cum_out = cum;
-      res->k = k;
-      res->nh = nh;
-      res->n_tail = 0;
-      res->stop = 0;
-      res->n_deferred = 0;
-      res->error = 1;
-    }
+    if (lane == 0) put_result(cum, k, nh, 0, 0, 0, 1);
     return;
   }
   // Ordered walk, one 64-hill slab at a time.  Between two crossings of the limit nothing depends
@@ -3110,10 +3151,16 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
   int n_def = 0;
   int stop = (int)ntail;
   bool stopped = false;
+  // (the next slab's hills are requested before the current slab is walked: one memory round trip per slab hidden)
+  auto load_a = [&](long long i) { return (i < nh) ? (COHERENT ? acquire(&added[i]) : added[i]) : 0.0; };
+  auto load_h = [&](long long i) { return (i < nh) ? (heights ? heights[i] : h_const) : 0.0; };
+  double a_next = load_a(k + lane), h_next = load_h(k + lane);
   for (long long base = 0; base < ntail; base += 64) {
-    const long long mine = k + base + lane;
-    const double a_l = (mine < nh) ? (COHERENT ? acquire(&added[mine]) : added[mine]) : 0.0;
-    const double h_l = (mine < nh) ? (heights ? heights[mine] : h_const) : 0.0;
+    const double a_l = a_next, h_l = h_next;
+    if (base + 64 < ntail) {
+      a_next = load_a(k + base + 64 + lane);
+      h_next = load_h(k + base + 64 + lane);
+    }
     // add_value(pos, h) is linear in h: the undo hill's bias is h2 * (added / height)
     const double q_l = (h_l != 0.0) ? a_l / h_l : 0.0;
     double o_h1 = 0, o_h2 = 0, o_a2 = 0, o_cum = 0;
@@ -3182,21 +3229,13 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
     if (lane < lim) {
       const long long ti = base + lane;
       tail.h1[ti] = o_h1;
-      tail.h2[ti] = o_h2;
-      tail.added2[ti] = o_a2;
+      put_f64(&tail.h2[ti], o_h2);
+      put_f64(&tail.added2[ti], o_a2);
       tail.cum_after[ti] = o_cum;
-      tail.flags[ti] = o_fl;
+      put_i32(&tail.flags[ti], o_fl);
     }
   }
-  if (lane == 0) {
-    res->cum_out = cum;
-    res->k = k;
-    res->nh = nh;
-    res->n_tail = (int)ntail;
-    res->stop = stop;
-    res->n_deferred = n_def;
-    res->error = 0;
-  }
+  if (lane == 0) put_result(cum, k, nh, (int)ntail, stop, n_def, 0);
 }
 
 __global__ void __launch_bounds__(64) k_limit(long long nh_bound, const double *__restrict__ added,
