@@ -1129,14 +1129,14 @@ __global__ void __launch_bounds__(BLOCK) k_hill_prep(Geom g, HillList h, const d
 // 128-byte line.  Hundreds of workgroups incrementing ONE address serialise at ~12 ns per atomic -- 6 us
 // for the 512 workgroups of the selection kernel, measured -- so workgroups count on sub-counter
 // (id mod FAN) and only the last arrival of each sub-counter touches the top one.)
-__device__ __forceinline__ bool last_block_done(int *ticket, unsigned total_blocks, unsigned id) {
+__device__ __forceinline__ bool last_block_done(int *ticket, unsigned total_blocks, unsigned id, bool flat = false) {
   __shared__ int s_is_last;
   // every thread's published stores (publish()) have reached the coherence point before the barrier
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) {
     int last = 0;
-    if (total_blocks <= 2 * EDM_TICKET_FAN) {
+    if (total_blocks <= 2 * EDM_TICKET_FAN || flat) {
       const unsigned t = (unsigned)__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (t == total_blocks - 1) {
         last = 1;
@@ -1932,12 +1932,13 @@ struct PostArgs {
   long long rb_bytes;
 };
 
-// PARTS (1 or 4; 4 on the 1-D grid only): the tile is BLOCK / PARTS nodes wide and thread (part, node)
+// PARTS (1 or 8; 8 on the 1-D grid only): the tile is BLOCK / PARTS nodes wide and thread (part, node)
 // accumulates every PARTS-th batch of the tile's hill list for its node; the parts are combined in LDS in a
 // fixed order.  A node's serial chain is its number of overlapping hills, and a tile's work lands on ONE CU:
 // on the 1-D grid hills pile up where the pair density is high (40 per 256-node tile at r ~ 2.7 against 10 at
-// r ~ 1.3; timestamps: the dense tiles finished at 11.5 us, the sparse ones at 4), so 64-node tiles with four
-// hill-quarters each spread the same work over four times as many CUs.
+// r ~ 1.3; timestamps: the dense tiles finished at 11.5 us, the sparse ones at 4), so 32-node tiles with eight
+// hill-parts each spread the same work over eight times as many CUs (four parts: dense tiles at 8.2 us, sparse
+// at 3.5; eight: W1 step 39.5 -> 37.9 us together with the flat ticket; sixteen: no further gain).
 template <int DIM, int PARTS>
 __device__ __forceinline__ constexpr int tile_extent(int d) {
   return (DIM == 1 && d == 0) ? BLOCK / PARTS : Tile<DIM>::T[d];
@@ -2301,7 +2302,11 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MOD
   }
   if (MODE == 0 && post.enabled) {
     // boundary duplication (K6) and the histogram updates (K7) by the last workgroup to finish
-    if (!last_block_done(post.ticket, gridDim.x * gridDim.y)) return;
+    // (a few hundred workgroups that finish spread over microseconds: one counter, one atomic round trip -- the
+    //  two-level ticket costs the last arrival two)
+    if (!last_block_done(post.ticket, gridDim.x * gridDim.y, blockIdx.x + gridDim.x * blockIdx.y,
+                         gridDim.x * gridDim.y <= 512))
+      return;
     // the three chores are independent: the waves of the workgroup split them (wave 0 the boundary copies --
     // at most 4^DIM = 64, one per lane -- the lower half of the rest the histogram, the upper half the read-back)
     constexpr int NW = BLOCK / 64;
@@ -2477,13 +2482,14 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
     if (!g.bper[d]) perb = false;
   const dim3 grid((unsigned)launch_tiles, (unsigned)plan.groups);
   if (DIM == 1 && !use_list) {
-    // 1-D: 64-node tiles, four hill-quarters per node (see hill_gather_body)
-    const dim3 grid4((unsigned)((g.n[0] + BLOCK / 4 - 1) / (BLOCK / 4)), (unsigned)plan.groups);
+    // 1-D: 32-node tiles, eight hill-parts per node (see hill_gather_body)
+    constexpr int P1 = (DIM == 1) ? 8 : 1;
+    const dim3 grid4((unsigned)((g.n[0] + BLOCK / 8 - 1) / (BLOCK / 8)), (unsigned)plan.groups);
     if (perb)
-      hipLaunchKernelGGL((k_hill_gather<DIM, 0, (DIM == 1) ? 4 : 1, true>), grid4, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan,
+      hipLaunchKernelGGL((k_hill_gather<DIM, 0, P1, true>), grid4, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan,
                          use_list, dirty_flag, post);
     else
-      hipLaunchKernelGGL((k_hill_gather<DIM, 0, (DIM == 1) ? 4 : 1, false>), grid4, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan,
+      hipLaunchKernelGGL((k_hill_gather<DIM, 0, P1, false>), grid4, dim3(BLOCK), 0, s, g, t, rec, h, hh, plan,
                          use_list, dirty_flag, post);
   } else {
     if (perb)
