@@ -1658,6 +1658,11 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
   const long long nh_eff = hill_count(h);
   if (TPH == 64 && hill >= nh_eff) return;  // (a whole workgroup shares one hill when TPH == BLOCK)
   const bool live = hill < nh_eff;
+  // chained limiter (a workgroup per hill, launched against a bound on the hill count): only the workgroups that
+  // own a hill take a ticket -- workgroup 0 alone when there is none -- so the last arrival is one of a few hundred
+  // and a single counter (one atomic round trip) does
+  const unsigned ticket_blocks = (unsigned)(nh_eff > 0 ? nh_eff : 1);
+  if (TPH != 64 && la.enabled && blockIdx.x >= ticket_blocks) return;
   TermConst<DIM> tc;
   term_const<DIM>(g, tc);
   double acc = 0;
@@ -1751,7 +1756,7 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
       if (la.enabled) publish(&added[hill], r); else added[hill] = r;
     }
     if (la.enabled) {
-      if (!last_block_done(la.ticket, gridDim.x)) return;
+      if (!last_block_done(la.ticket, ticket_blocks, blockIdx.x, ticket_blocks <= 512)) return;
       // wave 0 walks the limiter; with a read-back region (la.rb_dst) it stores its outputs to the device region and
       // to its host-mapped copy alike, while the other waves copy what does not depend on the limiter -- per-hill
       // bias and positions, by the true hill count -- so nothing is left to read back once the limiter is done
