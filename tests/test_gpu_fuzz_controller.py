@@ -22,15 +22,21 @@ def close(a, b, rtol, atol=0.0, what=""):
 
 
 def scenarios():
-    rng = np.random.default_rng(777)
+    # (EDM_FUZZ_SEED / EDM_FUZZ_COUNT in the environment: extended sweeps beyond the committed 24 configurations)
+    rng = np.random.default_rng(int(os.environ.get("EDM_FUZZ_SEED", "777")))
     out = []
-    for k in range(24):
+    for k in range(int(os.environ.get("EDM_FUZZ_COUNT", "24"))):
         dim = int(rng.choice([1, 1, 2, 3]))
         per = [int(rng.integers(0, 2)) for _ in range(dim)]
         L = [float(rng.uniform(2.0, 6.0)) for _ in range(dim)]
         nodes = {1: int(rng.integers(300, 3000)), 2: int(rng.integers(40, 160)), 3: int(rng.integers(16, 40))}[dim]
         sp = [L[d] / nodes for d in range(dim)]
         sg = [float(rng.uniform(1.5, 4.0)) * sp[d] for d in range(dim)]
+        # (a stencil half-width above a periodic dimension's node count is undefined behaviour in the reference --
+        #  see test_gpu_fuzz.py -- and cannot serve as an oracle case)
+        for d in range(dim):
+            if per[d] and int(np.floor(4.0 * np.sqrt(2.0) * sg[d] / sp[d])) > nodes:
+                sg[d] = 0.99 * nodes * sp[d] / (4.0 * np.sqrt(2.0))
         mode = str(rng.choice(["plain", "plain", "global", "local"]))
         if k % 5 == 4:
             mode = str(rng.choice(["plain", "global"]))
