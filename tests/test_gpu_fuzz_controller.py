@@ -63,7 +63,8 @@ def scenarios():
             " ".join("%.8g" % v for v in sp), " ".join("%.8g" % v for v in sg))
         out.append(dict(name="%02d_%dd_%s_%s_n%d%s" % (k, dim, mode, "dens" if density else "all", n, "_lim" if limit else ""),
                         cfg=cfg, dim=dim, per=per, L=L, n=n, steps=int(rng.integers(3, 6)), use_mask=bool(rng.random() < 0.4),
-                        seed=int(rng.integers(1, 1 << 30)), est_factor=float(rng.choice([1.0, 2.0]))))
+                        seed=int(rng.integers(1, 1 << 30)), est_factor=float(rng.choice([1.0, 2.0])),
+                        fused_step=bool(k % 2)))   # odd configurations go through edm_hip_bias_step (one call per step)
     return out
 
 
@@ -94,11 +95,21 @@ def test_random_controller_vs_oracle(sc, tmp_path):
         f_o = np.zeros_like(pos)
         for x in (b, o):
             x.set_mask(mask)
-        e_g = b.update_forces(pos, f_g, apply_mask)
+        if sc["fused_step"]:
+            # update_forces + add_hills as the single fused call of fix edm's post_force (forces and the hill cycle
+            # queued back to back, results polled from host-mapped memory)
+            d_x = H.DeviceArray.from_host(pos)
+            d_u = H.DeviceArray.from_host(ru)
+            d_f = H.DeviceArray.zeros(pos.shape)
+            e_g = b.step_device(d_x, 3, d_f, 3, n, d_u, apply_mask, n)
+            f_g = d_f.to_host()
+        else:
+            e_g = b.update_forces(pos, f_g, apply_mask)
         e_o = o.update_forces(pos, f_o, apply_mask)
         close(e_g, e_o, rtol=1e-9, atol=1e-12, what="energy step %d" % step)
         close(f_g, f_o, rtol=1e-8, atol=1e-10 * max(np.abs(f_o).max(), 1e-300), what="forces step %d" % step)
-        b.add_hills(pos, ru, apply_mask)
+        if not sc["fused_step"]:
+            b.add_hills(pos, ru, apply_mask)
         o.add_hills(pos, ru, apply_mask)
         close(b.get("cum_bias"), o.get("cum_bias"), rtol=1e-9, what="cum_bias step %d" % step)
         got = [int(b.get(k)) for k in ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added")]
