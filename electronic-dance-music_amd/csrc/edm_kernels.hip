@@ -1196,38 +1196,45 @@ __device__ __forceinline__ void select_emit(const SelectArgs &a, const Geom &g, 
 template <int DIM>
 __device__ __forceinline__ void select_prep_body(const SelectArgs &a, const Geom &g, const HillList &h, unsigned bid,
                                                  unsigned nblk) {
-  __shared__ int s_w[BLOCK / 64];
+  __shared__ int s_w[SEL_PER_THREAD][BLOCK / 64];
   __shared__ long long s_carry;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {
-    const long long base = (long long)bid * SEL_CHUNK + (long long)threadIdx.x * SEL_PER_THREAD;
+    // sample (row j, thread t) = chunk base + j * BLOCK + t: every row is one coalesced load per wave.  A
+    // sample's place in the chunk's ordered list = accepted samples of the rows before it + accepted samples of
+    // its own row in lower waves + lower lanes of its wave (ballot): eight ballots, no shuffle scan.
+    const long long base = (long long)bid * SEL_CHUNK + threadIdx.x;
     bool fl[SEL_PER_THREAD];
-    int c = 0;
+    unsigned long long bal[SEL_PER_THREAD];
+    bool any = false;
 #pragma unroll
     for (int j = 0; j < SEL_PER_THREAD; j++) {
-      fl[j] = sel_flag(base + j, a.n, a.ru, a.thr, a.use_thr, a.mask, a.apply_mask, a.rng);
-      c += fl[j] ? 1 : 0;
+      fl[j] = sel_flag(base + (long long)j * BLOCK, a.n, a.ru, a.thr, a.use_thr, a.mask, a.apply_mask, a.rng);
+      any |= fl[j];
     }
-    int inc = c;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += up;
+    for (int j = 0; j < SEL_PER_THREAD; j++) {
+      bal[j] = __ballot(fl[j]);
+      if (lane == 0) s_w[j][wave] = __popcll(bal[j]);
     }
-    if (lane == 63) s_w[wave] = inc;
     __syncthreads();
-    int before = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < BLOCK / 64; w++) {
-      if (w < wave) before += s_w[w];
-      tot += s_w[w];
-    }
-    int pos = before + inc - c;
     int *mine = a.stage + (long long)bid * SEL_CHUNK;
+    if (any || threadIdx.x == 0) {
+      int run = 0;   // accepted samples of the rows walked so far
 #pragma unroll
-    for (int j = 0; j < SEL_PER_THREAD; j++)
-      if (fl[j]) publish(&mine[pos++], (int)(threadIdx.x * SEL_PER_THREAD + j));
-    if (threadIdx.x == 0) publish(&a.counts[bid], tot);
+      for (int j = 0; j < SEL_PER_THREAD; j++) {
+        int before = 0, row = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) {
+          if (w < wave) before += s_w[j][w];
+          row += s_w[j][w];
+        }
+        if (fl[j])
+          publish(&mine[run + before + __popcll(bal[j] & ((1ull << lane) - 1ull))], (int)(j * BLOCK + threadIdx.x));
+        run += row;
+      }
+      if (threadIdx.x == 0) publish(&a.counts[bid], run);
+    }
   }
   if (!last_block_done(a.ticket, nblk, bid)) return;
 
