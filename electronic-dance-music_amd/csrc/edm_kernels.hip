@@ -1662,6 +1662,28 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
   const int lane = threadIdx.x & 63;
   const int lt = threadIdx.x % TPH;
   const long long hill = (long long)blockIdx.x * (NT / TPH) + (threadIdx.x / TPH);
+  // The hill's fields are requested BEFORE the hill count is known (the arrays hold h.nh entries, the launch bound:
+  // an entry beyond the true count is stale and masked below): one memory round trip instead of three dependent
+  // ones (count -> centre node -> the other fields).
+  int c_r[DIM];
+  double hx_r[DIM], ht_r[2 * DIM];
+  double height_r = h_const;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    c_r[d] = INT_MIN;
+    hx_r[d] = 0;
+    ht_r[2 * d] = ht_r[2 * d + 1] = 0;
+  }
+  if (hill < h.nh) {
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      c_r[d] = h.hc[hill * DIM + d];
+      hx_r[d] = h.hx[hill * DIM + d];
+      ht_r[2 * d] = h.ht[hill * 2 * DIM + 2 * d];
+      ht_r[2 * d + 1] = h.ht[hill * 2 * DIM + 2 * d + 1];
+    }
+    if (heights) height_r = heights[hill];
+  }
   const long long nh_eff = hill_count(h);
   if (TPH == 64 && hill >= nh_eff) return;  // (a whole workgroup shares one hill when TPH == BLOCK)
   const bool live = hill < nh_eff;
@@ -1673,7 +1695,7 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
   TermConst<DIM> tc;
   term_const<DIM>(g, tc);
   double acc = 0;
-  const int c0 = live ? h.hc[hill * DIM] : INT_MIN;
+  const int c0 = live ? c_r[0] : INT_MIN;
   if (c0 != INT_MIN) {
     int c[DIM];
     double hx[DIM], ht[2 * DIM];
@@ -1681,14 +1703,14 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
     long long total = 1;
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
-      c[d] = h.hc[hill * DIM + d];
-      hx[d] = h.hx[hill * DIM + d];
-      ht[2 * d] = h.ht[hill * 2 * DIM + 2 * d];
-      ht[2 * d + 1] = h.ht[hill * 2 * DIM + 2 * d + 1];
+      c[d] = c_r[d];
+      hx[d] = hx_r[d];
+      ht[2 * d] = ht_r[2 * d];
+      ht[2 * d + 1] = ht_r[2 * d + 1];
       vol *= g.dx[d];
       total *= (2 * g.msize[d] + 1);
     }
-    const double height = heights ? heights[hill] : h_const;
+    const double height = height_r;
     // ILP stencil points per trip (independent decode + exp chains overlap; a workgroup-per-hill launch
     // has one wave per SIMD, so nothing else hides their latency); sums stay in stencil order.
     // 32-bit decode: the stencil has < 2^31 points whenever it fits a grid at all.
