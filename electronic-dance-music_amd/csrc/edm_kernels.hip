@@ -14,8 +14,10 @@
 //   K5     k_hill_gather (+ k_mark_tiles)  tile-owned, ORDER-PRESERVING gather of hills onto nodes
 //   K6/K7  boundary duplication, CV histogram (chained onto K5, or k_post_batch)
 //   K8     block/wave reductions           fixed-order energy and bias sums
-// A short hill step is three launches: sel -> K3 (+K4) -> K5 (+K6, K7, read-back), each stage's small serial
-// tail run by the last workgroup to finish (last_block_done).
+// A short hill step is three launches: sel -> K3 (+K4, read-back) -> K5 (+K6, K7), each stage's small serial
+// tail run by the last workgroup to finish (last_block_done); in a fix edm_pair step K1 rides in the first launch
+// (k_pair_forces_select).  The host is released by a word K3's last workgroup stores behind the read-back region in
+// host-mapped memory: it polls that word, not the stream.
 #include "edm_kernels.h"
 
 #include <hip/hip_ext.h>
