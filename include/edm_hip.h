@@ -46,6 +46,14 @@ typedef struct edm_hip_gauss edm_hip_gauss; /* device-resident DimmedGaussGrid<D
 typedef struct edm_hip_grid edm_hip_grid;   /* device-resident plain DimmedGrid<DIM> (histogram, target) */
 typedef struct edm_hip_bias edm_hip_bias;   /* EDMBias controller */
 
+/* Completion: every call returns when its RESULTS (energies, forces already written by an earlier kernel of the
+ * call, limiter decisions, per-hill bias, log lines) are final and on the host.  The grid and histogram update of a
+ * short hill batch may still be executing on the object's stream at that moment: the library reads its results
+ * from host-mapped memory flagged by the device instead of waiting for the stream (EDM_HIP_POLL=0 in the
+ * environment: always wait).  Every later call on the same object is ordered behind that work; the streams are
+ * blocking streams, so edm_hip_memcpy_* / edm_hip_memset (null stream) and the writers wait for it as well;
+ * edm_hip_device_synchronize() waits for everything.  The caller's input arrays are not read after the call. */
+
 /* ---- runtime ---------------------------------------------------------- */
 const char *edm_hip_last_error(void);
 const char *edm_hip_version(void);
