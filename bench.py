@@ -247,6 +247,90 @@ def all_samples_line(args, rank, world, dist, H, W, tmpdir):
         dist.destroy_process_group()
 
 
+def headline_dict(args, world, npairs, elapsed, k_ms, k_launches, timed_every):
+    """The contract keys of the JSON line, complete once the timed region has ended."""
+    ms_per_step = elapsed / args.steps * 1e3
+    total_pairs = npairs * world
+    # the force kernel rides in one launch with the step's selection (k_pair_forces_select): per pair 8 B distance
+    # in + 8 B force out, per sample 8 B acceptance uniform in (the sample distances are read for accepted
+    # samples only)
+    step_bytes = BYTES_PER_EVAL * npairs + 8 * npairs
+    achieved = step_bytes / (k_ms / max(k_launches, 1) * 1e-3) / 1e9
+    return {
+        "metric": "million bias-force evals/sec (1M-pair 1D CV, force eval + hill step per step)",
+        "value": total_pairs / (elapsed / args.steps) / 1e6,
+        "unit": "million evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "W1: fix edm_pair 1-D r-CV, %d pair distances per GPU (32k-atom LJ melt ~ 1M half-list pairs), "
+                        "grid 0..2.8 spacing 0.00025 (11201 nodes) sigma 0.025 McGDP boundary, hill_density 250, "
+                        "bias_per_step = hill_prefactor, bias pre-populated with 4096 hills" % npairs,
+            "pairs_per_gpu": npairs,
+            "hill_step_every": 1,
+            "parallelism": "replicated bias grid, samples sharded, dp%d" % world,
+        },
+        "roofline": {
+            "kernel": "k_pair_forces_select (K1 = k_pair_forces_fast<false,256> body + the step's selection/preparation, one launch)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc_traffic("edm::k_pair_forces_select"),
+            "kernel_us": k_ms / max(k_launches, 1) * 1e3,
+            "kernel_us_rocprof": rocprof_avg_us("edm::k_pair_forces_select"),
+            "launches": k_launches,
+            "timed_every": timed_every,
+            "bytes_per_launch": step_bytes,
+            "bytes_per_launch_note": "16 B per pair (K1) + 8 B per sample (acceptance uniforms of the selection)",
+        },
+    }
+
+
+class ExtrasGuard:
+    """Prints the line exactly once: the full one when the informational extras are done, or -- from a timer thread,
+    should they not finish within limit_s -- the headline alone with a note, and ends the process."""
+
+    def __init__(self, rank, headline, limit_s):
+        import threading
+
+        self.rank, self.headline, self.limit_s = rank, headline, limit_s
+        self.lock = threading.Lock()
+        self.done = False
+        self.timer = threading.Timer(limit_s + (0.0 if rank == 0 else 15.0), self._expired)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _expired(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.rank == 0:
+                out = dict(self.headline)
+                out["extras_skipped"] = ("the informational extras did not finish within %.0f s; the keys above were "
+                                         "measured before them" % self.limit_s)
+                print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    def finish(self, out):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            self.timer.cancel()
+            if out is not None:
+                print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -353,6 +437,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Everything below is informational (component rates, the second quantity of the metric, the HBM-bound capture,
+    # the CPU baseline).  The headline numbers are complete at this point: if an extra ever failed to finish -- the
+    # multi-rank ones run collectives -- rank 0 still prints the line, marked, instead of losing the measurement.
+    headline = headline_dict(args, world, npairs, elapsed, k_ms, k_launches, TIMED_EVERY)
+    guard = ExtrasGuard(rank, headline, limit_s=300.0)
+
     # the same step with the acceptance uniforms drawn on the device (fast mode of the fixes' RNG: no array of
     # uniforms is generated, uploaded or read); informational, not part of `value`
     b.set_device_rng(True, 12345 + rank)
@@ -414,11 +504,14 @@ def main():
     extra = {}
     # second reported quantity of the metric (BASELINE.json: "... + hill-adds/sec"): STRONG scaling of the
     # all-samples hill mode -- 1,048,576 hills per step in total, split over the GPUs (collective: every rank runs it)
-    hs_hills, hs_sec, _ = all_samples_measure(rank, world, dist, H, W, tmpdir, steps=3, warmup=1)
-    extra["hill_adds_strong_scaling"] = dict(value=hs_hills / hs_sec, unit="hill adds/s", hills_per_step_total=hs_hills,
-                                             ms_per_step=hs_sec * 1e3, scaling="strong",
-                                             note="all-samples mode, hills sharded over the GPUs, integrals + delta grid "
-                                                  "all-reduced; same quantity as `bench.py --all-samples`")
+    try:
+        hs_hills, hs_sec, _ = all_samples_measure(rank, world, dist, H, W, tmpdir, steps=3, warmup=1)
+        extra["hill_adds_strong_scaling"] = dict(value=hs_hills / hs_sec, unit="hill adds/s", hills_per_step_total=hs_hills,
+                                                 ms_per_step=hs_sec * 1e3, scaling="strong",
+                                                 note="all-samples mode, hills sharded over the GPUs, integrals + delta "
+                                                      "grid all-reduced; same quantity as `bench.py --all-samples`")
+    except Exception as exc:  # noqa: BLE001  (reported, not fatal: the headline is measured)
+        extra["hill_adds_strong_scaling"] = dict(failed=repr(exc))
     if rank == 0:
         nh = 1 << 18
         hx = H.DeviceArray.from_host(W.pair_distances(nh, 9))
@@ -527,57 +620,15 @@ def main():
             del gg
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        total_pairs = npairs * world
-        # the force kernel rides in one launch with the step's selection (k_pair_forces_select): per pair 8 B distance
-        # in + 8 B force out, per sample 8 B acceptance uniform in (the sample distances are read for accepted
-        # samples only)
-        step_bytes = BYTES_PER_EVAL * npairs + 8 * npairs
-        achieved = step_bytes / (k_ms / max(k_launches, 1) * 1e-3) / 1e9
-        out = {
-            "metric": "million bias-force evals/sec (1M-pair 1D CV, force eval + hill step per step)",
-            "value": total_pairs / (elapsed / args.steps) / 1e6,
-            "unit": "million evals/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": "W1: fix edm_pair 1-D r-CV, %d pair distances per GPU (32k-atom LJ melt ~ 1M half-list pairs), "
-                            "grid 0..2.8 spacing 0.00025 (11201 nodes) sigma 0.025 McGDP boundary, hill_density 250, "
-                            "bias_per_step = hill_prefactor, bias pre-populated with 4096 hills" % npairs,
-                "pairs_per_gpu": npairs,
-                "hill_step_every": 1,
-                "parallelism": "replicated bias grid, samples sharded, dp%d" % world,
-            },
-            "roofline": {
-                "kernel": "k_pair_forces_select (K1 = k_pair_forces_fast<false,256> body + the step's selection/preparation, one launch)",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("edm::k_pair_forces_select"),
-                "kernel_us": k_ms / max(k_launches, 1) * 1e3,
-                "kernel_us_rocprof": rocprof_avg_us("edm::k_pair_forces_select"),
-                "launches": k_launches,
-                "timed_every": TIMED_EVERY,
-                "bytes_per_launch": step_bytes,
-                "bytes_per_launch_note": "16 B per pair (K1) + 8 B per sample (acceptance uniforms of the selection)",
-                # hipMemcpyAsync device-to-device of the same 8 B in + 8 B out per pair, for scale: at this size a
-                # launch is latency-bound whatever it computes
-                "device_copy_same_traffic_us": copy_us,
-            },
+        out = dict(headline)
+        out["roofline"] = dict(headline["roofline"])
+        out["roofline"]["device_copy_same_traffic_us"] = copy_us
+        out.update({
             "evals_only_million_per_s": npairs / t_eval / 1e6,
             "ms_per_step_device_rng": ms_step_device_rng,
             "lj_melt_32k_from_positions": lj,
             "energy_last_step": energy,
-        }
+        })
         out.update(extra)
         if roof_w2:
             out["roofline_w2"] = roof_w2
@@ -588,7 +639,9 @@ def main():
             out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(tmpdir)
         elif world > 1:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        guard.finish(out)
+    else:
+        guard.finish(None)
     if dist is not None:
         dist.destroy_process_group()
 
