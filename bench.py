@@ -441,7 +441,7 @@ def main():
     # the CPU baseline).  The headline numbers are complete at this point: if an extra ever failed to finish -- the
     # multi-rank ones run collectives -- rank 0 still prints the line, marked, instead of losing the measurement.
     headline = headline_dict(args, world, npairs, elapsed, k_ms, k_launches, TIMED_EVERY)
-    guard = ExtrasGuard(rank, headline, limit_s=300.0)
+    guard = ExtrasGuard(rank, headline, limit_s=float(os.environ.get("EDM_BENCH_EXTRAS_LIMIT", "180")))
 
     # the same step with the acceptance uniforms drawn on the device (fast mode of the fixes' RNG: no array of
     # uniforms is generated, uploaded or read); informational, not part of `value`
