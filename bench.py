@@ -628,6 +628,9 @@ def main():
             "ms_per_step_device_rng": ms_step_device_rng,
             "lj_melt_32k_from_positions": lj,
             "energy_last_step": energy,
+            # (batches released by the polled completion word / by the stream-wait fallback, whole run of this object)
+            "polled_batches": b.get("polled_batches"),
+            "poll_fallbacks": b.get("poll_fallbacks"),
         })
         out.update(extra)
         if roof_w2:

@@ -1139,6 +1139,9 @@ int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
   G("steps", b->steps)
   G("mpi_rank", b->mpi_rank)
   G("mpi_size", b->mpi_size)
+  // telemetry of the polled completion: batches released by the polled word / by the stream wait
+  G("polled_batches", b->bias ? b->bias->polled_batches : 0)
+  G("poll_fallbacks", b->bias ? b->bias->poll_fallbacks : 0)
 #undef G
   set_error(std::string("unknown EDMBias member ") + name);
   return EDM_HIP_ERR_ARG;

@@ -1209,10 +1209,13 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (seen)
+    if (seen) {
       g->wait_polled = true;
-    else
+      g->polled_batches++;
+    } else {
+      g->poll_fallbacks++;
       EDM_HIP_TRY(hipStreamSynchronize(s));
+    }
   } else {
     EDM_HIP_TRY(hipStreamSynchronize(s));
   }

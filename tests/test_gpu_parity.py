@@ -909,3 +909,25 @@ def test_polled_completion_equals_stream_wait(workdir):
         assert lines, res.stdout[-2000:]
         digests.append(lines[-1])
     assert digests[0] == digests[1]
+
+
+def test_polled_completion_is_what_releases_short_batches(workdir):
+    """Telemetry of the polled completion: with the default environment every short stochastic step is released by
+    the polled word, none by the stream-wait fallback (a fallback would be correct but slow, and silent)."""
+    if os.environ.get("EDM_HIP_POLL", "1")[:1] == "0":
+        pytest.skip("polling disabled in the environment")
+    cfg = str(workdir / "tele.edm")
+    open(cfg, "w").write("tempering 0\nhill_prefactor 0.5\nhill_density 40\nbias_per_step 0.12\ndimension 1\nbox_low 0\n"
+                         "box_high 2.8\nbias_spacing 0.001\nbias_sigma 0.05\nhills_filename %s/HILLS_t\n"
+                         "histogram_filename %s/HIST_t\n" % (workdir, workdir))
+    b = H.Bias(cfg)
+    b.setup(1.0, 1.0)
+    b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    n = 6000
+    for step in range(20):
+        d_r = H.DeviceArray.from_host(W.pair_distances(n, 700 + step))
+        d_u = H.DeviceArray.from_host(W.uniform(750 + step, n))
+        d_f = H.DeviceArray.zeros((n,))
+        b.pair_step_device(d_r, d_f, n, d_r, d_u, n, est=n)
+    assert b.get("poll_fallbacks") == 0
+    assert b.get("polled_batches") >= 20
