@@ -417,7 +417,10 @@ static void edm_bias_tests(const std::string& fx, const std::string& scratch) {
   double e1 = 0, f1[1] = {0};
   e1 = bias.update_force(x[300], f1);
   REQUIRE(std::fabs(f[300][0] - 2 * f1[0]) < 1e-12);  // row 300 is in the group: updated twice
-  REQUIRE(std::fabs(f[301][0] - f[301][0]) == 0 && f[301][1] == 0 && f[301][2] == 0);
+  double f2[1] = {0};
+  bias.update_force(x[301], f2);
+  // row 301 is outside the group: exactly one update (the unmasked call); columns beyond dim_ untouched
+  REQUIRE(f2[0] != 0 && std::fabs(f[301][0] - f2[0]) < 1e-12 && f[301][1] == 0 && f[301][2] == 0);
   REQUIRE(e1 > 0);
   // the batched pair entry equals per-sample update_force
   std::vector<double> r(n), fr(n);
