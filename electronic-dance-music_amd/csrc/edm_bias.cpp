@@ -77,6 +77,8 @@ struct edm_hip_bias {
   DevBuf<double> vs_r;     // virtual add_hill samples of the list (2 per entry)
   DevBuf<int> vs_mask;
   bool force_sync = false;      // redo of a deferred step whose launch bound proved too small
+  int debug_force_sync = 0;     // tests: never defer the count (every step takes the synchronous path)
+  long long bound_redos = 0;    // steps redone because the accepted count exceeded the deferred launch bound
   PendingForces pending;        // pair forces of a fused step waiting for the launch of the step's selection
   int debug_virtual_ranks = 0;  // tests: a one-rank communicator's packet is replicated, emulating that many ranks
   DevBuf<long long> xchg_cnt;
@@ -554,7 +556,8 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   bool packed_exchange = false;
   long long pack_bound = 0;
   int pack_ranks = b->nranks;
-  if (b->comm && use_thr && !b->b_targeting && !local_tempering && b->nranks <= EDM_MAX_RANKS && !b->force_sync) {
+  if (b->comm && use_thr && !b->b_targeting && !local_tempering && b->nranks <= EDM_MAX_RANKS && !b->force_sync &&
+      !b->debug_force_sync) {
     if (b->debug_virtual_ranks > 1 && b->nranks == 1) pack_ranks = b->debug_virtual_ranks;
     pack_bound = (long long)(4.0 * b->hill_density) + 128;
     if (pack_bound < 256) pack_bound = 256;
@@ -640,7 +643,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     // should the bound ever be too small the limiter reports it, nothing is applied and the step's hill
     // path is redone below with the exact count.
     long long bound = 0;
-    if (use_thr && !b->comm && !b->b_targeting && !local_tempering && !b->force_sync) {
+    if (use_thr && !b->comm && !b->b_targeting && !local_tempering && !b->force_sync && !b->debug_force_sync) {
       const double expected = thr * (double)n;
       bound = (long long)(4.0 * expected) + 128;
       if (bound < 256) bound = 256;
@@ -784,6 +787,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     // (practically never) more hills than the launch bound -- on every rank alike, since the count is
     // global: nothing was applied; redo the step's hill path the synchronous way with exact counts
     b->force_sync = true;
+    b->bound_redos++;
     rc = process_new_hills(b, n, d_x_in, x_stride_in, d_ru, apply_mask);
     b->force_sync = false;
     return rc;
@@ -1090,16 +1094,29 @@ int edm_hip_bias_post_add_hill(edm_hip_bias *b) {
 }
 
 // edm_bias.cpp:224-262
+// With a communicator the grids and the histogram are replicated bit-identically on every rank: like the
+// reference's multi_write (rank 0 opens the file, grid.h:549) only rank 0 writes; the other ranks just let
+// their queued updates finish, so a file is never truncated under another rank's writer.
+static bool writes_files(const edm_hip_bias *b) {
+  if (b->nranks <= 1 || b->rank == 0) return true;
+  if (b->bias) (void)hipStreamSynchronize(b->bias->stream);
+  return false;
+}
 int edm_hip_bias_write_bias(const edm_hip_bias *b, const char *filename, int serial_format) {
   if (!b->bias) return EDM_HIP_ERR_STATE;
+  if (!writes_files(b)) return EDM_HIP_OK;
   return serial_format ? edm_hip_gauss_write(b->bias, filename) : edm_hip_gauss_multi_write(b->bias, filename, 0);
 }
 int edm_hip_bias_write_lammps_table(const edm_hip_bias *b, const char *filename, int serial_format) {
   if (!b->bias) return EDM_HIP_ERR_STATE;
+  if (!writes_files(b)) return EDM_HIP_OK;
   return serial_format ? edm_hip_gauss_write(b->bias, filename) : edm_hip_gauss_multi_write(b->bias, filename, 1);
 }
 int edm_hip_bias_write_histogram(const edm_hip_bias *b, int serial_format) {
   if (!b->hist) return EDM_HIP_ERR_STATE;
+  if (!writes_files(b)) return EDM_HIP_OK;
+  // (the histogram is updated by kernels on the bias stream, which may still be running behind a polled batch)
+  if (b->bias) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
   if (serial_format) return edm_hip_grid_write(b->hist, b->hist_output.c_str());
   return edm_hip_grid_multi_write(b->hist, b->hist_output.c_str(), b->min.data(), b->max.data(), b->bper.data(), 0);
 }
@@ -1142,6 +1159,7 @@ int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
   // telemetry of the polled completion: batches released by the polled word / by the stream wait
   G("polled_batches", b->bias ? b->bias->polled_batches : 0)
   G("poll_fallbacks", b->bias ? b->bias->poll_fallbacks : 0)
+  G("bound_redos", b->bound_redos)
 #undef G
   set_error(std::string("unknown EDMBias member ") + name);
   return EDM_HIP_ERR_ARG;
@@ -1158,6 +1176,7 @@ int edm_hip_bias_set(edm_hip_bias *b, const char *name, double value) {
   S("cum_bias", b->cum_bias, double)
   S("total_volume", b->total_volume, double)
   S("debug_virtual_ranks", b->debug_virtual_ranks, int)
+  S("debug_force_sync", b->debug_force_sync, int)
 #undef S
   set_error(std::string("unknown or read-only EDMBias member ") + name);
   return EDM_HIP_ERR_ARG;

@@ -290,57 +290,257 @@ int edm_hip_device_synchronize(void) {
 }
 
 // ---- plain grid ---------------------------------------------------------------
-int edm_hip_grid_create(edm_hip_grid **out, int dim, const double *min, const double *max, const double *spacing,
-                        const int *periodic) {
+// DimmedGrid lookups know nothing of a gaussian boundary (no bounds test, no remap)
+static Geom plain_geom(const Geom &q) {
+  Geom p = q;
+  for (int d = 0; d < 3; d++) {
+    p.bper[d] = 1;
+    p.bmin[d] = -std::numeric_limits<double>::infinity();
+    p.bmax[d] = std::numeric_limits<double>::infinity();
+  }
+  return p;
+}
+static size_t grid_doubles(const Geom &q) { return (size_t)q.total * (size_t)q.rec; }
+// (re)allocates the node storage for the geometry in g->g, zero-filled (grid.h:892-904)
+static int grid_alloc(edm_hip_grid *g) {
+  if (!g->stream) EDM_HIP_TRY(hipStreamCreate(&g->stream));
+  if (g->values) {
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    EDM_HIP_TRY(hipFree(g->values));
+    g->values = nullptr;
+  }
+  const size_t bytes = sizeof(double) * (grid_doubles(g->g) ? grid_doubles(g->g) : 1);
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->values), bytes));
+  EDM_HIP_TRY(hipMemset(g->values, 0, bytes));
+  if (g->g.has_deriv && !g->scratch)
+    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->scratch), sizeof(double) * lookup_scratch_doubles()));
+  return EDM_HIP_OK;
+}
+// node values / derivatives of a record array to host arrays (either may be NULL)
+static int records_download(const Geom &q, const double *rec, hipStream_t s, double *h_values, double *h_derivs) {
+  double *dv = nullptr, *dd = nullptr;
+  if (h_values) EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dv), sizeof(double) * (size_t)q.total));
+  if (h_derivs) EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dd), sizeof(double) * (size_t)q.total * q.dim));
+  EDM_HIP_TRY(launch_unpack(q, rec, dv, dd, s));
+  EDM_HIP_TRY(hipStreamSynchronize(s));
+  if (h_values) EDM_HIP_TRY(hipMemcpy(h_values, dv, sizeof(double) * (size_t)q.total, hipMemcpyDeviceToHost));
+  if (h_derivs) EDM_HIP_TRY(hipMemcpy(h_derivs, dd, sizeof(double) * (size_t)q.total * q.dim, hipMemcpyDeviceToHost));
+  if (dv) (void)hipFree(dv);
+  if (dd) (void)hipFree(dd);
+  return EDM_HIP_OK;
+}
+static int records_upload(const Geom &q, double *rec, hipStream_t s, const double *h_values, const double *h_derivs) {
+  double *dv = nullptr, *dd = nullptr;
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dv), sizeof(double) * (size_t)q.total));
+  EDM_HIP_TRY(hipMemcpy(dv, h_values, sizeof(double) * (size_t)q.total, hipMemcpyHostToDevice));
+  if (h_derivs) {
+    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dd), sizeof(double) * (size_t)q.total * q.dim));
+    EDM_HIP_TRY(hipMemcpy(dd, h_derivs, sizeof(double) * (size_t)q.total * q.dim, hipMemcpyHostToDevice));
+  }
+  EDM_HIP_TRY(launch_pack(q, rec, dv, dd, s));
+  EDM_HIP_TRY(hipStreamSynchronize(s));
+  (void)hipFree(dv);
+  if (dd) (void)hipFree(dd);
+  return EDM_HIP_OK;
+}
+
+int edm_hip_grid_create_ex(edm_hip_grid **out, int dim, const double *min, const double *max, const double *spacing,
+                           const int *periodic, int b_derivatives, int b_interpolate) {
   if (!out || dim < 1 || dim > 3) {
     set_error("edm_hip_grid_create: bad arguments");
     return EDM_HIP_ERR_ARG;
   }
   edm_hip_grid *g = new edm_hip_grid;
-  make_geometry(g->g, dim, min, max, spacing, periodic, 0, 0);
-  EDM_HIP_TRY(hipStreamCreate(&g->stream));
-  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->values), sizeof(double) * (size_t)g->g.total));
-  EDM_HIP_TRY(hipMemset(g->values, 0, sizeof(double) * (size_t)g->g.total));
+  make_geometry(g->g, dim, min, max, spacing, periodic, b_derivatives ? 1 : 0, b_interpolate ? 1 : 0);
+  int rc = grid_alloc(g);
+  if (rc) return rc;
   *out = g;
+  return EDM_HIP_OK;
+}
+int edm_hip_grid_create(edm_hip_grid **out, int dim, const double *min, const double *max, const double *spacing,
+                        const int *periodic) {
+  return edm_hip_grid_create_ex(out, dim, min, max, spacing, periodic, 0, 0);
+}
+// DimmedGrid::read (grid.h:712-835): geometry, derivative flag and contents come from the file
+static int grid_load_file(edm_hip_grid *g, int dim, const char *filename, int b_interpolate) {
+  GridFile gf;
+  int rc = read_plumed(dim, filename, b_interpolate ? 1 : 0, gf);
+  if (rc) return rc;
+  g->g = gf.g;
+  rc = grid_alloc(g);
+  if (rc) return rc;
+  if (g->g.has_deriv) return records_upload(g->g, g->values, g->stream, gf.values.data(), gf.derivs.data());
+  EDM_HIP_TRY(hipMemcpy(g->values, gf.values.data(), sizeof(double) * gf.values.size(), hipMemcpyHostToDevice));
+  return EDM_HIP_OK;
+}
+int edm_hip_grid_read(edm_hip_grid **out, int dim, const char *filename, int b_interpolate) {
+  if (!out || dim < 1 || dim > 3 || !filename) {
+    set_error("edm_hip_grid_read: bad arguments");
+    return EDM_HIP_ERR_ARG;
+  }
+  edm_hip_grid *g = new edm_hip_grid;
+  int rc = grid_load_file(g, dim, filename, b_interpolate);
+  if (rc) {
+    edm_hip_grid_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return EDM_HIP_OK;
+}
+int edm_hip_grid_reread(edm_hip_grid *g, const char *filename) {
+  return grid_load_file(g, g->g.dim, filename, g->g.interp);   // b_interpolate_ is kept (grid.h:712-835 never sets it)
+}
+int edm_hip_grid_set_interpolation(edm_hip_grid *g, int b_interpolate) {
+  g->g.interp = b_interpolate ? 1 : 0;
   return EDM_HIP_OK;
 }
 int edm_hip_grid_destroy(edm_hip_grid *g) {
   if (!g) return EDM_HIP_OK;
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->values) (void)hipFree(g->values);
+  if (g->scratch) (void)hipFree(g->scratch);
   if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
   return EDM_HIP_OK;
 }
 int edm_hip_grid_geometry(const edm_hip_grid *g, edm_hip_geometry *out) {
   fill_public_geometry(g->g, out);
+  out->derivatives = g->g.has_deriv;
   return EDM_HIP_OK;
 }
 int edm_hip_grid_download(const edm_hip_grid *g, double *h_values) {
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  if (g->g.has_deriv) return records_download(g->g, g->values, g->stream, h_values, nullptr);
   EDM_HIP_TRY(hipMemcpy(h_values, g->values, sizeof(double) * (size_t)g->g.total, hipMemcpyDeviceToHost));
   return EDM_HIP_OK;
 }
+int edm_hip_grid_download_derivs(const edm_hip_grid *g, double *h_derivs) {
+  if (!g->g.has_deriv) {
+    set_error("edm_hip_grid_download_derivs: the grid stores no derivatives");
+    return EDM_HIP_ERR_ARG;
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return records_download(g->g, g->values, g->stream, nullptr, h_derivs);
+}
 int edm_hip_grid_upload(edm_hip_grid *g, const double *h_values) {
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  if (g->g.has_deriv) {   // node values replaced, derivative slots kept
+    double *dv = nullptr;
+    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dv), sizeof(double) * (size_t)g->g.total));
+    EDM_HIP_TRY(hipMemcpy(dv, h_values, sizeof(double) * (size_t)g->g.total, hipMemcpyHostToDevice));
+    EDM_HIP_TRY(launch_set_values(g->g, g->values, dv, g->stream));
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    (void)hipFree(dv);
+    return EDM_HIP_OK;
+  }
   EDM_HIP_TRY(hipMemcpy(g->values, h_values, sizeof(double) * (size_t)g->g.total, hipMemcpyHostToDevice));
   return EDM_HIP_OK;
 }
+int edm_hip_grid_upload_derivs(edm_hip_grid *g, const double *h_values, const double *h_derivs) {
+  if (!g->g.has_deriv) {
+    set_error("edm_hip_grid_upload_derivs: the grid stores no derivatives");
+    return EDM_HIP_ERR_ARG;
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return records_upload(g->g, g->values, g->stream, h_values, h_derivs);
+}
 int edm_hip_grid_clear(edm_hip_grid *g) {
-  EDM_HIP_TRY(hipMemsetAsync(g->values, 0, sizeof(double) * (size_t)g->g.total, g->stream));
+  EDM_HIP_TRY(hipMemsetAsync(g->values, 0, sizeof(double) * grid_doubles(g->g), g->stream));
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
   return EDM_HIP_OK;
 }
 int edm_hip_grid_add_values(edm_hip_grid *g, long long n, const double *d_x, int x_stride, const double *d_w,
                             double w_const) {
+  if (g->g.interp) {   // grid.h:371-373
+    set_error("Cannot add_value when using derivatives");
+    return EDM_HIP_ERR_STATE;
+  }
   EDM_HIP_TRY(launch_hist_add(g->g, g->values, n, d_x, x_stride, nullptr, d_w, w_const, g->stream));
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
   return EDM_HIP_OK;
 }
+// DimmedGrid::get_value / get_value_deriv batched (grid.h:343-365, :390-446): cubic-Hermite interpolation when
+// the grid interpolates and stores derivatives, else the nearest-lower node (value and stored derivatives)
+int edm_hip_grid_get_value_deriv(const edm_hip_grid *g, long long n, const double *d_x, int x_stride, double *d_value,
+                                 double *d_deriv) {
+  if (n <= 0) return EDM_HIP_OK;
+  if (g->g.has_deriv) {
+    LookupArgs a{};
+    a.n = n; a.x = d_x; a.x_stride = x_stride; a.energy = d_value; a.f = d_deriv; a.apply_mask = -1;
+    EDM_HIP_TRY(launch_lookup(plain_geom(g->g), g->values, LOOKUP_VALUES, a, g->scratch, nullptr, g->stream));
+  } else {
+    EDM_HIP_TRY(launch_nearest_values(g->g, g->values, n, d_x, x_stride, d_value, d_deriv, g->stream));
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return EDM_HIP_OK;
+}
 int edm_hip_grid_write(const edm_hip_grid *g, const char *filename) {
-  std::vector<double> v((size_t)g->g.total);
+  std::vector<double> v((size_t)g->g.total), dv;
   int rc = edm_hip_grid_download(g, v.data());
   if (rc) return rc;
-  return write_plumed(g->g, v.data(), nullptr, filename);
+  if (g->g.has_deriv) {
+    dv.resize((size_t)g->g.total * g->g.dim);
+    rc = edm_hip_grid_download_derivs(g, dv.data());
+    if (rc) return rc;
+  }
+  return write_plumed(g->g, v.data(), g->g.has_deriv ? dv.data() : nullptr, filename);
 }
+
+// Grid::add (grid.h:275-290): dst += scale * src(x_node) + offset, node by node, `src` evaluated through ITS
+// get_value_deriv (src_geom carries the gaussian boundary when src is a GaussGrid, plain_geom otherwise; a
+// source without derivative records answers with its nearest-lower node).  Chunked so that a 512^3 grid needs
+// a bounded scratch.
+static int grid_add_from(const Geom &dst, double *dst_base, hipStream_t s, double *scratch, const Geom &src_geom,
+                         const double *src_base, double scale, double offset) {
+  const long long chunk = dst.total < (1ll << 22) ? dst.total : (1ll << 22);
+  if (chunk <= 0) return EDM_HIP_OK;
+  double *dx = nullptr, *dE = nullptr, *dD = nullptr;
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dx), sizeof(double) * (size_t)chunk * dst.dim));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dE), sizeof(double) * (size_t)chunk));
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dD), sizeof(double) * (size_t)chunk * dst.dim));
+  for (long long first = 0; first < dst.total; first += chunk) {
+    const long long cnt = (dst.total - first < chunk) ? dst.total - first : chunk;
+    EDM_HIP_TRY(launch_node_coords(dst, first, cnt, dx, s));
+    if (src_geom.has_deriv) {
+      LookupArgs a{};
+      a.n = cnt; a.x = dx; a.x_stride = dst.dim; a.energy = dE; a.f = dD; a.apply_mask = -1;
+      EDM_HIP_TRY(launch_lookup(src_geom, src_base, LOOKUP_VALUES, a, scratch, nullptr, s));
+    } else {
+      EDM_HIP_TRY(launch_nearest_values(src_geom, src_base, cnt, dx, dst.dim, dE, dD, s));
+    }
+    EDM_HIP_TRY(launch_axpy_nodes(dst, dst_base, first, cnt, dE, dD, scale, offset, s));
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(s));
+  (void)hipFree(dx); (void)hipFree(dE); (void)hipFree(dD);
+  return EDM_HIP_OK;
+}
+static int need_scratch(edm_hip_grid *g) {
+  if (!g->scratch) EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->scratch), sizeof(double) * lookup_scratch_doubles()));
+  return EDM_HIP_OK;
+}
+int edm_hip_grid_add_grid(edm_hip_grid *g, const edm_hip_grid *other, double scale, double offset) {
+  if (!g || !other || g->g.dim != other->g.dim) {
+    set_error("Grid::add: dimensions differ");
+    return EDM_HIP_ERR_ARG;
+  }
+  int rc = need_scratch(g);
+  if (rc) return rc;
+  EDM_HIP_TRY(hipStreamSynchronize(other->stream));
+  return grid_add_from(g->g, g->values, g->stream, g->scratch, plain_geom(other->g), other->values, scale, offset);
+}
+int edm_hip_grid_add_gauss(edm_hip_grid *g, const edm_hip_gauss *other, double scale, double offset) {
+  if (!g || !other || g->g.dim != other->g.dim) {
+    set_error("Grid::add: dimensions differ");
+    return EDM_HIP_ERR_ARG;
+  }
+  int rc = need_scratch(g);
+  if (rc) return rc;
+  EDM_HIP_TRY(hipStreamSynchronize(other->stream));
+  return grid_add_from(g->g, g->values, g->stream, g->scratch, other->g, other->rec, scale, offset);
+}
+
+static int multi_write_records(const Geom &q, const double *rec, hipStream_t s, double *scratch, const char *filename,
+                               const double *box_min, const double *box_max, const int *b_periodic, int b_lammps_format);
 
 // grid.h:509-674 for one rank, no derivatives: nodes are re-sampled by the nearest-lower lookup
 // of DimmedGrid::get_value (grid.h:343-365) -- plain indexing of the downloaded bins
@@ -350,6 +550,10 @@ int edm_hip_grid_multi_write(const edm_hip_grid *g, const char *filename, const 
   if (b_lammps_format == 1 && q.dim > 1) {
     set_error("Lammps format only valid for 1D grids");
     return EDM_HIP_ERR_ARG;
+  }
+  if (q.has_deriv) {   // b_derivatives_: re-sampled through get_value_deriv, derivative columns written (:650-661)
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    return multi_write_records(q, g->values, g->stream, g->scratch, filename, box_min, box_max, b_periodic, b_lammps_format);
   }
   std::vector<double> v((size_t)q.total);
   int rc = edm_hip_grid_download(g, v.data());
@@ -461,6 +665,35 @@ int edm_hip_gauss_create(edm_hip_gauss **out, int dim, const double *min, const 
   return EDM_HIP_OK;
 }
 
+// read_gauss_grid (gaussian_grid.h:647, gaussian_grid.cpp:23-33) = DimmedGaussGrid(filename, sigma)
+// (gaussian_grid.h:85-93): the underlying grid is read with interpolation on, sigma is given again (files do
+// not store it), the boundary is the grid's own extent and periodicity
+int edm_hip_gauss_read(edm_hip_gauss **out, int dim, const char *filename, const double *sigma) {
+  if (!out || dim < 1 || dim > 3 || !filename || !sigma) {
+    set_error("edm_hip_gauss_read: bad arguments");
+    return EDM_HIP_ERR_ARG;
+  }
+  GridFile gf;
+  int rc = read_plumed(dim, filename, 1, gf);
+  if (rc) return rc;
+  if (!gf.g.has_deriv) {
+    set_error("a gaussian grid needs the derivative columns (FORCE 1)");
+    return EDM_HIP_ERR_IO;
+  }
+  edm_hip_gauss *g = new edm_hip_gauss;
+  g->g = gf.g;
+  for (int d = 0; d < dim; d++) g->g.sigma[d] = sigma[d] * sqrt(2.);
+  rc = gauss_alloc(g);
+  if (rc) return rc;
+  rc = edm_hip_gauss_set_boundary(g, g->g.min, g->g.max, g->g.periodic);
+  if (rc) return rc;
+  update_minigrid(g->g);
+  rc = records_upload(g->g, g->rec, g->stream, gf.values.data(), gf.derivs.data());
+  if (rc) return rc;
+  *out = g;
+  return EDM_HIP_OK;
+}
+
 int edm_hip_gauss_destroy(edm_hip_gauss *g) {
   if (!g) return EDM_HIP_OK;
   if (g->stream) (void)hipStreamSynchronize(g->stream);
@@ -529,34 +762,25 @@ int edm_hip_gauss_geometry(const edm_hip_gauss *g, edm_hip_geometry *out) {
   return EDM_HIP_OK;
 }
 
-int edm_hip_gauss_download(const edm_hip_gauss *g, double *h_values, double *h_derivs) {
-  const Geom &q = g->g;
-  double *dv = nullptr, *dd = nullptr;
-  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dv), sizeof(double) * (size_t)q.total));
-  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dd), sizeof(double) * (size_t)q.total * q.dim));
-  EDM_HIP_TRY(launch_unpack(q, g->rec, dv, dd, g->stream));
+int edm_hip_gauss_download_tables(const edm_hip_gauss *g, int dim_index, double *h_denom, double *h_denom_deriv) {
+  if (!g || dim_index < 0 || dim_index >= g->g.dim || g->g.bper[dim_index] || !g->tab[dim_index][0]) {
+    set_error("edm_hip_gauss_download_tables: no boundary tables for this dimension (periodic boundary)");
+    return EDM_HIP_ERR_ARG;
+  }
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
-  if (h_values) EDM_HIP_TRY(hipMemcpy(h_values, dv, sizeof(double) * (size_t)q.total, hipMemcpyDeviceToHost));
-  if (h_derivs) EDM_HIP_TRY(hipMemcpy(h_derivs, dd, sizeof(double) * (size_t)q.total * q.dim, hipMemcpyDeviceToHost));
-  (void)hipFree(dv);
-  (void)hipFree(dd);
+  const size_t bytes = sizeof(double) * EDM_BC_TABLE_SIZE;
+  if (h_denom) EDM_HIP_TRY(hipMemcpy(h_denom, g->tab[dim_index][0], bytes, hipMemcpyDeviceToHost));
+  if (h_denom_deriv) EDM_HIP_TRY(hipMemcpy(h_denom_deriv, g->tab[dim_index][1], bytes, hipMemcpyDeviceToHost));
   return EDM_HIP_OK;
 }
 
+int edm_hip_gauss_download(const edm_hip_gauss *g, double *h_values, double *h_derivs) {
+  return records_download(g->g, g->rec, g->stream, h_values, h_derivs);
+}
+
 int edm_hip_gauss_upload(edm_hip_gauss *g, const double *h_values, const double *h_derivs) {
-  const Geom &q = g->g;
-  double *dv = nullptr, *dd = nullptr;
-  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dv), sizeof(double) * (size_t)q.total));
-  EDM_HIP_TRY(hipMemcpy(dv, h_values, sizeof(double) * (size_t)q.total, hipMemcpyHostToDevice));
-  if (h_derivs) {
-    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dd), sizeof(double) * (size_t)q.total * q.dim));
-    EDM_HIP_TRY(hipMemcpy(dd, h_derivs, sizeof(double) * (size_t)q.total * q.dim, hipMemcpyHostToDevice));
-  }
-  EDM_HIP_TRY(launch_pack(q, g->rec, dv, dd, g->stream));
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
-  (void)hipFree(dv);
-  if (dd) (void)hipFree(dd);
-  return EDM_HIP_OK;
+  return records_upload(g->g, g->rec, g->stream, h_values, h_derivs);
 }
 
 int edm_hip_gauss_clear(edm_hip_gauss *g) {
@@ -1323,17 +1547,13 @@ int edm_hip_gauss_write(const edm_hip_gauss *g, const char *filename) {
   return write_plumed(q, v.data(), dv.data(), filename);
 }
 
-// grid.h:509-674 for one rank: points box_min + k*dx that are in_grid are re-sampled
-// by INTERPOLATION (a batched device lookup without the gaussian boundary handling,
-// because multi_write calls DimmedGrid::get_value_deriv directly).
-int edm_hip_gauss_multi_write(const edm_hip_gauss *g, const char *filename, int b_lammps_format) {
-  const Geom &q = g->g;
-  if (b_lammps_format == 1 && q.dim > 1) {
-    set_error("Lammps format only valid for 1D grids");
-    return EDM_HIP_ERR_ARG;
-  }
-  const double *box_min = q.bmin, *box_max = q.bmax;
-  const int *b_periodic = q.bper;
+}  // extern "C" (the record writer below is internal)
+
+// grid.h:509-674 for one rank on a grid with derivative records: points box_min + k*dx that are in_grid are
+// re-sampled by DimmedGrid::get_value_deriv (a batched device lookup in the reference's operation order,
+// without the gaussian boundary handling) and written with their derivative columns.
+static int multi_write_records(const Geom &q, const double *rec, hipStream_t stream, double *scratch, const char *filename,
+                               const double *box_min, const double *box_max, const int *b_periodic, int b_lammps_format) {
   unsigned int counts[3] = {1, 1, 1}, extra_n = 0;
   if (b_lammps_format) extra_n = (unsigned int)(box_min[0] / q.dx[0]);
   size_t total = 1;
@@ -1369,12 +1589,7 @@ int edm_hip_gauss_multi_write(const edm_hip_gauss *g, const char *filename, int 
   const size_t m = which.size();
   std::vector<double> E(m), der(m * q.dim);
   if (m) {
-    Geom plain = q;  // DimmedGrid lookup: no boundary test, no remap
-    for (int d = 0; d < 3; d++) {
-      plain.bper[d] = 1;
-      plain.bmin[d] = -std::numeric_limits<double>::infinity();
-      plain.bmax[d] = std::numeric_limits<double>::infinity();
-    }
+    const Geom plain = plain_geom(q);  // DimmedGrid lookup: no boundary test, no remap
     double *dx = nullptr, *dE = nullptr, *dD = nullptr;
     EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dx), sizeof(double) * m * q.dim));
     EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dE), sizeof(double) * m));
@@ -1382,8 +1597,8 @@ int edm_hip_gauss_multi_write(const edm_hip_gauss *g, const char *filename, int 
     EDM_HIP_TRY(hipMemcpy(dx, xs.data(), sizeof(double) * m * q.dim, hipMemcpyHostToDevice));
     LookupArgs a{};
     a.n = (long long)m; a.x = dx; a.x_stride = q.dim; a.energy = dE; a.f = dD; a.apply_mask = -1;
-    EDM_HIP_TRY(launch_lookup(plain, g->rec, LOOKUP_VALUES, a, g->scratch, nullptr, g->stream));
-    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    EDM_HIP_TRY(launch_lookup(plain, rec, LOOKUP_VALUES, a, scratch, nullptr, stream));
+    EDM_HIP_TRY(hipStreamSynchronize(stream));
     EDM_HIP_TRY(hipMemcpy(E.data(), dE, sizeof(double) * m, hipMemcpyDeviceToHost));
     EDM_HIP_TRY(hipMemcpy(der.data(), dD, sizeof(double) * m * q.dim, hipMemcpyDeviceToHost));
     (void)hipFree(dx);
@@ -1417,59 +1632,89 @@ int edm_hip_gauss_multi_write(const edm_hip_gauss *g, const char *filename, int 
   return EDM_HIP_OK;
 }
 
-// Grid::add (grid.h:275-290): this += scale * other(x_node) + offset with `other` read from
-// a PLUMED file and evaluated by interpolation at every node of this grid.
+extern "C" {
+
+// DimmedGaussGrid::multi_write / lammps_multi_write (gaussian_grid.h:150-158): the grid's own boundary is the box
+int edm_hip_gauss_multi_write(const edm_hip_gauss *g, const char *filename, int b_lammps_format) {
+  return edm_hip_gauss_multi_write_box(g, filename, g->g.bmin, g->g.bmax, g->g.bper, b_lammps_format);
+}
+// DimmedGrid::multi_write on the underlying grid with an explicit box (grid.h:509-674)
+int edm_hip_gauss_multi_write_box(const edm_hip_gauss *g, const char *filename, const double *box_min,
+                                  const double *box_max, const int *b_periodic, int b_lammps_format) {
+  if (b_lammps_format == 1 && g->g.dim > 1) {
+    set_error("Lammps format only valid for 1D grids");
+    return EDM_HIP_ERR_ARG;
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return multi_write_records(g->g, g->rec, g->stream, g->scratch, filename, box_min, box_max, b_periodic, b_lammps_format);
+}
+
+// Grid::add (grid.h:275-290) with `other` a plain grid / another gaussian grid
+int edm_hip_gauss_add_grid(edm_hip_gauss *g, const edm_hip_grid *other, double scale, double offset) {
+  if (!g || !other || g->g.dim != other->g.dim) {
+    set_error("Grid::add: dimensions differ");
+    return EDM_HIP_ERR_ARG;
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(other->stream));
+  return grid_add_from(g->g, g->rec, g->stream, g->scratch, plain_geom(other->g), other->values, scale, offset);
+}
+int edm_hip_gauss_add_gauss(edm_hip_gauss *g, const edm_hip_gauss *other, double scale, double offset) {
+  if (!g || !other || g->g.dim != other->g.dim) {
+    set_error("Grid::add: dimensions differ");
+    return EDM_HIP_ERR_ARG;
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(other->stream));
+  return grid_add_from(g->g, g->rec, g->stream, g->scratch, other->g, other->rec, scale, offset);
+}
+// Grid::add (grid.h:275-290) from a PLUMED grid file read with interpolation (read_grid(dim, file, 1)):
+// the initial_bias_filename path of EDMBias::subdivide (edm_bias.cpp:166-167, :1066-1072)
 int edm_hip_gauss_add_from_file(edm_hip_gauss *g, const char *filename, double scale, double offset) {
-  const Geom &q = g->g;
-  GridFile gf;
-  int rc = read_plumed(q.dim, filename, 1, gf);
+  edm_hip_grid *other = nullptr;
+  int rc = edm_hip_grid_read(&other, g->g.dim, filename, 1);
   if (rc) return rc;
-  if (!gf.g.has_deriv) {
+  if (!other->g.has_deriv) {
+    edm_hip_grid_destroy(other);
     set_error("initial bias file has no derivatives (FORCE 0)");
     return EDM_HIP_ERR_IO;
   }
-  // upload `other` as a temporary record array
-  edm_hip_gauss tmp;
-  tmp.g = gf.g;
-  tmp.stream = g->stream;
-  const size_t bytes = sizeof(double) * (size_t)gf.g.total * gf.g.rec;
-  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp.rec), bytes));
-  double *dv = nullptr, *dd = nullptr;
-  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dv), sizeof(double) * gf.values.size()));
-  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dd), sizeof(double) * gf.derivs.size()));
-  EDM_HIP_TRY(hipMemcpy(dv, gf.values.data(), sizeof(double) * gf.values.size(), hipMemcpyHostToDevice));
-  EDM_HIP_TRY(hipMemcpy(dd, gf.derivs.data(), sizeof(double) * gf.derivs.size(), hipMemcpyHostToDevice));
-  EDM_HIP_TRY(launch_pack(gf.g, tmp.rec, dv, dd, g->stream));
-  // node coordinates of this grid
-  std::vector<double> xs((size_t)q.total * q.dim);
-  for (long long i = 0; i < q.total; i++) {
-    long long idx[3];
-    edm::one2multi(q, i, idx);
-    for (int d = 0; d < q.dim; d++) xs[(size_t)i * q.dim + d] = q.min[d] + q.dx[d] * (size_t)idx[d];
-  }
-  double *dx = nullptr, *dE = nullptr, *dD = nullptr;
-  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dx), sizeof(double) * xs.size()));
-  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dE), sizeof(double) * (size_t)q.total));
-  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dD), sizeof(double) * xs.size()));
-  EDM_HIP_TRY(hipMemcpy(dx, xs.data(), sizeof(double) * xs.size(), hipMemcpyHostToDevice));
-  LookupArgs a{};
-  a.n = q.total; a.x = dx; a.x_stride = q.dim; a.energy = dE; a.f = dD; a.apply_mask = -1;
-  EDM_HIP_TRY(launch_lookup(gf.g, tmp.rec, LOOKUP_VALUES, a, g->scratch, nullptr, g->stream));
-  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
-  std::vector<double> E((size_t)q.total), D(xs.size()), v((size_t)q.total), dvv(xs.size());
-  EDM_HIP_TRY(hipMemcpy(E.data(), dE, sizeof(double) * E.size(), hipMemcpyDeviceToHost));
-  EDM_HIP_TRY(hipMemcpy(D.data(), dD, sizeof(double) * D.size(), hipMemcpyDeviceToHost));
-  rc = edm_hip_gauss_download(g, v.data(), dvv.data());
-  if (rc) return rc;
-  for (size_t i = 0; i < E.size(); i++) {
-    v[i] += scale * E[i] + offset;
-    for (int d = 0; d < q.dim; d++) dvv[i * q.dim + d] += scale * D[i * q.dim + d];
-  }
-  rc = edm_hip_gauss_upload(g, v.data(), dvv.data());
-  (void)hipFree(dx); (void)hipFree(dE); (void)hipFree(dD); (void)hipFree(dv); (void)hipFree(dd); (void)hipFree(tmp.rec);
-  tmp.rec = nullptr;
-  tmp.stream = nullptr;
+  rc = edm_hip_gauss_add_grid(g, other, scale, offset);
+  edm_hip_grid_destroy(other);
   return rc;
 }
 
+// DimmedGaussGrid::read (gaussian_grid.h:140-142 -> grid.h:712-835): the node storage and grid geometry come
+// from the file; sigma, boundary, tables and the stencil half-widths stay as they are (the reference does not
+// touch them either)
+int edm_hip_gauss_reread(edm_hip_gauss *g, const char *filename) {
+  GridFile gf;
+  int rc = read_plumed(g->g.dim, filename, g->g.interp, gf);
+  if (rc) return rc;
+  if (!gf.g.has_deriv) {
+    set_error("a gaussian grid needs the derivative columns (FORCE 1)");
+    return EDM_HIP_ERR_IO;
+  }
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  Geom q = gf.g;
+  for (int d = 0; d < 3; d++) {
+    q.sigma[d] = g->g.sigma[d];
+    q.bmin[d] = g->g.bmin[d];
+    q.bmax[d] = g->g.bmax[d];
+    q.bper[d] = g->g.bper[d];
+    q.msize[d] = g->g.msize[d];
+  }
+  if (q.total != g->g.total) {
+    EDM_HIP_TRY(hipFree(g->rec));
+    g->rec = nullptr;
+    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->rec), sizeof(double) * (size_t)q.total * q.rec));
+  }
+  g->g = q;
+  g->tiles_per_hill = 0;
+  return records_upload(g->g, g->rec, g->stream, gf.values.data(), gf.derivs.data());
+}
+int edm_hip_gauss_set_interpolation(edm_hip_gauss *g, int b_interpolate) {
+  g->g.interp = b_interpolate ? 1 : 0;
+  return EDM_HIP_OK;
+}
+
 }  // extern "C"
+

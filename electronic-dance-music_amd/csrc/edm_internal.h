@@ -87,8 +87,11 @@ int read_plumed(int dim, const char *filename, int b_interpolate, GridFile &out)
 
 struct edm_hip_grid {
   edm::Geom g;
-  double *values = nullptr;   // device, g.total doubles
+  // device: g.total doubles, or -- when the grid stores derivatives (g.has_deriv) -- g.total node records of
+  // g.rec doubles (V, dV/ds_0 .., pad), the layout of the gaussian grid's records
+  double *values = nullptr;
   hipStream_t stream = nullptr;
+  double *scratch = nullptr;  // lookup partial sums (record grids; allocated on demand)
 };
 
 struct edm_hip_gauss {

@@ -78,6 +78,21 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
 hipError_t launch_pack(const Geom &g, double *rec, const double *values, const double *derivs, hipStream_t s);
 hipError_t launch_unpack(const Geom &g, const double *rec, double *values, double *derivs, hipStream_t s);
 
+// base[i * rec] = values[i] (derivative slots of a record grid kept)
+hipError_t launch_set_values(const Geom &g, double *base, const double *values, hipStream_t s);
+
+// ---- plain DimmedGrid lookups and Grid::add --------------------------------------
+// get_value / get_value_deriv on a grid WITHOUT derivative records (grid.h:343-365): nearest-lower node value,
+// 0 outside in_grid, derivative 0.  out_value / out_deriv [n][dim] may be NULL.
+hipError_t launch_nearest_values(const Geom &g, const double *values, long long n, const double *x, int x_stride,
+                                 double *out_value, double *out_deriv, hipStream_t s);
+// Grid::add (grid.h:275-290) in two kernels around a lookup of `other`: node coordinates min + dx * index of
+// nodes [first, first + count) (rows of dim doubles), then grid_[i] += scale * E + offset (and the derivative
+// slots += scale * D where the grid has them) for the same nodes
+hipError_t launch_node_coords(const Geom &g, long long first, long long count, double *out, hipStream_t s);
+hipError_t launch_axpy_nodes(const Geom &g, double *base, long long first, long long count, const double *E,
+                             const double *D, double scale, double offset, hipStream_t s);
+
 // ---- plain-grid histogram add (K7) ------------------------------------------
 hipError_t launch_hist_add(const Geom &g, double *values, long long n, const double *x, int x_stride,
                            const long long *sel, const double *w, double w_const, hipStream_t s);

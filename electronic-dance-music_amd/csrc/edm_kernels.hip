@@ -151,6 +151,93 @@ hipError_t launch_target_heights(const Geom &target, const double *target_values
   return hipGetLastError();
 }
 
+// DimmedGrid::get_value / get_value_deriv on a grid that stores NO derivatives (grid.h:343-365): the value of
+// the nearest-lower node, 0 outside in_grid; the derivative (which the reference would read through a NULL
+// grid_deriv_) is reported as 0
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_nearest_values(Geom g, const double *__restrict__ values, long long n,
+                                                          const double *__restrict__ x, int x_stride,
+                                                          double *__restrict__ out_value, double *__restrict__ out_deriv) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    double xx[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) xx[d] = x[i * x_stride + d];
+    if (out_value) out_value[i] = target_value<DIM>(g, values, xx);
+    if (out_deriv) {
+#pragma unroll
+      for (int d = 0; d < DIM; d++) out_deriv[i * DIM + d] = 0.0;
+    }
+  }
+}
+hipError_t launch_nearest_values(const Geom &g, const double *values, long long n, const double *x, int x_stride,
+                                 double *out_value, double *out_deriv, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  long long b = (n + BLOCK - 1) / BLOCK;
+  if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL(k_nearest_values<1>, dim3((unsigned)b), dim3(BLOCK), 0, s, g, values, n, x, x_stride, out_value, out_deriv); break;
+    case 2: hipLaunchKernelGGL(k_nearest_values<2>, dim3((unsigned)b), dim3(BLOCK), 0, s, g, values, n, x, x_stride, out_value, out_deriv); break;
+    default: hipLaunchKernelGGL(k_nearest_values<3>, dim3((unsigned)b), dim3(BLOCK), 0, s, g, values, n, x, x_stride, out_value, out_deriv); break;
+  }
+  return hipGetLastError();
+}
+
+// Grid::add (grid.h:275-290), device side.  k_node_coords: the coordinates min + dx * index (:282-284) of nodes
+// [first, first + count), rows of dim doubles; k_axpy_nodes: grid_[i] += scale * E + offset and
+// grid_deriv_[i][j] += scale * D[j] (:285-287) for the same nodes (derivative slots only where the grid has them).
+__global__ void __launch_bounds__(BLOCK) k_node_coords(Geom g, long long first, long long count, double *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) {
+    long long index = first + i;
+    int d;
+    for (d = 0; d < g.dim - 1; d++) {
+      const long long k = index % g.n[d];
+      index = (index - k) / g.n[d];
+      out[i * g.dim + d] = g.min[d] + g.dx[d] * (double)(unsigned long long)k;
+    }
+    out[i * g.dim + d] = g.min[d] + g.dx[d] * (double)(unsigned long long)index;
+  }
+}
+hipError_t launch_node_coords(const Geom &g, long long first, long long count, double *out, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  long long b = (count + BLOCK - 1) / BLOCK;
+  if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+  hipLaunchKernelGGL(k_node_coords, dim3((unsigned)b), dim3(BLOCK), 0, s, g, first, count, out);
+  return hipGetLastError();
+}
+__global__ void __launch_bounds__(BLOCK) k_axpy_nodes(Geom g, double *__restrict__ base, long long first, long long count,
+                                                      const double *__restrict__ E, const double *__restrict__ D,
+                                                      double scale, double offset) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) {
+    double *r = base + (first + i) * g.rec;
+    r[0] += scale * E[i] + offset;
+    if (g.has_deriv)
+      for (int d = 0; d < g.dim; d++) r[1 + d] += scale * D[i * g.dim + d];
+  }
+}
+hipError_t launch_axpy_nodes(const Geom &g, double *base, long long first, long long count, const double *E,
+                             const double *D, double scale, double offset, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  long long b = (count + BLOCK - 1) / BLOCK;
+  if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+  hipLaunchKernelGGL(k_axpy_nodes, dim3((unsigned)b), dim3(BLOCK), 0, s, g, base, first, count, E, D, scale, offset);
+  return hipGetLastError();
+}
+// base[i * rec] = values[i]: node values of a record grid replaced, derivative slots kept
+__global__ void __launch_bounds__(BLOCK) k_set_values(Geom g, double *__restrict__ base, const double *__restrict__ values) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < g.total; i += stride) base[i * g.rec] = values[i];
+}
+hipError_t launch_set_values(const Geom &g, double *base, const double *values, hipStream_t s) {
+  long long b = (g.total + BLOCK - 1) / BLOCK;
+  if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(k_set_values, dim3((unsigned)b), dim3(BLOCK), 0, s, g, base, values);
+  return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(BLOCK) k_gather_positions(long long n, const double *__restrict__ x, int x_stride,
                                                             const long long *__restrict__ sel, int dim,
                                                             double *__restrict__ out) {
@@ -877,7 +964,7 @@ __global__ void __launch_bounds__(BLOCK) k_hist_add(Geom g, double *__restrict__
     long long flat = idx[DIM - 1];
 #pragma unroll
     for (int d = DIM - 1; d > 0; d--) flat = flat * g.n[d - 1] + idx[d - 1];
-    atomicAdd(&values[flat], wi);
+    atomicAdd(&values[flat * g.rec], wi);   // (rec == 1 for a histogram; a grid with derivative records keeps V first)
   }
 }
 hipError_t launch_hist_add(const Geom &g, double *values, long long n, const double *x, int x_stride,

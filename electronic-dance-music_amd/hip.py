@@ -61,6 +61,7 @@ _PROTOS = {
     "edm_hip_gauss_destroy": (C.c_int, [vp]),
     "edm_hip_gauss_set_boundary": (C.c_int, [vp, c_dp, c_dp, c_ip]),
     "edm_hip_gauss_geometry": (C.c_int, [vp, C.POINTER(Geometry)]),
+    "edm_hip_gauss_download_tables": (C.c_int, [vp, C.c_int, c_dp, c_dp]),
     "edm_hip_gauss_download": (C.c_int, [vp, c_dp, c_dp]),
     "edm_hip_gauss_upload": (C.c_int, [vp, c_dp, c_dp]),
     "edm_hip_gauss_clear": (C.c_int, [vp]),
@@ -339,6 +340,12 @@ class Gauss(_Geom):
 
     def set_boundary(self, lo, hi, periodic):
         check(lib().edm_hip_gauss_set_boundary(self.h, _dp(_vec(lo)), _dp(_vec(hi)), _ivec(periodic).ctypes.data_as(c_ip)))
+
+    def bc_tables(self, dim_index):
+        """the two McGovern-De Pablo tables of one non-periodic boundary dimension, read back from HBM"""
+        t0, t1 = np.empty(65536), np.empty(65536)
+        check(lib().edm_hip_gauss_download_tables(self.h, dim_index, _dp(t0), _dp(t1)))
+        return t0, t1
 
     def download(self):
         v = np.empty(self.size)

@@ -84,26 +84,51 @@ typedef struct {
   double boundary_max[EDM_HIP_MAXDIM];
   int minisize[EDM_HIP_MAXDIM];            /* gaussian_grid.h:559-569 */
   long long total;                         /* grid_size_ */
+  int derivatives;                         /* b_derivatives_ (always 1 for a gaussian grid) */
 } edm_hip_geometry;
 
-/* ---- plain grid: DimmedGrid<DIM> without interpolation (lib/grid.h) ------ */
-/* make_grid (grid.h:911, grid.cpp:3-20) with b_derivatives = b_interpolate = 0 */
+/* ---- plain grid: DimmedGrid<DIM> (lib/grid.h) ------------------------------ */
+/* make_grid (grid.h:911, grid.cpp:3-20) with b_derivatives = b_interpolate = 0: the CV histogram flavour */
 int edm_hip_grid_create(edm_hip_grid **out, int dim, const double *min, const double *max,
                         const double *spacing, const int *periodic);
+/* make_grid with any flags (DimmedGrid(min, max, spacing, periodic, b_derivatives, b_interpolate), grid.h:190-213).
+ * A grid with derivatives keeps one (V, dV/ds_0 ..) record per node in HBM like the gaussian grid. */
+int edm_hip_grid_create_ex(edm_hip_grid **out, int dim, const double *min, const double *max,
+                           const double *spacing, const int *periodic, int b_derivatives, int b_interpolate);
+/* read_grid (grid.h:923,:928, grid.cpp:22-45) = DimmedGrid(filename, b_interpolate) (grid.h:218-227): PLUMED-1
+ * grid file, b_derivatives_ taken from its FORCE line (grid.h:712-835).  read_grid(dim, file) is b_interpolate 1. */
+int edm_hip_grid_read(edm_hip_grid **out, int dim, const char *filename, int b_interpolate);
+/* Grid::read (grid.h:712-835) on an existing grid: geometry, derivative flag and contents replaced */
+int edm_hip_grid_reread(edm_hip_grid *g, const char *filename);
+/* Grid::set_interpolation (grid.h:837-839) */
+int edm_hip_grid_set_interpolation(edm_hip_grid *g, int b_interpolate);
 int edm_hip_grid_destroy(edm_hip_grid *g);
 int edm_hip_grid_geometry(const edm_hip_grid *g, edm_hip_geometry *out);
-/* Grid::get_grid / clear (grid.h:841, :679) */
+/* Grid::get_grid / grid_deriv_ / clear (grid.h:841, :880, :679); derivs are [total][dim] */
 int edm_hip_grid_download(const edm_hip_grid *g, double *h_values);
+int edm_hip_grid_download_derivs(const edm_hip_grid *g, double *h_derivs);
 int edm_hip_grid_upload(edm_hip_grid *g, const double *h_values);
+int edm_hip_grid_upload_derivs(edm_hip_grid *g, const double *h_values, const double *h_derivs);
 int edm_hip_grid_clear(edm_hip_grid *g);
 /* DimmedGrid::add_value batched (grid.h:370-385): values[bin(x_i)] += w_i, silently
- * ignoring samples outside in_grid.  d_w may be NULL (w = w_const). */
+ * ignoring samples outside in_grid.  d_w may be NULL (w = w_const).  An interpolating grid refuses
+ * (EDM_HIP_ERR_STATE, grid.h:371-373). */
 int edm_hip_grid_add_values(edm_hip_grid *g, long long n, const double *d_x, int x_stride,
                             const double *d_w, double w_const);
+/* DimmedGrid::get_value / get_value_deriv batched (grid.h:343-365, :390-446): cubic-Hermite interpolation
+ * (interp<DIM>, grid.h:52-139) when the grid interpolates AND stores derivatives, else the nearest-lower node's
+ * value and stored derivatives (0 where there are none); (0, 0) outside in_grid.  d_value / d_deriv [n][dim]
+ * may be NULL. */
+int edm_hip_grid_get_value_deriv(const edm_hip_grid *g, long long n, const double *d_x, int x_stride,
+                                 double *d_value, double *d_deriv);
+/* Grid::add (grid.h:275-290): this(node) += scale * other(x_node) + offset, derivatives += scale * d other */
+int edm_hip_grid_add_grid(edm_hip_grid *g, const edm_hip_grid *other, double scale, double offset);
+int edm_hip_grid_add_gauss(edm_hip_grid *g, const edm_hip_gauss *other, double scale, double offset);
 /* DimmedGrid::write (grid.h:448-503), byte-identical text */
 int edm_hip_grid_write(const edm_hip_grid *g, const char *filename);
-/* DimmedGrid::multi_write (grid.h:509-674) for one rank on a grid without derivatives: the
- * CV histogram written by the MPI build's write_histogram (edm_bias.cpp:239) */
+/* DimmedGrid::multi_write (grid.h:509-674) for one rank: the CV histogram written by the MPI build's
+ * write_histogram (edm_bias.cpp:239) when the grid has no derivatives, re-sampled by interpolation with the
+ * derivative columns when it has */
 int edm_hip_grid_multi_write(const edm_hip_grid *g, const char *filename, const double *box_min,
                              const double *box_max, const int *b_periodic, int b_lammps_format);
 
@@ -112,6 +137,14 @@ int edm_hip_grid_multi_write(const edm_hip_grid *g, const char *filename, const 
 int edm_hip_gauss_create(edm_hip_gauss **out, int dim, const double *min, const double *max,
                          const double *spacing, const int *periodic, int b_interpolate,
                          const double *sigma);
+/* read_gauss_grid (gaussian_grid.h:647, gaussian_grid.cpp:23-33) = DimmedGaussGrid(filename, sigma)
+ * (gaussian_grid.h:85-93); the file must carry derivative columns (FORCE 1) */
+int edm_hip_gauss_read(edm_hip_gauss **out, int dim, const char *filename, const double *sigma);
+/* GaussGrid::read (gaussian_grid.h:140-142): node storage and grid geometry replaced from the file, sigma /
+ * boundary / tables kept */
+int edm_hip_gauss_reread(edm_hip_gauss *g, const char *filename);
+/* GaussGrid::set_interpolation (gaussian_grid.h:168-170) */
+int edm_hip_gauss_set_interpolation(edm_hip_gauss *g, int b_interpolate);
 int edm_hip_gauss_destroy(edm_hip_gauss *g);
 /* GaussGrid::set_boundary (gaussian_grid.h:378-435): rebuilds the two 65536-entry
  * McGovern-De Pablo tables per non-periodic dimension on the host with libm erf
@@ -119,6 +152,11 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g);
 int edm_hip_gauss_set_boundary(edm_hip_gauss *g, const double *min, const double *max,
                                const int *periodic);
 int edm_hip_gauss_geometry(const edm_hip_gauss *g, edm_hip_geometry *out);
+/* reads the two McGovern-De Pablo tables of dimension dim_index back from HBM (bc_denom_table_ /
+ * bc_denom_deriv_table_, gaussian_grid.h:394-431): EDM_HIP_BC_TABLE_SIZE doubles each, either pointer may be
+ * NULL.  A periodic boundary dimension has no tables: EDM_HIP_ERR_ARG. */
+#define EDM_HIP_BC_TABLE_SIZE 65536     /* gaussian_grid.h:11 */
+int edm_hip_gauss_download_tables(const edm_hip_gauss *g, int dim_index, double *h_denom, double *h_denom_deriv);
 /* Grid::get_grid + grid_deriv_ (grid.h:879-880): host layout values[total],
  * derivs[total][dim]; the device keeps one (V, dV/ds_0..) record per node. */
 int edm_hip_gauss_download(const edm_hip_gauss *g, double *h_values, double *h_derivs);
@@ -175,6 +213,12 @@ int edm_hip_gauss_hill_integrals(const edm_hip_gauss *g, long long n, const doub
  * multi_write evaluated for one rank, lammps != 0 selects the LAMMPS table format) */
 int edm_hip_gauss_write(const edm_hip_gauss *g, const char *filename);
 int edm_hip_gauss_multi_write(const edm_hip_gauss *g, const char *filename, int b_lammps_format);
+/* GaussGrid::multi_write(filename, box_low, box_high, b_periodic, fmt) (gaussian_grid.h:160-166) */
+int edm_hip_gauss_multi_write_box(const edm_hip_gauss *g, const char *filename, const double *box_min,
+                                  const double *box_max, const int *b_periodic, int b_lammps_format);
+/* Grid::add (grid.h:275-290) with another device grid as `other` (evaluated through ITS get_value_deriv) */
+int edm_hip_gauss_add_grid(edm_hip_gauss *g, const edm_hip_grid *other, double scale, double offset);
+int edm_hip_gauss_add_gauss(edm_hip_gauss *g, const edm_hip_gauss *other, double scale, double offset);
 /* Grid::add (grid.h:275-290) from a PLUMED grid file read with interpolation:
  * the initial_bias_filename path of EDMBias::subdivide (edm_bias.cpp:166-167) */
 int edm_hip_gauss_add_from_file(edm_hip_gauss *g, const char *filename, double scale, double offset);

@@ -143,3 +143,74 @@ def test_skipped_round_when_buffer_not_drained(tmp_path, oracle_lib):
         assert [b.get(k) for k in keys] == [o.get(k) for k in keys], step
         assert abs(b.get("cum_bias") - o.get("cum_bias")) <= 1e-10 * o.get("cum_bias")
     assert np.array_equal(b.hist.values, o.hist.values)
+
+
+@pytest.mark.parametrize("entry", ["add_hills", "pair_step", "communicator"])
+def test_deferred_bound_exceeded_redo(entry, tmp_path, oracle_lib):
+    """A stochastic step is queued against a launch bound (4 x the expected count + 128) before the accepted count
+    is known; when the count exceeds the bound the limiter flags it (error 2), the chained gather / histogram /
+    read-back / tile-flag clean-up must all stand down, and the controller redoes the hill path synchronously with
+    the same device-RNG cycle.  Driven here by uniforms that accept EVERY sample (3000 against a bound of 256),
+    through add_hills, the fused pair_step (forces ride in the aborted launch and must stay valid) and the packed
+    exchange of a one-rank communicator.  Bit for bit against a handle that never defers (debug_force_sync), at the
+    parity tolerance against the oracle, and with ordinary steps before and after (tickets / flags left clean)."""
+    text = BASE + "hill_prefactor 0.5\nhill_density 20\nbias_per_step 50\n"
+    n = 3000
+    runs = {}
+    for tag in ("deferred", "sync"):
+        b = _bias(tmp_path, entry + "_" + tag, text)
+        if entry == "communicator":
+            b.comm_init(H.comm_unique_id(), 1, 0)
+        if tag == "sync":
+            b.set("debug_force_sync", 1)
+        out = []
+        for step in range(4):
+            r = W.pair_distances(n, 880 + step)
+            u = np.zeros(n) if step == 1 else W.uniform(890 + step, n)   # step 1: everything accepted
+            d_r = H.DeviceArray.from_host(r)
+            d_u = H.DeviceArray.from_host(u)
+            d_f = H.DeviceArray.zeros((n,))
+            if entry == "pair_step":
+                e = b.pair_step_device(d_r, d_f, n, d_r, d_u, n, est=n)
+            else:
+                e = b.pair_forces_device(d_r, d_f, n)
+                b.add_hills_device(d_r, n, 1, d_u, -1, est=n)
+            out.append((e, d_f.to_host(), [b.get(k) for k in ("overflow_left", "overflow_right", "b_skip_hill_add",
+                                                              "hills_added", "steps", "cum_bias")]))
+        v, dv = b.gauss.download()
+        runs[tag] = (out, v, dv, b.hist.values, b.get("bound_redos"))
+        del b
+    assert runs["deferred"][4] == 1 and runs["sync"][4] == 0, "exactly the all-accepted step must take the redo path"
+    for (e1, f1, s1), (e2, f2, s2) in zip(runs["deferred"][0], runs["sync"][0]):
+        assert e1 == e2 and np.array_equal(f1, f2) and s1 == s2
+    for k in (1, 2, 3):
+        assert np.array_equal(runs["deferred"][k], runs["sync"][k])
+    assert open(str(tmp_path / ("H_%s_deferred_0" % entry))).read() == open(str(tmp_path / ("H_%s_sync_0" % entry))).read()
+    # ... and against the oracle (fix_edm_pair order: pre_add_hill, forces, add_hill per sample, post_add_hill)
+    cfg_o = str(tmp_path / (entry + "_o.edm"))
+    open(cfg_o, "w").write(text + "hills_filename %s/H_o_%s\nhistogram_filename %s/HIST_o_%s\n" % (tmp_path, entry, tmp_path, entry))
+    o = B.Bias(oracle_lib, cfg_o)
+    o.setup(1.0, 1.0)
+    o.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    for step in range(4):
+        r = W.pair_distances(n, 880 + step)
+        u = np.zeros(n) if step == 1 else W.uniform(890 + step, n)
+        fo = np.zeros((n, 1))
+        if entry == "pair_step":
+            o.pre_add_hill(n)
+            eo = o.update_forces(r.reshape(-1, 1).copy(), fo)
+        else:
+            eo = o.update_forces(r.reshape(-1, 1).copy(), fo)
+            o.pre_add_hill(n)
+        for i in np.nonzero(u < 20.0 / n)[0]:
+            o.add_hill([r[i]], float(u[i]))
+        o.post_add_hill()
+        e1, f1, s1 = runs["deferred"][0][step]
+        assert abs(e1 - eo) <= 1e-9 * max(abs(eo), 1e-300)
+        assert np.allclose(f1, fo[:, 0], rtol=1e-8, atol=1e-11 * max(np.abs(fo).max(), 1e-300))
+        assert s1[:5] == [o.get(k) for k in ("overflow_left", "overflow_right", "b_skip_hill_add", "hills_added", "steps")]
+        assert abs(s1[5] - o.get("cum_bias")) <= 1e-10 * o.get("cum_bias")
+    ov = o.gauss.grid.values
+    assert np.allclose(runs["deferred"][1], ov, rtol=1e-9, atol=1e-13 * np.abs(ov).max())
+    assert np.array_equal(runs["deferred"][3], o.hist.values)
+    assert runs["deferred"][0][1][2][1] > 0, "the all-accepted step must have pushed hills into the overflow buffer"

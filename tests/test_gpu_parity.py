@@ -7,6 +7,7 @@ bit-exact; energies / forces / grid values within 1e-6 relative.  The tolerances
 below are much tighter (they are what the kernels achieve: differences come only from
 device exp() ulps and fixed-order tree reductions) and are written next to each check.
 """
+import hashlib
 import os
 
 import numpy as np
@@ -63,6 +64,15 @@ def test_gauss_golden(sc):
     assert [float(v) for v in g.dx] == sc["dx"]
     assert [float(v) for v in g.max] == sc["grid_max"]
     assert [float(v) for v in g.sigma] == sc["sigma_eff"]
+    # McGovern-De Pablo tables as they sit in HBM (host libm, gaussian_grid.h:394-431): bit-identical to the reference's
+    for dkey, tab in sc["tables"].items():
+        t0, t1 = g.bc_tables(int(dkey))
+        assert hashlib.sha256(t0.tobytes() + t1.tobytes()).hexdigest() == tab["sha256"], "McGDP tables differ from the reference's"
+        assert [float(v) for v in t0[::4099]] == tab["denom"]
+    for dd in range(g.dim):
+        if str(dd) not in sc["tables"]:
+            with pytest.raises(H.EdmHipError):
+                g.bc_tables(dd)   # a periodic boundary dimension has no tables
     dim = g.dim
     pad = np.zeros((len(d["hill_x"]), 3))
     pad[:, :dim] = d["hill_x"]
