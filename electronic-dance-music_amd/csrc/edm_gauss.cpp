@@ -845,6 +845,13 @@ int edm_hip_gauss_sample_index(const edm_hip_gauss *g, long long n, const double
   return EDM_HIP_OK;
 }
 
+int edm_hip_gauss_remap(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride, double *d_out) {
+  if (n <= 0) return EDM_HIP_OK;
+  EDM_HIP_TRY(launch_remap(g->g, n, d_x, x_stride, d_out, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return EDM_HIP_OK;
+}
+
 int edm_hip_gauss_update_forces(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride, double *d_f,
                                 int f_stride, const int *d_mask, int apply_mask, double *energy) {
   if (energy) *energy = 0;

@@ -81,6 +81,9 @@ hipError_t launch_unpack(const Geom &g, const double *rec, double *values, doubl
 // base[i * rec] = values[i] (derivative slots of a record grid kept)
 hipError_t launch_set_values(const Geom &g, double *base, const double *values, hipStream_t s);
 
+// DimmedGaussGrid::remap (gaussian_grid.h:504-541) batched: out rows of dim doubles
+hipError_t launch_remap(const Geom &g, long long n, const double *x, int x_stride, double *out, hipStream_t s);
+
 // ---- plain DimmedGrid lookups and Grid::add --------------------------------------
 // get_value / get_value_deriv on a grid WITHOUT derivative records (grid.h:343-365): nearest-lower node value,
 // 0 outside in_grid, derivative 0.  out_value / out_deriv [n][dim] may be NULL.

@@ -183,6 +183,33 @@ hipError_t launch_nearest_values(const Geom &g, const double *values, long long 
   return hipGetLastError();
 }
 
+// DimmedGaussGrid::remap (gaussian_grid.h:504-541) as the lookup and hill kernels apply it, on its own: out rows of
+// dim doubles
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_remap(Geom g, long long n, const double *__restrict__ x, int x_stride,
+                                                 double *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    double xx[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) xx[d] = x[i * x_stride + d];
+    remap<DIM>(g, xx);
+#pragma unroll
+    for (int d = 0; d < DIM; d++) out[i * DIM + d] = xx[d];
+  }
+}
+hipError_t launch_remap(const Geom &g, long long n, const double *x, int x_stride, double *out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  long long b = (n + BLOCK - 1) / BLOCK;
+  if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+  switch (g.dim) {
+    case 1: hipLaunchKernelGGL(k_remap<1>, dim3((unsigned)b), dim3(BLOCK), 0, s, g, n, x, x_stride, out); break;
+    case 2: hipLaunchKernelGGL(k_remap<2>, dim3((unsigned)b), dim3(BLOCK), 0, s, g, n, x, x_stride, out); break;
+    default: hipLaunchKernelGGL(k_remap<3>, dim3((unsigned)b), dim3(BLOCK), 0, s, g, n, x, x_stride, out); break;
+  }
+  return hipGetLastError();
+}
+
 // Grid::add (grid.h:275-290), device side.  k_node_coords: the coordinates min + dx * index (:282-284) of nodes
 // [first, first + count), rows of dim doubles; k_axpy_nodes: grid_[i] += scale * E + offset and
 // grid_deriv_[i][j] += scale * D[j] (:285-287) for the same nodes (derivative slots only where the grid has them).

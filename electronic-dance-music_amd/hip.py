@@ -31,7 +31,7 @@ class Geometry(C.Structure):
         ("n", C.c_int * 3), ("periodic", C.c_int * 3),
         ("min", C.c_double * 3), ("max", C.c_double * 3), ("dx", C.c_double * 3), ("sigma", C.c_double * 3),
         ("boundary_periodic", C.c_int * 3), ("boundary_min", C.c_double * 3), ("boundary_max", C.c_double * 3),
-        ("minisize", C.c_int * 3), ("total", C.c_longlong),
+        ("minisize", C.c_int * 3), ("total", C.c_longlong), ("derivatives", C.c_int),
     ]
 
 
@@ -49,7 +49,16 @@ _PROTOS = {
     "edm_hip_memset": (C.c_int, [vp, C.c_int, C.c_size_t]),
     "edm_hip_device_synchronize": (C.c_int, []),
     "edm_hip_grid_create": (C.c_int, [C.POINTER(vp), C.c_int, c_dp, c_dp, c_dp, c_ip]),
+    "edm_hip_grid_create_ex": (C.c_int, [C.POINTER(vp), C.c_int, c_dp, c_dp, c_dp, c_ip, C.c_int, C.c_int]),
+    "edm_hip_grid_read": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, C.c_int]),
+    "edm_hip_grid_reread": (C.c_int, [vp, C.c_char_p]),
+    "edm_hip_grid_set_interpolation": (C.c_int, [vp, C.c_int]),
     "edm_hip_grid_destroy": (C.c_int, [vp]),
+    "edm_hip_grid_download_derivs": (C.c_int, [vp, c_dp]),
+    "edm_hip_grid_upload_derivs": (C.c_int, [vp, c_dp, c_dp]),
+    "edm_hip_grid_get_value_deriv": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, vp]),
+    "edm_hip_grid_add_grid": (C.c_int, [vp, vp, C.c_double, C.c_double]),
+    "edm_hip_grid_add_gauss": (C.c_int, [vp, vp, C.c_double, C.c_double]),
     "edm_hip_grid_geometry": (C.c_int, [vp, C.POINTER(Geometry)]),
     "edm_hip_grid_download": (C.c_int, [vp, c_dp]),
     "edm_hip_grid_upload": (C.c_int, [vp, c_dp]),
@@ -58,6 +67,9 @@ _PROTOS = {
     "edm_hip_grid_write": (C.c_int, [vp, C.c_char_p]),
     "edm_hip_grid_multi_write": (C.c_int, [vp, C.c_char_p, c_dp, c_dp, c_ip, C.c_int]),
     "edm_hip_gauss_create": (C.c_int, [C.POINTER(vp), C.c_int, c_dp, c_dp, c_dp, c_ip, C.c_int, c_dp]),
+    "edm_hip_gauss_read": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, c_dp]),
+    "edm_hip_gauss_reread": (C.c_int, [vp, C.c_char_p]),
+    "edm_hip_gauss_set_interpolation": (C.c_int, [vp, C.c_int]),
     "edm_hip_gauss_destroy": (C.c_int, [vp]),
     "edm_hip_gauss_set_boundary": (C.c_int, [vp, c_dp, c_dp, c_ip]),
     "edm_hip_gauss_geometry": (C.c_int, [vp, C.POINTER(Geometry)]),
@@ -68,6 +80,7 @@ _PROTOS = {
     "edm_hip_gauss_device_buffer": (C.c_int, [vp, C.POINTER(vp), c_ip, C.POINTER(C.c_longlong)]),
     "edm_hip_gauss_get_value_deriv": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, vp]),
     "edm_hip_gauss_sample_index": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp]),
+    "edm_hip_gauss_remap": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp]),
     "edm_hip_gauss_update_forces": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, vp, C.c_int, c_dp]),
     "edm_hip_gauss_pair_forces": (C.c_int, [vp, C.c_longlong, vp, vp, c_dp]),
     "edm_hip_gauss_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -76,6 +89,9 @@ _PROTOS = {
     "edm_hip_gauss_hill_integrals": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_double, vp]),
     "edm_hip_gauss_write": (C.c_int, [vp, C.c_char_p]),
     "edm_hip_gauss_multi_write": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "edm_hip_gauss_multi_write_box": (C.c_int, [vp, C.c_char_p, c_dp, c_dp, c_ip, C.c_int]),
+    "edm_hip_gauss_add_grid": (C.c_int, [vp, vp, C.c_double, C.c_double]),
+    "edm_hip_gauss_add_gauss": (C.c_int, [vp, vp, C.c_double, C.c_double]),
     "edm_hip_gauss_add_from_file": (C.c_int, [vp, C.c_char_p, C.c_double, C.c_double]),
     "edm_hip_bias_create": (C.c_int, [C.POINTER(vp), C.c_char_p]),
     "edm_hip_bias_destroy": (C.c_int, [vp]),
@@ -263,12 +279,55 @@ class Grid(_Geom):
         self.h, self.owned, self._keep = handle, owned, keep
 
     @classmethod
-    def create(cls, lo, hi, spacing, periodic):
+    def create(cls, lo, hi, spacing, periodic, b_derivatives=0, b_interpolate=0):
+        """make_grid (grid.h:911)"""
         dim = len(np.atleast_1d(lo))
         h = vp()
-        check(lib().edm_hip_grid_create(C.byref(h), dim, _dp(_vec(lo)), _dp(_vec(hi)), _dp(_vec(spacing)),
-                                        _ivec(periodic).ctypes.data_as(c_ip)))
+        check(lib().edm_hip_grid_create_ex(C.byref(h), dim, _dp(_vec(lo)), _dp(_vec(hi)), _dp(_vec(spacing)),
+                                           _ivec(periodic).ctypes.data_as(c_ip), b_derivatives, b_interpolate))
         return cls(h.value)
+
+    @classmethod
+    def read_file(cls, dim, filename, b_interpolate=1):
+        """read_grid (grid.h:923, :928)"""
+        h = vp()
+        check(lib().edm_hip_grid_read(C.byref(h), dim, os.fsencode(filename), b_interpolate))
+        return cls(h.value)
+
+    def read(self, filename):
+        """Grid::read (grid.h:712-835)"""
+        check(lib().edm_hip_grid_reread(self.h, os.fsencode(filename)))
+
+    def set_interpolation(self, b):
+        check(lib().edm_hip_grid_set_interpolation(self.h, int(b)))
+
+    has_derivatives = property(lambda s: bool(s.geometry.derivatives))
+
+    @property
+    def derivs(self):
+        d = np.empty((self.size, self.dim))
+        check(lib().edm_hip_grid_download_derivs(self.h, _dp(d)))
+        return d
+
+    def upload_derivs(self, values, derivs):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        d = np.ascontiguousarray(derivs, dtype=np.float64)
+        check(lib().edm_hip_grid_upload_derivs(self.h, _dp(v), _dp(d)))
+
+    def get_value_deriv(self, x):
+        """DimmedGrid::get_value_deriv batched: x [n, >=dim] -> (V[n], der[n, dim])"""
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        n, stride = x.shape
+        dx = DeviceArray.from_host(x)
+        dE = DeviceArray((n,))
+        dD = DeviceArray((n, self.dim))
+        check(lib().edm_hip_grid_get_value_deriv(self.h, n, dx.ptr, stride, dE.ptr, dD.ptr))
+        return dE.to_host(), dD.to_host()
+
+    def add(self, other, scale=1.0, offset=0.0):
+        """Grid::add (grid.h:275-290)"""
+        fn = lib().edm_hip_grid_add_gauss if isinstance(other, Gauss) else lib().edm_hip_grid_add_grid
+        check(fn(self.h, other.h, scale, offset))
 
     def __del__(self):
         try:
@@ -319,6 +378,29 @@ class Gauss(_Geom):
         check(lib().edm_hip_gauss_create(C.byref(h), dim, _dp(_vec(lo)), _dp(_vec(hi)), _dp(_vec(spacing)),
                                          _ivec(periodic).ctypes.data_as(c_ip), b_interp, _dp(_vec(sigma))))
         return cls(h.value)
+
+    @classmethod
+    def read_file(cls, dim, filename, sigma):
+        """read_gauss_grid (gaussian_grid.h:647)"""
+        h = vp()
+        check(lib().edm_hip_gauss_read(C.byref(h), dim, os.fsencode(filename), _dp(_vec(sigma))))
+        return cls(h.value)
+
+    def read(self, filename):
+        """GaussGrid::read (gaussian_grid.h:140-142)"""
+        check(lib().edm_hip_gauss_reread(self.h, os.fsencode(filename)))
+
+    def set_interpolation(self, b):
+        check(lib().edm_hip_gauss_set_interpolation(self.h, int(b)))
+
+    def add(self, other, scale=1.0, offset=0.0):
+        """Grid::add (grid.h:275-290) with another device grid"""
+        fn = lib().edm_hip_gauss_add_gauss if isinstance(other, Gauss) else lib().edm_hip_gauss_add_grid
+        check(fn(self.h, other.h, scale, offset))
+
+    def multi_write_box(self, filename, box_min, box_max, periodic, lammps=0):
+        check(lib().edm_hip_gauss_multi_write_box(self.h, os.fsencode(filename), _dp(_vec(box_min)), _dp(_vec(box_max)),
+                                                  _ivec(periodic).ctypes.data_as(c_ip), lammps))
 
     def __del__(self):
         try:
@@ -386,6 +468,15 @@ class Gauss(_Geom):
         df = DeviceArray((n,), np.int64)
         check(lib().edm_hip_gauss_sample_index(self.h, n, dx.ptr, stride, df.ptr))
         return df.to_host()
+
+    def remap(self, x):
+        """DimmedGaussGrid::remap batched: x [n, >=dim] -> remapped [n, dim]"""
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        n, stride = x.shape
+        dx = DeviceArray.from_host(x)
+        do = DeviceArray((n, self.dim))
+        check(lib().edm_hip_gauss_remap(self.h, n, dx.ptr, stride, do.ptr))
+        return do.to_host()
 
     def update_forces(self, x, f, mask=None, apply_mask=-1):
         """EDMBias::update_forces on host arrays (f updated in place); returns the energy."""

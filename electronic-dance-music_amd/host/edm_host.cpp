@@ -66,6 +66,8 @@ void HipGrid::refresh_geometry() {
   check(edm_hip_grid_geometry(h_, &g), "grid.h:geometry");
   dim_ = (unsigned int)g.dim;
   grid_size_ = (size_t)g.total;
+  b_derivatives_ = g.derivatives;
+  b_interpolate_ = g.interpolate;
   for (int d = 0; d < 3; d++) {
     dx_[d] = g.dx[d];
     min_[d] = g.min[d];
@@ -76,9 +78,15 @@ void HipGrid::refresh_geometry() {
 }
 
 HipGrid::HipGrid(unsigned int dim, const double* min, const double* max, const double* bin_spacing,
-                 const int* b_periodic)
+                 const int* b_periodic, int b_derivatives, int b_interpolate)
     : h_(NULL), owned_(true) {
-  check(edm_hip_grid_create(&h_, (int)dim, min, max, bin_spacing, b_periodic), "grid.h:DimmedGrid");
+  check(edm_hip_grid_create_ex(&h_, (int)dim, min, max, bin_spacing, b_periodic, b_derivatives, b_interpolate),
+        "grid.h:DimmedGrid");
+  refresh_geometry();
+}
+
+HipGrid::HipGrid(unsigned int dim, const std::string& input_grid, int b_interpolate) : h_(NULL), owned_(true) {
+  check(edm_hip_grid_read(&h_, (int)dim, input_grid.c_str(), b_interpolate), "grid.h:read");
   refresh_geometry();
 }
 
@@ -93,35 +101,68 @@ double* HipGrid::get_grid() {
   check(edm_hip_grid_download(h_, snapshot_.data()), "grid.h:get_grid");
   return snapshot_.data();
 }
+const double* HipGrid::get_grid_deriv() {
+  if (!b_derivatives_) return NULL;   // grid_deriv_ stays NULL without derivatives (grid.h:898)
+  snapshot_deriv_.resize((grid_size_ ? grid_size_ : 1) * dim_);
+  check(edm_hip_grid_download_derivs(h_, snapshot_deriv_.data()), "grid.h:get_grid_deriv");
+  return snapshot_deriv_.data();
+}
+void HipGrid::set_grid(const double* values, const double* derivs) {
+  if (derivs && b_derivatives_)
+    check(edm_hip_grid_upload_derivs(h_, values, derivs), "grid.h:set_grid");
+  else
+    check(edm_hip_grid_upload(h_, values), "grid.h:set_grid");
+}
 
-// grid.h:343-365 without interpolation: the value of the nearest-lower node
-double HipGrid::get_value(const double* x) const {
+// grid.h:865-874, :264-273, :315-325
+int HipGrid::in_grid(const double* x) const {
   for (unsigned int d = 0; d < dim_; d++)
     if (!b_periodic_[d] && (x[d] < min_[d] || x[d] >= max_[d] - dx_[d])) return 0;
-  const double* v = const_cast<HipGrid*>(this)->get_grid();
-  size_t flat = 0, mul = 1;
+  return 1;
+}
+void HipGrid::get_index(const double* x, size_t* result) const {
   for (unsigned int d = 0; d < dim_; d++) {
     double xi = x[d];
     if (b_periodic_[d]) xi -= (max_[d] - min_[d]) * std::floor((xi - min_[d]) / (max_[d] - min_[d]));
-    size_t idx = (size_t)std::floor((xi - min_[d]) / dx_[d]);
-    if (idx >= (size_t)grid_number_[d]) idx = (size_t)grid_number_[d] - 1;
-    flat += idx * mul;
-    mul *= (size_t)grid_number_[d];
+    result[d] = (size_t)std::floor((xi - min_[d]) / dx_[d]);
   }
-  return v[flat];
+}
+size_t HipGrid::multi2one(const size_t* index) const {
+  size_t result = index[dim_ - 1];
+  for (int d = (int)dim_ - 2; d >= 0; d--) result = result * (size_t)grid_number_[d] + index[d];
+  return result;
 }
 
+// DimmedGrid::get_value / get_value_deriv (grid.h:343-365, :390-446) as batches on the device
+void HipGrid::get_value_deriv_batch(size_t n, const double* x, int stride, double* value, double* deriv) const {
+  if (n == 0) return;
+  DevMem dx, dE, dD;
+  dx.reserve(sizeof(double) * n * stride);
+  dE.reserve(sizeof(double) * n);
+  dD.reserve(sizeof(double) * n * dim_);
+  check(edm_hip_memcpy_h2d(dx.p, x, sizeof(double) * n * stride), "grid.h:get_value_deriv");
+  check(edm_hip_grid_get_value_deriv(h_, (long long)n, (const double*)dx.p, stride, (double*)dE.p, (double*)dD.p),
+        "grid.h:get_value_deriv");
+  if (value) check(edm_hip_memcpy_d2h(value, dE.p, sizeof(double) * n), "grid.h:get_value_deriv");
+  if (deriv) check(edm_hip_memcpy_d2h(deriv, dD.p, sizeof(double) * n * dim_), "grid.h:get_value_deriv");
+}
+double HipGrid::get_value(const double* x) const {
+  double v = 0;
+  get_value_deriv_batch(1, x, (int)dim_, &v, NULL);
+  return v;
+}
 double HipGrid::get_value_deriv(const double* x, double* der) const {
-  for (unsigned int d = 0; d < dim_; d++) der[d] = 0;
-  return get_value(x);
+  double v = 0;
+  get_value_deriv_batch(1, x, (int)dim_, &v, der);
+  return v;
 }
 
 double HipGrid::add_value(const double* x0, double value) {
+  if (b_interpolate_) edm_error("Cannot add_value when using derivatives", "grid.h:add_value");  // grid.h:371-373
+  if (!in_grid(x0)) return 0;
   DevMem dx;
   dx.reserve(sizeof(double) * dim_);
   check(edm_hip_memcpy_h2d(dx.p, x0, sizeof(double) * dim_), "grid.h:add_value");
-  for (unsigned int d = 0; d < dim_; d++)
-    if (!b_periodic_[d] && (x0[d] < min_[d] || x0[d] >= max_[d] - dx_[d])) return 0;
   check(edm_hip_grid_add_values(h_, 1, (const double*)dx.p, (int)dim_, NULL, value), "grid.h:add_value");
   return value;
 }
@@ -131,9 +172,13 @@ void HipGrid::multi_write(const std::string& filename, const double* box_low, co
                           const int* b_periodic, int b_lammps_format) const {
   check(edm_hip_grid_multi_write(h_, filename.c_str(), box_low, box_high, b_periodic, b_lammps_format), "grid.h:multi_write");
 }
-void HipGrid::read(const std::string&) { edm_error("reading into a device histogram grid is not supported", "grid.h:read"); }
+void HipGrid::read(const std::string& filename) {
+  check(edm_hip_grid_reread(h_, filename.c_str()), "grid.h:read");
+  refresh_geometry();
+}
 void HipGrid::set_interpolation(int b_interpolate) {
-  if (b_interpolate) edm_error("the device histogram grid has no derivatives to interpolate with", "grid.h:set_interpolation");
+  check(edm_hip_grid_set_interpolation(h_, b_interpolate), "grid.h:set_interpolation");
+  b_interpolate_ = b_interpolate ? 1 : 0;
 }
 const double* HipGrid::get_dx() const { return dx_; }
 const double* HipGrid::get_max() const { return max_; }
@@ -150,7 +195,15 @@ double HipGrid::min_value() const {
   for (size_t i = 0; i < grid_size_; i++) m = std::fmin(m, v[i]);
   return m;
 }
-void HipGrid::add(const Grid*, double, double) { edm_error("Grid::add is only available on the bias grid", "grid.h:add"); }
+// Grid::add (grid.h:275-290): `other` is evaluated on the device through its own get_value_deriv
+void HipGrid::add(const Grid* other, double scale, double offset) {
+  if (const HipGrid* g = dynamic_cast<const HipGrid*>(other))
+    check(edm_hip_grid_add_grid(h_, g->handle(), scale, offset), "grid.h:add");
+  else if (const HipGaussGrid* gg = dynamic_cast<const HipGaussGrid*>(other))
+    check(edm_hip_grid_add_gauss(h_, gg->handle(), scale, offset), "grid.h:add");
+  else
+    edm_error("Grid::add needs a device-resident grid (make_grid / read_grid / make_gauss_grid)", "grid.h:add");
+}
 size_t HipGrid::get_grid_size() const { return grid_size_; }
 void HipGrid::one2multi(size_t index, size_t* result) const {
   unsigned int d;
@@ -170,12 +223,19 @@ double HipGrid::expected_bias() const {
 }
 void HipGrid::clear() { check(edm_hip_grid_clear(h_), "grid.h:clear"); }
 
+// grid.cpp:3-45
 Grid* make_grid(unsigned int dim, const double* min, const double* max, const double* bin_spacing,
                 const int* b_periodic, int b_derivatives, int b_interpolate) {
   if (dim < 1 || dim > 3) return NULL;
-  if (b_derivatives || b_interpolate)
-    edm_error("device grids with derivatives are GaussGrids: use make_gauss_grid", "grid.cpp:make_grid");
-  return new HipGrid(dim, min, max, bin_spacing, b_periodic);
+  return new HipGrid(dim, min, max, bin_spacing, b_periodic, b_derivatives, b_interpolate);
+}
+Grid* read_grid(unsigned int dim, const std::string& filename, int b_interpolate) {
+  if (dim < 1 || dim > 3) return NULL;
+  return new HipGrid(dim, filename, b_interpolate);
+}
+Grid* read_grid(unsigned int dim, const std::string& filename) {
+  if (dim < 1 || dim > 3) return NULL;
+  return new HipGrid(dim, filename, 1);
 }
 
 // ================================================================================
@@ -205,6 +265,10 @@ HipGaussGrid::HipGaussGrid(unsigned int dim, const double* min, const double* ma
     : h_(NULL), owned_(true) {
   check(edm_hip_gauss_create(&h_, (int)dim, min, max, bin_spacing, b_periodic, b_interpolate, sigma),
         "gaussian_grid.h:DimmedGaussGrid");
+  refresh_geometry();
+}
+HipGaussGrid::HipGaussGrid(unsigned int dim, const std::string& filename, const double* sigma) : h_(NULL), owned_(true) {
+  check(edm_hip_gauss_read(&h_, (int)dim, filename.c_str(), sigma), "gaussian_grid.h:DimmedGaussGrid");
   refresh_geometry();
 }
 HipGaussGrid::HipGaussGrid(edm_hip_gauss* borrowed) : h_(borrowed), owned_(false) { refresh_geometry(); }
@@ -262,8 +326,9 @@ double HipGaussGrid::add_value(const double* x0, double height) {
   return added;
 }
 
-void HipGaussGrid::read(const std::string&) {
-  edm_error("use EDMBias' initial_bias_filename (Grid::add from a file) to load a bias", "gaussian_grid.h:read");
+void HipGaussGrid::read(const std::string& filename) {
+  check(edm_hip_gauss_reread(h_, filename.c_str()), "gaussian_grid.h:read");
+  refresh_geometry();
 }
 void HipGaussGrid::write(const std::string& filename) const { check(edm_hip_gauss_write(h_, filename.c_str()), "gaussian_grid.h:write"); }
 void HipGaussGrid::multi_write(const std::string& filename) const {
@@ -272,12 +337,13 @@ void HipGaussGrid::multi_write(const std::string& filename) const {
 void HipGaussGrid::lammps_multi_write(const std::string& filename) const {
   check(edm_hip_gauss_multi_write(h_, filename.c_str(), 1), "gaussian_grid.h:lammps_multi_write");
 }
-// gaussian_grid.h:160-166 ignores the box arguments' format flag and writes with its own boundary
-void HipGaussGrid::multi_write(const std::string& filename, const double*, const double*, const int*, int) const {
-  check(edm_hip_gauss_multi_write(h_, filename.c_str(), 0), "gaussian_grid.h:multi_write");
+// gaussian_grid.h:160-166: the caller's box, always the PLUMED layout (the format flag is ignored there)
+void HipGaussGrid::multi_write(const std::string& filename, const double* box_low, const double* box_high,
+                               const int* b_periodic, int) const {
+  check(edm_hip_gauss_multi_write_box(h_, filename.c_str(), box_low, box_high, b_periodic, 0), "gaussian_grid.h:multi_write");
 }
 void HipGaussGrid::set_interpolation(int b_interpolate) {
-  if (!b_interpolate) edm_error("the device bias grid always interpolates (INTERPOLATE 1, edm_bias.h:18)", "gaussian_grid.h:set_interpolation");
+  check(edm_hip_gauss_set_interpolation(h_, b_interpolate), "gaussian_grid.h:set_interpolation");
 }
 void HipGaussGrid::set_boundary(const double* min, const double* max, const int* b_periodic) {
   check(edm_hip_gauss_set_boundary(h_, min, max, b_periodic), "gaussian_grid.h:set_boundary");
@@ -324,8 +390,14 @@ double HipGaussGrid::min_value() const {
   for (size_t i = 0; i < grid_size_; i++) m = std::fmin(m, v[i]);
   return m;
 }
-void HipGaussGrid::add(const Grid*, double, double) {
-  edm_error("Grid::add takes a PLUMED grid file on the device path (initial_bias_filename)", "gaussian_grid.h:add");
+// Grid::add through the underlying grid (gaussian_grid.h:474-476 -> grid.h:275-290)
+void HipGaussGrid::add(const Grid* other, double scale, double offset) {
+  if (const HipGrid* g = dynamic_cast<const HipGrid*>(other))
+    check(edm_hip_gauss_add_grid(h_, g->handle(), scale, offset), "gaussian_grid.h:add");
+  else if (const HipGaussGrid* gg = dynamic_cast<const HipGaussGrid*>(other))
+    check(edm_hip_gauss_add_gauss(h_, gg->handle(), scale, offset), "gaussian_grid.h:add");
+  else
+    edm_error("Grid::add needs a device-resident grid (make_grid / read_grid / make_gauss_grid)", "gaussian_grid.h:add");
 }
 double HipGaussGrid::expected_bias() const {
   const double* v = const_cast<HipGaussGrid*>(this)->get_grid();
@@ -343,10 +415,23 @@ int HipGaussGrid::in_bounds(const double* x) const {
   return 1;
 }
 
+void HipGaussGrid::remap(double* x) const {
+  DevMem dx, dout;
+  dx.reserve(sizeof(double) * dim_);
+  dout.reserve(sizeof(double) * dim_);
+  check(edm_hip_memcpy_h2d(dx.p, x, sizeof(double) * dim_), "gaussian_grid.h:remap");
+  check(edm_hip_gauss_remap(h_, 1, (const double*)dx.p, (int)dim_, (double*)dout.p), "gaussian_grid.h:remap");
+  check(edm_hip_memcpy_d2h(x, dout.p, sizeof(double) * dim_), "gaussian_grid.h:remap");
+}
+
 GaussGrid* make_gauss_grid(unsigned int dim, const double* min, const double* max, const double* bin_spacing,
                            const int* b_periodic, int b_interpolate, const double* sigma) {
   if (dim < 1 || dim > 3) return NULL;
   return new HipGaussGrid(dim, min, max, bin_spacing, b_periodic, b_interpolate, sigma);
+}
+GaussGrid* read_gauss_grid(unsigned int dim, const std::string& filename, const double* sigma) {
+  if (dim < 1 || dim > 3) return NULL;
+  return new HipGaussGrid(dim, filename, sigma);
 }
 
 // ================================================================================

@@ -32,6 +32,7 @@ class HipGaussGrid : public GaussGrid {
  public:
   HipGaussGrid(unsigned int dim, const double* min, const double* max, const double* bin_spacing,
                const int* b_periodic, int b_interpolate, const double* sigma);
+  HipGaussGrid(unsigned int dim, const std::string& filename, const double* sigma);  // DimmedGaussGrid(filename, sigma)
   explicit HipGaussGrid(edm_hip_gauss* borrowed);  // view of the grid owned by an EDMBias
   ~HipGaussGrid();
 
@@ -59,6 +60,8 @@ class HipGaussGrid : public GaussGrid {
   void clear();
   size_t get_grid_size() const;
   int in_bounds(const double* x) const;
+  // DimmedGaussGrid::remap (gaussian_grid.h:504-541), evaluated by the device code the lookups use; x updated in place
+  void remap(double* x) const;
 
   // ---- batched entry points (host arrays; staged through HBM) ----
   // positions/derivs row-major [n][stride]; returns sum of values
@@ -90,6 +93,8 @@ class HipGaussGrid : public GaussGrid {
 
 GaussGrid* make_gauss_grid(unsigned int dim, const double* min, const double* max, const double* bin_spacing,
                            const int* b_periodic, int b_interpolate, const double* sigma);
+// read_gauss_grid (gaussian_grid.h:647, gaussian_grid.cpp:23-33)
+GaussGrid* read_gauss_grid(unsigned int dim, const std::string& filename, const double* sigma);
 
 }  // namespace EDM
 #endif

@@ -42,11 +42,14 @@ class Grid {
   virtual void clear() = 0;
 };
 
-// Device-resident DimmedGrid<DIM> without derivatives/interpolation: the CV histogram
-// (reference: make_grid(dim, ..., 0, 0), edm_bias.cpp:163).
+// Device-resident DimmedGrid<DIM> (grid.h:184-905): the CV histogram and target flavour (no derivatives, no
+// interpolation, make_grid(dim, ..., 0, 0), edm_bias.cpp:163) as well as grids with derivative records and
+// cubic-Hermite interpolation (what read_grid returns for a PLUMED file with FORCE 1).
 class HipGrid : public Grid {
  public:
-  HipGrid(unsigned int dim, const double* min, const double* max, const double* bin_spacing, const int* b_periodic);
+  HipGrid(unsigned int dim, const double* min, const double* max, const double* bin_spacing, const int* b_periodic,
+          int b_derivatives = 0, int b_interpolate = 0);
+  HipGrid(unsigned int dim, const std::string& input_grid, int b_interpolate = 1);  // DimmedGrid(filename[, b_interpolate])
   explicit HipGrid(edm_hip_grid* borrowed);  // view of a grid owned by an EDMBias
   ~HipGrid();
   double get_value(const double* x) const;
@@ -69,8 +72,20 @@ class HipGrid : public Grid {
   double expected_bias() const;
   void clear();
 
-  // DimmedGrid's public geometry members (grid.h:876-885)
+  // index helpers of DimmedGrid (grid.h:264-273, :315-325, :865-874), host arithmetic in the reference's order
+  void get_index(const double* x, size_t* result) const;
+  size_t multi2one(const size_t* index) const;
+  int in_grid(const double* x) const;
+  // host snapshot of grid_deriv_ [grid_size][dim] (grids with derivatives)
+  const double* get_grid_deriv();
+  // overwrite node values / derivatives from host arrays (what writing grid_[i] / grid_deriv_[i] does in the reference)
+  void set_grid(const double* values, const double* derivs);
+  // batched lookup on host arrays: rows [n][stride]; value / deriv [n][dim] may be NULL
+  void get_value_deriv_batch(size_t n, const double* x, int stride, double* value, double* deriv) const;
+
+  // DimmedGrid's public members (grid.h:876-885)
   size_t grid_size_;
+  int b_derivatives_, b_interpolate_;
   unsigned int dim_;
   double dx_[3], min_[3], max_[3];
   int grid_number_[3], b_periodic_[3];
@@ -80,13 +95,14 @@ class HipGrid : public Grid {
   void refresh_geometry();
   edm_hip_grid* h_;
   bool owned_;
-  mutable std::vector<double> snapshot_;
+  mutable std::vector<double> snapshot_, snapshot_deriv_;
 };
 
-// make_grid (grid.h:911-917): only the histogram flavour (no derivatives, no interpolation)
-// exists on the device; any other combination is an error like an unsupported dimension.
+// make_grid / read_grid (grid.h:911-928, grid.cpp:3-45)
 Grid* make_grid(unsigned int dim, const double* min, const double* max, const double* bin_spacing,
                 const int* b_periodic, int b_derivatives, int b_interpolate);
+Grid* read_grid(unsigned int dim, const std::string& filename, int b_interpolate);
+Grid* read_grid(unsigned int dim, const std::string& filename);
 
 }  // namespace EDM
 #endif

@@ -177,6 +177,11 @@ int edm_hip_gauss_get_value_deriv(const edm_hip_gauss *g, long long n, const dou
 int edm_hip_gauss_sample_index(const edm_hip_gauss *g, long long n, const double *d_x,
                                int x_stride, long long *d_flat);
 
+/* DimmedGaussGrid::remap batched (gaussian_grid.h:504-541): the image of each sample the lookup and hill kernels
+ * work with (periodic grid: wrapped into the grid; non-periodic grid inside a periodic boundary: shifted by the
+ * boundary period that lands nearest the grid's minimum or maximum).  d_out rows of dim doubles. */
+int edm_hip_gauss_remap(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride, double *d_out);
+
 /* EDMBias::update_forces (edm_bias.cpp:276-295): for every sample with
  * (apply_mask < 0 || d_mask[i] & apply_mask): E += V(x_i); f[i][j] -= dV/ds_j.
  * d_mask may be NULL when apply_mask < 0.  *energy = sum of V (host double). */

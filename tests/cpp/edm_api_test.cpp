@@ -1,7 +1,7 @@
 // edm_api_test.cpp -- the reference's unit tests (tests/edm_test.cpp, Boost.Test) restated
 // against the source-compatible C++ API of this build (include/edm/*.h over libedm_hip.so).
 // Expectations and tolerances are the reference's own (cited per case); needs an MI355X.
-//   usage: edm_api_test <fixture-dir> <scratch-dir>
+//   usage: edm_api_test <fixture-dir> <scratch-dir> [<golden-dir>]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -78,6 +78,189 @@ static void grid_3d_sanity() {  // edm_test.cpp:61-107
     REQUIRE(g->get_grid()[flat] == 7.0);
   }
   delete g;
+}
+
+static bool same_file(const std::string& a, const std::string& b) {
+  FILE* fa = std::fopen(a.c_str(), "rb");
+  FILE* fb = std::fopen(b.c_str(), "rb");
+  bool same = fa && fb;
+  while (same) {
+    const int ca = std::fgetc(fa), cb = std::fgetc(fb);
+    if (ca != cb) same = false;
+    if (ca == EOF || cb == EOF) break;
+  }
+  if (fa) std::fclose(fa);
+  if (fb) std::fclose(fb);
+  return same;
+}
+
+static void grid_1d_read(const std::string& fx) {  // edm_test.cpp:109-115
+  HipGrid g(1, fx + "/1.grid");
+  REQUIRE(g.min_[0] == 0);
+  REQUIRE(g.max_[0] == 2.5 + g.dx_[0]);
+  REQUIRE(g.grid_number_[0] == 101);
+  REQUIRE(g.b_derivatives_ == 1 && g.b_interpolate_ == 1);
+}
+
+static void grid_3d_read(const std::string& fx) {  // edm_test.cpp:117-125
+  Grid* gp = read_grid(3, fx + "/3.grid");
+  HipGrid& g = *static_cast<HipGrid*>(gp);
+  REQUIRE(g.min_[2] == 0);
+  REQUIRE(g.max_[2] == 2.5 + g.dx_[2]);
+  REQUIRE(g.grid_number_[2] == 11);
+  double temp[] = {0.75, 0, 1.00};
+  REQUIRE(std::pow(g.get_value(temp) - 1.260095, 2) < EPSILON);
+  // a node read back without interpolation is the file's value to all printed digits
+  g.set_interpolation(0);
+  REQUIRE(std::fabs(g.get_value(temp) - 1.260095) < 5e-7);
+  delete gp;
+}
+
+static void derivative_direction(const std::string& fx) {  // edm_test.cpp:127-138
+  HipGrid g(3, fx + "/3.grid");
+  g.set_interpolation(1);
+  double temp[] = {0.75, 0, 1.00};
+  double temp2[] = {0.76, 0, 1.00};
+  REQUIRE(g.get_value(temp2) > g.get_value(temp));
+  temp2[0] = 0.75;
+  temp2[2] = 0.99;
+  REQUIRE(g.get_value(temp2) < g.get_value(temp));
+  // files store the force, grids the gradient (grid.h:828): dV/dx at the node is MINUS the file's column
+  double der[3];
+  g.get_value_deriv(temp, der);
+  REQUIRE(der[0] > 0);
+}
+
+static void grid_read_write_consistency(const std::string& fx, const std::string& scratch, const std::string& golden) {
+  // edm_test.cpp:142-180, plus: the re-written files are byte-identical to the reference's own re-writes
+  for (int i = 1; i <= 3; i++) {
+    const std::string name = std::to_string(i) + ".grid";
+    const std::string output = scratch + "/" + name + ".test";
+    Grid* g = read_grid((unsigned)i, fx + "/" + name);
+    g->write(output);
+    const size_t ref_length = g->get_grid_size();
+    std::vector<double> ref_grid(g->get_grid(), g->get_grid() + ref_length);
+    g->read(output);
+    REQUIRE(g->get_grid_size() == ref_length);
+    const double* again = g->get_grid();
+    bool ok = true;
+    for (size_t j = 0; j < ref_length; j++) ok = ok && std::pow(ref_grid[j] - again[j], 2) < EPSILON;
+    REQUIRE(ok);
+    if (!golden.empty()) REQUIRE(same_file(output, golden + "/file_" + std::to_string(i) + "_rewritten.grid"));
+    delete g;
+  }
+}
+
+static void edm_bias_reader(const std::string& fx) {  // edm_test.cpp:846-852
+  // read_test.edm names its target grid "2.grid.test", relative to the working directory: the file
+  // grid_read_write_consistency has just written there (the reference's test has the same dependency)
+  EDMBias bias(fx + "/read_test.edm");
+  REQUIRE(bias.dim_ == 2);
+  REQUIRE(bias.b_tempering_ == 0);
+  REQUIRE(std::pow(bias.bias_sigma_[0] - 2, 2) < EPSILON);
+  REQUIRE(std::pow(bias.bias_dx_[1] - 1.0, 2) < EPSILON);
+  REQUIRE(bias.b_targeting_ == 1 && bias.hill_density_ == 1 && bias.hill_prefactor_ == 1.0);
+}
+
+static void grid_add_and_gauss_read(const std::string& fx, const std::string& scratch) {
+  // Grid::add (grid.h:275-290) and read_gauss_grid (gaussian_grid.h:647): a gaussian grid rebuilt from 1.grid, a
+  // fresh gaussian grid of the same geometry + add(file grid) -- the same node values; add with scale / offset
+  double sg[] = {0.05};
+  GaussGrid* a = read_gauss_grid(1, fx + "/1.grid", sg);
+  Grid* file = read_grid(1, fx + "/1.grid", 1);
+  double mn[] = {0}, mx[] = {2.5}, sp[] = {0.025};
+  int per[] = {0};
+  GaussGrid* b = make_gauss_grid(1, mn, mx, sp, per, 1, sg);
+  REQUIRE(a->get_grid_size() == 101 && b->get_grid_size() == 101);
+  b->add(file, 1.0, 0.0);
+  std::vector<double> va(a->get_grid(), a->get_grid() + 101), vb(b->get_grid(), b->get_grid() + 101);
+  bool same = true;
+  for (int i = 0; i < 100; i++) same = same && std::fabs(va[i] - vb[i]) < 1e-12;   // (node 100 lies outside in_grid of the file grid: 0)
+  REQUIRE(same);
+  REQUIRE(vb[100] == 0);
+  b->add(a, 2.0, 0.5);   // other = a GaussGrid: evaluated through its boundary-aware get_value_deriv
+  const double* v3 = b->get_grid();
+  bool ok = true;
+  for (int i = 0; i < 100; i++) ok = ok && std::fabs(v3[i] - (3 * va[i] + 0.5)) < 1e-12;
+  REQUIRE(ok);
+  // plain grids with derivatives: make_grid(.., 1, 1), add, interpolate
+  HipGrid* p = static_cast<HipGrid*>(make_grid(1, mn, mx, sp, per, 1, 1));
+  REQUIRE(p->b_derivatives_ == 1 && p->grid_number_[0] == 101);
+  p->add(file, 1.0, 0.0);
+  double x[] = {1.2345}, d1[1], d2[1];
+  const double e1 = p->get_value_deriv(x, d1), e2 = file->get_value_deriv(x, d2);
+  REQUIRE(std::fabs(e1 - e2) < 1e-12 && std::fabs(d1[0] - d2[0]) < 1e-10);
+  // a re-read gaussian grid writes the file it was read from (8-decimal text of 6-decimal input)
+  a->write(scratch + "/1.gauss.test");
+  file->write(scratch + "/1.plain.test");
+  REQUIRE(same_file(scratch + "/1.gauss.test", scratch + "/1.plain.test"));
+  a->read(scratch + "/1.gauss.test");
+  REQUIRE(std::fabs(a->get_grid()[7] - va[7]) < 1e-12);
+  delete a; delete b; delete file; delete p;
+}
+
+static void boundary_remap_wraps() {  // edm_test.cpp:252-333 (boundary_remap_wrap, _wrap_2) and :363-387 (nowrap_1)
+  {
+    double mn[] = {0, 0}, mx[] = {10, 5}, sp[] = {1, 1}, sg[] = {0.1, 0.1};
+    int per[] = {1, 0, 0};
+    HipGaussGrid* g = gauss(2, mn, mx, sp, per, 1, sg);
+    mx[1] = 10;
+    per[1] = 1;
+    g->set_boundary(mn, mx, per);
+    double t[] = {0, 1};
+    g->remap(t);
+    REQUIRE(std::pow(t[0] - 0, 2) < 0.1 && std::pow(t[1] - 1, 2) < 0.1);
+    t[0] = -1;  // on grid, at 9
+    g->remap(t);
+    REQUIRE(std::pow(t[0] - 9, 2) < 0.1 && std::pow(t[1] - 1, 2) < 0.1);
+    t[1] = 6;   // closest point is 6
+    g->remap(t);
+    REQUIRE(std::pow(t[0] - 9, 2) < 0.1 && std::pow(t[1] - 6, 2) < 0.1);
+    t[1] = 11;  // actually in grid at 1
+    g->remap(t);
+    REQUIRE(std::pow(t[0] - 9, 2) < 0.1 && std::pow(t[1] - 1, 2) < 0.1);
+    t[1] = 9;   // closest point is -1
+    g->remap(t);
+    REQUIRE(std::pow(t[0] - 9, 2) < 0.1 && std::pow(t[1] - -1, 2) < 0.1);
+    t[1] = -1;
+    g->remap(t);
+    REQUIRE(std::pow(t[0] - 9, 2) < 0.1 && std::pow(t[1] - -1, 2) < 0.1);
+    delete g;
+  }
+  {
+    double mn[] = {-2}, mx[] = {7}, sp[] = {0.1}, sg[] = {0.1};
+    int per[] = {0};
+    HipGaussGrid* g = gauss(1, mn, mx, sp, per, 1, sg);
+    mn[0] = 0; mx[0] = 10; per[0] = 1;
+    g->set_boundary(mn, mx, per);
+    double t[] = {0};
+    g->remap(t);
+    REQUIRE(std::pow(t[0] - 0, 2) < 0.1);
+    t[0] = -1;  // should not remap
+    g->remap(t);
+    REQUIRE(std::pow(t[0] - -1, 2) < 0.1);
+    t[0] = 9;   // should remap
+    g->remap(t);
+    REQUIRE(std::pow(t[0] - -1, 2) < 0.1);
+    t[0] = 6;   // should not remap
+    g->remap(t);
+    REQUIRE(std::pow(t[0] - 6, 2) < 0.1);
+    delete g;
+  }
+  {  // boundary_remap_nowrap_1: a hill just outside a NON-periodic boundary is rejected, nothing is remapped
+    double mn[] = {-2}, mx[] = {7}, sp[] = {0.1}, sg[] = {0.1};
+    int per[] = {0};
+    HipGaussGrid* g = gauss(1, mn, mx, sp, per, 1, sg);
+    mn[0] = 0; mx[0] = 10; per[0] = 0;
+    g->set_boundary(mn, mx, per);
+    double point[] = {-0.01};
+    REQUIRE(g->add_value(point, 1) == 0);
+    double der[1];
+    point[0] = 0;
+    g->get_value_deriv(point, der);
+    REQUIRE(std::fabs(point[0]) < EPSILON && der[0] == 0);
+    delete g;
+  }
 }
 
 static void interpolation_1d() {  // edm_test.cpp:182-218
@@ -474,11 +657,18 @@ static void edm_bias_tests(const std::string& fx, const std::string& scratch) {
 
 int main(int argc, char** argv) {
   if (argc < 3) {
-    std::printf("usage: %s <fixture-dir> <scratch-dir>\n", argv[0]);
+    std::printf("usage: %s <fixture-dir> <scratch-dir> [<golden-dir>]\n", argv[0]);
     return 2;
   }
   grid_1d_sanity();
   grid_3d_sanity();
+  grid_1d_read(argv[1]);
+  grid_3d_read(argv[1]);
+  derivative_direction(argv[1]);
+  grid_read_write_consistency(argv[1], argv[2], argc > 3 ? argv[3] : "");
+  edm_bias_reader(argv[1]);
+  grid_add_and_gauss_read(argv[1], argv[2]);
+  boundary_remap_wraps();
   interpolation_1d();
   interp_1d_periodic();
   interp_3d_mixed();
