@@ -701,6 +701,7 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
     for (int k = 0; k < 2; k++)
       if (g->tab[d][k]) (void)hipFree(g->tab[d][k]);
   if (g->rec) (void)hipFree(g->rec);
+  if (g->faces) (void)hipFree(g->faces);
   if (g->scratch) (void)hipFree(g->scratch);
   if (g->d_scalars) (void)hipFree(g->d_scalars);
   if (g->h_scalars) (void)hipHostFree(g->h_scalars);
@@ -780,16 +781,23 @@ int edm_hip_gauss_download(const edm_hip_gauss *g, double *h_values, double *h_d
 
 int edm_hip_gauss_upload(edm_hip_gauss *g, const double *h_values, const double *h_derivs) {
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  faces_touch(g);
   return records_upload(g->g, g->rec, g->stream, h_values, h_derivs);
 }
 
 int edm_hip_gauss_clear(edm_hip_gauss *g) {
+  faces_touch(g);
   EDM_HIP_TRY(hipMemsetAsync(g->rec, 0, sizeof(double) * (size_t)g->g.total * g->g.rec, g->stream));
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
   return EDM_HIP_OK;
 }
 
 int edm_hip_gauss_device_buffer(edm_hip_gauss *g, double **d_records, int *doubles_per_node, long long *nodes) {
+  // the caller may write the records behind the library's back (a collective): wait for queued updates, and
+  // keep the lookups on the node records themselves from here on
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  g->faces_mode = 0;
+  faces_touch(g);
   if (d_records) *d_records = g->rec;
   if (doubles_per_node) *doubles_per_node = g->g.rec;
   if (nodes) *nodes = g->g.total;
@@ -830,7 +838,10 @@ int edm_hip_gauss_get_value_deriv(const edm_hip_gauss *g, long long n, const dou
   if (n <= 0) return EDM_HIP_OK;
   LookupArgs a{};
   a.n = n; a.x = d_x; a.x_stride = x_stride; a.energy = d_energy; a.f = d_deriv; a.apply_mask = -1;
-  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_VALUES, a, g->scratch, nullptr, g->stream));
+  const double *faces = nullptr;
+  int rc = faces_prepare(const_cast<edm_hip_gauss *>(g), &faces);
+  if (rc) return rc;
+  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_VALUES, a, g->scratch, nullptr, g->stream, nullptr, nullptr, nullptr, faces));
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
   return EDM_HIP_OK;
 }
@@ -909,6 +920,41 @@ int edm_hip_gauss_profile_read(edm_hip_gauss *g, double *kernel_ms_total, long l
 // ---- hill application pipeline --------------------------------------------------
 namespace edm {
 
+static bool faces_wanted(const edm_hip_gauss *g) {
+  const Geom &q = g->g;
+  if (g->faces_mode == 0 || q.dim < 2 || !q.interp || q.rec != 4) return false;
+  for (int d = 0; d < q.dim; d++)
+    if (!q.bper[d]) return false;   // (walls: the boundary duplication writes node values the replica would miss)
+  if (g->faces_mode == 1) return true;
+  // automatic: only where the node records outgrow the L2s (8 x 4 MB): below that the corner gathers hit cache
+  return (size_t)q.total * q.rec * sizeof(double) >= ((size_t)32 << 20) && !g->faces_unavailable;
+}
+int faces_prepare(edm_hip_gauss *g, const double **faces) {
+  *faces = nullptr;
+  if (!faces_wanted(g)) return EDM_HIP_OK;
+  const size_t bytes = (size_t)g->g.total * 16 * sizeof(double);
+  if (!g->faces) {
+    size_t free_b = 0, total_b = 0;
+    const bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > bytes + ((size_t)2 << 30);
+    hipError_t e = fits ? hipMalloc(reinterpret_cast<void **>(&g->faces), bytes) : hipErrorOutOfMemory;
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      g->faces = nullptr;
+      if (g->faces_mode == 1) return hip_fail(e, "hipMalloc(lookup replica)");
+      g->faces_unavailable = true;   // an optimisation, not a requirement: the node records serve the lookups
+      return EDM_HIP_OK;
+    }
+    g->faces_state = 2;
+  }
+  if (g->faces_state != 1) {
+    EDM_HIP_TRY(launch_build_faces(g->g, g->rec, g->faces, g->stream));
+    g->faces_state = 1;
+    g->faces_builds++;
+  }
+  *faces = g->faces;
+  return EDM_HIP_OK;
+}
+
 // K1 without the host wait: the launch is queued, the per-workgroup energy sums land in host-mapped
 // memory; pair_forces_finish() adds them up after the stream has been synchronised by the caller
 int pair_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_r, double *d_force, int *nblk) {
@@ -936,7 +982,10 @@ int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x
   a.n = n; a.x = d_x; a.x_stride = x_stride; a.f = d_f; a.f_stride = f_stride; a.mask = d_mask; a.apply_mask = apply_mask;
   hipEvent_t e0, e1;
   profile_slot(g, &e0, &e1);
-  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, a, g->d_partials, nullptr, g->stream, e0, e1, nblk));
+  const double *faces = nullptr;
+  int rcf = faces_prepare(const_cast<edm_hip_gauss *>(g), &faces);
+  if (rcf) return rcf;
+  EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, a, g->d_partials, nullptr, g->stream, e0, e1, nblk, faces));
   return EDM_HIP_OK;
 }
 int pending_forces_flush(const edm_hip_gauss *g, PendingForces *pf) {
@@ -1301,6 +1350,16 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       plan.tile_bound = plan_nh * per_hill;
     }
   }
+  // lookup replica: the in-place gather keeps it current; every other way of applying the batch leaves it stale
+  plan.faces = nullptr;
+  plan.slots = nullptr;
+  plan.slots_per_hill = 0;
+  if (g->faces && g->faces_state == 1) {
+    if (!fused && !sharded && !spec.ordered && plan.groups == 1)
+      plan.faces = g->faces;
+    else
+      g->faces_state = 2;
+  }
   const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
   bool chain_post = false;
   if (sharded) {
@@ -1663,6 +1722,7 @@ int edm_hip_gauss_add_grid(edm_hip_gauss *g, const edm_hip_grid *other, double s
     return EDM_HIP_ERR_ARG;
   }
   EDM_HIP_TRY(hipStreamSynchronize(other->stream));
+  faces_touch(g);
   return grid_add_from(g->g, g->rec, g->stream, g->scratch, plain_geom(other->g), other->values, scale, offset);
 }
 int edm_hip_gauss_add_gauss(edm_hip_gauss *g, const edm_hip_gauss *other, double scale, double offset) {
@@ -1671,6 +1731,7 @@ int edm_hip_gauss_add_gauss(edm_hip_gauss *g, const edm_hip_gauss *other, double
     return EDM_HIP_ERR_ARG;
   }
   EDM_HIP_TRY(hipStreamSynchronize(other->stream));
+  faces_touch(g);
   return grid_add_from(g->g, g->rec, g->stream, g->scratch, other->g, other->rec, scale, offset);
 }
 // Grid::add (grid.h:275-290) from a PLUMED grid file read with interpolation (read_grid(dim, file, 1)):
@@ -1709,7 +1770,11 @@ int edm_hip_gauss_reread(edm_hip_gauss *g, const char *filename) {
     q.bper[d] = g->g.bper[d];
     q.msize[d] = g->g.msize[d];
   }
+  faces_touch(g);
   if (q.total != g->g.total) {
+    if (g->faces) (void)hipFree(g->faces);
+    g->faces = nullptr;
+    g->faces_state = 0;
     EDM_HIP_TRY(hipFree(g->rec));
     g->rec = nullptr;
     EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->rec), sizeof(double) * (size_t)q.total * q.rec));
@@ -1717,6 +1782,24 @@ int edm_hip_gauss_reread(edm_hip_gauss *g, const char *filename) {
   g->g = q;
   g->tiles_per_hill = 0;
   return records_upload(g->g, g->rec, g->stream, gf.values.data(), gf.derivs.data());
+}
+int edm_hip_gauss_set_lookup_replica(edm_hip_gauss *g, int mode) {
+  if (mode < -1 || mode > 1) return EDM_HIP_ERR_ARG;
+  g->faces_mode = mode;
+  g->faces_unavailable = false;
+  if (mode == 0 && g->faces) {
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    EDM_HIP_TRY(hipFree(g->faces));
+    g->faces = nullptr;
+    g->faces_state = 0;
+  }
+  return EDM_HIP_OK;
+}
+int edm_hip_gauss_lookup_replica_info(const edm_hip_gauss *g, int *in_use, long long *bytes, long long *rebuilds) {
+  if (in_use) *in_use = (g->faces && g->faces_state == 1) ? 1 : 0;
+  if (bytes) *bytes = g->faces ? (long long)g->g.total * 128 : 0;
+  if (rebuilds) *rebuilds = g->faces_builds;
+  return EDM_HIP_OK;
 }
 int edm_hip_gauss_set_interpolation(edm_hip_gauss *g, int b_interpolate) {
   g->g.interp = b_interpolate ? 1 : 0;

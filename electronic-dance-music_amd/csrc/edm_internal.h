@@ -115,6 +115,14 @@ struct edm_hip_gauss {
   int *d_dirty = nullptr;
   long long tiles_per_hill = 0;          // cached tiles_per_hill_bound() of the current geometry / boundary
   int *d_tickets = nullptr;              // three last-workgroup tickets (EDM_TICKET_INTS ints each), kept zero
+  // lookup replica of a 2-D / 3-D grid with a periodic boundary (see lookup_one / launch_build_faces): g.total
+  // blocks of 128 bytes, 4x the node records -- memory spent so that a coordinate-CV sample reads 1 or 2 aligned
+  // lines instead of 2.5 / 5.  faces_mode: -1 = automatic (grids beyond the L2s' reach), 0 = off, 1 = always.
+  double *faces = nullptr;
+  int faces_mode = -1;
+  int faces_state = 0;                   // 0 = not built, 1 = current, 2 = stale (a path other than the in-place gather wrote the records)
+  bool faces_unavailable = false;        // automatic mode: the allocation did not fit, stay on the node records
+  long long faces_builds = 0;            // full rebuilds so far (telemetry / tests)
   // bench support: HIP events around the dominant lookup kernel
   // (a ring of event pairs: the launches of a timed loop are stamped without any host-side read in between;
   //  the elapsed times are summed up by profile_read, outside the loop)
@@ -194,6 +202,11 @@ struct ApplyOutcome {
 // prep -> integrals -> (limiter) -> ordered gather -> boundary duplication.
 // Leaves per-hill `added` in g->ws.added and the tail arrays in g->ws.tail_*.
 int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool want_total);
+// the lookup replica, built or rebuilt if it is wanted and not current; *faces = NULL when the grid does not use one
+int faces_prepare(edm_hip_gauss *g, const double **faces);
+inline void faces_touch(edm_hip_gauss *g) {   // the node records were written by a path that does not maintain the replica
+  if (g->faces_state == 1) g->faces_state = 2;
+}
 int pair_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_r, double *d_force, int *nblk);
 int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride, double *d_f, int f_stride,
                           const int *d_mask, int apply_mask, int *nblk);

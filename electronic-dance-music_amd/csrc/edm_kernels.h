@@ -41,9 +41,15 @@ size_t lookup_scratch_doubles();
 // time exactly that launch with hipEventElapsedTime.
 // blocks_out (may be NULL) receives the number of per-block partial sums written to `scratch`;
 // a caller that passes energy_out == NULL can sum them itself in index order.
+// faces (may be NULL): the lookup replica of a 2-D / 3-D grid (launch_build_faces) -- interpolating lookups then
+// read their corner records from it (1 or 2 aligned 128-byte lines per sample) with bit-identical results
 hipError_t launch_lookup(const Geom &g, const double *rec, LookupMode mode, const LookupArgs &a,
                          double *scratch, double *energy_out, hipStream_t s,
-                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int *blocks_out = nullptr);
+                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int *blocks_out = nullptr,
+                         const double *faces = nullptr);
+// lookup replica of a 2-D / 3-D grid: g.total blocks of 16 doubles; block(i0, i1[, i2]) = the records of nodes
+// (i0, i1), (i0+1, i1), (i0, i1+1), (i0+1, i1+1) [at i2], periodic wrap applied
+hipError_t launch_build_faces(const Geom &g, const double *rec, double *faces, hipStream_t s);
 // 1-D pair-distance form: force[i] = -dV/dr(r_i)
 // fix edm_pair on a device-resident neighbour list (fix_edm_pair.cpp:177-238 over flattened pair records).
 // Pass 1, one thread per list entry: pair distance from the positions, bias lookup, the entry's force vector
@@ -208,6 +214,8 @@ struct GatherPlan {
   // (rare) hills the limiter changed.
   double *slots;
   int slots_per_hill;
+  // lookup replica kept current by an in-place gather (groups == 1, MODE 0) of a 2-D / 3-D grid, or NULL
+  double *faces;
 };
 // slots per hill needed by the fused gather for this geometry
 int gather_slots_per_hill(const Geom &g);

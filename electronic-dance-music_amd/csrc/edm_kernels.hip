@@ -320,9 +320,15 @@ struct Rec<4> {
 
 // Returns the flat start node (or -1 where the reference returns 0) and the
 // interpolated value / POSITIVE gradient.
-template <int DIM>
+// FACES (2-D / 3-D): the corner records come from the lookup replica instead of the node records -- one 128-byte
+// block per node holding rec(i0, i1[, i2]), rec(i0+1, i1), rec(i0, i1+1), rec(i0+1, i1+1) (periodic wrap applied),
+// i.e. the four corners of a cell in 2-D and one face of it in 3-D: a sample touches ONE (2-D) or TWO (3-D) aligned
+// 128-byte lines where the node records cost it 2.5 / 5 (each corner pair is 64 B somewhere inside a line, and a
+// random atom shares its lines with nobody).  Same arithmetic, same operand order: the results are bit-identical.
+template <int DIM, bool FACES = false>
 __device__ __forceinline__ long long lookup_one(const Geom &g, const double *__restrict__ rec,
-                                                const double *xin, double &value, double *der) {
+                                                const double *xin, double &value, double *der,
+                                                const double *__restrict__ faces = nullptr) {
   constexpr int R = (DIM == 1) ? 2 : 4;
   double xx[DIM];
 #pragma unroll
@@ -376,7 +382,13 @@ __device__ __forceinline__ long long lookup_one(const Geom &g, const double *__r
 #pragma unroll
     for (int d = 0; d < DIM; d++) shift += stride[d] * ((corner >> d) & 1);
     Rec<R> r;
-    r.load(rec, flat + shift);
+    if (FACES && DIM > 1) {
+      // block of the cell's start node, or (3-D, upper four corners) of the node above it; slot = corner & 3
+      const long long blk = (DIM == 3 && (corner & 4)) ? flat + stride[DIM - 1] : flat;
+      r.load(faces, blk * 4 + (corner & 3));
+    } else {
+      r.load(rec, flat + shift);
+    }
     const double tf = r.v[0];
     double C[DIM], D[DIM];
     double ff = 1.0;
@@ -411,9 +423,10 @@ __device__ __forceinline__ long long lookup_one(const Geom &g, const double *__r
   return flat;
 }
 
-template <int DIM, int MODE>
+template <int DIM, int MODE, bool FACES = false>
 __global__ void __launch_bounds__(BLOCK) k_lookup(Geom g, const double *__restrict__ rec, LookupArgs a,
-                                                  double *__restrict__ block_energy) {
+                                                  double *__restrict__ block_energy,
+                                                  const double *__restrict__ faces = nullptr) {
   __shared__ double lds[BLOCK / 64];
   double e_acc = 0;
   const long long stride = (long long)gridDim.x * BLOCK;
@@ -422,7 +435,7 @@ __global__ void __launch_bounds__(BLOCK) k_lookup(Geom g, const double *__restri
     double xin[DIM], der[DIM], v;
 #pragma unroll
     for (int d = 0; d < DIM; d++) xin[d] = a.x[i * a.x_stride + d];
-    const long long flat = lookup_one<DIM>(g, rec, xin, v, der);
+    const long long flat = lookup_one<DIM, FACES>(g, rec, xin, v, der, faces);
     if (MODE == LOOKUP_FORCES) {
       e_acc += v;
 #pragma unroll
@@ -447,19 +460,27 @@ size_t lookup_scratch_doubles() { return MAX_BLOCKS + 8; }
 template <int DIM>
 static hipError_t lookup_dim(const Geom &g, const double *rec, LookupMode mode, const LookupArgs &a,
                              double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
-                             int *blocks_out) {
+                             int *blocks_out, const double *faces) {
   int blocks = (int)((a.n + BLOCK - 1) / BLOCK);
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
+  const double *none = nullptr;
+  const bool use_faces = faces && DIM > 1 && g.interp;
   switch (mode) {
     case LOOKUP_FORCES:
-      EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_FORCES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch);
+      if (use_faces)
+        EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_FORCES, (DIM > 1)>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, faces);
+      else
+        EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_FORCES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, none);
       break;
     case LOOKUP_VALUES:
-      EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_VALUES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch);
+      if (use_faces)
+        EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_VALUES, (DIM > 1)>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, faces);
+      else
+        EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_VALUES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, none);
       break;
     default:
-      EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_INDEX>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch);
+      EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_INDEX>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, none);
       break;
   }
   if (blocks_out) *blocks_out = blocks;
@@ -470,11 +491,63 @@ static hipError_t lookup_dim(const Geom &g, const double *rec, LookupMode mode, 
 
 hipError_t launch_lookup(const Geom &g, const double *rec, LookupMode mode, const LookupArgs &a,
                          double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
-                         int *blocks_out) {
+                         int *blocks_out, const double *faces) {
   switch (g.dim) {
-    case 1: return lookup_dim<1>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1, blocks_out);
-    case 2: return lookup_dim<2>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1, blocks_out);
-    default: return lookup_dim<3>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1, blocks_out);
+    case 1: return lookup_dim<1>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1, blocks_out, nullptr);
+    case 2: return lookup_dim<2>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1, blocks_out, faces);
+    default: return lookup_dim<3>(g, rec, mode, a, scratch, energy_out, s, ev0, ev1, blocks_out, faces);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// lookup replica ("faces"): see lookup_one.  Built from the node records by k_build_faces (one thread per
+// 32-byte slot: coalesced stores, gathered loads); kept current by the in-place tile-owned gather, whose
+// workgroups store every node record they rewrite into the four blocks it appears in (face_store).
+// ---------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_build_faces(Geom g, const double *__restrict__ rec, double *__restrict__ faces) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  const long long nslots = g.total * 4;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < nslots; i += stride) {
+    const long long blk = i >> 2;
+    const int slot = (int)(i & 3);
+    long long rest = blk;
+    const int b0 = (int)(rest % g.n[0]);
+    rest /= g.n[0];
+    const int b1 = (int)(rest % g.n[1]);
+    const long long b2 = rest / g.n[1];   // (0 in 2-D)
+    int q0 = b0 + (slot & 1), q1 = b1 + (slot >> 1);
+    bool none = false;   // the +1 neighbour of the last node of a non-periodic dimension does not exist (never read)
+    if (q0 >= g.n[0]) { if (g.periodic[0]) q0 -= g.n[0]; else none = true; }
+    if (q1 >= g.n[1]) { if (g.periodic[1]) q1 -= g.n[1]; else none = true; }
+    double4 v = make_double4(0, 0, 0, 0);
+    if (!none) v = reinterpret_cast<const double4 *>(rec)[q0 + (long long)g.n[0] * (q1 + (long long)g.n[1] * b2)];
+    reinterpret_cast<double4 *>(faces)[i] = v;
+  }
+}
+hipError_t launch_build_faces(const Geom &g, const double *rec, double *faces, hipStream_t s) {
+  if (g.dim < 2) return hipErrorInvalidValue;
+  long long b = (g.total * 4 + BLOCK - 1) / BLOCK;
+  if (b > 8 * MAX_BLOCKS) b = 8 * MAX_BLOCKS;
+  if (b < 1) b = 1;
+  if (g.dim == 2)
+    hipLaunchKernelGGL(k_build_faces<2>, dim3((unsigned)b), dim3(BLOCK), 0, s, g, rec, faces);
+  else
+    hipLaunchKernelGGL(k_build_faces<3>, dim3((unsigned)b), dim3(BLOCK), 0, s, g, rec, faces);
+  return hipGetLastError();
+}
+// the record of node p (V, dV/ds_0 .., pad) into the four blocks of the replica it belongs to
+template <int DIM>
+__device__ __forceinline__ void face_store(const Geom &g, double *__restrict__ faces, const int *p, const double *acc) {
+  if (DIM < 2) return;
+  const double4 v = make_double4(acc[0], acc[1], acc[DIM >= 2 ? 2 : 0], DIM == 3 ? acc[DIM == 3 ? 3 : 0] : 0.0);
+#pragma unroll
+  for (int slot = 0; slot < 4; slot++) {
+    int b0 = p[0] - (slot & 1), b1 = p[DIM >= 2 ? 1 : 0] - (slot >> 1);
+    if (b0 < 0) { if (!g.periodic[0]) continue; b0 += g.n[0]; }
+    if (b1 < 0) { if (!g.periodic[1]) continue; b1 += g.n[1]; }
+    const long long blk = b0 + (long long)g.n[0] * (b1 + (long long)g.n[1] * (DIM == 3 ? p[DIM == 3 ? 2 : 0] : 0));
+    reinterpret_cast<double4 *>(faces)[blk * 4 + slot] = v;
   }
 }
 
@@ -2417,6 +2490,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       for (int j = 0; j <= DIM; j++) dst[j] = acc[j];
       if (any_corr) *dirty_flag = 1;
     }
+    if (DIM > 1 && in_place && plan.faces) face_store<DIM>(g, plan.faces, p, acc);   // keep the lookup replica current
   } else if (!in_place) {
     // inactive nodes of a partial buffer must read as zero in the reduction
     bool in_grid_node = true;

@@ -70,6 +70,8 @@ _PROTOS = {
     "edm_hip_gauss_read": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, c_dp]),
     "edm_hip_gauss_reread": (C.c_int, [vp, C.c_char_p]),
     "edm_hip_gauss_set_interpolation": (C.c_int, [vp, C.c_int]),
+    "edm_hip_gauss_set_lookup_replica": (C.c_int, [vp, C.c_int]),
+    "edm_hip_gauss_lookup_replica_info": (C.c_int, [vp, c_ip, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "edm_hip_gauss_destroy": (C.c_int, [vp]),
     "edm_hip_gauss_set_boundary": (C.c_int, [vp, c_dp, c_dp, c_ip]),
     "edm_hip_gauss_geometry": (C.c_int, [vp, C.POINTER(Geometry)]),
@@ -392,6 +394,16 @@ class Gauss(_Geom):
 
     def set_interpolation(self, b):
         check(lib().edm_hip_gauss_set_interpolation(self.h, int(b)))
+
+    def set_lookup_replica(self, mode):
+        """-1 automatic, 0 off, 1 always (edm_hip_gauss_set_lookup_replica)"""
+        check(lib().edm_hip_gauss_set_lookup_replica(self.h, int(mode)))
+
+    def lookup_replica_info(self):
+        """(in use, bytes, full rebuilds so far)"""
+        u, b, r = C.c_int(0), C.c_longlong(0), C.c_longlong(0)
+        check(lib().edm_hip_gauss_lookup_replica_info(self.h, C.byref(u), C.byref(b), C.byref(r)))
+        return bool(u.value), b.value, r.value
 
     def add(self, other, scale=1.0, offset=0.0):
         """Grid::add (grid.h:275-290) with another device grid"""

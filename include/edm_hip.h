@@ -143,6 +143,16 @@ int edm_hip_gauss_read(edm_hip_gauss **out, int dim, const char *filename, const
 /* GaussGrid::read (gaussian_grid.h:140-142): node storage and grid geometry replaced from the file, sigma /
  * boundary / tables kept */
 int edm_hip_gauss_reread(edm_hip_gauss *g, const char *filename);
+/* Lookup replica (no reference counterpart; a memory-for-bandwidth trade sized for 288 GB of HBM): a 2-D / 3-D
+ * grid whose boundary is periodic in every dimension (the coordinate CV of fix edm in a periodic box) keeps, next
+ * to its node records, one aligned 128-byte block per node with the records of nodes (i0, i1), (i0+1, i1),
+ * (i0, i1+1), (i0+1, i1+1) [at i2] -- 4x the grid's bytes (17 GB for 512^3) -- so that the interpolation of a sample
+ * (grid.h:390-446) reads 1 (2-D) or 2 (3-D) lines instead of 2.5 / 5.  Results are bit-identical to lookups on
+ * the node records.  The in-place hill gather keeps the replica current; any other write of the grid marks it
+ * stale and the next lookup rebuilds it.  mode: -1 automatic (default: grids of 32 MB and more, memory
+ * permitting), 0 off (and freed), 1 always. */
+int edm_hip_gauss_set_lookup_replica(edm_hip_gauss *g, int mode);
+int edm_hip_gauss_lookup_replica_info(const edm_hip_gauss *g, int *in_use, long long *bytes, long long *rebuilds);
 /* GaussGrid::set_interpolation (gaussian_grid.h:168-170) */
 int edm_hip_gauss_set_interpolation(edm_hip_gauss *g, int b_interpolate);
 int edm_hip_gauss_destroy(edm_hip_gauss *g);
