@@ -320,15 +320,9 @@ struct Rec<4> {
 
 // Returns the flat start node (or -1 where the reference returns 0) and the
 // interpolated value / POSITIVE gradient.
-// FACES (2-D / 3-D): the corner records come from the lookup replica instead of the node records -- one 128-byte
-// block per node holding rec(i0, i1[, i2]), rec(i0+1, i1), rec(i0, i1+1), rec(i0+1, i1+1) (periodic wrap applied),
-// i.e. the four corners of a cell in 2-D and one face of it in 3-D: a sample touches ONE (2-D) or TWO (3-D) aligned
-// 128-byte lines where the node records cost it 2.5 / 5 (each corner pair is 64 B somewhere inside a line, and a
-// random atom shares its lines with nobody).  Same arithmetic, same operand order: the results are bit-identical.
-template <int DIM, bool FACES = false>
+template <int DIM>
 __device__ __forceinline__ long long lookup_one(const Geom &g, const double *__restrict__ rec,
-                                                const double *xin, double &value, double *der,
-                                                const double *__restrict__ faces = nullptr) {
+                                                const double *xin, double &value, double *der) {
   constexpr int R = (DIM == 1) ? 2 : 4;
   double xx[DIM];
 #pragma unroll
@@ -382,13 +376,7 @@ __device__ __forceinline__ long long lookup_one(const Geom &g, const double *__r
 #pragma unroll
     for (int d = 0; d < DIM; d++) shift += stride[d] * ((corner >> d) & 1);
     Rec<R> r;
-    if (FACES && DIM > 1) {
-      // block of the cell's start node, or (3-D, upper four corners) of the node above it; slot = corner & 3
-      const long long blk = (DIM == 3 && (corner & 4)) ? flat + stride[DIM - 1] : flat;
-      r.load(faces, blk * 4 + (corner & 3));
-    } else {
-      r.load(rec, flat + shift);
-    }
+    r.load(rec, flat + shift);
     const double tf = r.v[0];
     double C[DIM], D[DIM];
     double ff = 1.0;
@@ -423,10 +411,9 @@ __device__ __forceinline__ long long lookup_one(const Geom &g, const double *__r
   return flat;
 }
 
-template <int DIM, int MODE, bool FACES = false>
+template <int DIM, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_lookup(Geom g, const double *__restrict__ rec, LookupArgs a,
-                                                  double *__restrict__ block_energy,
-                                                  const double *__restrict__ faces = nullptr) {
+                                                  double *__restrict__ block_energy) {
   __shared__ double lds[BLOCK / 64];
   double e_acc = 0;
   const long long stride = (long long)gridDim.x * BLOCK;
@@ -435,7 +422,7 @@ __global__ void __launch_bounds__(BLOCK) k_lookup(Geom g, const double *__restri
     double xin[DIM], der[DIM], v;
 #pragma unroll
     for (int d = 0; d < DIM; d++) xin[d] = a.x[i * a.x_stride + d];
-    const long long flat = lookup_one<DIM, FACES>(g, rec, xin, v, der, faces);
+    const long long flat = lookup_one<DIM>(g, rec, xin, v, der);
     if (MODE == LOOKUP_FORCES) {
       e_acc += v;
 #pragma unroll
@@ -457,6 +444,177 @@ __global__ void __launch_bounds__(BLOCK) k_lookup(Geom g, const double *__restri
 
 size_t lookup_scratch_doubles() { return MAX_BLOCKS + 8; }
 
+// ---------------------------------------------------------------------------
+// K2 on the lookup replica: FOUR LANES PER SAMPLE.
+//
+// The replica keeps one aligned 128-byte block per node with the records of nodes (i0, i1), (i0+1, i1), (i0, i1+1),
+// (i0+1, i1+1) [at i2] (periodic wrap applied): the four corners of a 2-D cell, one face of a 3-D cell.  Lane q of
+// a sample's quad loads slot q of the cell's block (3-D: and of the block above), so the quad reads whole lines and
+// a wave-instruction touches 16 lines / pages instead of 64.  That, not the byte count, is what the coordinate-CV
+// lookup was short of: measured on MI355X (tools/randline.hip) random 128-byte lines of a 16 GiB buffer read at
+// 5.9 TB/s with four lanes per line and at 1.1-1.2 TB/s with one lane per line -- 64 address translations per
+// instruction -- while the node-record layout made every sample touch 2.5 (2-D) / 5 (3-D) lines of which it used
+// 96 / 256 bytes.  The arithmetic is the reference's, operation for operation (grid.h:390-446, interp<DIM> :52-139),
+// spread over the quad: lane d derives node index and cell coordinate of dimension d, lane q evaluates corner q
+// (3-D: corners q and q + 4), and every lane adds the corner terms up in the reference's corner order, so values
+// and gradients are bit-identical to k_lookup's.  Lane d < DIM updates force component d, lane 3 keeps the energy.
+// ---------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v) {   // the value lane K of this lane's quad holds
+  constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);   // DPP quad_perm:[K,K,K,K]
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int K>
+__device__ __forceinline__ int quad_bcast_i(int v) {
+  constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
+  return __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true);
+}
+// one corner of interp<DIM> (grid.h:85-131): tf * prod C and tf * D_d * prod_{e != d} C_e
+template <int DIM>
+__device__ __forceinline__ void corner_terms(const Geom &g, const double4 &r, const double *wod, int b0, int b1, int b2,
+                                             double &tF, double *tD) {
+  const double tf = r.x;
+  const double dv[3] = {r.y, r.z, r.w};
+  double C[DIM], D[DIM];
+  double ff = 1.0;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    const int bit = (d == 0) ? b0 : (d == 1) ? b1 : b2;
+    const int sgn = bit ? -1 : 1;
+    const double X = fabs(wod[d] - bit);
+    const double X2 = X * X;
+    const double X3 = X2 * X;
+    double qq;
+    if (fabs(tf) < 0.0000001)  // grid.h:113-116: derivative term dropped near zero
+      qq = 0.0;
+    else
+      qq = -dv[d] / tf;
+    C[d] = (1 - 3 * X2 + 2 * X3) - sgn * qq * (X - 2 * X2 + X3) * g.dx[d];
+    D[d] = (-6 * X + 6 * X2) - sgn * qq * (1 - 4 * X + 3 * X2) * g.dx[d];
+    D[d] *= sgn / g.dx[d];
+    ff *= C[d];
+  }
+  tF = tf * ff;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    double fd = D[d];
+#pragma unroll
+    for (int e = 0; e < DIM; e++)
+      if (e != d) fd *= C[e];
+    tD[d] = tf * fd;
+  }
+}
+template <int DIM, int MODE>
+__global__ void __launch_bounds__(BLOCK) k_lookup_quad(Geom g, const double *__restrict__ faces, LookupArgs a,
+                                                       double *__restrict__ block_energy) {
+  static_assert(DIM == 2 || DIM == 3, "the replica serves 2-D and 3-D grids");
+  __shared__ double lds[BLOCK / 64];
+  const int q = threadIdx.x & 3;
+  const int b0 = q & 1, b1 = q >> 1;
+  double e_acc = 0;
+  const long long stride = (long long)gridDim.x * (BLOCK / 4);
+  for (long long i = (long long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2); i < a.n; i += stride) {
+    if (MODE == LOOKUP_FORCES && !(a.apply_mask < 0 || (a.mask[i] & a.apply_mask))) continue;   // (uniform over the quad)
+    double xx[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) xx[d] = a.x[i * a.x_stride + d];
+    // the force component this lane will update: requested now, needed last
+    double f_old = 0;
+    if (MODE == LOOKUP_FORCES && q < DIM) f_old = a.f[i * a.f_stride + q];
+    bool ok = true;
+    if (!in_bounds<DIM>(g, xx)) {
+      remap<DIM>(g, xx);
+      if (!in_bounds<DIM>(g, xx)) ok = false;
+    }
+    if (ok && !in_grid<DIM>(g, xx)) ok = false;
+    double value = 0, der[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) der[d] = 0;
+    if (ok) {   // (uniform over the quad: every lane holds the same xx)
+      // lane d: node index, offset inside the cell and scaled coordinate of dimension d (grid.h:264-273, :426-430, :99)
+      const int myd = (q < DIM) ? q : 0;
+      const double mn = (myd == 0) ? g.min[0] : (myd == 1) ? g.min[1] : g.min[2];
+      const double mx = (myd == 0) ? g.max[0] : (myd == 1) ? g.max[1] : g.max[2];
+      const double dxd = (myd == 0) ? g.dx[0] : (myd == 1) ? g.dx[1] : g.dx[2];
+      const int nd = (myd == 0) ? g.n[0] : (myd == 1) ? g.n[1] : g.n[2];
+      const int perd = (myd == 0) ? g.periodic[0] : (myd == 1) ? g.periodic[1] : g.periodic[2];
+      double xi = (myd == 0) ? xx[0] : (myd == 1) ? xx[1] : xx[DIM - 1];
+      if (perd) xi -= (mx - mn) * ifloor((xi - mn) / (mx - mn));
+      long long id = (long long)floor((xi - mn) / dxd);
+      if (id > nd - 1) id = nd - 1;   // (the reference reads past the array when the wrap rounds up to max: stay inside)
+      if (id < 0) id = 0;
+      const double wh = xi - mn - id * dxd;
+      const double wd = wh / dxd;
+      const int my_idx = (int)id;
+      int idx[DIM];
+      double wod[DIM];
+      idx[0] = quad_bcast_i<0>(my_idx);
+      wod[0] = quad_bcast<0>(wd);
+      idx[1] = quad_bcast_i<1>(my_idx);
+      wod[1] = quad_bcast<1>(wd);
+      if (DIM == 3) {
+        idx[DIM - 1] = quad_bcast_i<2>(my_idx);
+        wod[DIM - 1] = quad_bcast<2>(wd);
+      }
+      long long blk = idx[DIM - 1];
+#pragma unroll
+      for (int d = DIM - 1; d > 0; d--) blk = blk * g.n[d - 1] + idx[d - 1];
+      const double4 *f4 = reinterpret_cast<const double4 *>(faces);
+      const double4 rA = f4[blk * 4 + q];
+      double tFA, tDA[DIM], tFB = 0, tDB[DIM];
+      if (DIM == 3) {
+        // the face above: node i2 + 1, or node 0 across a periodic seam (grid.h:432-433)
+        long long up = (long long)g.n[0] * g.n[1];
+        if (g.periodic[DIM - 1] && idx[DIM - 1] == g.n[DIM - 1] - 1) up *= (1 - g.n[DIM - 1]);
+        const double4 rB = f4[(blk + up) * 4 + q];
+        corner_terms<DIM>(g, rA, wod, b0, b1, 0, tFA, tDA);
+        corner_terms<DIM>(g, rB, wod, b0, b1, 1, tFB, tDB);
+      } else {
+        corner_terms<DIM>(g, rA, wod, b0, b1, 0, tFA, tDA);
+      }
+      // sums in the reference's corner order: corner c = b0 + 2 b1 + 4 b2 sits in lane c & 3
+      value += quad_bcast<0>(tFA);
+      value += quad_bcast<1>(tFA);
+      value += quad_bcast<2>(tFA);
+      value += quad_bcast<3>(tFA);
+      if (DIM == 3) {
+        value += quad_bcast<0>(tFB);
+        value += quad_bcast<1>(tFB);
+        value += quad_bcast<2>(tFB);
+        value += quad_bcast<3>(tFB);
+      }
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        der[d] += quad_bcast<0>(tDA[d]);
+        der[d] += quad_bcast<1>(tDA[d]);
+        der[d] += quad_bcast<2>(tDA[d]);
+        der[d] += quad_bcast<3>(tDA[d]);
+        if (DIM == 3) {
+          der[d] += quad_bcast<0>(tDB[d]);
+          der[d] += quad_bcast<1>(tDB[d]);
+          der[d] += quad_bcast<2>(tDB[d]);
+          der[d] += quad_bcast<3>(tDB[d]);
+        }
+      }
+    }
+    const double my_der = (q == 0) ? der[0] : (q == 1) ? der[1] : der[DIM - 1];
+    if (MODE == LOOKUP_FORCES) {
+      if (q < DIM) a.f[i * a.f_stride + q] = f_old - my_der;
+      if (q == 3) e_acc += value;
+    } else {
+      if (q < DIM && a.f) a.f[i * DIM + q] = my_der;
+      if (q == 3) {
+        if (a.energy) a.energy[i] = value;
+        e_acc += value;
+      }
+    }
+  }
+  double r = block_sum(e_acc, lds);
+  if (threadIdx.x == 0) block_energy[blockIdx.x] = r;
+}
+
 template <int DIM>
 static hipError_t lookup_dim(const Geom &g, const double *rec, LookupMode mode, const LookupArgs &a,
                              double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
@@ -464,24 +622,28 @@ static hipError_t lookup_dim(const Geom &g, const double *rec, LookupMode mode, 
   int blocks = (int)((a.n + BLOCK - 1) / BLOCK);
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
-  const double *none = nullptr;
-  const bool use_faces = faces && DIM > 1 && g.interp;
-  switch (mode) {
-    case LOOKUP_FORCES:
-      if (use_faces)
-        EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_FORCES, (DIM > 1)>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, faces);
-      else
-        EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_FORCES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, none);
-      break;
-    case LOOKUP_VALUES:
-      if (use_faces)
-        EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_VALUES, (DIM > 1)>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, faces);
-      else
-        EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_VALUES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, none);
-      break;
-    default:
-      EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_INDEX>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, none);
-      break;
+  const bool use_faces = faces && DIM > 1 && g.interp && mode != LOOKUP_INDEX;
+  if (use_faces) {   // four lanes per sample
+    constexpr int QD = (DIM > 1) ? DIM : 2;
+    long long qb = (a.n * 4 + BLOCK - 1) / BLOCK;
+    if (qb > MAX_BLOCKS) qb = MAX_BLOCKS;
+    blocks = (int)(qb < 1 ? 1 : qb);
+    if (mode == LOOKUP_FORCES)
+      EDM_LAUNCH_TIMED((k_lookup_quad<QD, LOOKUP_FORCES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, faces, a, scratch);
+    else
+      EDM_LAUNCH_TIMED((k_lookup_quad<QD, LOOKUP_VALUES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, faces, a, scratch);
+  } else {
+    switch (mode) {
+      case LOOKUP_FORCES:
+        EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_FORCES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch);
+        break;
+      case LOOKUP_VALUES:
+        EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_VALUES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch);
+        break;
+      default:
+        EDM_LAUNCH_TIMED((k_lookup<DIM, LOOKUP_INDEX>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch);
+        break;
+    }
   }
   if (blocks_out) *blocks_out = blocks;
   if (energy_out)
@@ -500,7 +662,7 @@ hipError_t launch_lookup(const Geom &g, const double *rec, LookupMode mode, cons
 }
 
 // ---------------------------------------------------------------------------
-// lookup replica ("faces"): see lookup_one.  Built from the node records by k_build_faces (one thread per
+// lookup replica ("faces"): see k_lookup_quad.  Built from the node records by k_build_faces (one thread per
 // 32-byte slot: coalesced stores, gathered loads); kept current by the in-place tile-owned gather, whose
 // workgroups store every node record they rewrite into the four blocks it appears in (face_store).
 // ---------------------------------------------------------------------------

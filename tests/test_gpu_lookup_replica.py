@@ -1,5 +1,5 @@
 """The lookup replica of 2-D / 3-D coordinate-CV grids (edm_hip_gauss_set_lookup_replica): lookups through it must
-be BIT-IDENTICAL to lookups on the node records -- same arithmetic, only the addresses differ -- after every way the
+be BIT-IDENTICAL to lookups on the node records -- the same arithmetic spread over four lanes per sample -- after every way the
 grid can be written: short hill batches (the in-place tile-owned gather maintains the replica node by node; no
 rebuild may happen), dense batches / uploads / clears / Grid::add (replica marked stale, rebuilt on the next lookup),
 through the gaussian-grid entry points, the controller's fused step, and at BASELINE's full sizes (2048^2, 512^3)
@@ -51,7 +51,8 @@ def _same_lookups(a, b, q, what):
     fb = fa.copy()
     ea = a.update_forces(q, fa, mask, 1)
     eb = b.update_forces(q, fb, mask, 1)
-    assert ea == eb and np.array_equal(fa, fb), what
+    # (forces bit-identical; the energy is a sum over samples whose association differs between the two kernels)
+    assert abs(ea - eb) <= 1e-12 * max(abs(ea), abs(eb)) and np.array_equal(fa, fb), what
     return Ea
 
 
@@ -151,7 +152,7 @@ def test_controller_steps_with_replica(dim, workdir):
         runs.append((out, v, dv, b.hist.values, g.lookup_replica_info()))
         del b
     for (e1, f1, s1), (e2, f2, s2) in zip(runs[0][0], runs[1][0]):
-        assert e1 == e2 and np.array_equal(f1, f2) and s1 == s2
+        assert abs(e1 - e2) <= 1e-12 * abs(e2) and np.array_equal(f1, f2) and s1 == s2
     assert runs[0][0][-1][0] > 0
     for k in (1, 2, 3):
         assert np.array_equal(runs[0][k], runs[1][k])
@@ -178,7 +179,7 @@ def test_full_size_automatic_mode(tag):
             e = H.C.c_double(0)
             H.check(H.lib().edm_hip_gauss_update_forces(g.h, n, d_x.ptr, 3, d_f.ptr, 3, None, -1, H.C.byref(e)))
             out.append((e.value, d_f.to_host()))
-        assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+        assert abs(out[0][0] - out[1][0]) <= 1e-12 * abs(out[1][0]) and np.array_equal(out[0][1], out[1][1])
         assert np.abs(out[0][1]).max() > 0
     used, nbytes, builds = a.lookup_replica_info()
     assert used and nbytes == a.size * 128 and builds == 1
