@@ -12,12 +12,17 @@ Inputs are resident in HBM before the timed region.  N > 1 is weak scaling: ever
 (one process per GPU) owns its own W1-sized pair set of the same system, hill_density is
 a per-system quantity (divided by the rank count exactly like EDMBias::subdivide does
 under MPI) and ranks exchange over RCCL.  value = pairs evaluated by all ranks / time.
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts the N ranks itself
+(python -m torch.distributed.run, one process per GPU) before anything touches a GPU.
 
-Rank 0 prints ONE JSON line (see the driver contract) with two extra objects:
-  roofline     -- dominant kernel (k_pair_forces): algorithmic 16 B/eval over its HIP-event
-                  duration measured on the kernel's own stream inside the timed region
-  cpu_baseline -- the CPU oracle (or the real reference build when present) timed on a
-                  bounded sample of the same workload on the host cores
+Rank 0 prints ONE JSON line (see the driver contract) with these extra objects:
+  roofline      -- dominant kernel of the W1 step: algorithmic 16 B/eval over its HIP-event duration
+                   measured on the kernel's own stream inside the timed region
+  hill_adds_strong_scaling -- the metric's second quantity: 1,048,576 hills per step split over the GPUs
+  coordinate_cv -- BASELINE configs[3] / [4] (2048^2 and 512^3 coordinate-CV grids, 262 144 atoms): lookup kernel
+                   time, algorithmic bytes per atom, roofline fraction, full fix-edm step
+  pcie_inclusive -- the same W1 step with pair arrays starting and ending in HOST memory
+  cpu_baseline  -- the real reference build (or the CPU oracle) timed on a bounded sample on the host cores
 """
 import ctypes as C
 import argparse
@@ -138,20 +143,18 @@ def cpu_baseline(tmpdir, seconds=12.0):
         b.update_forces(r, f)
         evals += n
     t_eval = time.perf_counter() - t0
-    # hill adds: GaussGrid::add_value on the C1D stencil (1131 nodes, McGDP boundary)
-    hills = W.pair_distances(200000, 5)
+    # hill adds: GaussGrid::add_value on the C1D stencil (1131 nodes, McGDP boundary), batches of 2048 hills per C call
+    hills = W.pair_distances(1 << 20, 5).reshape(-1, 1).copy()
     t0 = time.perf_counter()
     done = 0
-    for x in hills:
-        g.add_value([x], 1e-6)
-        done += 1
-        if (done & 1023) == 0 and time.perf_counter() - t0 > seconds * 0.4:
-            break
+    while done + 2048 <= len(hills) and time.perf_counter() - t0 < seconds * 0.4:
+        g.add_values(hills[done:done + 2048], 1e-6)
+        done += 2048
     t_hill = time.perf_counter() - t0
     return dict(value=evals / t_eval / 1e6, unit="million bias-force evals/s", cores=1, kind=kind,
-                hill_adds_per_s=done / t_hill,
-                sample="%d update_forces passes over %d C1D pair distances (%.1f s) + %d add_value hills (%.1f s), 1 thread"
-                       % (evals // n, n, t_eval, done, t_hill))
+                hill_adds_per_s=done / t_hill, host_cores_visible=os.cpu_count(),
+                sample="%d update_forces passes over %d C1D pair distances (%.1f s) + %d add_value hills in C-side batches of "
+                       "2048 (%.1f s), 1 thread" % (evals // n, n, t_eval, done, t_hill))
 
 
 def cpu_baseline_all_cores(tmpdir, seconds=8.0):
@@ -160,8 +163,8 @@ def cpu_baseline_all_cores(tmpdir, seconds=8.0):
     single-core baseline concurrently; the rates add up."""
     import subprocess
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))   # (a one-GPU slice of the host: 16 cores)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, 16))   # (a one-GPU slice of the host: at most 16 replicas; `nproc` is reported beside it)
     env = dict(os.environ, OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds),
                                "--cpu-worker-dir", os.path.join(tmpdir, "w%d" % i)],
@@ -179,8 +182,8 @@ def cpu_baseline_all_cores(tmpdir, seconds=8.0):
             p.kill()
     if ok == 0:
         return None
-    return dict(value=ev, unit="million bias-force evals/s", cores=ok, hill_adds_per_s=hl,
-                sample="%d concurrent single-core replicas of the baseline above, %.0f s each" % (ok, seconds))
+    return dict(value=ev, unit="million bias-force evals/s", cores=ok, nproc=avail, hill_adds_per_s=hl,
+                sample="%d concurrent single-core replicas of the baseline above (nproc = %d), %.0f s each" % (ok, avail, seconds))
 
 
 def all_samples_measure(rank, world, dist, H, W, tmpdir, steps, warmup):
@@ -251,11 +254,13 @@ def headline_dict(args, world, npairs, elapsed, k_ms, k_launches, timed_every):
     """The contract keys of the JSON line, complete once the timed region has ended."""
     ms_per_step = elapsed / args.steps * 1e3
     total_pairs = npairs * world
-    # the force kernel rides in one launch with the step's selection (k_pair_forces_select): per pair 8 B distance
-    # in + 8 B force out, per sample 8 B acceptance uniform in (the sample distances are read for accepted
-    # samples only)
-    step_bytes = BYTES_PER_EVAL * npairs + 8 * npairs
-    achieved = step_bytes / (k_ms / max(k_launches, 1) * 1e-3) / 1e9
+    k_s = k_ms / max(k_launches, 1) * 1e-3
+    # SURVEY 8(d): 16 B per evaluation (8 B distance in + 8 B force out) x the pairs one launch processes.  The
+    # launch also carries the step's selection, which reads one 8-B acceptance uniform per staged sample -- real
+    # traffic of the same launch, reported beside the 8(d) figure, not inside it
+    alg_bytes = BYTES_PER_EVAL * npairs
+    achieved = alg_bytes / k_s / 1e9
+    with_u = (alg_bytes + 8 * npairs) / k_s / 1e9
     return {
         "metric": "million bias-force evals/sec (1M-pair 1D CV, force eval + hill step per step)",
         "value": total_pairs / (elapsed / args.steps) / 1e6,
@@ -285,19 +290,26 @@ def headline_dict(args, world, npairs, elapsed, k_ms, k_launches, timed_every):
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic("edm::k_pair_forces_select"),
-            "kernel_us": k_ms / max(k_launches, 1) * 1e3,
+            "kernel_us": k_s * 1e6,
             "kernel_us_rocprof": rocprof_avg_us("edm::k_pair_forces_select"),
             "launches": k_launches,
             "timed_every": timed_every,
-            "bytes_per_launch": step_bytes,
-            "bytes_per_launch_note": "16 B per pair (K1) + 8 B per sample (acceptance uniforms of the selection)",
+            "bytes_per_launch": alg_bytes,
+            "bytes_per_launch_note": "16 B per pair (SURVEY 8d: distance in + force out)",
+            "achieved_incl_selection_uniforms": with_u,
+            "frac_incl_selection_uniforms": with_u / HBM_PEAK_GBS,
+            "bytes_per_launch_incl_selection_uniforms": alg_bytes + 8 * npairs,
         },
     }
 
 
 class ExtrasGuard:
     """Prints the line exactly once: the full one when the informational extras are done, or -- from a timer thread,
-    should they not finish within limit_s -- the headline alone with a note, and ends the process."""
+    should they not finish within limit_s -- the headline alone, naming the extra that was running, and ends the
+    process with status 3 (a stalled extra is a failure of the run, not a clean finish).  The limit is a backstop
+    for a hang nobody has seen; the extras of a default run take well under a minute."""
+
+    EXIT_STALLED = 3
 
     def __init__(self, rank, headline, limit_s):
         import threading
@@ -305,9 +317,15 @@ class ExtrasGuard:
         self.rank, self.headline, self.limit_s = rank, headline, limit_s
         self.lock = threading.Lock()
         self.done = False
-        self.timer = threading.Timer(limit_s + (0.0 if rank == 0 else 15.0), self._expired)
+        self.current = "none"
+        # every rank gives up at the same moment: no rank is left inside a collective its peers have abandoned for
+        # longer than the peers' own exit takes
+        self.timer = threading.Timer(limit_s, self._expired)
         self.timer.daemon = True
         self.timer.start()
+
+    def stage(self, name):
+        self.current = name
 
     def _expired(self):
         with self.lock:
@@ -316,10 +334,10 @@ class ExtrasGuard:
             self.done = True
             if self.rank == 0:
                 out = dict(self.headline)
-                out["extras_skipped"] = ("the informational extras did not finish within %.0f s; the keys above were "
-                                         "measured before them" % self.limit_s)
+                out["extras_skipped"] = ("the informational extra '%s' did not finish within %.0f s; the keys above were "
+                                         "measured before it; exit status %d" % (self.current, self.limit_s, self.EXIT_STALLED))
                 print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(self.EXIT_STALLED)
 
     def finish(self, out):
         with self.lock:
@@ -329,6 +347,147 @@ class ExtrasGuard:
             self.timer.cancel()
             if out is not None:
                 print(json.dumps(out), flush=True)
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks as fresh child processes (one per GPU, RCCL over xGMI) and
+    return their exit status.  Nothing in this process has touched a GPU (counting devices does not)."""
+    import socket
+    import subprocess
+
+    import torch
+
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        print("bench.py: --gpus %d but only %d GPU(s) are visible" % (args.gpus, ndev), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def coordinate_cv_measure(H, W, tmpdir):
+    """BASELINE configs[3] / [4]: the coordinate-CV grids (2048^2, 512^3), 262 144 atoms at random positions resident
+    in HBM.  Lookup kernel timed by its own dispatch timestamps; algorithmic bytes per atom from SURVEY 8(d)."""
+    nd = {}
+    for tag, c, per_atom in (("c2d_2048sq", W.C2D, 156), ("c3d_512cube", W.C3D, 332)):
+        gg = H.Gauss.create(c["lo"], c["hi"], c["spacing"], c["periodic"], 1, c["sigma"])
+        dim = c["dim"]
+        natoms = 262144
+        x = W.atom_positions(natoms, 21 if dim == 2 else 31)
+        d_x = H.DeviceArray.from_host(x)
+        d_ff = H.DeviceArray.zeros((natoms, 3))
+        d_uu = H.DeviceArray.from_host(W.uniform(77, natoms))
+        hills = H.DeviceArray.from_host(np.ascontiguousarray(x[:250]))
+        tot = H.C.c_double(0)
+        H.check(H.lib().edm_hip_gauss_add_values(gg.h, 250, hills.ptr, 3, None, 0.01, None, H.C.byref(tot)))
+        e = H.C.c_double(0)
+        H.check(H.lib().edm_hip_gauss_update_forces(gg.h, natoms, d_x.ptr, 3, d_ff.ptr, 3, None, -1, H.C.byref(e)))
+        gg.profile_enable(True)
+        gg.profile_read(reset=True)
+        for _ in range(20):
+            H.check(H.lib().edm_hip_gauss_update_forces(gg.h, natoms, d_x.ptr, 3, d_ff.ptr, 3, None, -1, H.C.byref(e)))
+        ms, ln = gg.profile_read(reset=True)
+        # the same atoms in LAMMPS' default memory order: spatially sorted into bins of half the neighbour
+        # cutoff (atom_modify sort, binsize 1.4)
+        nb = int(np.ceil(64.0 / 1.4))
+        bins = np.floor(x / 1.4).astype(np.int64)
+        order = np.argsort(bins[:, 0] + nb * (bins[:, 1] + nb * bins[:, 2]), kind="stable")
+        d_xs = H.DeviceArray.from_host(np.ascontiguousarray(x[order]))
+        H.check(H.lib().edm_hip_gauss_update_forces(gg.h, natoms, d_xs.ptr, 3, d_ff.ptr, 3, None, -1, H.C.byref(e)))
+        gg.profile_read(reset=True)
+        for _ in range(20):
+            H.check(H.lib().edm_hip_gauss_update_forces(gg.h, natoms, d_xs.ptr, 3, d_ff.ptr, 3, None, -1, H.C.byref(e)))
+        ms_s, ln_s = gg.profile_read(reset=True)
+        gg.profile_enable(False)
+        H.synchronize()
+        t3 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            H.check(H.lib().edm_hip_gauss_add_values(gg.h, 250, hills.ptr, 3, None, 0.01, None, H.C.byref(tot)))
+        H.synchronize()
+        t_h = (time.perf_counter() - t3) / reps
+        replica = gg.lookup_replica_info()
+        gbs = per_atom * natoms / (ms / ln * 1e-3) / 1e9
+        # one hill-depositing fix edm step on this grid (W3 / W4 of SURVEY 8d): update_forces over all atoms +
+        # add_hills (hill_density 250; W4: bias_per_step = 0.4 x the expected per-step sum, so the limiter and
+        # the overflow buffer work every step) through edm_hip_bias_step, atoms resident in HBM
+        cfgp = os.path.join(tmpdir, "bench_%s.edm" % tag)
+        with open(cfgp, "w") as fh:
+            fh.write("tempering 0\nhill_prefactor %g\nhill_density 250\n%sdimension %d\nbox_low %s\nbox_high %s\n"
+                     "bias_spacing %s\nbias_sigma %s\nhills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (
+                         0.02 if dim == 3 else 0.5, "bias_per_step 0.008\n" if dim == 3 else "", dim,
+                         " ".join("0" for _ in range(dim)), " ".join("64" for _ in range(dim)),
+                         " ".join("%.10g" % v for v in c["spacing"]), " ".join("%.10g" % v for v in c["sigma"]),
+                         tmpdir, tag, tmpdir, tag))
+        del gg
+        bb = H.Bias(cfgp)
+        bb.setup(1.0, 1.0)
+        bb.subdivide([0.0] * dim, [64.0] * dim, [0.0] * dim, [64.0] * dim, [1] * dim, [0.0] * dim)
+        bb.set_hill_log(False)
+        d_fs = H.DeviceArray.zeros((natoms, 3))
+        for _ in range(3):
+            bb.step_device(d_x, 3, d_fs, 3, natoms, d_uu, -1, natoms)
+        H.synchronize()
+        t4 = time.perf_counter()
+        for _ in range(20):
+            bb.step_device(d_x, 3, d_fs, 3, natoms, d_uu, -1, natoms)
+        H.synchronize()
+        t_step = (time.perf_counter() - t4) / 20
+        hills_step = bb.get("hills_added") / 23.0
+        del bb
+        kname = "edm::k_lookup_quad<%d" % dim
+        nd[tag] = dict(workload="BASELINE configs[%d]: fix edm coordinate CV, %s periodic bias grid, %d atoms at random positions"
+                                % (3 if dim == 2 else 4, "2048^2" if dim == 2 else "512^3", natoms),
+                       atoms=natoms,
+                       roofline=dict(kernel="k_lookup_quad<%d, forces> (K2 on the lookup replica, four lanes per atom)" % dim,
+                                     bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                                     traffic=pmc_traffic(kname), kernel_us=ms / ln * 1e3,
+                                     kernel_us_rocprof=rocprof_avg_us(kname), launches=ln,
+                                     bytes_per_launch=per_atom * natoms,
+                                     bytes_per_launch_note="%d B per atom (SURVEY 8d: position row + mask + force RMW + %d corner records)"
+                                                           % (per_atom, 2 ** dim)),
+                       million_atom_evals_per_s=natoms / (ms / ln * 1e-3) / 1e6,
+                       lookup_replica=dict(in_use=replica[0], bytes=replica[1]),
+                       lookup_kernel_us_bin_sorted_atoms=ms_s / ln_s * 1e3,
+                       frac_of_hbm_peak_bin_sorted_atoms=per_atom * natoms / (ms_s / ln_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       step_ms=t_step * 1e3, step_million_atom_evals_per_s=natoms / t_step / 1e6,
+                       step_hills_added_avg=hills_step,
+                       hill_batch_250_ms=t_h * 1e3, hill_adds_per_s=250 / t_h)
+    return nd
+
+
+def pcie_inclusive_measure(H, b, r, u, npairs, est, steps=20):
+    """The W1 step as the host-list `fix edm_pair` pays for it: pair distances, sample uniforms in and pair forces
+    out cross PCIe every step (pageable host arrays, what libedm.so's EDMBias::pair_step does around the same
+    edm_hip_bias_pair_step call).  Never the headline `value`."""
+    d_r = H.DeviceArray((npairs,))
+    d_u = H.DeviceArray((npairs,))
+    d_f = H.DeviceArray((npairs,))
+    f_host = np.empty(npairs)
+
+    def one():
+        H.check(H.lib().edm_hip_memcpy_h2d(d_r.ptr, r.ctypes.data, r.nbytes))
+        H.check(H.lib().edm_hip_memcpy_h2d(d_u.ptr, u.ctypes.data, u.nbytes))
+        e = b.pair_step_device(d_r, d_f, npairs, d_r, d_u, npairs, est)
+        H.check(H.lib().edm_hip_memcpy_d2h(f_host.ctypes.data, d_f.ptr, f_host.nbytes))
+        return e
+
+    for _ in range(3):
+        one()
+    H.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    H.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dict(ms_per_step=dt * 1e3, million_evals_per_s=npairs / dt / 1e6,
+                bytes_over_pcie_per_step=3 * 8 * npairs,
+                note="host arrays in pageable memory: 8 B distance + 8 B uniform in, 8 B force out per pair, per step")
 
 
 def main():
@@ -341,7 +500,9 @@ def main():
     ap.add_argument("--no-w2", action="store_true",
                     help="skip the 38.8M-pair interpolation capture (W2 = BASELINE configs[2], the HBM-bound case)")
     ap.add_argument("--w2", action="store_true", help=argparse.SUPPRESS)  # kept for older command lines (now the default)
-    ap.add_argument("--nd", action="store_true", help="also time the 2-D (2048^2) and 3-D (512^3) coordinate-CV kernels")
+    ap.add_argument("--no-nd", action="store_true",
+                    help="skip the coordinate-CV section (BASELINE configs[3]/[4]: 2048^2 and 512^3 grids; part of the default line)")
+    ap.add_argument("--nd", action="store_true", help=argparse.SUPPRESS)  # kept for older command lines (now the default)
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # (child of cpu_baseline_all_cores)
     ap.add_argument("--cpu-worker-dir", default="", help=argparse.SUPPRESS)
     ap.add_argument("--all-samples", action="store_true",
@@ -354,10 +515,13 @@ def main():
         print(json.dumps(cpu_baseline(args.cpu_worker_dir, args.cpu_worker)))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (fresh child processes, before any GPU call in this one)
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     dist = None
@@ -441,7 +605,17 @@ def main():
     # the CPU baseline).  The headline numbers are complete at this point: if an extra ever failed to finish -- the
     # multi-rank ones run collectives -- rank 0 still prints the line, marked, instead of losing the measurement.
     headline = headline_dict(args, world, npairs, elapsed, k_ms, k_launches, TIMED_EVERY)
-    guard = ExtrasGuard(rank, headline, limit_s=float(os.environ.get("EDM_BENCH_EXTRAS_LIMIT", "180")))
+    # second quantity of the metric (BASELINE.json: "... + hill-adds/sec", target: strong scaling at 8 GPUs): the
+    # all-samples hill mode, 1,048,576 hills per step in total split over the GPUs (a collective: every rank runs it);
+    # part of the measured line, not of the guarded extras
+    hs_hills, hs_sec, _ = all_samples_measure(rank, world, dist, H, W, tmpdir, steps=5, warmup=2)
+    headline["hill_adds_strong_scaling"] = dict(
+        value=hs_hills / hs_sec, unit="hill adds/s", hills_per_step_total=hs_hills, n_gpus=world, ms_per_step=hs_sec * 1e3,
+        scaling="strong", steps=5, warmup=2,
+        note="all-samples mode, hills sharded over the GPUs, per-hill integrals + delta grid exchanged over RCCL; same "
+             "quantity as the main line of `bench.py --all-samples`")
+    guard = ExtrasGuard(rank, headline, limit_s=float(os.environ.get("EDM_BENCH_EXTRAS_LIMIT", "300")))
+    guard.stage("device_rng_step")
 
     # the same step with the acceptance uniforms drawn on the device (fast mode of the fixes' RNG: no array of
     # uniforms is generated, uploaded or read); informational, not part of `value`
@@ -459,6 +633,7 @@ def main():
     # BASELINE configs[1] end to end from POSITIONS: 32k atoms at the LJ-melt density, half neighbour list within
     # r_c + skin = 2.8 resident on the GPU (fix edm_pair ... gpu_list), every step deposits hills; informational
     lj = None
+    guard.stage("lj_melt_32k_from_positions")
     if rank == 0:
         try:
             from scipy.spatial import cKDTree
@@ -492,6 +667,7 @@ def main():
         except Exception as exc:  # noqa: BLE001  (scipy missing: skip the extra)
             lj = dict(skipped=repr(exc))
 
+    guard.stage("component_rates")
     copy_us = copy_probe(H, d_r.ptr, d_f.ptr, 8 * npairs) if rank == 0 else None
     # component rates (not part of `value`): force evaluation alone, all-samples hill adds
     reps = 20
@@ -502,16 +678,6 @@ def main():
     H.synchronize()
     t_eval = (time.perf_counter() - t1) / reps
     extra = {}
-    # second reported quantity of the metric (BASELINE.json: "... + hill-adds/sec"): STRONG scaling of the
-    # all-samples hill mode -- 1,048,576 hills per step in total, split over the GPUs (collective: every rank runs it)
-    try:
-        hs_hills, hs_sec, _ = all_samples_measure(rank, world, dist, H, W, tmpdir, steps=3, warmup=1)
-        extra["hill_adds_strong_scaling"] = dict(value=hs_hills / hs_sec, unit="hill adds/s", hills_per_step_total=hs_hills,
-                                                 ms_per_step=hs_sec * 1e3, scaling="strong",
-                                                 note="all-samples mode, hills sharded over the GPUs, integrals + delta "
-                                                      "grid all-reduced; same quantity as `bench.py --all-samples`")
-    except Exception as exc:  # noqa: BLE001  (reported, not fatal: the headline is measured)
-        extra["hill_adds_strong_scaling"] = dict(failed=repr(exc))
     if rank == 0:
         nh = 1 << 18
         hx = H.DeviceArray.from_host(W.pair_distances(nh, 9))
@@ -523,7 +689,12 @@ def main():
         H.synchronize()
         extra["hill_adds_per_s_all_samples"] = nh / (time.perf_counter() - t2)
         extra["hill_adds_sample"] = "%d add_value hills in one batch, C1D stencil 1131 nodes, fused gather + integrals pass" % nh
+    pcie = None
+    if rank == 0 and dist is None:   # (with a communicator pair_step is a collective: single-GPU runs only)
+        guard.stage("pcie_inclusive")
+        pcie = pcie_inclusive_measure(H, b, r, u, npairs, est)
     roof_w2 = None
+    guard.stage("w2_interpolation_capture")
     if not args.no_w2 and rank == 0:
         n2 = W.W2_PAIRS
         d_r2 = H.DeviceArray.from_host(W.pair_distances(n2, 11))
@@ -544,80 +715,9 @@ def main():
                        kernel_ms_rocprof=(rocprof_avg_us("edm::k_pair_forces_fast<true") or 0) / 1e3 or None)
 
     nd = None
-    if args.nd and rank == 0:
-        nd = {}
-        for tag, c, per_atom in (("c2d_2048sq", W.C2D, 156), ("c3d_512cube", W.C3D, 332)):
-            gg = H.Gauss.create(c["lo"], c["hi"], c["spacing"], c["periodic"], 1, c["sigma"])
-            dim = c["dim"]
-            natoms = 262144
-            x = W.atom_positions(natoms, 21 if dim == 2 else 31)
-            d_x = H.DeviceArray.from_host(x)
-            d_ff = H.DeviceArray.zeros((natoms, 3))
-            d_uu = H.DeviceArray.from_host(W.uniform(77, natoms))
-            hills = H.DeviceArray.from_host(np.ascontiguousarray(x[:250]))
-            tot = H.C.c_double(0)
-            H.check(H.lib().edm_hip_gauss_add_values(gg.h, 250, hills.ptr, 3, None, 0.01, None, H.C.byref(tot)))
-            e = H.C.c_double(0)
-            H.check(H.lib().edm_hip_gauss_update_forces(gg.h, natoms, d_x.ptr, 3, d_ff.ptr, 3, None, -1, H.C.byref(e)))
-            gg.profile_enable(True)
-            gg.profile_read(reset=True)
-            for _ in range(20):
-                H.check(H.lib().edm_hip_gauss_update_forces(gg.h, natoms, d_x.ptr, 3, d_ff.ptr, 3, None, -1, H.C.byref(e)))
-            ms, ln = gg.profile_read(reset=True)
-            # the same atoms in LAMMPS' default memory order: spatially sorted into bins of half the neighbour
-            # cutoff (atom_modify sort, binsize 1.4) -- neighbouring lanes then share the 128-B lines they gather
-            nb = int(np.ceil(64.0 / 1.4))
-            bins = np.floor(x / 1.4).astype(np.int64)
-            order = np.argsort(bins[:, 0] + nb * (bins[:, 1] + nb * bins[:, 2]), kind="stable")
-            d_xs = H.DeviceArray.from_host(np.ascontiguousarray(x[order]))
-            H.check(H.lib().edm_hip_gauss_update_forces(gg.h, natoms, d_xs.ptr, 3, d_ff.ptr, 3, None, -1, H.C.byref(e)))
-            gg.profile_read(reset=True)
-            for _ in range(20):
-                H.check(H.lib().edm_hip_gauss_update_forces(gg.h, natoms, d_xs.ptr, 3, d_ff.ptr, 3, None, -1, H.C.byref(e)))
-            ms_s, ln_s = gg.profile_read(reset=True)
-            gg.profile_enable(False)
-            H.synchronize()
-            t3 = time.perf_counter()
-            reps = 10
-            for _ in range(reps):
-                H.check(H.lib().edm_hip_gauss_add_values(gg.h, 250, hills.ptr, 3, None, 0.01, None, H.C.byref(tot)))
-            H.synchronize()
-            t_h = (time.perf_counter() - t3) / reps
-            gbs = per_atom * natoms / (ms / ln * 1e-3) / 1e9
-            # one hill-depositing fix edm step on this grid (W3 / W4 of SURVEY 8d): update_forces over all atoms +
-            # add_hills (hill_density 250; W4: bias_per_step = 0.4 x the expected per-step sum, so the limiter and
-            # the overflow buffer work every step) through edm_hip_bias_step, atoms resident in HBM
-            cfgp = os.path.join(tmpdir, "bench_%s.edm" % tag)
-            with open(cfgp, "w") as fh:
-                fh.write("tempering 0\nhill_prefactor %g\nhill_density 250\n%sdimension %d\nbox_low %s\nbox_high %s\n"
-                         "bias_spacing %s\nbias_sigma %s\nhills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (
-                             0.02 if dim == 3 else 0.5, "bias_per_step 0.008\n" if dim == 3 else "", dim,
-                             " ".join("0" for _ in range(dim)), " ".join("64" for _ in range(dim)),
-                             " ".join("%.10g" % v for v in c["spacing"]), " ".join("%.10g" % v for v in c["sigma"]),
-                             tmpdir, tag, tmpdir, tag))
-            bb = H.Bias(cfgp)
-            bb.setup(1.0, 1.0)
-            bb.subdivide([0.0] * dim, [64.0] * dim, [0.0] * dim, [64.0] * dim, [1] * dim, [0.0] * dim)
-            bb.set_hill_log(False)
-            d_fs = H.DeviceArray.zeros((natoms, 3))
-            for _ in range(3):
-                bb.step_device(d_x, 3, d_fs, 3, natoms, d_uu, -1, natoms)
-            H.synchronize()
-            t4 = time.perf_counter()
-            for _ in range(20):
-                bb.step_device(d_x, 3, d_fs, 3, natoms, d_uu, -1, natoms)
-            H.synchronize()
-            t_step = (time.perf_counter() - t4) / 20
-            hills_step = bb.get("hills_added") / 23.0
-            del bb
-            nd[tag] = dict(atoms=natoms, lookup_kernel_us=ms / ln * 1e3,
-                           step_ms=t_step * 1e3, step_million_atom_evals_per_s=natoms / t_step / 1e6,
-                           step_hills_added_avg=hills_step, million_atom_evals_per_s=natoms / (ms / ln * 1e-3) / 1e6,
-                           algorithmic_bytes_per_atom=per_atom, achieved_GBs=gbs, frac_of_hbm_peak=gbs / HBM_PEAK_GBS,
-                           lookup_kernel_us_bin_sorted_atoms=ms_s / ln_s * 1e3,
-                           frac_of_hbm_peak_bin_sorted_atoms=per_atom * natoms / (ms_s / ln_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           hill_batch_250_ms=t_h * 1e3, hill_adds_per_s=250 / t_h)
-            del gg
+    if not args.no_nd and rank == 0:
+        guard.stage("coordinate_cv")
+        nd = coordinate_cv_measure(H, W, tmpdir)
 
     if rank == 0:
         out = dict(headline)
@@ -637,6 +737,8 @@ def main():
             out["roofline_w2"] = roof_w2
         if nd:
             out["coordinate_cv"] = nd
+        out["pcie_inclusive"] = pcie
+        guard.stage("cpu_baseline")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(tmpdir)
             out["cpu_baseline"]["all_cores"] = cpu_baseline_all_cores(tmpdir)

@@ -100,6 +100,7 @@ class Lib:
         s("gauss_grid", vp, [vp])
         s("gauss_set_boundary", None, [vp, c_dp, c_dp, c_ip])
         s("gauss_add_value", C.c_double, [vp, c_dp, C.c_double])
+        s("gauss_add_values", C.c_double, [vp, C.c_longlong, c_dp, C.c_int, C.c_double])
         s("gauss_get_value", C.c_double, [vp, c_dp])
         s("gauss_get_value_deriv", C.c_double, [vp, c_dp, c_dp])
         s("gauss_remap", None, [vp, c_dp])
@@ -298,6 +299,11 @@ class Gauss:
 
     def add_value(self, x, height):
         return self.lib.fn("gauss_add_value")(self.h, _dp(_vec(x, 3)), height)
+
+    def add_values(self, x, height):
+        """n add_value calls in one C call; x: float64 [n, stride] C-contiguous.  Returns the summed bias_added."""
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        return self.lib.fn("gauss_add_values")(self.h, x.shape[0], _dp(x), x.shape[1], height)
 
     def get_value(self, x):
         return self.lib.fn("gauss_get_value")(self.h, _dp(_vec(x, 3)))

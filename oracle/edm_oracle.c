@@ -743,6 +743,14 @@ static void gauss_duplicate_boundary(ora_gauss *g) {
 }
 
 /* gaussian_grid.h:176-372 */
+double ora_gauss_add_value(ora_gauss *g, const double *x0, double height);
+/* n calls of add_value in one C call (bench.py's CPU baseline: no per-hill FFI overhead) */
+double ora_gauss_add_values(ora_gauss *g, long long n, const double *x, int stride, double height) {
+  double total = 0;
+  long long i;
+  for (i = 0; i < n; i++) total += ora_gauss_add_value(g, x + i * stride, height);
+  return total;
+}
 double ora_gauss_add_value(ora_gauss *g, const double *x0, double height) {
   ora_grid *q = g->grid;
   const int dim = g->dim;

@@ -75,6 +75,7 @@ ora_grid *ora_gauss_grid(ora_gauss *g);
 void ora_gauss_set_boundary(ora_gauss *g, const double *min, const double *max,
                             const int *periodic);
 double ora_gauss_add_value(ora_gauss *g, const double *x, double height);
+double ora_gauss_add_values(ora_gauss *g, long long n, const double *x, int stride, double height);
 double ora_gauss_get_value(const ora_gauss *g, const double *x);
 double ora_gauss_get_value_deriv(const ora_gauss *g, const double *x, double *der);
 void ora_gauss_remap(const ora_gauss *g, double *x);

@@ -187,6 +187,12 @@ void ref_gauss_set_boundary(ref_gauss *h, const double *min, const double *max, 
   h->g->set_boundary(min, max, periodic);
 }
 double ref_gauss_add_value(ref_gauss *h, const double *x, double height) { return h->g->add_value(x, height); }
+/* n calls of GaussGrid::add_value in one C call (bench.py's CPU baseline: no per-hill FFI overhead) */
+double ref_gauss_add_values(ref_gauss *h, long long n, const double *x, int stride, double height) {
+  double total = 0;
+  for (long long i = 0; i < n; i++) total += h->g->add_value(x + i * stride, height);
+  return total;
+}
 double ref_gauss_get_value(const ref_gauss *h, const double *x) { return h->g->get_value(x); }
 double ref_gauss_get_value_deriv(const ref_gauss *h, const double *x, double *der) {
   return h->g->get_value_deriv(x, der);

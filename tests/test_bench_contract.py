@@ -35,4 +35,30 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
     assert "traffic" in r and r["launches"] > 0
     # the second quantity of the metric, reported beside it
-    assert d["hill_adds_strong_scaling"]["value"] > 0
+    assert d["hill_adds_strong_scaling"]["value"] > 0 and d["hill_adds_strong_scaling"]["scaling"] == "strong"
+    # both conventions for the fused launch's bytes: SURVEY 8(d)'s 16 B per evaluation is `frac`
+    assert r["bytes_per_launch"] == 16 * d["config"]["pairs_per_gpu"]
+    assert r["frac_incl_selection_uniforms"] > r["frac"]
+    # BASELINE configs[3] / [4] in the default line: coordinate-CV lookups with their own roofline objects
+    for tag, per_atom in (("c2d_2048sq", 156), ("c3d_512cube", 332)):
+        c = d["coordinate_cv"][tag]
+        rr = c["roofline"]
+        assert rr["bytes_per_launch"] == per_atom * c["atoms"] and rr["bound"] == "hbm"
+        assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) <= 1e-9 and 0 < rr["frac"] < 1
+        assert c["step_ms"] > 0 and c["lookup_replica"]["in_use"] is True
+    assert d["pcie_inclusive"]["ms_per_step"] > d["ms_per_step"]
+
+
+def test_gpus_flag_without_launcher_never_reports_a_smaller_job():
+    """`bench.py --gpus N` with no WORLD_SIZE starts the N ranks itself; where the GPUs are not there it must fail
+    loudly (non-zero status, nothing on stdout) -- never run one rank and print n_gpus: 1."""
+    import edm_amd.hip as H
+
+    if H.device_count() >= 8:
+        pytest.skip("an 8-GPU node would really run the job")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert res.returncode != 0
+    assert not res.stdout.strip(), res.stdout[-500:]
+    assert "--gpus 8" in res.stderr
