@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "edm_comm.h"
 #include "edm_internal.h"
 
 using namespace edm;
@@ -83,7 +84,7 @@ struct edm_hip_bias {
   int debug_virtual_ranks = 0;  // tests: a one-rank communicator's packet is replicated, emulating that many ranks
   DevBuf<long long> xchg_cnt;
   // multi-GPU
-  ncclComm_t comm = nullptr;
+  Transport *comm = nullptr;   // RCCL over xGMI, or the host-staged carrier (edm_comm.h)
   int nranks = 1, rank = 0;
   bool split_applied = false;
 };
@@ -246,7 +247,7 @@ int edm_hip_bias_create(edm_hip_bias **out, const char *input_filename) {
 
 int edm_hip_bias_destroy(edm_hip_bias *b) {
   if (!b) return EDM_HIP_OK;
-  if (b->comm) (void)ncclCommDestroy(b->comm);
+  delete b->comm;
   edm_hip_gauss_destroy(b->bias);
   edm_hip_grid_destroy(b->hist);
   edm_hip_grid_destroy(b->target);
@@ -484,10 +485,8 @@ static int exchange_hills(edm_hip_bias *b, long long nh_local, const double *d_x
   h_cnt[0] = nh_local;
   h_cnt[1] = b->est_hill_count;
   EDM_HIP_TRY(hipMemcpyAsync(b->xchg_cnt.p + 2 * N, h_cnt, 2 * sizeof(long long), hipMemcpyHostToDevice, s));
-  if (ncclAllGather(b->xchg_cnt.p + 2 * N, b->xchg_cnt.p, 2, ncclInt64, b->comm, s) != ncclSuccess) {
-    set_error("ncclAllGather(hill counts) failed");
-    return EDM_HIP_ERR_COMM;
-  }
+  int rcx = b->comm->all_gather(b->xchg_cnt.p + 2 * N, b->xchg_cnt.p, 2 * sizeof(long long), s);   // hill counts
+  if (rcx) return rcx;
   EDM_HIP_TRY(hipMemcpyAsync(h_cnt, b->xchg_cnt.p, sizeof(long long) * (size_t)(2 * N), hipMemcpyDeviceToHost, s));
   EDM_HIP_TRY(hipStreamSynchronize(s));
   long long counts[EDM_MAX_RANKS], total = 0, maxc = 0;
@@ -505,10 +504,8 @@ static int exchange_hills(edm_hip_bias *b, long long nh_local, const double *d_x
   EDM_HIP_TRY(b->xchg_recv.reserve((size_t)maxc * dim * N));
   EDM_HIP_TRY(b->xchg_all.reserve((size_t)total * dim));
   EDM_HIP_TRY(launch_gather_positions(nh_local, d_x, x_stride, d_sel, dim, b->xchg_send.p, s));
-  if (ncclAllGather(b->xchg_send.p, b->xchg_recv.p, (size_t)maxc * dim, ncclDouble, b->comm, s) != ncclSuccess) {
-    set_error("ncclAllGather(hill records) failed");
-    return EDM_HIP_ERR_COMM;
-  }
+  rcx = b->comm->all_gather(b->xchg_send.p, b->xchg_recv.p, sizeof(double) * (size_t)maxc * dim, s);   // padded hill records
+  if (rcx) return rcx;
   long long off = 0;
   for (int r = 0; r < N; r++) {   // rank-major global order
     if (counts[r] > 0)
@@ -607,9 +604,9 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       if (rcp) return rcp;
       EDM_HIP_TRY(hipMemsetAsync(b->xchg_send.p, 0, sizeof(double), s));  // an empty packet
     }
-    if (ncclAllGather(b->xchg_send.p, b->xchg_recv.p, (size_t)packet, ncclDouble, b->comm, s) != ncclSuccess) {
-      set_error("ncclAllGather(hill packets) failed");
-      return EDM_HIP_ERR_COMM;
+    {
+      int rcx = b->comm->all_gather(b->xchg_send.p, b->xchg_recv.p, sizeof(double) * (size_t)packet, s);   // hill packets
+      if (rcx) return rcx;
     }
     for (int r = 1; r < pack_ranks && b->nranks == 1; r++)   // (test hook: emulate more ranks with copies)
       EDM_HIP_TRY(hipMemcpyAsync(b->xchg_recv.p + (size_t)r * packet, b->xchg_recv.p, sizeof(double) * (size_t)packet,
@@ -746,6 +743,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     // dense batches on a small grid: this rank applies only its own slice of the global list, the ranks'
     // delta grids are summed (apply_hills decides whether the batch qualifies)
     spec.shard_comm = b->comm;
+    spec.shard_counts = b->xchg_counts;
     long long off = 0;
     for (int r = 0; r < b->rank; r++) off += b->xchg_counts[r];
     spec.shard_off = off;
@@ -1224,29 +1222,34 @@ int edm_hip_bias_comm_init(edm_hip_bias *b, const void *id_bytes, int nranks, in
   b->mpi_size = nranks;
   if (rank != b->mpi_rank) {
     // the HILLS log is per rank (<name>_<rank>, edm_bias.cpp:1104-1107)
+    // (the handle was created before its rank was known and opened <name>_0 -- which IS rank 0's log: close our
+    //  descriptor, never remove the file)
     if (b->hills_fp) {
       fclose(b->hills_fp);
       b->hills_fp = nullptr;
-      remove(clean_string(b->hills_name, true, b->mpi_rank).c_str());
     }
     b->mpi_rank = rank;
     open_hills(b);
   }
   if (!id_bytes) return EDM_HIP_OK;  // rank bookkeeping only, no communicator
-  ncclUniqueId id;
-  memcpy(&id, id_bytes, sizeof(id));
-  if (ncclCommInitRank(&b->comm, nranks, id, rank) != ncclSuccess) {
-    set_error("ncclCommInitRank failed");
-    return EDM_HIP_ERR_COMM;
-  }
-  return EDM_HIP_OK;
+  delete b->comm;
+  b->comm = nullptr;
+  return make_rccl_transport(id_bytes, nranks, rank, &b->comm);
+}
+
+// the same exchange with the payloads staged through POSIX shared memory (edm_comm.h): ranks of one host
+// without RCCL peer access, e.g. several ranks on ONE GPU (tests), or debugging
+int edm_hip_bias_comm_init_shm(edm_hip_bias *b, const char *shm_name, int nranks, int rank) {
+  int rc = edm_hip_bias_comm_init(b, nullptr, nranks, rank);
+  if (rc) return rc;
+  delete b->comm;
+  b->comm = nullptr;
+  return make_shm_transport(shm_name, nranks, rank, &b->comm);
 }
 
 int edm_hip_bias_comm_destroy(edm_hip_bias *b) {
-  if (b->comm) {
-    (void)ncclCommDestroy(b->comm);
-    b->comm = nullptr;
-  }
+  delete b->comm;
+  b->comm = nullptr;
   return EDM_HIP_OK;
 }
 

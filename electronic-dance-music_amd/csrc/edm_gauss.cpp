@@ -13,9 +13,9 @@
 #include <chrono>
 #include <limits>
 
+#include "edm_comm.h"
 #include "edm_internal.h"
 
-#include <rccl/rccl.h>
 #include <utility>
 #include <vector>
 
@@ -31,7 +31,7 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 void HillWorkspace::release() {
-  slots.release(); heights.release(); hx.release(); hx0.release(); ht.release(); added.release(); partial.release(); scratch.release();
+  gath.release(); slots.release(); heights.release(); hx.release(); hx0.release(); ht.release(); added.release(); partial.release(); scratch.release();
   tail_h1.release(); tail_h2.release(); tail_a2.release(); tail_cum.release();
   hc.release(); tail_flags.release(); tile_flags.release(); tile_list.release(); result.release(); rb.release();
 }
@@ -1229,10 +1229,35 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
                                            p_added + slices[k].first, g->d_dirty, s));
       EDM_HIP_TRY(launch_add_partials(q, ws.delta.p, fplan.partial, fplan.groups, nullptr, s));
     }
-    if (spec.shard_comm &&
-        ncclAllReduce(p_added, p_added, (size_t)nh, ncclDouble, ncclSum, static_cast<ncclComm_t>(spec.shard_comm), s) != ncclSuccess) {
-      set_error("ncclAllReduce(hill integrals) failed");
-      return EDM_HIP_ERR_COMM;
+    if (spec.shard_comm) {
+      // every rank holds the integrals of its own slice: ONE all-gather of the (padded) slices completes the list
+      // on all ranks -- half the bytes of the all-reduce of the zero-filled full-length array this replaces
+      Transport *tr = static_cast<Transport *>(spec.shard_comm);
+      const int N = tr->nranks();
+      long long maxc = 0, run = 0;
+      for (int r = 0; r < N; r++) {
+        const long long c = spec.shard_counts ? spec.shard_counts[r] : 0;
+        if (c > maxc) maxc = c;
+        run += c;
+      }
+      if (!spec.shard_counts || run != nh) {
+        set_error("apply_hills: the ranks' hill counts do not add up to the global list");
+        return EDM_HIP_ERR_ARG;
+      }
+      EDM_HIP_TRY(ws.gath.reserve((size_t)maxc * (size_t)(N + 1)));
+      double *sendb = ws.gath.p + (size_t)maxc * N;   // (own slice, padded to the common length)
+      EDM_HIP_TRY(hipMemsetAsync(sendb, 0, sizeof(double) * (size_t)maxc, s));
+      if (spec.shard_cnt > 0)
+        EDM_HIP_TRY(hipMemcpyAsync(sendb, p_added + spec.shard_off, sizeof(double) * (size_t)spec.shard_cnt, hipMemcpyDeviceToDevice, s));
+      int rcg = tr->all_gather(sendb, ws.gath.p, sizeof(double) * (size_t)maxc, s);
+      if (rcg) return rcg;
+      long long off = 0;
+      for (int r = 0; r < N; r++) {
+        const long long c = spec.shard_counts[r];
+        if (c > 0)
+          EDM_HIP_TRY(hipMemcpyAsync(p_added + off, ws.gath.p + (size_t)r * maxc, sizeof(double) * (size_t)c, hipMemcpyDeviceToDevice, s));
+        off += c;
+      }
     }
   } else if (fused) {
     EDM_HIP_TRY(launch_hill_gather_fused(q, tabs, hl, spec.d_h, spec.h_const, fplan, p_added, g->d_dirty, s));
@@ -1373,10 +1398,9 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         EDM_HIP_TRY(launch_add_partials(q, ws.delta.p, fplan.partial + (size_t)fplan.groups * grid_doubles, 1, dres, s));
       }
     }
-    if (spec.shard_comm && ncclAllReduce(ws.delta.p, ws.delta.p, grid_doubles, ncclDouble, ncclSum,
-                                         static_cast<ncclComm_t>(spec.shard_comm), s) != ncclSuccess) {
-      set_error("ncclAllReduce(delta grid) failed");
-      return EDM_HIP_ERR_COMM;
+    if (spec.shard_comm) {
+      int rcd = static_cast<Transport *>(spec.shard_comm)->all_reduce_sum(ws.delta.p, grid_doubles, s);   // the RCCL bias-grid all-reduce
+      if (rcd) return rcd;
     }
     EDM_HIP_TRY(launch_add_partials(q, g->rec, ws.delta.p, 1, spec.limited ? dres : nullptr, s));
     // whether some hill of some rank had a boundary correction is not known locally: duplicate whenever

@@ -58,7 +58,7 @@ struct DevBuf {
 
 // workspace of the hill path, shared by add_values / the controller
 struct HillWorkspace {
-  DevBuf<double> hx, hx0, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum, heights, slots, delta;
+  DevBuf<double> hx, hx0, ht, added, partial, scratch, tail_h1, tail_h2, tail_a2, tail_cum, heights, slots, delta, gath;
   DevBuf<int> hc, tail_flags, tile_flags, tile_list;
   int tile_parity = 0;      // which of tile_list's two counters the next culled gather uses
   DevBuf<char> result;      // LimitResult
@@ -181,7 +181,8 @@ struct ApplySpec {
   // integrals and the delta grid are summed over the ranks (ncclAllReduce) and every rank adds the same
   // total.  shard_virtual > 1 (tests): the slices of that many ranks are processed one after the other
   // in this process, with plain adds in place of the collectives.
-  void *shard_comm = nullptr;  // ncclComm_t
+  void *shard_comm = nullptr;  // edm::Transport *
+  const long long *shard_counts = nullptr;   // hills per rank of the global list (nranks entries), with shard_comm
   long long shard_off = 0, shard_cnt = 0;
   int shard_virtual = 0;
   // heights that depend on the bias under construction (local tempering): strictly ordered kernel

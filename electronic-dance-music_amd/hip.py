@@ -124,6 +124,7 @@ _PROTOS = {
     "edm_hip_bias_set_hill_log": (C.c_int, [vp, C.c_int]),
     "edm_hip_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
     "edm_hip_bias_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "edm_hip_bias_comm_init_shm": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
     "edm_hip_bias_comm_destroy": (C.c_int, [vp]),
 }
 
@@ -699,6 +700,14 @@ class Bias:
     def comm_init(self, id_bytes, nranks, rank):
         buf = C.create_string_buffer(bytes(id_bytes), 128) if id_bytes is not None else None
         check(lib().edm_hip_bias_comm_init(self.h, C.cast(buf, vp) if buf is not None else None, nranks, rank))
+
+
+def _bias_comm_init_shm(self, shm_name, nranks, rank):
+    """the exchange staged through POSIX shared memory (edm_hip_bias_comm_init_shm)"""
+    check(lib().edm_hip_bias_comm_init_shm(self.h, shm_name.encode(), nranks, rank))
+
+
+Bias.comm_init_shm = _bias_comm_init_shm
 
 
 def comm_unique_id():

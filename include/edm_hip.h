@@ -334,6 +334,12 @@ int edm_hip_bias_set_hill_log(edm_hip_bias *b, int enabled);
  * torch.distributed in bench.py). */
 int edm_hip_comm_unique_id(void *id_bytes, size_t cap);
 int edm_hip_bias_comm_init(edm_hip_bias *b, const void *id_bytes, int nranks, int rank);
+/* The same exchange protocol with the payloads staged through POSIX shared memory instead of RCCL (device -> host
+ * slot, barrier, host -> device): ranks of one host that cannot form an RCCL communicator -- several ranks on ONE
+ * GPU in the tests -- or debugging.  shm_name ("/name", unique to the job) is the same on every rank; the call
+ * returns when all nranks ranks have attached.  A rank that waits more than two minutes at a barrier gets
+ * EDM_HIP_ERR_COMM instead of hanging. */
+int edm_hip_bias_comm_init_shm(edm_hip_bias *b, const char *shm_name, int nranks, int rank);
 int edm_hip_bias_comm_destroy(edm_hip_bias *b);
 
 #ifdef __cplusplus
