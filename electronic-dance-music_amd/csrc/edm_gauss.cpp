@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <limits>
@@ -709,6 +710,7 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
   if (g->h_partials) (void)hipHostFree(g->h_partials);
   if (g->d_dirty) (void)hipFree(g->d_dirty);
   if (g->d_tickets) (void)hipFree(g->d_tickets);
+  if (g->d_ready) (void)hipFree(g->d_ready);
   if (g->prof_ev) {
     for (int i = 0; i < 2 * edm_hip_gauss::PROF_RING; i++) (void)hipEventDestroy(g->prof_ev[i]);
     delete[] g->prof_ev;
@@ -1204,6 +1206,82 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     own.hx0 = hl.hx0 ? hl.hx0 + sl.first * dim : nullptr;
     return own;
   };
+  // gather plan: hill groups when a small grid meets a long hill list, tile culling
+  // when a large grid meets a short one
+  GatherPlan plan;
+  plan.groups = 1;
+  plan.adaptive = 0;
+  plan.partial = nullptr;
+  plan.tile_flags = nullptr;
+  plan.tile_list = nullptr;
+  plan.tile_parity = 0;
+  plan.tile_bound = 0;
+  const long long ntiles = gather_tiles(q);
+  if (fused) {
+    // planned above
+  } else if (nh >= 4096 && ntiles < 1024) {
+    long long G = (2048 + ntiles - 1) / ntiles;
+    if (G > 64) G = 64;
+    if (G > nh / 256) G = nh / 256;
+    if (G < 1) G = 1;
+    plan.groups = (int)G;
+    if (G > 1) {
+      EDM_HIP_TRY(ws.partial.reserve((size_t)G * (size_t)q.total * q.rec));
+      plan.partial = ws.partial.p;
+    }
+  } else if (ntiles < 128) {
+    // a few hundred hills on a grid of a few dozen tiles (the stochastic 1-D step): the tile loop is a
+    // serial chain per node, so spread it over up to ~256 workgroups.  The split is a function of the
+    // true hill count alone (resolved on the device when the count is deferred).
+    long long G = (256 + ntiles - 1) / ntiles;
+    if (G > 16) G = 16;
+    // (the cap follows the EXPECTED batch size, which does not depend on how the batch was queued)
+    const double expected = spec.expected_nh >= 0 ? spec.expected_nh : (double)nh;
+    if (expected < 512) G = 1;
+    if (G > nh / 128) G = nh / 128;
+    if (G < 1) G = 1;
+    plan.groups = (int)G;
+    plan.adaptive = 1;
+    if (G > 1) {
+      EDM_HIP_TRY(ws.partial.reserve((size_t)G * (size_t)q.total * q.rec));
+      plan.partial = ws.partial.p;
+    }
+  } else if (ntiles > 2048) {
+    if (g->tiles_per_hill <= 0) g->tiles_per_hill = tiles_per_hill_bound(q);
+    long long per_hill = g->tiles_per_hill;
+    bool narrow = true;  // (a stencil wider than a periodic dimension crosses more than one seam: no culling)
+    for (int d = 0; d < q.dim; d++)
+      if (q.periodic[d] && 2 * q.msize[d] + 1 > q.n[d]) narrow = false;
+    // a batch queued against a launch bound (deferred count) is sized by its EXPECTED hill count: the
+    // workgroups of a culled gather stride over the tile list, so an optimistic launch stays correct
+    long long plan_nh = nh;
+    if (spec.d_nh && spec.expected_nh >= 0) {
+      const long long e = (long long)(1.5 * spec.expected_nh) + 64;
+      if (e < plan_nh) plan_nh = e;
+    }
+    if (narrow && plan_nh * per_hill < ntiles / 2) {
+      EDM_HIP_TRY(ws.tile_flags.reserve_zeroed((size_t)ntiles));
+      EDM_HIP_TRY(ws.tile_list.reserve_zeroed((size_t)ntiles + 2));
+      plan.tile_flags = ws.tile_flags.p;
+      plan.tile_list = ws.tile_list.p;
+      plan.tile_parity = ws.tile_parity;
+      ws.tile_parity ^= 1;
+      plan.tile_bound = plan_nh * per_hill;
+    }
+  }
+  // lookup replica: the in-place gather keeps it current; every other way of applying the batch leaves it stale
+  plan.faces = nullptr;
+  plan.slots = nullptr;
+  plan.slots_per_hill = 0;
+  if (g->faces && g->faces_state == 1) {
+    if (!fused && !sharded && !spec.ordered && plan.groups == 1)
+      plan.faces = g->faces;
+    else
+      g->faces_state = 2;
+  }
+  const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
+  bool chain_post = false;
+  bool gather_done = false;   // the gather rode in the integrals' launch (launch_integrals_gather)
   if (sharded) {
     if (spec.shard_comm) {
       if (spec.shard_off < 0 || spec.shard_cnt < 0 || spec.shard_off + spec.shard_cnt > nh) {
@@ -1296,8 +1374,68 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         polled = true;
       }
     }
-    EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s, &la));
     hh.res_dev = dres;
+    if (integrals_gather_fusable(q, nh, plan)) {
+      // 1-D: integrals + limiter and the in-place gather side by side in ONE launch (the gather waits for the
+      // limiter's word only before it applies heights); bookkeeping chained onto the gather as before
+      if (!g->d_ready) {
+        EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_ready), 128));
+        EDM_HIP_TRY(hipMemset(g->d_ready, 0, 128));
+      }
+      la.ready_flag = g->d_ready;
+      la.ready_seq = ++g->ready_seq;
+      static const bool tracing = getenv("EDM_HIP_TRACE") != nullptr;   // development aid: stamps of one launch to stderr
+      const size_t trace_wgs = (size_t)nh + (size_t)((q.n[0] + 31) / 32);
+      unsigned long long *d_trace = nullptr;
+      if (tracing && g->ready_seq == 150) {
+        EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_trace), trace_wgs * 64));
+        EDM_HIP_TRY(hipMemset(d_trace, 0, trace_wgs * 64));
+        la.trace = d_trace;
+      }
+      PostSpec ps;
+      ps.ticket = g->d_tickets + 2 * EDM_TICKET_INTS;
+      ps.hist_geom = spec.hist_g;
+      ps.hist = spec.hist_values;
+      ps.flags = p_flags;
+      ps.flush_mode = spec.flush_mode;
+      ps.rb_src = nullptr;
+      ps.rb_dst = nullptr;
+      ps.rb_bytes = 0;
+      chain_post = fused_post && nh <= 4096;
+      if (!rb_pushed && chain_post && small && rb_bytes + 128 <= g->h_stage_bytes) {
+        ps.rb_src = ws.rb.p;
+        ps.rb_dst = g->d_stage;
+        ps.rb_bytes = (long long)rb_bytes;
+        rb_pushed = true;
+      }
+      EDM_HIP_TRY(launch_integrals_gather(q, tabs, g->rec, hl, spec.d_h, spec.h_const, p_added, la, hh, plan, g->d_dirty, s,
+                                          chain_post ? &ps : nullptr));
+      gather_done = true;
+      if (d_trace) {
+        EDM_HIP_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned long long> tr(trace_wgs * 8);
+        EDM_HIP_TRY(hipMemcpy(tr.data(), d_trace, trace_wgs * 64, hipMemcpyDeviceToHost));
+        (void)hipFree(d_trace);
+        unsigned long long t0 = ~0ull;
+        for (size_t w = 0; w < trace_wgs; w++)
+          if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
+        const char *names_i[8] = {"start", "integral done", "last wg: ticket", "flag published", "host copy done", "", "", "end"};
+        const char *names_g[8] = {"start", "terms parked", "flag seen", "", "", "", "body end", "post end"};
+        for (int role = 0; role < 2; role++) {
+          for (int k = 0; k < 8; k++) {
+            std::vector<double> v;
+            for (size_t w = role ? (size_t)nh : 0; w < (role ? trace_wgs : (size_t)nh); w++)
+              if (tr[w * 8 + k]) v.push_back((double)(tr[w * 8 + k] - t0) * 0.01);
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[edm trace] %s %-16s n=%4zu  min %6.2f  med %6.2f  max %6.2f us\n", role ? "gather   " : "integrals",
+                    role ? names_g[k] : names_i[k], v.size(), v.front(), v[v.size() / 2], v.back());
+          }
+        }
+      }
+    } else {
+      EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s, &la));
+    }
   } else if (spec.limited || want_total) {
     EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s));
   }
@@ -1312,81 +1450,6 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     EDM_HIP_TRY(launch_sum(nh, p_added, g->d_scalars + 1, ws.scratch.p, s));
   }
 
-  // gather plan: hill groups when a small grid meets a long hill list, tile culling
-  // when a large grid meets a short one
-  GatherPlan plan;
-  plan.groups = 1;
-  plan.adaptive = 0;
-  plan.partial = nullptr;
-  plan.tile_flags = nullptr;
-  plan.tile_list = nullptr;
-  plan.tile_parity = 0;
-  plan.tile_bound = 0;
-  const long long ntiles = gather_tiles(q);
-  if (fused) {
-    // planned above
-  } else if (nh >= 4096 && ntiles < 1024) {
-    long long G = (2048 + ntiles - 1) / ntiles;
-    if (G > 64) G = 64;
-    if (G > nh / 256) G = nh / 256;
-    if (G < 1) G = 1;
-    plan.groups = (int)G;
-    if (G > 1) {
-      EDM_HIP_TRY(ws.partial.reserve((size_t)G * (size_t)q.total * q.rec));
-      plan.partial = ws.partial.p;
-    }
-  } else if (ntiles < 128) {
-    // a few hundred hills on a grid of a few dozen tiles (the stochastic 1-D step): the tile loop is a
-    // serial chain per node, so spread it over up to ~256 workgroups.  The split is a function of the
-    // true hill count alone (resolved on the device when the count is deferred).
-    long long G = (256 + ntiles - 1) / ntiles;
-    if (G > 16) G = 16;
-    // (the cap follows the EXPECTED batch size, which does not depend on how the batch was queued)
-    const double expected = spec.expected_nh >= 0 ? spec.expected_nh : (double)nh;
-    if (expected < 512) G = 1;
-    if (G > nh / 128) G = nh / 128;
-    if (G < 1) G = 1;
-    plan.groups = (int)G;
-    plan.adaptive = 1;
-    if (G > 1) {
-      EDM_HIP_TRY(ws.partial.reserve((size_t)G * (size_t)q.total * q.rec));
-      plan.partial = ws.partial.p;
-    }
-  } else if (ntiles > 2048) {
-    if (g->tiles_per_hill <= 0) g->tiles_per_hill = tiles_per_hill_bound(q);
-    long long per_hill = g->tiles_per_hill;
-    bool narrow = true;  // (a stencil wider than a periodic dimension crosses more than one seam: no culling)
-    for (int d = 0; d < q.dim; d++)
-      if (q.periodic[d] && 2 * q.msize[d] + 1 > q.n[d]) narrow = false;
-    // a batch queued against a launch bound (deferred count) is sized by its EXPECTED hill count: the
-    // workgroups of a culled gather stride over the tile list, so an optimistic launch stays correct
-    long long plan_nh = nh;
-    if (spec.d_nh && spec.expected_nh >= 0) {
-      const long long e = (long long)(1.5 * spec.expected_nh) + 64;
-      if (e < plan_nh) plan_nh = e;
-    }
-    if (narrow && plan_nh * per_hill < ntiles / 2) {
-      EDM_HIP_TRY(ws.tile_flags.reserve_zeroed((size_t)ntiles));
-      EDM_HIP_TRY(ws.tile_list.reserve_zeroed((size_t)ntiles + 2));
-      plan.tile_flags = ws.tile_flags.p;
-      plan.tile_list = ws.tile_list.p;
-      plan.tile_parity = ws.tile_parity;
-      ws.tile_parity ^= 1;
-      plan.tile_bound = plan_nh * per_hill;
-    }
-  }
-  // lookup replica: the in-place gather keeps it current; every other way of applying the batch leaves it stale
-  plan.faces = nullptr;
-  plan.slots = nullptr;
-  plan.slots_per_hill = 0;
-  if (g->faces && g->faces_state == 1) {
-    if (!fused && !sharded && !spec.ordered && plan.groups == 1)
-      plan.faces = g->faces;
-    else
-      g->faces_state = 2;
-  }
-  const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
-  bool chain_post = false;
   if (sharded) {
     if (spec.limited) {
       for (size_t k = 0; k < slices.size(); k++) {
@@ -1412,6 +1475,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
   } else if (fused) {
     EDM_HIP_TRY(launch_hill_gather_correct_and_apply(q, tabs, g->rec, hl, hh, fplan, spec.limited ? 1 : 0, g->d_dirty, s));
+    if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
+  } else if (gather_done) {
     if (!fused_post) EDM_HIP_TRY(launch_duplicate_boundary(q, g->rec, g->d_dirty, s));
   } else if (!spec.ordered) {
     // short limited batch applied in place: boundary duplication and histogram ride on the gather launch

@@ -234,6 +234,14 @@ long long gather_tiles(const Geom &g);
 hipError_t launch_hill_gather(const Geom &g, const Tables &t, double *rec, const HillList &h,
                               const HillHeights &hh, const GatherPlan &plan, int *dirty_flag, hipStream_t s,
                               const PostSpec *chain = nullptr);
+// Short 1-D batches: the per-hill integrals + chained limiter (launch_hill_integrals with `chain`) and the in-place
+// gather (launch_hill_gather with plan.groups == 1) as ONE launch whose two halves run side by side; the gather
+// waits for the limiter's word (chain.ready_flag == chain.ready_seq, a zero-initialised device word and a sequence
+// number that grows with every such launch) only before it applies heights.  hh.res_dev is the limiter's result.
+bool integrals_gather_fusable(const Geom &g, long long nh_bound, const GatherPlan &plan);
+hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, const HillList &h, const double *heights,
+                                   double h_const, double *added, const LimitArgs &chain, const HillHeights &hh,
+                                   const GatherPlan &plan, int *dirty_flag, hipStream_t s, const PostSpec *post_chain);
 // pieces of launch_hill_gather_correct_and_apply for the sharded multi-GPU application: the correction pass
 // alone (writes partial buffer [plan.groups], zeroed first) and dst[i] += sum of `groups` partial buffers
 hipError_t launch_hill_gather_correction(const Geom &g, const Tables &t, const HillList &h, const HillHeights &hh,
@@ -291,6 +299,11 @@ struct LimitArgs {
   char *rb_dst;
   unsigned long long *done_flag;
   unsigned long long done_seq;
+  // k_integrals_gather: device word the gather workgroups of the same launch poll for ready_seq
+  unsigned long long *ready_flag;
+  unsigned long long ready_seq;
+  // development aid (EDM_HIP_TRACE=1): 8 wall-clock stamps (10 ns units) per workgroup of k_integrals_gather, or NULL
+  unsigned long long *trace;
 };
 bool hill_integrals_can_chain_limit(long long nh);
 // boundary duplication + histogram chained onto the gather (plan.groups == 1, hh.res_dev and h.hx0 set)

@@ -1527,6 +1527,26 @@ __device__ __forceinline__ T acquire(const T *p) {
   return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The word the limiter's workgroup of k_integrals_gather publishes and the gather's workgroups poll:
+// [sequence number of the launch : 24][limiter error : 8][k, first hill of the ordered tail : 32]
+__device__ __forceinline__ unsigned long long ready_word(unsigned long long seq, int err, long long k) {
+  return ((seq & 0xFFFFFFull) << 40) | ((unsigned long long)(err & 0xFF) << 32) | (unsigned long long)(unsigned)k;
+}
+// one thread waits until the word of launch `seq` is there and returns it (a few hundred workgroups poll the same
+// word: spaced ~0.2 us apart so that the polls do not crowd the round trips of the workgroup that will store it)
+__device__ __forceinline__ unsigned long long wait_for_word(const unsigned long long *word, unsigned long long seq) {
+  const unsigned long long want = seq & 0xFFFFFFull;
+  unsigned long long w = acquire(word);
+  if ((w >> 40) == want) return w;
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    __builtin_amdgcn_s_sleep(7);   // ~450 cycles
+    w = acquire(word);
+    if ((w >> 40) == want) return w;
+    if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();   // 10 s at 100 MHz: never, short of a lost launch
+  }
+}
+
 // Selection + hill preparation in one launch (stochastic steps with a deferred count): every
 // workgroup compacts its SEL_CHUNK samples IN ORDER into its own stretch of `stage`, the last one
 // scans the per-workgroup counts, moves at most `h.nh` (the launch bound of the step) entries to the
@@ -1971,6 +1991,26 @@ __device__ __forceinline__ void readback_copy(const char *rb_src, char *rb_dst, 
         __hip_atomic_store(&dst[seg_off[sgm] / 8 + w], v[sgm], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+// the limiter's part of the same region: result header + tail flags, undo heights, undo bias
+template <int DIM>
+__device__ __forceinline__ void readback_copy_limiter(const char *rb_src, char *rb_dst, long long nb, long long na, int me,
+                                                      int nthr) {
+  const long long off_flags = 64, off_h2 = off_flags + ((4 * nb + 7) & ~7LL), off_a2 = off_h2 + 8 * nb;
+  const long long seg_off[3] = {0, off_h2, off_a2};
+  const long long seg_len[3] = {off_flags + ((4 * na + 7) & ~7LL), 8 * na, 8 * na};
+  const long long *src = reinterpret_cast<const long long *>(rb_src);
+  long long *dst = reinterpret_cast<long long *>(rb_dst);
+  const long long longest = seg_len[0] > seg_len[1] ? seg_len[0] : seg_len[1];
+  for (long long w = me; w < longest / 8; w += nthr) {
+    long long v[3];
+#pragma unroll
+    for (int sgm = 0; sgm < 3; sgm++) v[sgm] = (w < seg_len[sgm] / 8) ? acquire(&src[seg_off[sgm] / 8 + w]) : 0;
+#pragma unroll
+    for (int sgm = 0; sgm < 3; sgm++)
+      if (w < seg_len[sgm] / 8)
+        __hip_atomic_store(&dst[seg_off[sgm] / 8 + w], v[sgm], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 // the limiter-independent part of the same region: per-hill bias and original positions of hills [0, na)
 template <int DIM>
 __device__ __forceinline__ void readback_copy_hills(const char *rb_src, char *rb_dst, long long nb, long long na, int me,
@@ -1999,20 +2039,21 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            double h_const, double limit, double cum_in, int flush_mode,
                                            const LimitTail &tail, LimitResult *res, long long nchunks,
                                            const double *chunk_sum, const double *chunk_max,
-                                           const long long *nh_dev, long long mirror = 0);
+                                           const long long *nh_dev, long long mirror = 0, long long *k_out = nullptr,
+                                           int *err_out = nullptr, long long nh_known = -1);
 
 // `la` (TPH == BLOCK only): the ordered limiter is chained onto the last workgroup to finish
+// (bid: this workgroup's index among the integrals workgroups -- blockIdx.x, except inside k_integrals_gather)
+// returns true (workgroup-uniform) in the workgroup that ran the chained limiter, once its results are out
 template <int DIM, int TPH, bool PERB>
-__global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(Geom g, Tables t, HillList h,
-                                                                                const double *__restrict__ heights,
-                                                                                double h_const,
-                                                                                double *__restrict__ added,
-                                                                                LimitArgs la) {
+__device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables &t, const HillList &h,
+                                                    const double *__restrict__ heights, double h_const,
+                                                    double *__restrict__ added, const LimitArgs &la, unsigned bid) {
   constexpr int NT = (TPH > BLOCK) ? TPH : BLOCK;  // workgroup size: 512 threads per hill for the 3-D stencil
   __shared__ double s_red[NT / 64];
   const int lane = threadIdx.x & 63;
   const int lt = threadIdx.x % TPH;
-  const long long hill = (long long)blockIdx.x * (NT / TPH) + (threadIdx.x / TPH);
+  const long long hill = (long long)bid * (NT / TPH) + (threadIdx.x / TPH);
   // The hill's fields are requested BEFORE the hill count is known (the arrays hold h.nh entries, the launch bound:
   // an entry beyond the true count is stale and masked below): one memory round trip instead of three dependent
   // ones (count -> centre node -> the other fields).
@@ -2036,13 +2077,13 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
     if (heights) height_r = heights[hill];
   }
   const long long nh_eff = hill_count(h);
-  if (TPH == 64 && hill >= nh_eff) return;  // (a whole workgroup shares one hill when TPH == BLOCK)
+  if (TPH == 64 && hill >= nh_eff) return false;  // (a whole workgroup shares one hill when TPH == BLOCK)
   const bool live = hill < nh_eff;
   // chained limiter (a workgroup per hill, launched against a bound on the hill count): only the workgroups that
   // own a hill take a ticket -- workgroup 0 alone when there is none -- so the last arrival is one of a few hundred
   // and a single counter (one atomic round trip) does
   const unsigned ticket_blocks = (unsigned)(nh_eff > 0 ? nh_eff : 1);
-  if (TPH != 64 && la.enabled && blockIdx.x >= ticket_blocks) return;
+  if (TPH != 64 && la.enabled && bid >= ticket_blocks) return false;
   TermConst<DIM> tc;
   term_const<DIM>(g, tc);
   double acc = 0;
@@ -2136,28 +2177,60 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
       if (la.enabled) publish(&added[hill], r); else added[hill] = r;
     }
     if (la.enabled) {
-      if (!last_block_done(la.ticket, ticket_blocks, blockIdx.x, ticket_blocks <= 512)) return;
+      if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 1] = wall_clock64();
+      if (!last_block_done(la.ticket, ticket_blocks, bid, ticket_blocks <= 512)) return false;
+      if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 2] = wall_clock64();
       // wave 0 walks the limiter; with a read-back region (la.rb_dst) it stores its outputs to the device region and
       // to its host-mapped copy alike, while the other waves copy what does not depend on the limiter -- per-hill
-      // bias and positions, by the true hill count -- so nothing is left to read back once the limiter is done
-      const long long mirror = la.rb_dst ? (long long)(la.rb_dst - la.rb_src) : 0;
+      // bias and positions, by the true hill count -- so nothing is left to read back once the limiter is done.
+      // k_integrals_gather (la.ready_flag): the gather workgroups of the same launch wait for the limiter, so its
+      // outputs go to the device region only (agent scope), the word the gather polls follows as soon as wave 0's
+      // stores are acknowledged -- no host round trip in front of it -- and the copy to the host comes after.
+      const bool concurrent = la.ready_flag != nullptr;
+      const long long mirror = (la.rb_dst && !concurrent) ? (long long)(la.rb_dst - la.rb_src) : 0;
+      const long long nb = h.nh;   // the layout is sized by the launch bound
+      const long long n_true = h.nh_dev ? *h.nh_dev : nb;   // (already on its way for hill_count() above: no new round trip)
+      long long na = n_true;
+      if (na > nb) na = 0;         // (bound exceeded: the limiter reports it, nothing is read)
       if (threadIdx.x < 64) {
+        long long k_first = 0;
+        int err = 0;
         limit_wave<true>(h.nh, added, heights, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr,
-                   nullptr, h.nh_dev, mirror);
+                   nullptr, h.nh_dev, mirror, &k_first, &err, h.nh_dev ? n_true : -1);
+        if (concurrent) {
+          // the word carries what every gather workgroup needs first -- the error code and k, the first hill of the
+          // ordered tail -- so that seeing it is all the waiting workgroups have to do when there is no tail
+          __builtin_amdgcn_s_waitcnt(0);
+          if (threadIdx.x == 0) publish(la.ready_flag, ready_word(la.ready_seq, err, k_first));
+          if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 3] = wall_clock64();
+        }
       } else if (la.rb_dst) {
-        const long long nb = h.nh;   // the layout is sized by the launch bound
-        long long na = h.nh_dev ? *h.nh_dev : nb;
-        if (na > nb) na = 0;         // (bound exceeded: the limiter reports it, nothing is read)
         readback_copy_hills<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x - 64, NT - 64);
       }
       if (la.rb_dst) {
+        if (concurrent) {
+          __syncthreads();
+          readback_copy_limiter<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x, NT);
+        }
         __builtin_amdgcn_s_waitcnt(0);   // every wave's stores into the host-mapped region have been acknowledged
         __syncthreads();
         if (threadIdx.x == 0 && la.done_flag)
           __hip_atomic_store(la.done_flag, la.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
+      if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 4] = wall_clock64();
+      __syncthreads();
+      return true;
     }
   }
+  return false;
+}
+template <int DIM, int TPH, bool PERB>
+__global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(Geom g, Tables t, HillList h,
+                                                                                const double *__restrict__ heights,
+                                                                                double h_const,
+                                                                                double *__restrict__ added,
+                                                                                LimitArgs la) {
+  (void)hill_integrals_body<DIM, TPH, PERB>(g, t, h, heights, h_const, added, la, blockIdx.x);
 }
 
 bool hill_integrals_can_chain_limit(long long nh) { return nh > 0 && nh <= 2048; }
@@ -2306,6 +2379,7 @@ __device__ __forceinline__ void hist_batch(const Geom &hg, double *hist, long lo
 // bookkeeping chained onto the last gather workgroup (see last_block_done)
 struct PostArgs {
   int enabled;
+  int skip_hist;   // the histogram is updated elsewhere (k_integrals_gather: by the limiter's workgroup)
   int *ticket;
   DupPlan dp;
   Geom hg;
@@ -2316,6 +2390,38 @@ struct PostArgs {
   char *rb_dst;
   long long rb_bytes;
 };
+
+// boundary duplication (K6) and the histogram updates (K7) by the last gather workgroup to finish
+// (a few hundred workgroups that finish spread over microseconds: one counter, one atomic round trip -- the
+//  two-level ticket costs the last arrival two)
+template <int DIM, bool PERB>
+__device__ __forceinline__ void gather_post(const Geom &g, double *__restrict__ rec, const HillList &h, const HillHeights &hh,
+                                            int *__restrict__ dirty_flag, const PostArgs &post, unsigned nblocks, unsigned id) {
+  if (!last_block_done(post.ticket, nblocks, id, nblocks <= 512)) return;
+  // the three chores are independent: the waves of the workgroup split them (wave 0 the boundary copies --
+  // at most 4^DIM = 64, one per lane -- the lower half of the rest the histogram, the upper half the read-back)
+  constexpr int NW = BLOCK / 64;
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  if (wv == 0) {
+    if (!PERB && acquire(dirty_flag) != 0) {   // (no walls, no boundary corrections, nothing to duplicate)
+      duplicate_boundary_wave(g, rec, post.dp, ln);
+      if (ln == 0) *dirty_flag = 0;
+    }
+  } else if (wv <= (NW - 1) / 2) {
+    const int nh_w = (NW - 1) / 2;   // waves 1 .. nh_w
+    if (!post.skip_hist && !hh.res_dev->error)
+      hist_batch<DIM>(post.hg, post.hist, h.nh, h.hx0, hh.res_dev, post.flags, post.flush_mode, (wv - 1) * 64 + ln,
+                      nh_w * 64);
+  } else if (post.rb_dst) {
+    // read-back region (written by the earlier launches of the step) -> host-mapped memory; only the part
+    // the batch's true hill count fills: header + flags | h2 | added2 | added | positions (apply_hills' layout)
+    const int first = (NW - 1) / 2 + 1, nthr = (NW - first) * 64, me = (wv - first) * 64 + ln;
+    const long long nb = h.nh;                                  // the layout is sized by the launch bound
+    long long na = hh.res_dev->nh < nb ? hh.res_dev->nh : nb;   // ... the hills are fewer
+    if (hh.res_dev->error) na = 0;
+    readback_copy<DIM>(post.rb_src, post.rb_dst, nb, na, me, nthr);
+  }
+}
 
 // PARTS (1 or 8; 8 on the 1-D grid only): the tile is BLOCK / PARTS nodes wide and thread (part, node)
 // accumulates every PARTS-th batch of the tile's hill list for its node; the parts are combined in LDS in a
@@ -2328,11 +2434,18 @@ template <int DIM, int PARTS>
 __device__ __forceinline__ constexpr int tile_extent(int d) {
   return (DIM == 1 && d == 0) ? BLOCK / PARTS : Tile<DIM>::T[d];
 }
-template <int DIM, int MODE, int PARTS, bool PERB>
+// DEFER (k_integrals_gather: 1-D, in place, the limiter running in OTHER workgroups of the same launch): the
+// first chunk of the hill list is staged without heights, its stencil terms -- the exp-heavy part, which does not
+// depend on the limiter -- are computed and parked in LDS, and only then does the workgroup wait for the limiter's
+// word (ready_flag == ready_seq), fetch k and the tail heights and accumulate.  Hills the limiter deferred (height 0)
+// are skipped at that point instead of at staging.
+template <int DIM, int MODE, int PARTS, bool PERB, bool DEFER = false>
 __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t, double *__restrict__ rec,
                                                  const HillList &h, const HillHeights &hh, const GatherPlan &plan,
                                                  int use_list, int *__restrict__ dirty_flag, int coherent,
-                                                 long long tile) {
+                                                 long long tile, const unsigned long long *ready_flag = nullptr,
+                                                 unsigned long long ready_seq = 0, unsigned long long *trace = nullptr) {
+  static_assert(!DEFER || (DIM == 1 && MODE == 0), "deferred heights: the 1-D in-place gather only");
   constexpr int R = (DIM == 1) ? 2 : 4;
   constexpr int NODES = BLOCK / PARTS;
   const int tnode = threadIdx.x % NODES;   // this thread's node within the tile
@@ -2378,7 +2491,10 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   // (limiter result and hill count in one round trip: the kernel is a chain of dependent loads)
   long long k_first_tail = hh.k;
   long long nh_eff = h.nh;
-  if (hh.res_dev) {
+  if (DEFER) {
+    nh_eff = hill_count(h);   // (the selection's count; the limiter's result is read after the wait below)
+    k_first_tail = nh_eff;
+  } else if (hh.res_dev) {
     const int err = hh.res_dev->error;
     const long long kk = hh.res_dev->k, nn = hh.res_dev->nh;
     if (err) return;  // limiter overflow / bound exceeded: the host handles it, nothing is applied
@@ -2426,7 +2542,13 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   __shared__ double s_t[PERB ? 1 : BLOCK][2 * DIM];  // (hill-side wall exponentials: none without walls)
   __shared__ double s_h1[BLOCK], s_h2[BLOCK];
   __shared__ int s_wcnt[BLOCK / 64];
-  __shared__ long long s_id[(MODE == 1) ? BLOCK : 1];
+  __shared__ long long s_id[(MODE == 1 || DEFER) ? BLOCK : 1];
+  // DEFER: parked stencil terms of the first chunk, NTS per thread (value, derivative, multiplicity | nz << 30)
+  constexpr int DEFER_ILP = 4;
+  constexpr int NTS = 8;
+  __shared__ double s_tv[DEFER ? NTS : 1][DEFER ? BLOCK : 1], s_td[DEFER ? NTS : 1][DEFER ? BLOCK : 1];
+  __shared__ int s_tm[DEFER ? NTS : 1][DEFER ? BLOCK : 1];
+  bool waited = !DEFER;   // (block-uniform) the limiter's result is known
   __shared__ double s_wpart[(MODE == 1) ? BLOCK / 64 : 1][(MODE == 1) ? BLOCK : 1];
   __shared__ double s_pacc[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? NODES : 1][1 + DIM];
   __shared__ int s_ptouch[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? NODES : 1];
@@ -2441,6 +2563,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (long long base = hbeg; base < hend; base += BLOCK) {
     const long long cur = base + threadIdx.x;   // (every thread stages one hill of the chunk)
+    const bool defer_chunk = DEFER && !waited;
     bool take = false;
     int c[DIM];
     double h1 = 0, h2 = 0;
@@ -2461,11 +2584,11 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
         }
       }
       const double hb = hh.h ? hh.h[cur] : hh.h_const;
-      const bool in_tail = (MODE == 2) || (MODE == 0 && cur >= k_first_tail);
+      const bool in_tail = !defer_chunk && ((MODE == 2) || (MODE == 0 && cur >= k_first_tail));
       double th1 = 0, th2 = 0;
       if (in_tail) {
-        th1 = hh.tail_h1[cur - k_first_tail];
-        th2 = hh.tail_h2[cur - k_first_tail];
+        th1 = DEFER ? acquire(&hh.tail_h1[cur - k_first_tail]) : hh.tail_h1[cur - k_first_tail];
+        th2 = DEFER ? acquire(&hh.tail_h2[cur - k_first_tail]) : hh.tail_h2[cur - k_first_tail];
       }
       if (c[0] != INT_MIN) {
         take = true;
@@ -2486,7 +2609,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
             }
           }
         }
-        if (take) {
+        if (take && !defer_chunk) {
           if (MODE == 1) {
             h1 = hb;
             h2 = 0;
@@ -2526,26 +2649,89 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       }
       s_h1[pos] = h1;
       s_h2[pos] = h2;
-      if (MODE == 1) s_id[pos] = cur;
+      if (MODE == 1 || DEFER) s_id[pos] = cur;
     }
     __syncthreads();
+    if (DEFER && defer_chunk) {
+      // 1. the stencil terms of this thread's first NTS staged hills, computed while the limiter still runs
+      static_assert(!DEFER || ILP == DEFER_ILP, "parked-term layout");
+      if (active) {
+        int it = 0;
+        for (int q0 = part * ILP; q0 < cnt && it < NTS / ILP; q0 += PARTS * ILP, it++) {
+#pragma unroll
+          for (int q = 0; q < ILP; q++) {
+            double v = 0, dv[DIM];
+#pragma unroll
+            for (int d = 0; d < DIM; d++) dv[d] = 0;
+            int m = 0;
+            bool nz = false;
+            if (q0 + q < cnt) {
+              m = 1;
+#pragma unroll
+              for (int d = 0; d < DIM; d++) m *= images(g, d, s_c[q0 + q][d], p[d], p[d]);
+              if (!(m > 0 && pair_term<DIM, PERB>(g, tc, nt, s_x[q0 + q], s_t[PERB ? 0 : q0 + q], v, dv, nz, interior))) m = 0;
+            }
+            s_tv[it * ILP + q][threadIdx.x] = v;
+            s_td[it * ILP + q][threadIdx.x] = dv[0];
+            s_tm[it * ILP + q][threadIdx.x] = m | (nz ? (1 << 30) : 0);
+          }
+        }
+      }
+      // 2. the limiter's word (its workgroups were dispatched ahead of this one and wait for nobody)
+      if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
+      __shared__ unsigned long long s_word;
+      if (threadIdx.x == 0) s_word = wait_for_word(ready_flag, ready_seq);
+      __syncthreads();
+      if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
+      waited = true;
+      const unsigned long long word = s_word;
+      if ((word >> 32) & 0xFF) return;  // limiter overflow / bound exceeded: the host handles it, nothing is applied
+      k_first_tail = (long long)(unsigned)(word & 0xFFFFFFFFull);
+      // 3. heights of the staged hills
+      if ((int)threadIdx.x < cnt) {
+        const long long id = s_id[threadIdx.x];
+        double a1 = hh.h ? hh.h[id] : hh.h_const, a2 = 0;
+        if (id >= k_first_tail) {
+          a1 = acquire(&hh.tail_h1[id - k_first_tail]);
+          a2 = acquire(&hh.tail_h2[id - k_first_tail]);
+        }
+        if (id >= nh_eff) a1 = a2 = 0;
+        s_h1[threadIdx.x] = a1;
+        s_h2[threadIdx.x] = a2;
+      }
+      __syncthreads();
+    }
     if (active || MODE == 1) {
-      for (int q0 = part * ILP; q0 < cnt; q0 += PARTS * ILP) {
+      int it_acc = 0;
+      for (int q0 = part * ILP; q0 < cnt; q0 += PARTS * ILP, it_acc++) {
         double val[ILP], dval[ILP][DIM];
         int mult[ILP];
+        bool nzq[ILP];
+        const bool parked = DEFER && defer_chunk && it_acc < NTS / ILP;
 #pragma unroll
         for (int q = 0; q < ILP; q++) {
           mult[q] = 0;
-          if (active && q0 + q < cnt) {
+          nzq[q] = false;
+          if (parked) {
+            const int mm = s_tm[DEFER ? it_acc * ILP + q : 0][DEFER ? threadIdx.x : 0];
+            val[q] = s_tv[DEFER ? it_acc * ILP + q : 0][DEFER ? threadIdx.x : 0];
+            dval[q][0] = s_td[DEFER ? it_acc * ILP + q : 0][DEFER ? threadIdx.x : 0];
+            mult[q] = mm & ((1 << 30) - 1);
+            nzq[q] = (mm >> 30) != 0;
+          } else if (active && q0 + q < cnt) {
             int m = 1;
 #pragma unroll
             for (int d = 0; d < DIM; d++) m *= images(g, d, s_c[q0 + q][d], p[d], p[d]);
             bool nz = false;
             if (m > 0 && pair_term<DIM, PERB>(g, tc, nt, s_x[q0 + q], s_t[PERB ? 0 : q0 + q], val[q], dval[q], nz, interior)) {
               mult[q] = m;
-              any_corr |= nz;
-              touched = true;
+              nzq[q] = nz;
             }
+          }
+          if (DEFER && mult[q] > 0 && s_h1[q0 + q] == 0 && s_h2[q0 + q] == 0) mult[q] = 0;  // a deferred / unchanged hill adds nothing
+          if (mult[q] > 0) {
+            any_corr |= nzq[q];
+            touched = true;
           }
         }
 #pragma unroll
@@ -2686,37 +2872,47 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MOD
   } else {
     hill_gather_body<DIM, MODE, PARTS, PERB>(g, t, rec, h, hh, plan, 0, dirty_flag, (MODE == 0) ? post.enabled : 0, blockIdx.x);
   }
-  if (MODE == 0 && post.enabled) {
-    // boundary duplication (K6) and the histogram updates (K7) by the last workgroup to finish
-    // (a few hundred workgroups that finish spread over microseconds: one counter, one atomic round trip -- the
-    //  two-level ticket costs the last arrival two)
-    if (!last_block_done(post.ticket, gridDim.x * gridDim.y, blockIdx.x + gridDim.x * blockIdx.y,
-                         gridDim.x * gridDim.y <= 512))
-      return;
-    // the three chores are independent: the waves of the workgroup split them (wave 0 the boundary copies --
-    // at most 4^DIM = 64, one per lane -- the lower half of the rest the histogram, the upper half the read-back)
-    constexpr int NW = BLOCK / 64;
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    if (wv == 0) {
-      if (!PERB && acquire(dirty_flag) != 0) {   // (no walls, no boundary corrections, nothing to duplicate)
-        duplicate_boundary_wave(g, rec, post.dp, ln);
-        if (ln == 0) *dirty_flag = 0;
-      }
-    } else if (wv <= (NW - 1) / 2) {
-      const int nh_w = (NW - 1) / 2;   // waves 1 .. nh_w
-      if (!hh.res_dev->error)
-        hist_batch<DIM>(post.hg, post.hist, h.nh, h.hx0, hh.res_dev, post.flags, post.flush_mode, (wv - 1) * 64 + ln,
-                        nh_w * 64);
-    } else if (post.rb_dst) {
-      // read-back region (written by the earlier launches of the step) -> host-mapped memory; only the part
-      // the batch's true hill count fills: header + flags | h2 | added2 | added | positions (apply_hills' layout)
-      const int first = (NW - 1) / 2 + 1, nthr = (NW - first) * 64, me = (wv - first) * 64 + ln;
-      const long long nb = h.nh;                                  // the layout is sized by the launch bound
-      long long na = hh.res_dev->nh < nb ? hh.res_dev->nh : nb;   // ... the hills are fewer
-      if (hh.res_dev->error) na = 0;
-      readback_copy<DIM>(post.rb_src, post.rb_dst, nb, na, me, nthr);
-    }
+  if (MODE == 0 && post.enabled)
+    gather_post<DIM, PERB>(g, rec, h, hh, dirty_flag, post, gridDim.x * gridDim.y, blockIdx.x + gridDim.x * blockIdx.y);
+}
+
+// One launch for the two halves of a short 1-D hill step that do not depend on each other: workgroups
+// [0, nb_int) compute the per-hill integrals and -- the last of them -- run the ordered limiter and the read-back
+// (k_hill_integrals' body); the rest are the tile-owned gather, which computes its stencil terms while the limiter
+// still runs and waits for the limiter's word only before it applies heights (hill_gather_body<.., DEFER>).  The
+// integrals workgroups have the lower ids: they are dispatched first and wait for nobody, so the waiting gather
+// workgroups can never keep them off the machine.  Arithmetic per node and per hill is that of the two separate
+// launches; what changes is that the gather's ~10 us of exp-bound work no longer starts after the limiter's ~10 us
+// chain of dependent round trips but beside it (W1 step: 37.9 -> see DESIGN.md section 5).
+template <bool PERB>
+__global__ void __launch_bounds__(BLOCK) k_integrals_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
+                                                            const double *__restrict__ heights, double h_const,
+                                                            double *__restrict__ added, LimitArgs la, HillHeights hh,
+                                                            GatherPlan plan, int *__restrict__ dirty_flag, PostArgs post,
+                                                            unsigned nb_int) {
+#define EDM_STAMP(k) do { if (la.trace && threadIdx.x == 0) la.trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+  EDM_STAMP(0);
+  if (blockIdx.x < nb_int) {
+    const bool ran_limiter = hill_integrals_body<1, BLOCK, PERB>(g, t, h, heights, h_const, added, la, blockIdx.x);
+    // the CV histogram needs the limiter's flags and the hills' positions, nothing of the gather: the limiter's
+    // workgroup updates it while the gather applies heights (edm_bias.cpp:601-610)
+    if (ran_limiter && post.enabled && !la.res->error)
+      hist_batch<1>(post.hg, post.hist, h.nh, h.hx0, la.res, post.flags, post.flush_mode, threadIdx.x, BLOCK);
+    EDM_STAMP(7);
+    return;
   }
+  const unsigned tile = blockIdx.x - nb_int, ntile = gridDim.x - nb_int;
+  hill_gather_body<1, 0, 8, PERB, true>(g, t, rec, h, hh, plan, 0, dirty_flag, post.enabled, tile, la.ready_flag, la.ready_seq,
+                                        la.trace ? la.trace + (size_t)blockIdx.x * 8 : nullptr);
+  EDM_STAMP(6);
+  if (!post.enabled) return;
+  // (the bookkeeping reads the limiter's result: a workgroup whose tile met no hill has not waited for it yet)
+  __syncthreads();
+  if (threadIdx.x == 0) (void)wait_for_word(la.ready_flag, la.ready_seq);
+  __syncthreads();
+  gather_post<1, PERB>(g, rec, h, hh, dirty_flag, post, ntile, tile);
+  EDM_STAMP(7);
+#undef EDM_STAMP
 }
 
 // rec[p] += partial[0][p] + partial[1][p] + ... in group (= hill list) order
@@ -2899,6 +3095,42 @@ hipError_t launch_hill_gather(const Geom &g, const Tables &t, double *rec, const
     case 2: return gather_dim<2>(g, t, rec, h, hh, plan, dirty_flag, s, chain);
     default: return gather_dim<3>(g, t, rec, h, hh, plan, dirty_flag, s, chain);
   }
+}
+
+bool integrals_gather_fusable(const Geom &g, long long nh_bound, const GatherPlan &plan) {
+  return g.dim == 1 && hill_integrals_can_chain_limit(nh_bound) && plan.groups == 1 && !plan.tile_list;
+}
+hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, const HillList &h, const double *heights,
+                                   double h_const, double *added, const LimitArgs &chain, const HillHeights &hh,
+                                   const GatherPlan &plan, int *dirty_flag, hipStream_t s, const PostSpec *post_chain) {
+  if (!integrals_gather_fusable(g, h.nh, plan) || !chain.ready_flag || !hh.res_dev) return hipErrorInvalidValue;
+  LimitArgs la = chain;
+  la.enabled = 1;
+  PostArgs post;
+  memset(&post, 0, sizeof(post));
+  if (post_chain) {
+    if (!h.hx0) return hipErrorInvalidValue;
+    post.enabled = 1;
+    post.ticket = post_chain->ticket;
+    post.dp = make_dup_plan(g);
+    post.hg = *post_chain->hist_geom;
+    post.hist = post_chain->hist;
+    post.flags = post_chain->flags;
+    post.flush_mode = post_chain->flush_mode;
+    post.rb_src = post_chain->rb_src;
+    post.rb_dst = post_chain->rb_dst;
+    post.rb_bytes = post_chain->rb_bytes;
+    post.skip_hist = 1;
+  }
+  const unsigned nb_int = (unsigned)h.nh;
+  const unsigned nb_tiles = (unsigned)((g.n[0] + BLOCK / 8 - 1) / (BLOCK / 8));
+  if (!g.bper[0])
+    hipLaunchKernelGGL((k_integrals_gather<false>), dim3(nb_int + nb_tiles), dim3(BLOCK), 0, s, g, t, rec, h, heights, h_const,
+                       added, la, hh, plan, dirty_flag, post, nb_int);
+  else
+    hipLaunchKernelGGL((k_integrals_gather<true>), dim3(nb_int + nb_tiles), dim3(BLOCK), 0, s, g, t, rec, h, heights, h_const,
+                       added, la, hh, plan, dirty_flag, post, nb_int);
+  return hipGetLastError();
 }
 
 int gather_slots_per_hill(const Geom &g) {
@@ -3465,23 +3697,28 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            double h_const, double limit, double cum_in, int flush_mode,
                                            const LimitTail &tail, LimitResult *res, long long nchunks,
                                            const double *chunk_sum, const double *chunk_max,
-                                           const long long *nh_dev, long long mirror) {
+                                           const long long *nh_dev, long long mirror, long long *k_out, int *err_out,
+                                           long long nh_known) {
+  // (k_out / err_out: the first tail hill and the error code, for a caller that hands them on in registers;
+  //  nh_known >= 0: the caller has already read *nh_dev)
   // `mirror` != 0: the result and the tail's flags / h2 / added2 live in the packed read-back region, whose copy in
   // host-mapped memory sits `mirror` bytes away -- they are stored to both as they are produced (see LimitArgs)
+  // (COHERENT: the outputs are read by other workgroups of the SAME launch -- the gather of k_integrals_gather --
+  //  so the device copies travel at agent scope like everything else that is handed between workgroups)
   auto put_f64 = [mirror](double *p, double v) {
-    *p = v;
+    if (COHERENT) publish(p, v); else *p = v;
     if (mirror)
       __hip_atomic_store(reinterpret_cast<double *>(reinterpret_cast<char *>(p) + mirror), v, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
   };
   auto put_i32 = [mirror](int *p, int v) {
-    *p = v;
+    if (COHERENT) publish(p, v); else *p = v;
     if (mirror)
       __hip_atomic_store(reinterpret_cast<int *>(reinterpret_cast<char *>(p) + mirror), v, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
   };
   auto put_i64 = [mirror](long long *p, long long v) {
-    *p = v;
+    if (COHERENT) publish(p, v); else *p = v;
     if (mirror)
       __hip_atomic_store(reinterpret_cast<long long *>(reinterpret_cast<char *>(p) + mirror), v, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
@@ -3496,10 +3733,13 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
     put_i32(&res->error, error);
   };
   long long nh = nh_bound;
+  if (k_out) *k_out = 0;
+  if (err_out) *err_out = 0;
   if (nh_dev) {
-    nh = *nh_dev;
+    nh = nh_known >= 0 ? nh_known : *nh_dev;
     if (nh > nh_bound) {  // the batch was queued with too small a bound: nothing is applied
       if (threadIdx.x == 0) put_result(cum_in, 0, nh, 0, 0, 0, 2);
+      if (err_out) *err_out = 2;
       return;
     }
   }
@@ -3534,6 +3774,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
   const long long ntail = nh - k;
   if (ntail > EDM_TAIL_CAP) {
     if (lane == 0) put_result(cum, k, nh, 0, 0, 0, 1);
+    if (err_out) *err_out = 1;
     return;
   }
   // Ordered walk, one 64-hill slab at a time.  Between two crossings of the limit nothing depends
@@ -3620,7 +3861,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
     }
     if (lane < lim) {
       const long long ti = base + lane;
-      tail.h1[ti] = o_h1;
+      if (COHERENT) publish(&tail.h1[ti], o_h1); else tail.h1[ti] = o_h1;
       put_f64(&tail.h2[ti], o_h2);
       put_f64(&tail.added2[ti], o_a2);
       tail.cum_after[ti] = o_cum;
@@ -3628,6 +3869,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
     }
   }
   if (lane == 0) put_result(cum, k, nh, (int)ntail, stop, n_def, 0);
+  if (k_out) *k_out = k;
 }
 
 __global__ void __launch_bounds__(64) k_limit(long long nh_bound, const double *__restrict__ added,
