@@ -73,7 +73,11 @@ struct edm_hip_bias {
   // device-resident neighbour list (edm_hip_bias_pair_list_upload / _step)
   DevBuf<int> pl_i, pl_j, pl_type, pl_it_idx, pl_jt_idx;
   DevBuf<long long> pl_it_off, pl_jt_off;
-  DevBuf<double> pl_force;
+  // which virtual samples of the uploaded list are live, and how many (static until the list, nlocal or the type
+  // pair change): built on the device by the first step that needs them
+  bool pl_mask_valid = false;
+  int pl_mask_nlocal = -1, pl_mask_itype = 0, pl_mask_jtype = 0;
+  long long pl_calls = 0;
   long long pl_npairs = -1, pl_nall = 0;
   DevBuf<double> vs_r;     // virtual add_hill samples of the list (2 per entry)
   DevBuf<int> vs_mask;
@@ -81,6 +85,8 @@ struct edm_hip_bias {
   int debug_force_sync = 0;     // tests: never defer the count (every step takes the synchronous path)
   long long bound_redos = 0;    // steps redone because the accepted count exceeded the deferred launch bound
   PendingForces pending;        // pair forces of a fused step waiting for the launch of the step's selection
+  const double *pl_view_x = nullptr;   // pair_list_step: the samples of this add_hill cycle are the virtual samples of the
+                                       // uploaded list, their CVs recomputed from these positions ([nall][3])
   int debug_virtual_ranks = 0;  // tests: a one-rank communicator's packet is replicated, emulating that many ranks
   DevBuf<long long> xchg_cnt;
   // multi-GPU
@@ -255,7 +261,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   b->sel.release(); b->sel_scratch.release(); b->count_dev.release(); b->sel_stage.release();
   if (b->h_flush) (void)hipHostFree(b->h_flush);
   b->vs_r.release(); b->vs_mask.release(); b->pl_i.release(); b->pl_j.release(); b->pl_type.release();
-  b->pl_it_idx.release(); b->pl_jt_idx.release(); b->pl_it_off.release(); b->pl_jt_off.release(); b->pl_force.release();
+  b->pl_it_idx.release(); b->pl_jt_idx.release(); b->pl_it_off.release(); b->pl_jt_off.release();
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
   delete b;
@@ -597,6 +603,11 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       src.nh = pack_bound;
       src.x = d_x;
       src.x_stride = x_stride;
+      if (b->pl_view_x) {
+        src.pl_x = b->pl_view_x;
+        src.pl_i = b->pl_i.p;
+        src.pl_j = b->pl_j.p;
+      }
       int rcs = select_prep_enqueue(b->bias, sel_args, src, &b->pending);
       if (rcs) return rcs;
     } else {
@@ -728,6 +739,11 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   spec.nh = nh;
   spec.d_x = d_x;
   spec.x_stride = x_stride;
+  if (b->pl_view_x && !packed_exchange) {
+    spec.pl_x = b->pl_view_x;
+    spec.pl_i = b->pl_i.p;
+    spec.pl_j = b->pl_j.p;
+  }
   spec.d_sel = d_sel;
   spec.d_h = d_heights;
   spec.h_const = this_h;
@@ -962,7 +978,6 @@ int edm_hip_bias_pair_list_upload(edm_hip_bias *b, long long npairs, const int *
   EDM_HIP_TRY(b->pl_type.reserve(na1));
   EDM_HIP_TRY(b->pl_it_off.reserve(na1 + 1));
   EDM_HIP_TRY(b->pl_jt_off.reserve(na1 + 1));
-  EDM_HIP_TRY(b->pl_force.reserve(3 * np1));
   if (npairs > 0) {
     EDM_HIP_TRY(hipMemcpy(b->pl_i.p, h_pair_i, sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice));
     EDM_HIP_TRY(hipMemcpy(b->pl_j.p, h_pair_j, sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice));
@@ -974,6 +989,7 @@ int edm_hip_bias_pair_list_upload(edm_hip_bias *b, long long npairs, const int *
   EDM_HIP_TRY(hipMemcpy(b->pl_jt_off.p, jt_off.data(), sizeof(long long) * ((size_t)nall + 1), hipMemcpyHostToDevice));
   b->pl_npairs = npairs;
   b->pl_nall = nall;
+  b->pl_mask_valid = false;
   return EDM_HIP_OK;
 }
 
@@ -1019,39 +1035,56 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   a.nlocal = nlocal;
   a.nall = (int)nall;
   a.x = d_x;
-  a.pair_force = b->pl_force.p;
   a.it_off = b->pl_it_off.p;
   a.jt_off = b->pl_jt_off.p;
   a.it_idx = b->pl_it_idx.p;
   a.jt_idx = b->pl_jt_idx.p;
   a.fdelta = d_fdelta;
-  if (hill_step && npairs > 0) {
-    EDM_HIP_TRY(b->vs_r.reserve((size_t)2 * npairs));
+  if (hill_step && npairs > 0 && !(b->pl_mask_valid && b->pl_mask_nlocal == nlocal && b->pl_mask_itype == itype &&
+                                   b->pl_mask_jtype == jtype)) {
+    // live virtual samples of this list (fix_edm_pair.cpp:230-237): once per uploaded list
     EDM_HIP_TRY(b->vs_mask.reserve((size_t)2 * npairs));
-    a.vs_r = b->vs_r.p;
     a.vs_mask = b->vs_mask.p;
+    int mb = 0;
+    EDM_HIP_TRY(launch_pairlist_mask(a, b->bias->d_partials, s, &mb));
+    EDM_HIP_TRY(hipStreamSynchronize(s));
+    double c = 0;
+    for (int k = 0; k < mb; k++) c += b->bias->h_partials[k];
+    b->pl_calls = (long long)c;
+    b->pl_mask_valid = true;
+    b->pl_mask_nlocal = nlocal;
+    b->pl_mask_itype = itype;
+    b->pl_mask_jtype = jtype;
   }
   int nblk = 0;
   b->bias->wait_polled = false;
   EDM_HIP_TRY(launch_pairlist_forces(b->bias->g, b->bias->rec, a, b->bias->d_partials, s, &nblk));
-  if (npairs <= 0) nblk = 0;
-  if (hill_step) {
-    // add_hill(r, u) for the two virtual samples of every list entry, in list order; dead ones are masked out
+  if (hill_step && npairs > 0) {
+    // add_hill(r, u) for the two virtual samples of every list entry, in list order; dead ones are masked out.
+    // The CV of an accepted sample is recomputed from the positions when its hill is prepared; only the paths
+    // that read sample positions as a plain array (synchronous multi-GPU exchange, target heights) get one.
+    const double *sample_r = nullptr;
+    if (b->comm || b->b_targeting) {
+      EDM_HIP_TRY(b->vs_r.reserve((size_t)2 * npairs));
+      a.vs_r = b->vs_r.p;
+      EDM_HIP_TRY(launch_pairlist_samples(a, s));
+      sample_r = b->vs_r.p;
+    } else {
+      b->pl_view_x = d_x;
+    }
     const int *saved_mask = b->d_mask;
     b->d_mask = b->vs_mask.p;
-    rc = process_new_hills(b, 2 * npairs, b->vs_r.p, 1, nullptr, 1);
+    rc = process_new_hills(b, 2 * npairs, sample_r, 1, nullptr, 1);
     b->d_mask = saved_mask;
+    b->pl_view_x = nullptr;
     if (rc) return rc;
   }
-  // (a polled hill batch has shown the stream past the force passes queued ahead of it)
+  // (a polled hill batch has shown the stream past the force pass queued ahead of it)
   if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(s));
-  double e = 0, c = 0;
-  for (int k = 0; k < nblk; k++) {
-    e += b->bias->h_partials[k];
-    c += b->bias->h_partials[EDM_PAIRLIST_MAX_BLOCKS + k];
-  }
+  double e = 0;
+  for (int k = 0; k < nblk; k++) e += b->bias->h_partials[k];
   if (energy) *energy = e;
-  if (ncalls) *ncalls = (long long)c;
+  if (ncalls) *ncalls = hill_step ? b->pl_calls : 0;
   return hill_step ? do_post_add_hill(b) : EDM_HIP_OK;
 }
 

@@ -1143,6 +1143,9 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hl.nh = nh;
   hl.x = spec.d_x;
   hl.x_stride = spec.x_stride;
+  hl.pl_x = spec.pl_x;
+  hl.pl_i = spec.pl_i;
+  hl.pl_j = spec.pl_j;
   hl.sel = spec.d_sel;
   hl.hx = ws.hx.p;
   hl.hc = ws.hc.p;

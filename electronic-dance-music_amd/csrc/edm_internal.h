@@ -156,6 +156,9 @@ struct ApplySpec {
   long long nh = 0;
   const double *d_x = nullptr;     // sample positions
   int x_stride = 1;
+  // ... or (d_x == NULL, 1-D): the virtual samples of a device-resident neighbour list, see HillList::pl_x
+  const double *pl_x = nullptr;
+  const int *pl_i = nullptr, *pl_j = nullptr;
   const long long *d_sel = nullptr;
   const double *d_h = nullptr;     // per-hill heights or NULL
   double h_const = 0;

@@ -52,12 +52,15 @@ hipError_t launch_lookup(const Geom &g, const double *rec, LookupMode mode, cons
 hipError_t launch_build_faces(const Geom &g, const double *rec, double *faces, hipStream_t s);
 // 1-D pair-distance form: force[i] = -dV/dr(r_i)
 // fix edm_pair on a device-resident neighbour list (fix_edm_pair.cpp:177-238 over flattened pair records).
-// Pass 1, one thread per list entry: pair distance from the positions, bias lookup, the entry's force vector
-// del * f_r into pair_force[entry] (zero when the types do not match), energy, and -- on hill steps -- the two
-// virtual add_hill samples of the entry (the second one live iff j is owned) for the selection.  Pass 2, 16 lanes
-// per atom: the atom's bias force = sum over its entries as i minus sum over its entries as j (owned atoms only:
-// newton off), both through index lists built when the list was uploaded, in a fixed order -- no atomics, the
-// forces are bit-reproducible.
+// ONE pass, 16 lanes per owned atom: the atom's bias force = sum over its entries as i of del * f_r minus the sum
+// over its entries as j (newton off: ghost atoms receive nothing), each term computed on the spot from the two
+// positions (pair distance, bias lookup) -- nothing per entry is written to memory, a pair is simply evaluated from
+// both of its ends -- in a fixed order through the index lists built when the list was uploaded: no atomics,
+// bit-reproducible forces.  Energy is summed on the i side (every entry has an owned i).
+// The two virtual add_hill samples of an entry (fix_edm_pair.cpp:230-237: the second one live iff j is owned) need
+// no per-step arrays either: which of them are live depends on the list, the types and nlocal only
+// (launch_pairlist_mask, once per uploaded list), and the CV of an ACCEPTED sample is recomputed from the
+// positions when its hill is prepared (HillList::pl_x).
 struct PairListArgs {
   long long npairs;
   const int *pair_i, *pair_j;   // list entries in neighbour-list order (j already masked with NEIGHMASK)
@@ -65,17 +68,22 @@ struct PairListArgs {
   int itype, jtype;
   int nlocal, nall;
   const double *x;              // [nall][3]
-  double *pair_force;           // [npairs][3] scratch
   const long long *it_off, *jt_off;   // [nall + 1] CSR offsets of the entries with pair_i == a / pair_j == a
   const int *it_idx, *jt_idx;         // [npairs] entry indices, each atom's run in list order
   double *fdelta;               // out [nall][3]: bias force per atom (ghost atoms: zero)
-  double *vs_r;                 // [2 * npairs] virtual-sample CVs, or NULL on steps without hills
-  int *vs_mask;                 // [2 * npairs] 1 = live sample
+  double *vs_r;                 // launch_pairlist_samples: out [2 * npairs] virtual-sample CVs
+  int *vs_mask;                 // launch_pairlist_mask: out [2 * npairs] 1 = live sample
 };
-// partials[0 .. blocks) and partials[EDM_PAIRLIST_MAX_BLOCKS .. +blocks): energy and add_hill-call partials
+// partials[0 .. blocks): energy partial sums (launch_pairlist_forces) / live-sample counts (launch_pairlist_mask)
 #define EDM_PAIRLIST_MAX_BLOCKS 1024
 hipError_t launch_pairlist_forces(const Geom &g, const double *rec, const PairListArgs &a, double *partials,
                                   hipStream_t s, int *blocks_out);
+// vs_mask[2 e + slot] for every entry, and the number of live samples (= add_hill calls of a hill step) as
+// partial sums
+hipError_t launch_pairlist_mask(const PairListArgs &a, double *partials, hipStream_t s, int *blocks_out);
+// vs_r[2 e + slot] = r_e for every entry: only for the paths that read sample positions as a plain array (the
+// synchronous multi-GPU exchange, target heights)
+hipError_t launch_pairlist_samples(const PairListArgs &a, hipStream_t s);
 hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, const double *r,
                               double *force, double *scratch, double *energy_out, hipStream_t s,
                               hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int *blocks_out = nullptr);
@@ -120,6 +128,10 @@ struct HillList {
   long long nh;
   const double *x;        // sample positions [.. ][x_stride]
   int x_stride;
+  // alternative source of 1-D sample positions (x == NULL): sample s is the virtual add_hill sample of entry s >> 1
+  // of a device-resident neighbour list, its CV the pair distance |pl_x[pl_i[e]] - pl_x[pl_j[e]]| (rows of 3)
+  const int *pl_i = nullptr, *pl_j = nullptr;
+  const double *pl_x = nullptr;
   const long long *sel;   // optional indirection into x (NULL = identity)
   // prepared per-hill records (device, capacity >= nh):
   double *hx;             // remapped position            [nh][dim]

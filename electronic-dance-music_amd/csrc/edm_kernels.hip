@@ -983,110 +983,187 @@ __global__ void __launch_bounds__(NT) k_pair_forces_fast(Geom g, const double *_
 // ---------------------------------------------------------------------------
 // fix edm_pair over a device-resident neighbour list (see PairListArgs)
 // ---------------------------------------------------------------------------
+// distance of list entry (i, j) exactly as every user computes it (the force pass, the sample positions)
+__device__ __forceinline__ double pairlist_distance(const double *__restrict__ x, int i, int j, double &delx, double &dely,
+                                                    double &delz) {
+  delx = x[3 * (long long)i] - x[3 * (long long)j];
+  dely = x[3 * (long long)i + 1] - x[3 * (long long)j + 1];
+  delz = x[3 * (long long)i + 2] - x[3 * (long long)j + 2];
+  return sqrt(delx * delx + dely * dely + delz * delz);
+}
+// the type filter of fix_edm_pair.cpp:181-202: i of type ipair pairs with j of type jpair, and vice versa
+__device__ __forceinline__ bool pairlist_types_match(const PairListArgs &a, int ti, int tj) {
+  if (ti == a.itype) return tj == a.jtype;
+  if (ti == a.jtype) return tj == a.itype;
+  return false;
+}
+// One side of an atom's sum: entries idx[q], q = beg + sub, beg + sub + 16, ...; `as_i`: the atom is the entry's i
+// (partner = pair_j, the term is added and its energy counted), else its j (partner = pair_i, subtracted).  Four
+// entries per trip: their index, partner, type and position loads are requested together (an entry is a chain of
+// four dependent loads -- index -> partner -> position -> grid record -- and a lane walks a handful of entries), the
+// terms are still added in list order.
+template <bool FAST>
+__device__ __forceinline__ void pairlist_side(const Geom &g, const double *__restrict__ rec, const PairListArgs &a,
+                                              double inv_dx, int atom, int ta, const double *xa, bool as_i,
+                                              const int *__restrict__ idx, long long beg, long long end, int sub,
+                                              double &fx, double &fy, double &fz, double &e_acc) {
+  constexpr int ILP = 4;
+  const int *__restrict__ partner_of = as_i ? a.pair_j : a.pair_i;
+  for (long long q0 = beg + sub; q0 < end; q0 += 16 * ILP) {
+    int other[ILP];
+    bool ok[ILP];
+    double xo[ILP][3];
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+      const long long q = q0 + 16 * u;
+      ok[u] = q < end;
+      other[u] = ok[u] ? idx[q] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < ILP; u++) other[u] = ok[u] ? partner_of[other[u]] : 0;
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+      const int to = ok[u] ? a.type[other[u]] : 0;
+      if (ok[u]) {
+        xo[u][0] = a.x[3 * (long long)other[u]];
+        xo[u][1] = a.x[3 * (long long)other[u] + 1];
+        xo[u][2] = a.x[3 * (long long)other[u] + 2];
+      } else {
+        xo[u][0] = xo[u][1] = xo[u][2] = 0;
+      }
+      ok[u] = ok[u] && (as_i ? pairlist_types_match(a, ta, to) : pairlist_types_match(a, to, ta));
+    }
+    double px[ILP], py[ILP], pz[ILP], pv[ILP];
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+      px[u] = py[u] = pz[u] = pv[u] = 0;
+      if (ok[u]) {
+        // del = x_i - x_j of the ENTRY (fix_edm_pair.cpp:206-213), whichever end this atom is
+        double delx = as_i ? xa[0] - xo[u][0] : xo[u][0] - xa[0];
+        double dely = as_i ? xa[1] - xo[u][1] : xo[u][1] - xa[1];
+        double delz = as_i ? xa[2] - xo[u][2] : xo[u][2] - xa[2];
+        double r = sqrt(delx * delx + dely * dely + delz * delz);
+        const double rinv = 1.0 / r;
+        delx *= rinv;
+        dely *= rinv;
+        delz *= rinv;
+        double v, d;
+        if (FAST)
+          pair_one<false>(g, rec, nullptr, 0, 0, inv_dx, r, v, d);
+        else
+          lookup_one<1>(g, rec, &r, v, &d);
+        const double fr = 0.0 - d;   // update_force on a zeroed accumulator (fix_edm_pair.cpp:215-217)
+        px[u] = delx * fr;
+        py[u] = dely * fr;
+        pz[u] = delz * fr;
+        pv[u] = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < ILP; u++) {
+      if (ok[u]) {
+        if (as_i) {
+          fx += px[u];
+          fy += py[u];
+          fz += pz[u];
+          e_acc += pv[u];
+        } else {
+          fx -= px[u];
+          fy -= py[u];
+          fz -= pz[u];
+        }
+      }
+    }
+  }
+}
 template <bool FAST>
 __global__ void __launch_bounds__(BLOCK) k_pairlist_forces(Geom g, const double *__restrict__ rec, PairListArgs a,
                                                            double *__restrict__ partials, double inv_dx) {
   __shared__ double lds[BLOCK / 64];
-  double e_acc = 0, calls = 0;
-  const long long stride = (long long)gridDim.x * BLOCK;
-  for (long long p = (long long)blockIdx.x * BLOCK + threadIdx.x; p < a.npairs; p += stride) {
-    const int i = a.pair_i[p], j = a.pair_j[p];
-    // the type filter of fix_edm_pair.cpp:181-202: i of type ipair pairs with j of type jpair, and vice versa
-    const int ti = a.type[i], tj = a.type[j];
-    bool ok = false;
-    if (ti == a.itype) ok = (tj == a.jtype);
-    else if (ti == a.jtype) ok = (tj == a.itype);
-    double r = 0, fx = 0, fy = 0, fz = 0;
-    if (ok) {
-      double delx = a.x[3 * (long long)i] - a.x[3 * (long long)j];
-      double dely = a.x[3 * (long long)i + 1] - a.x[3 * (long long)j + 1];
-      double delz = a.x[3 * (long long)i + 2] - a.x[3 * (long long)j + 2];
-      r = sqrt(delx * delx + dely * dely + delz * delz);
-      const double rinv = 1.0 / r;
-      delx *= rinv;
-      dely *= rinv;
-      delz *= rinv;
-      double v, d;
-      if (FAST)
-        pair_one<false>(g, rec, nullptr, 0, 0, inv_dx, r, v, d);
-      else
-        lookup_one<1>(g, rec, &r, v, &d);
-      const double fr = 0.0 - d;   // update_force on a zeroed accumulator (fix_edm_pair.cpp:215-217)
-      e_acc += v;
-      fx = delx * fr;
-      fy = dely * fr;
-      fz = delz * fr;
+  const int sub = threadIdx.x & 15;
+  double e_acc = 0;
+  const long long astride = ((long long)gridDim.x * BLOCK) >> 4;
+  for (long long atom = ((long long)blockIdx.x * BLOCK + threadIdx.x) >> 4; atom < a.nall; atom += astride) {
+    double fx = 0, fy = 0, fz = 0;
+    if (atom < a.nlocal) {   // (ghost atoms never appear as i and receive nothing as j: newton off)
+      const int ta = a.type[atom];
+      const double xa[3] = {a.x[3 * atom], a.x[3 * atom + 1], a.x[3 * atom + 2]};
+      const long long ib = a.it_off[atom], ie = a.it_off[atom + 1], jb = a.jt_off[atom], je = a.jt_off[atom + 1];
+      pairlist_side<FAST>(g, rec, a, inv_dx, (int)atom, ta, xa, true, a.it_idx, ib, ie, sub, fx, fy, fz, e_acc);
+      pairlist_side<FAST>(g, rec, a, inv_dx, (int)atom, ta, xa, false, a.jt_idx, jb, je, sub, fx, fy, fz, e_acc);
     }
-    a.pair_force[3 * p] = fx;
-    a.pair_force[3 * p + 1] = fy;
-    a.pair_force[3 * p + 2] = fz;
-    if (a.vs_r) {
-      const bool second = ok && (j < a.nlocal);
-      a.vs_r[2 * p] = r;
-      a.vs_r[2 * p + 1] = r;
-      a.vs_mask[2 * p] = ok ? 1 : 0;
-      a.vs_mask[2 * p + 1] = second ? 1 : 0;
-      calls += (ok ? 1.0 : 0.0) + (second ? 1.0 : 0.0);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {   // fixed tree within the 16-lane group
+      fx += __shfl_xor(fx, o, 64);
+      fy += __shfl_xor(fy, o, 64);
+      fz += __shfl_xor(fz, o, 64);
+    }
+    if (sub == 0) {
+      a.fdelta[3 * atom] = fx;
+      a.fdelta[3 * atom + 1] = fy;
+      a.fdelta[3 * atom + 2] = fz;
     }
   }
   const double se = block_sum(e_acc, lds);
-  __syncthreads();
-  const double sc = block_sum(calls, lds);
-  if (threadIdx.x == 0) {
-    partials[blockIdx.x] = se;
-    partials[EDM_PAIRLIST_MAX_BLOCKS + blockIdx.x] = sc;
-  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = se;
 }
 
-// pass 2: 16 lanes per atom; f[a] = sum_{entries with i == a} pf - sum_{entries with j == a} pf (owned atoms)
-__global__ void __launch_bounds__(BLOCK) k_pairlist_reduce(PairListArgs a) {
-  const long long atom = ((long long)blockIdx.x * BLOCK + threadIdx.x) >> 4;
-  const int sub = threadIdx.x & 15;
-  double fx = 0, fy = 0, fz = 0;
-  if (atom < a.nlocal) {   // (ghost atoms never appear as i and receive nothing as j: newton off)
-    for (long long q = a.it_off[atom] + sub; q < a.it_off[atom + 1]; q += 16) {
-      const long long e = a.it_idx[q];
-      fx += a.pair_force[3 * e];
-      fy += a.pair_force[3 * e + 1];
-      fz += a.pair_force[3 * e + 2];
-    }
-    for (long long q = a.jt_off[atom] + sub; q < a.jt_off[atom + 1]; q += 16) {
-      const long long e = a.jt_idx[q];
-      fx -= a.pair_force[3 * e];
-      fy -= a.pair_force[3 * e + 1];
-      fz -= a.pair_force[3 * e + 2];
-    }
+// which virtual samples of the list are live (static between list uploads) + their number
+__global__ void __launch_bounds__(BLOCK) k_pairlist_mask(PairListArgs a, double *__restrict__ partials) {
+  __shared__ double lds[BLOCK / 64];
+  double calls = 0;
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long p = (long long)blockIdx.x * BLOCK + threadIdx.x; p < a.npairs; p += stride) {
+    const int i = a.pair_i[p], j = a.pair_j[p];
+    const bool ok = pairlist_types_match(a, a.type[i], a.type[j]);
+    const bool second = ok && (j < a.nlocal);
+    a.vs_mask[2 * p] = ok ? 1 : 0;
+    a.vs_mask[2 * p + 1] = second ? 1 : 0;
+    calls += (ok ? 1.0 : 0.0) + (second ? 1.0 : 0.0);
   }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) {   // fixed tree within the 16-lane group
-    fx += __shfl_xor(fx, o, 64);
-    fy += __shfl_xor(fy, o, 64);
-    fz += __shfl_xor(fz, o, 64);
-  }
-  if (sub == 0 && atom < a.nall) {
-    a.fdelta[3 * atom] = fx;
-    a.fdelta[3 * atom + 1] = fy;
-    a.fdelta[3 * atom + 2] = fz;
+  const double sc = block_sum(calls, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = sc;
+}
+__global__ void __launch_bounds__(BLOCK) k_pairlist_samples(PairListArgs a) {
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long p = (long long)blockIdx.x * BLOCK + threadIdx.x; p < a.npairs; p += stride) {
+    double dx, dy, dz;
+    const double r = pairlist_distance(a.x, a.pair_i[p], a.pair_j[p], dx, dy, dz);
+    a.vs_r[2 * p] = r;
+    a.vs_r[2 * p + 1] = r;
   }
 }
 
 hipError_t launch_pairlist_forces(const Geom &g, const double *rec, const PairListArgs &a, double *partials,
                                   hipStream_t s, int *blocks_out) {
   if (g.dim != 1) return hipErrorInvalidValue;
-  long long nb = (a.npairs + BLOCK - 1) / BLOCK;
-  if (nb > EDM_PAIRLIST_MAX_BLOCKS) nb = EDM_PAIRLIST_MAX_BLOCKS;
-  if (nb < 1) nb = 1;
+  if (blocks_out) *blocks_out = 0;
+  if (a.nall <= 0) return hipSuccess;
+  const long long threads = (long long)a.nall * 16;
+  long long nb = (threads + BLOCK - 1) / BLOCK;
+  if (nb > MAX_BLOCKS) nb = MAX_BLOCKS;   // (one energy partial per workgroup; the atoms are strided over)
   const bool fast = (g.interp && !g.periodic[0] && !g.bper[0] && g.n[0] >= 2);
   const double inv_dx = 1.0 / g.dx[0];
   if (fast)
     hipLaunchKernelGGL(k_pairlist_forces<true>, dim3((unsigned)nb), dim3(BLOCK), 0, s, g, rec, a, partials, inv_dx);
   else
     hipLaunchKernelGGL(k_pairlist_forces<false>, dim3((unsigned)nb), dim3(BLOCK), 0, s, g, rec, a, partials, inv_dx);
-  if (a.nall > 0) {
-    const long long threads = (long long)a.nall * 16;
-    hipLaunchKernelGGL(k_pairlist_reduce, dim3((unsigned)((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
-  }
   if (blocks_out) *blocks_out = (int)nb;
+  return hipGetLastError();
+}
+hipError_t launch_pairlist_mask(const PairListArgs &a, double *partials, hipStream_t s, int *blocks_out) {
+  long long nb = (a.npairs + BLOCK - 1) / BLOCK;
+  if (nb > EDM_PAIRLIST_MAX_BLOCKS) nb = EDM_PAIRLIST_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_pairlist_mask, dim3((unsigned)nb), dim3(BLOCK), 0, s, a, partials);
+  if (blocks_out) *blocks_out = (int)nb;
+  return hipGetLastError();
+}
+hipError_t launch_pairlist_samples(const PairListArgs &a, hipStream_t s) {
+  long long nb = (a.npairs + BLOCK - 1) / BLOCK;
+  if (nb > EDM_PAIRLIST_MAX_BLOCKS) nb = EDM_PAIRLIST_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_pairlist_samples, dim3((unsigned)nb), dim3(BLOCK), 0, s, a);
   return hipGetLastError();
 }
 
@@ -1420,11 +1497,22 @@ hipError_t launch_select(long long n, const double *ru, double thr, int use_thr,
 // ---------------------------------------------------------------------------
 template <int DIM>
 __device__ __forceinline__ void hill_prep_vals(const Geom &g, const HillList &h, long long i, double *x);
+// position of sample `src`: a row of h.x, or (1-D, h.pl_x) the pair distance of neighbour-list entry src >> 1
+template <int DIM>
+__device__ __forceinline__ void sample_position(const HillList &h, long long src, double *x) {
+  if (DIM == 1 && h.pl_x) {
+    const long long e = src >> 1;
+    double dx, dy, dz;
+    x[0] = pairlist_distance(h.pl_x, h.pl_i[e], h.pl_j[e], dx, dy, dz);
+    return;
+  }
+#pragma unroll
+  for (int d = 0; d < DIM; d++) x[d] = h.x[src * h.x_stride + d];
+}
 template <int DIM>
 __device__ __forceinline__ void hill_prep_one(const Geom &g, const HillList &h, long long i, long long src) {
   double x[DIM];
-#pragma unroll
-  for (int d = 0; d < DIM; d++) x[d] = h.x[src * h.x_stride + d];
+  sample_position<DIM>(h, src, x);
   hill_prep_vals<DIM>(g, h, i, x);
 }
 // (x holds the sample's CV on entry and is remapped in place)
@@ -1470,7 +1558,8 @@ __global__ void __launch_bounds__(BLOCK) k_hill_prep(Geom g, HillList h, const d
 
 // ---------------------------------------------------------------------------
 // "Last workgroup done" chaining.  A short hill step is a chain of tiny dependent kernels, each
-// costing a launch; instead every workgroup of a stage publishes its results (agent-scope fence),
+// costing a launch; instead every workgroup of a stage publishes its results (agent-scope relaxed atomic stores,
+// see publish() below -- NOT a fence, which would write back the XCD's whole L2),
 // takes a ticket, and the workgroup that draws the last ticket runs the next (small, serial) stage
 // in the same launch.  The ticket is reset by that workgroup, so the counters stay zero between
 // launches.  Returns true (block-uniform) in the last workgroup, with the other workgroups' writes
@@ -1556,8 +1645,10 @@ template <int DIM>
 __device__ __forceinline__ void select_emit(const SelectArgs &a, const Geom &g, const HillList &h, long long i,
                                             long long src) {
   if (a.pack) {
+    double x[DIM];
+    sample_position<DIM>(h, src, x);
 #pragma unroll
-    for (int d = 0; d < DIM; d++) a.pack[1 + i * DIM + d] = h.x[src * h.x_stride + d];
+    for (int d = 0; d < DIM; d++) a.pack[1 + i * DIM + d] = x[d];
   } else {
     a.sel[i] = src;
     hill_prep_one<DIM>(g, h, i, src);
@@ -2214,6 +2305,15 @@ __device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables 
         }
         __builtin_amdgcn_s_waitcnt(0);   // every wave's stores into the host-mapped region have been acknowledged
         __syncthreads();
+        // The flag is a RELAXED system-scope store on purpose.  A release at system scope would first write back the
+        // XCD's whole L2 (~35 us measured, the cost this design exists to avoid).  Ordering rests on the hardware
+        // instead: every store into the region above was itself a system-scope (write-through, uncached) store to
+        // host memory; s_waitcnt(0) + the barrier mean each wave has its acknowledgements; PCIe posted writes of one
+        // requester are not reordered, so the flag cannot overtake the data on the way to host memory.  The host
+        // reads the flag (volatile) and then the data behind an acquire fence.  Guarded twice over: the polled word
+        // is checked against byte-identical results of the stream-wait path (EDM_HIP_POLL=0) in
+        // test_polled_completion_equals_stream_wait, and a poll that does not see its word within 2 ms falls back
+        // to hipStreamSynchronize.
         if (threadIdx.x == 0 && la.done_flag)
           __hip_atomic_store(la.done_flag, la.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }

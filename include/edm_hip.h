@@ -15,8 +15,9 @@
  *     which is the reference's convention (lib/edm.cpp:4-7).
  *   - "d_" parameters are DEVICE pointers (HBM of the current device); "h_" or
  *     unprefixed pointers are host memory, borrowed for the call only.
- *   - handles own their device memory.  One HIP stream per handle; calls are
- *     synchronous at return unless the name ends in _async.
+ *   - handles own their device memory.  One HIP stream per handle.  A call returns when its RESULTS are on the
+ *     host (see "Completion" below): what it queued to update the grid may still be running, and every later
+ *     call on the object is ordered behind it.
  *   - positions/forces use the LAMMPS layout: row-major [n][stride] doubles, of
  *     which the first `dim` columns are read/updated.
  *   - there is NO CPU fallback behind any of these calls.
@@ -172,8 +173,10 @@ int edm_hip_gauss_download_tables(const edm_hip_gauss *g, int dim_index, double 
 int edm_hip_gauss_download(const edm_hip_gauss *g, double *h_values, double *h_derivs);
 int edm_hip_gauss_upload(edm_hip_gauss *g, const double *h_values, const double *h_derivs);
 int edm_hip_gauss_clear(edm_hip_gauss *g);
-/* the raw device record array ((1+dim) doubles per node padded to 2 or 4) for
- * collectives: pointer, doubles per node, node count */
+/* the raw device record array ((1+dim) doubles per node padded to 2 or 4) for a caller's own collectives:
+ * pointer, doubles per node, node count.  The call waits for the updates queued on the handle's stream, and --
+ * since the caller may now write the records behind the library's back -- switches the lookup replica of this
+ * grid off for good. */
 int edm_hip_gauss_device_buffer(edm_hip_gauss *g, double **d_records, int *doubles_per_node,
                                 long long *nodes);
 
