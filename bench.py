@@ -462,32 +462,48 @@ def coordinate_cv_measure(H, W, tmpdir):
 
 
 def pcie_inclusive_measure(H, b, r, u, npairs, est, steps=20):
-    """The W1 step as the host-list `fix edm_pair` pays for it: pair distances, sample uniforms in and pair forces
-    out cross PCIe every step (pageable host arrays, what libedm.so's EDMBias::pair_step does around the same
-    edm_hip_bias_pair_step call).  Never the headline `value`."""
+    """The W1 step as the host-list `fix edm_pair` pays for it: pair distances and sample uniforms in, pair forces out
+    cross PCIe every step.  Three ways: synchronous copies around edm_hip_bias_pair_step (round 1's libedm.so),
+    edm_hip_bias_pair_step_host on pageable arrays, and on page-locked arrays (what EDMBias::pair_step and the
+    fix's pinned vectors do now: copies queued around the kernels, the forces travelling down while the uniforms
+    travel up).  Never the headline `value`."""
     d_r = H.DeviceArray((npairs,))
     d_u = H.DeviceArray((npairs,))
     d_f = H.DeviceArray((npairs,))
     f_host = np.empty(npairs)
 
-    def one():
+    def sync_copies():
         H.check(H.lib().edm_hip_memcpy_h2d(d_r.ptr, r.ctypes.data, r.nbytes))
         H.check(H.lib().edm_hip_memcpy_h2d(d_u.ptr, u.ctypes.data, u.nbytes))
         e = b.pair_step_device(d_r, d_f, npairs, d_r, d_u, npairs, est)
         H.check(H.lib().edm_hip_memcpy_d2h(f_host.ctypes.data, d_f.ptr, f_host.nbytes))
         return e
 
-    for _ in range(3):
-        one()
-    H.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    H.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return dict(ms_per_step=dt * 1e3, million_evals_per_s=npairs / dt / 1e6,
+    p_r, p_u, p_f = H.pinned_array(npairs), H.pinned_array(npairs), H.pinned_array(npairs)
+    p_r[:] = r
+    p_u[:] = u
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        H.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        H.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    dt_sync = timed(sync_copies)
+    dt_pageable = timed(lambda: b.pair_step_host(r, f_host, r, u, est))
+    dt_pinned = timed(lambda: b.pair_step_host(p_r, p_f, p_r, p_u, est))
+    return dict(ms_per_step=dt_pinned * 1e3, million_evals_per_s=npairs / dt_pinned / 1e6,
                 bytes_over_pcie_per_step=3 * 8 * npairs,
-                note="host arrays in pageable memory: 8 B distance + 8 B uniform in, 8 B force out per pair, per step")
+                effective_GBs=3 * 8 * npairs / dt_pinned / 1e9,
+                ms_per_step_pageable_arrays=dt_pageable * 1e3,
+                ms_per_step_synchronous_copies=dt_sync * 1e3,
+                note="8 B distance + 8 B uniform in, 8 B force out per pair, per step; ms_per_step = "
+                     "edm_hip_bias_pair_step_host on page-locked host arrays (copies queued around the kernels, forces "
+                     "down while uniforms go up)")
 
 
 def main():

@@ -85,6 +85,11 @@ struct edm_hip_bias {
   int debug_force_sync = 0;     // tests: never defer the count (every step takes the synchronous path)
   long long bound_redos = 0;    // steps redone because the accepted count exceeded the deferred launch bound
   PendingForces pending;        // pair forces of a fused step waiting for the launch of the step's selection
+  // staging of the *_host entry points: device copies of the caller's host arrays, a second stream for the copy
+  // that runs against the direction of the others, and the event that orders it behind the force kernel
+  DevBuf<double> hs_r, hs_f, hs_x, hs_u;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_event = nullptr;
   const double *pl_view_x = nullptr;   // pair_list_step: the samples of this add_hill cycle are the virtual samples of the
                                        // uploaded list, their CVs recomputed from these positions ([nall][3])
   int debug_virtual_ranks = 0;  // tests: a one-rank communicator's packet is replicated, emulating that many ranks
@@ -254,6 +259,12 @@ int edm_hip_bias_create(edm_hip_bias **out, const char *input_filename) {
 int edm_hip_bias_destroy(edm_hip_bias *b) {
   if (!b) return EDM_HIP_OK;
   delete b->comm;
+  if (b->copy_stream) {
+    (void)hipStreamSynchronize(b->copy_stream);
+    (void)hipStreamDestroy(b->copy_stream);
+  }
+  if (b->copy_event) (void)hipEventDestroy(b->copy_event);
+  b->hs_r.release(); b->hs_f.release(); b->hs_x.release(); b->hs_u.release();
   edm_hip_gauss_destroy(b->bias);
   edm_hip_grid_destroy(b->hist);
   edm_hip_grid_destroy(b->target);
@@ -940,6 +951,69 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
   //  stream, is complete and its partial sums are in host memory)
   if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
   const double e = pair_forces_finish(b->bias, b->pending.nblk);
+  if (energy) *energy = e;
+  return do_post_add_hill(b);
+}
+
+// The same step for a caller whose arrays live in HOST memory (the host-list fix edm_pair): staged through HBM with
+// the copies queued around the kernels -- distances up, forces evaluated, then the forces travel down WHILE the hill
+// samples and their uniforms travel up (opposite directions of the link, two streams), then the hill cycle.  With
+// page-locked arrays (edm_hip_host_malloc) the copies are true DMA transfers; pageable arrays work, staged by the
+// runtime.
+int edm_hip_bias_pair_step_host(edm_hip_bias *b, long long n, const double *h_r, double *h_force, long long n_samples,
+                                const double *h_sample_r, const double *h_runiform, long long est_hill_count,
+                                double *energy) {
+  if (energy) *energy = 0;
+  if (!b->bias && !b->b_outofbounds) {
+    set_error("pair_step before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  if (b->dim != 1) {
+    set_error("pair_step: the pair-distance CV is 1-D (fix_edm_pair.cpp:52)");
+    return EDM_HIP_ERR_ARG;
+  }
+  if (n < 0) n = 0;
+  if (n_samples < 0) n_samples = 0;
+  int rc = do_pre_add_hill(b, est_hill_count < 0 ? n_samples : est_hill_count);
+  if (rc) return rc;
+  if (b->b_outofbounds) {
+    if (n > 0) memset(h_force, 0, sizeof(double) * (size_t)n);
+    return do_post_add_hill(b);
+  }
+  hipStream_t s = b->bias->stream;
+  if (!b->copy_stream) {
+    EDM_HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+    EDM_HIP_TRY(hipEventCreateWithFlags(&b->copy_event, hipEventDisableTiming));
+  }
+  EDM_HIP_TRY(b->hs_r.reserve((size_t)(n > 0 ? n : 1)));
+  EDM_HIP_TRY(b->hs_f.reserve((size_t)(n > 0 ? n : 1)));
+  EDM_HIP_TRY(b->hs_x.reserve((size_t)(n_samples > 0 ? n_samples : 1)));
+  EDM_HIP_TRY(b->hs_u.reserve((size_t)(n_samples > 0 ? n_samples : 1)));
+  int nblk = 0;
+  b->bias->wait_polled = false;
+  if (n > 0) {
+    EDM_HIP_TRY(hipMemcpyAsync(b->hs_r.p, h_r, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+    rc = pair_forces_enqueue(b->bias, n, b->hs_r.p, b->hs_f.p, &nblk);   // (behind the overflow flush, ahead of the new hills)
+    if (rc) return rc;
+    EDM_HIP_TRY(hipEventRecord(b->copy_event, s));
+    EDM_HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->copy_event, 0));
+    EDM_HIP_TRY(hipMemcpyAsync(h_force, b->hs_f.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, b->copy_stream));
+  }
+  const double *d_samples = b->hs_x.p;
+  if (n_samples > 0) {
+    if (h_sample_r == h_r && n_samples <= n)
+      d_samples = b->hs_r.p;   // (the samples ARE the pair distances: already there)
+    else
+      EDM_HIP_TRY(hipMemcpyAsync(b->hs_x.p, h_sample_r, sizeof(double) * (size_t)n_samples, hipMemcpyHostToDevice, s));
+    if (h_runiform)
+      EDM_HIP_TRY(hipMemcpyAsync(b->hs_u.p, h_runiform, sizeof(double) * (size_t)n_samples, hipMemcpyHostToDevice, s));
+  }
+  b->pending = PendingForces();
+  rc = process_new_hills(b, n_samples, d_samples, 1, h_runiform ? b->hs_u.p : nullptr, -1);
+  if (rc) return rc;
+  if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(s));
+  if (n > 0) EDM_HIP_TRY(hipStreamSynchronize(b->copy_stream));
+  const double e = pair_forces_finish(b->bias, nblk);
   if (energy) *energy = e;
   return do_post_add_hill(b);
 }

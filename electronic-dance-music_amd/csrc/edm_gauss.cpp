@@ -273,6 +273,14 @@ int edm_hip_free(void *d_ptr) {
   if (d_ptr) EDM_HIP_TRY(hipFree(d_ptr));
   return EDM_HIP_OK;
 }
+int edm_hip_host_malloc(void **h_ptr, size_t bytes) {
+  EDM_HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 8, hipHostMallocDefault));
+  return EDM_HIP_OK;
+}
+int edm_hip_host_free(void *h_ptr) {
+  if (h_ptr) EDM_HIP_TRY(hipHostFree(h_ptr));
+  return EDM_HIP_OK;
+}
 int edm_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes) {
   EDM_HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
   return EDM_HIP_OK;

@@ -44,6 +44,8 @@ _PROTOS = {
     "edm_hip_device_info": (C.c_int, [C.c_char_p, C.c_size_t, c_ip, C.POINTER(C.c_size_t)]),
     "edm_hip_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
     "edm_hip_free": (C.c_int, [vp]),
+    "edm_hip_host_malloc": (C.c_int, [C.POINTER(vp), C.c_size_t]),
+    "edm_hip_host_free": (C.c_int, [vp]),
     "edm_hip_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t]),
     "edm_hip_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t]),
     "edm_hip_memset": (C.c_int, [vp, C.c_int, C.c_size_t]),
@@ -109,6 +111,7 @@ _PROTOS = {
                                               C.POINTER(C.c_longlong)]),
     "edm_hip_bias_step": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
+    "edm_hip_bias_pair_step_host": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pre_add_hill": (C.c_int, [vp, C.c_longlong]),
     "edm_hip_bias_add_hill": (C.c_int, [vp, c_dp, C.c_double]),
     "edm_hip_bias_post_add_hill": (C.c_int, [vp]),
@@ -700,6 +703,33 @@ class Bias:
     def comm_init(self, id_bytes, nranks, rank):
         buf = C.create_string_buffer(bytes(id_bytes), 128) if id_bytes is not None else None
         check(lib().edm_hip_bias_comm_init(self.h, C.cast(buf, vp) if buf is not None else None, nranks, rank))
+
+
+def pinned_array(n, dtype=np.float64):
+    """numpy array over page-locked host memory (edm_hip_host_malloc); keep the returned array alive"""
+    dt = np.dtype(dtype)
+    p = vp()
+    check(lib().edm_hip_host_malloc(C.byref(p), max(1, n) * dt.itemsize))
+    buf = (C.c_char * (max(1, n) * dt.itemsize)).from_address(p.value)
+    a = np.frombuffer(buf, dtype=dt, count=n)
+    _pinned_keep.append((p.value, buf))
+    return a
+
+
+_pinned_keep = []
+
+
+def _bias_pair_step_host(self, r, force, sample_r, runiform, est=-1):
+    """edm_hip_bias_pair_step_host on host numpy arrays (force is written in place); returns the energy"""
+    e = C.c_double(0)
+    ns = 0 if sample_r is None else len(sample_r)
+    check(lib().edm_hip_bias_pair_step_host(self.h, len(r), r.ctypes.data, force.ctypes.data, ns,
+                                            None if sample_r is None else sample_r.ctypes.data,
+                                            None if runiform is None else runiform.ctypes.data, est, C.byref(e)))
+    return e.value
+
+
+Bias.pair_step_host = _bias_pair_step_host
 
 
 def _bias_comm_init_shm(self, shm_name, nranks, rank):

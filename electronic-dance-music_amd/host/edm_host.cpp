@@ -15,6 +15,13 @@
 
 namespace EDM {
 
+void* pinned_alloc(size_t bytes) {
+  void* p = NULL;
+  if (edm_hip_host_malloc(&p, bytes) != EDM_HIP_OK) edm_error(edm_hip_last_error(), "edm_bias.h:pinned_alloc");
+  return p;
+}
+void pinned_free(void* p) { edm_hip_host_free(p); }
+
 void edm_error(const char* error, const char* location) {
   std::cerr << "[EDM:" << location << "] " << error << std::endl;
   abort();
@@ -718,28 +725,14 @@ void EDMBias::add_pair_hills(int n, const double* r, const double* runiform, int
   refresh();
 }
 
+// One hill-depositing step of fix edm_pair on host arrays: copies and kernels queued back to back inside the library
+// (distances up, force kernel, forces down while the staged samples go up, hill cycle), one wait
 double EDMBias::pair_step(int npairs, const double* r, double* force_r, int n_samples, const double* sample_r,
                           const double* runiform, int est_hill_count) {
-  Stage& st = *st_;
-  const size_t pb = sizeof(double) * (size_t)(npairs > 0 ? npairs : 0);
-  const size_t sb = sizeof(double) * (size_t)(n_samples > 0 ? n_samples : 0);
-  if (npairs > 0) {
-    st.r.reserve(pb);
-    st.fr.reserve(pb);
-    check(edm_hip_memcpy_h2d(st.r.p, r, pb), "edm_bias.cpp:update_force");
-  }
-  if (n_samples > 0) {
-    st.x.reserve(sb);
-    st.u.reserve(sb);
-    check(edm_hip_memcpy_h2d(st.x.p, sample_r, sb), "edm_bias.cpp:add_hill");
-    if (runiform) check(edm_hip_memcpy_h2d(st.u.p, runiform, sb), "edm_bias.cpp:add_hill");
-  }
   double energy = 0;
-  check(edm_hip_bias_pair_step(h_, npairs > 0 ? npairs : 0, (const double*)st.r.p, (double*)st.fr.p,
-                               n_samples > 0 ? n_samples : 0, (const double*)st.x.p,
-                               runiform ? (const double*)st.u.p : NULL, est_hill_count, &energy),
+  check(edm_hip_bias_pair_step_host(h_, npairs > 0 ? npairs : 0, r, force_r, n_samples > 0 ? n_samples : 0, sample_r,
+                                    runiform, est_hill_count, &energy),
         "edm_bias.cpp:add_hill");
-  if (npairs > 0) check(edm_hip_memcpy_d2h(force_r, st.fr.p, pb), "edm_bias.cpp:update_force");
   refresh();
   return energy;
 }

@@ -49,8 +49,10 @@ class FixEDMPair : public Fix {
   int last_calls;  // an estimate of the number of add_hill calls on this processor
   int ipair, jpair;
   // per-step batch of pair records (host staging, reused across steps)
-  std::vector<double> pair_r, pair_f, pair_del;
-  std::vector<double> hill_r, hill_u;  // staged add_hill(r, uniform) calls of a hill step, in call order
+  // (page-locked: they cross PCIe every step, queued around the kernels by EDMBias::pair_step)
+  EDM::pinned_vector pair_r, pair_f;
+  std::vector<double> pair_del;
+  EDM::pinned_vector hill_r, hill_u;  // staged add_hill(r, uniform) calls of a hill step, in call order
   std::vector<int> pair_i, pair_j;
 };
 

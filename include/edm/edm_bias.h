@@ -31,6 +31,23 @@ struct edm_hip_bias;
 
 namespace EDM {
 
+// Page-locked host memory for the arrays a fix hands to the batched calls every step (pair distances, pair forces,
+// staged add_hill samples): std::vector<double, EDM::PinnedAllocator<double> >.  Such arrays travel to and from the
+// GPU by DMA, queued around the kernels (EDMBias::pair_step); ordinary arrays work too, staged by the runtime.
+void* pinned_alloc(size_t bytes);
+void pinned_free(void* p);
+template <class T>
+struct PinnedAllocator {
+  typedef T value_type;
+  PinnedAllocator() {}
+  template <class U> PinnedAllocator(const PinnedAllocator<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(pinned_alloc(n * sizeof(T))); }
+  void deallocate(T* p, size_t) { pinned_free(p); }
+  template <class U> bool operator==(const PinnedAllocator<U>&) const { return true; }
+  template <class U> bool operator!=(const PinnedAllocator<U>&) const { return false; }
+};
+typedef std::vector<double, PinnedAllocator<double> > pinned_vector;
+
 class EDMBias {
  public:
   EDMBias(const std::string& input_filename);

@@ -65,6 +65,10 @@ int edm_hip_device_info(char *name, size_t cap, int *compute_units, size_t *hbm_
 /* device memory helpers so that a C / ctypes / cgo host needs no HIP headers */
 int edm_hip_malloc(void **d_ptr, size_t bytes);
 int edm_hip_free(void *d_ptr);
+/* page-locked host memory: arrays handed to the *_host entry points travel by DMA instead of through the
+ * runtime's staging copies */
+int edm_hip_host_malloc(void **h_ptr, size_t bytes);
+int edm_hip_host_free(void *h_ptr);
 int edm_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
 int edm_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
 int edm_hip_memset(void *d_dst, int value, size_t bytes);
@@ -295,6 +299,13 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
 int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, double *d_force,
                            long long n_samples, const double *d_sample_r, const double *d_runiform,
                            long long est_hill_count, double *energy);
+/* edm_hip_bias_pair_step for a caller whose arrays are in HOST memory (the host-list fix edm_pair,
+ * fix_edm_pair.cpp:139-256): same results; the library stages them through HBM with the copies queued around the
+ * kernels -- distances up, force kernel, then the forces come down while the hill samples and uniforms go up
+ * (two streams, both directions of the link busy), then the hill cycle.  h_sample_r may be h_r itself. */
+int edm_hip_bias_pair_step_host(edm_hip_bias *b, long long n, const double *h_r, double *h_force,
+                                long long n_samples, const double *h_sample_r, const double *h_runiform,
+                                long long est_hill_count, double *energy);
 /* EDMBias::pre_add_hill / add_hill / post_add_hill (edm_bias.cpp:413-442, :528-563,
  * :565-583).  add_hill stages the sample (host values); the staged batch is
  * applied on the device, in call order, at post_add_hill. */

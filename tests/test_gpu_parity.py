@@ -946,3 +946,58 @@ def test_polled_completion_is_what_releases_short_batches(workdir):
     #  busy GPU; what must hold is that polling is what normally releases the host)
     assert b.get("poll_fallbacks") <= max(2, b.get("polled_batches") // 10)
     assert b.get("polled_batches") >= 20
+
+
+@pytest.mark.parametrize("pinned", [False, True], ids=["pageable", "pinned"])
+def test_pair_step_host_equals_device_arrays(pinned, workdir):
+    """edm_hip_bias_pair_step_host (host arrays staged by the library: distances up, force kernel, forces down while the
+    samples go up, hill cycle) against edm_hip_bias_pair_step on arrays resident in HBM: energies, forces, grid,
+    histogram and limiter state bit for bit; separate sample arrays and samples aliasing the distances; explicit
+    uniforms and the device stream."""
+    text = ("tempering 0\nhill_prefactor 0.5\nhill_density 40\nbias_per_step 0.12\ndimension 1\nbox_low 0\n"
+            "box_high 2.8\nbias_spacing 0.001\nbias_sigma 0.05\n")
+    n, ns = 50000, 70000
+    state = []
+    for tag in ("host", "device"):
+        cfg = str(workdir / (tag + ".edm"))
+        open(cfg, "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+        b = H.Bias(cfg)
+        b.setup(1.0, 1.0)
+        b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+        alloc = (lambda m: H.pinned_array(m)) if pinned else (lambda m: np.empty(m))
+        h_r, h_f, h_s, h_u = alloc(n), alloc(n), alloc(ns), alloc(ns)
+        out = []
+        for step in range(6):
+            h_r[:] = W.pair_distances(n, 300 + step)
+            h_s[:] = W.pair_distances(ns, 400 + step)
+            h_u[:] = W.uniform(350 + step, ns)
+            alias = step % 3 == 2        # the staged samples ARE the pair distances
+            rng = step == 4              # uniforms drawn on the device
+            if rng:
+                b.set_device_rng(True, 99)
+            samples, nsamp = (h_r, n) if alias else (h_s, ns)
+            uniforms = None if rng else h_u[:nsamp]
+            if tag == "host":
+                h_f[:] = -7.0
+                e = b.pair_step_host(h_r, h_f, samples[:nsamp], uniforms, est=nsamp)
+                f = h_f.copy()
+            else:
+                d_r = H.DeviceArray.from_host(h_r)
+                d_s = d_r if alias else H.DeviceArray.from_host(h_s)
+                d_u = None if rng else H.DeviceArray.from_host(np.ascontiguousarray(h_u[:nsamp]))
+                d_f = H.DeviceArray.zeros((n,))
+                e = b.pair_step_device(d_r, d_f, n, d_s, d_u, nsamp, est=nsamp)
+                f = d_f.to_host()
+            if rng:
+                b.set_device_rng(False, 0)
+            out.append((e, f, [b.get(k) for k in ("cum_bias", "overflow_left", "overflow_right", "b_skip_hill_add", "hills_added")]))
+        v, dv = b.gauss.download()
+        state.append((out, v, dv, b.hist.values))
+        del b
+    for (e1, f1, s1), (e2, f2, s2) in zip(state[0][0], state[1][0]):
+        # (the force kernel runs on its own in the host entry and inside the selection's launch in the other: the
+        #  per-pair forces are the same bits, the energy is a sum over differently shaped workgroups)
+        assert np.array_equal(f1, f2) and s1 == s2 and abs(e1 - e2) <= 1e-12 * abs(e2)
+    for k in (1, 2, 3):
+        assert np.array_equal(state[0][k], state[1][k])
+    assert state[0][1].max() > 0 and state[0][0][-1][2][2] > 0
