@@ -1395,6 +1395,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       }
       la.ready_flag = g->d_ready;
       la.ready_seq = ++g->ready_seq;
+      static const bool early = !(getenv("EDM_HIP_EARLY_WORD") && getenv("EDM_HIP_EARLY_WORD")[0] == '0');
+      la.early_word = early ? 1 : 0;
       static const bool tracing = getenv("EDM_HIP_TRACE") != nullptr;   // development aid: stamps of one launch to stderr
       const size_t trace_wgs = (size_t)nh + (size_t)((q.n[0] + 31) / 32);
       unsigned long long *d_trace = nullptr;

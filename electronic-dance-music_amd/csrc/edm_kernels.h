@@ -314,6 +314,7 @@ struct LimitArgs {
   // k_integrals_gather: device word the gather workgroups of the same launch poll for ready_seq
   unsigned long long *ready_flag;
   unsigned long long ready_seq;
+  int early_word;   // the last wave of the limiter's workgroup may publish EDM_READY_BELOW ahead of the limiter
   // development aid (EDM_HIP_TRACE=1): 8 wall-clock stamps (10 ns units) per workgroup of k_integrals_gather, or NULL
   unsigned long long *trace;
 };

@@ -1617,21 +1617,30 @@ __device__ __forceinline__ T acquire(const T *p) {
 }
 
 // The word the limiter's workgroup of k_integrals_gather publishes and the gather's workgroups poll:
-// [sequence number of the launch : 24][limiter error : 8][k, first hill of the ordered tail : 32]
-__device__ __forceinline__ unsigned long long ready_word(unsigned long long seq, int err, long long k) {
-  return ((seq & 0xFFFFFFull) << 40) | ((unsigned long long)(err & 0xFF) << 32) | (unsigned long long)(unsigned)k;
+// [sequence number of the launch : 24][state : 8][k, first hill of the ordered tail : 32].  It may be published twice:
+//   state EDM_READY_BELOW -- (early, optional) the batch provably stays below the limit: the limiter will change no
+//                            height, every hill keeps its base height.  Published by a wave that adds the per-hill
+//                            integrals up while the limiter's wave is still walking them -- one round trip after
+//                            the last integral instead of the limiter's three -- with a margin far above the sum's
+//                            rounding (a near-tie waits for the limiter).
+//   state = limiter error (0 = none) -- the limiter's outputs are published, k is valid
+#define EDM_READY_BELOW 0xFD
+__device__ __forceinline__ unsigned long long ready_word(unsigned long long seq, int state, long long k) {
+  return ((seq & 0xFFFFFFull) << 40) | ((unsigned long long)(state & 0xFF) << 32) | (unsigned long long)(unsigned)k;
 }
-// one thread waits until the word of launch `seq` is there and returns it (a few hundred workgroups poll the same
-// word: spaced ~0.2 us apart so that the polls do not crowd the round trips of the workgroup that will store it)
-__device__ __forceinline__ unsigned long long wait_for_word(const unsigned long long *word, unsigned long long seq) {
+// one thread waits until a word of launch `seq` is there (final: the limiter's own) and returns it (a few hundred
+// workgroups poll the same word: spaced ~0.2 us apart so that the polls do not crowd the round trips of the
+// workgroup that will store it)
+__device__ __forceinline__ unsigned long long wait_for_word(const unsigned long long *word, unsigned long long seq,
+                                                            bool final = true) {
   const unsigned long long want = seq & 0xFFFFFFull;
   unsigned long long w = acquire(word);
-  if ((w >> 40) == want) return w;
+  if ((w >> 40) == want && (!final || ((w >> 32) & 0xFF) != EDM_READY_BELOW)) return w;
   const unsigned long long t0 = wall_clock64();
   for (;;) {
     __builtin_amdgcn_s_sleep(7);   // ~450 cycles
     w = acquire(word);
-    if ((w >> 40) == want) return w;
+    if ((w >> 40) == want && (!final || ((w >> 32) & 0xFF) != EDM_READY_BELOW)) return w;
     if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();   // 10 s at 100 MHz: never, short of a lost launch
   }
 }
@@ -2295,8 +2304,23 @@ __device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables 
           if (threadIdx.x == 0) publish(la.ready_flag, ready_word(la.ready_seq, err, k_first));
           if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 3] = wall_clock64();
         }
+      } else if (concurrent && la.early_word && threadIdx.x >= NT - 64) {
+        // the last wave, beside the limiter's wave and the two that copy: does the batch stay below the limit
+        // whatever the order of the adds?
+        if (na <= 64 * 64 && la.cum_in >= 0) {
+          double part = 0;
+          for (long long i = threadIdx.x - (NT - 64); i < na; i += 64) part += fabs(acquire(&added[i]));
+          part = wave_sum(part);
+          if (threadIdx.x == NT - 64 && n_true <= nb && (la.cum_in + part) * (1.0 + 1e-9) < la.limit) {
+            // only over the PREVIOUS launch's word: the limiter's own word, should it already be there, must stay
+            unsigned long long seen = acquire(la.ready_flag);
+            if ((seen >> 40) != (la.ready_seq & 0xFFFFFFull))
+              (void)__hip_atomic_compare_exchange_strong(la.ready_flag, &seen, ready_word(la.ready_seq, EDM_READY_BELOW, na),
+                                                         __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
       } else if (la.rb_dst) {
-        readback_copy_hills<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x - 64, NT - 64);
+        readback_copy_hills<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x - 64, (concurrent && la.early_word) ? NT - 128 : NT - 64);
       }
       if (la.rb_dst) {
         if (concurrent) {
@@ -2780,13 +2804,18 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       // 2. the limiter's word (its workgroups were dispatched ahead of this one and wait for nobody)
       if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
       __shared__ unsigned long long s_word;
-      if (threadIdx.x == 0) s_word = wait_for_word(ready_flag, ready_seq);
+      if (threadIdx.x == 0) s_word = wait_for_word(ready_flag, ready_seq, false);
       __syncthreads();
       if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
       waited = true;
       const unsigned long long word = s_word;
-      if ((word >> 32) & 0xFF) return;  // limiter overflow / bound exceeded: the host handles it, nothing is applied
-      k_first_tail = (long long)(unsigned)(word & 0xFFFFFFFFull);
+      const int state = (int)((word >> 32) & 0xFF);
+      if (state == EDM_READY_BELOW) {
+        k_first_tail = nh_eff;   // no hill is touched by the limiter: base heights throughout
+      } else {
+        if (state) return;  // limiter overflow / bound exceeded: the host handles it, nothing is applied
+        k_first_tail = (long long)(unsigned)(word & 0xFFFFFFFFull);
+      }
       // 3. heights of the staged hills
       if ((int)threadIdx.x < cnt) {
         const long long id = s_id[threadIdx.x];
