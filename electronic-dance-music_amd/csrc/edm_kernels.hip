@@ -506,7 +506,11 @@ __device__ __forceinline__ void corner_terms(const Geom &g, const double4 &r, co
     tD[d] = tf * fd;
   }
 }
-template <int DIM, int MODE>
+// REPLICA false: the same four-lanes-per-sample kernel on the NODE RECORDS (grids without a replica: walls, or small
+// enough to sit in L2): lane q loads corner q (and q + 4) at its node's address -- a quad covers the 64-byte corner
+// pairs of two grid rows per instruction, 32 lines per wave-instruction instead of 64, a quarter of the load
+// instructions per sample.
+template <int DIM, int MODE, bool REPLICA = true>
 __global__ void __launch_bounds__(BLOCK) k_lookup_quad(Geom g, const double *__restrict__ faces, LookupArgs a,
                                                        double *__restrict__ block_energy) {
   static_assert(DIM == 2 || DIM == 3, "the replica serves 2-D and 3-D grids");
@@ -562,13 +566,24 @@ __global__ void __launch_bounds__(BLOCK) k_lookup_quad(Geom g, const double *__r
 #pragma unroll
       for (int d = DIM - 1; d > 0; d--) blk = blk * g.n[d - 1] + idx[d - 1];
       const double4 *f4 = reinterpret_cast<const double4 *>(faces);
-      const double4 rA = f4[blk * 4 + q];
+      long long at;   // this lane's record of the lower face
+      if (REPLICA) {
+        at = blk * 4 + q;
+      } else {
+        // node records: corner (b0, b1) sits b0 nodes along dimension 0 and b1 rows along dimension 1 from the
+        // cell's start node, each step wrapping to node 0 across a periodic seam (grid.h:432-433)
+        long long s0 = 1, s1 = g.n[0];
+        if (g.periodic[0] && idx[0] == g.n[0] - 1) s0 *= (1 - g.n[0]);
+        if (g.periodic[1] && idx[1] == g.n[1] - 1) s1 *= (1 - g.n[1]);
+        at = blk + (b0 ? s0 : 0) + (b1 ? s1 : 0);
+      }
+      const double4 rA = f4[at];
       double tFA, tDA[DIM], tFB = 0, tDB[DIM];
       if (DIM == 3) {
         // the face above: node i2 + 1, or node 0 across a periodic seam (grid.h:432-433)
         long long up = (long long)g.n[0] * g.n[1];
         if (g.periodic[DIM - 1] && idx[DIM - 1] == g.n[DIM - 1] - 1) up *= (1 - g.n[DIM - 1]);
-        const double4 rB = f4[(blk + up) * 4 + q];
+        const double4 rB = f4[REPLICA ? (blk + up) * 4 + q : at + up];
         corner_terms<DIM>(g, rA, wod, b0, b1, 0, tFA, tDA);
         corner_terms<DIM>(g, rB, wod, b0, b1, 1, tFB, tDB);
       } else {
@@ -622,16 +637,23 @@ static hipError_t lookup_dim(const Geom &g, const double *rec, LookupMode mode, 
   int blocks = (int)((a.n + BLOCK - 1) / BLOCK);
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
-  const bool use_faces = faces && DIM > 1 && g.interp && mode != LOOKUP_INDEX;
-  if (use_faces) {   // four lanes per sample
+  const bool use_quad = DIM > 1 && g.interp && g.rec == 4 && mode != LOOKUP_INDEX;
+  if (use_quad) {   // four lanes per sample: on the lookup replica where the grid keeps one, else on the node records
     constexpr int QD = (DIM > 1) ? DIM : 2;
     long long qb = (a.n * 4 + BLOCK - 1) / BLOCK;
     if (qb > MAX_BLOCKS) qb = MAX_BLOCKS;
     blocks = (int)(qb < 1 ? 1 : qb);
-    if (mode == LOOKUP_FORCES)
-      EDM_LAUNCH_TIMED((k_lookup_quad<QD, LOOKUP_FORCES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, faces, a, scratch);
-    else
-      EDM_LAUNCH_TIMED((k_lookup_quad<QD, LOOKUP_VALUES>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, faces, a, scratch);
+    if (faces) {
+      if (mode == LOOKUP_FORCES)
+        EDM_LAUNCH_TIMED((k_lookup_quad<QD, LOOKUP_FORCES, true>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, faces, a, scratch);
+      else
+        EDM_LAUNCH_TIMED((k_lookup_quad<QD, LOOKUP_VALUES, true>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, faces, a, scratch);
+    } else {
+      if (mode == LOOKUP_FORCES)
+        EDM_LAUNCH_TIMED((k_lookup_quad<QD, LOOKUP_FORCES, false>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch);
+      else
+        EDM_LAUNCH_TIMED((k_lookup_quad<QD, LOOKUP_VALUES, false>), dim3(blocks), dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch);
+    }
   } else {
     switch (mode) {
       case LOOKUP_FORCES:
