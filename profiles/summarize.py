@@ -27,9 +27,10 @@ import sys
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     here = os.path.dirname(os.path.abspath(__file__))
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)   # (a re-used directory may hold older captures)
+    stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
     shutil.copy(stats, os.path.join(here, "%s_kernel_stats.csv" % tag))
-    trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
+    trace = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
         key = (r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]))
@@ -50,7 +51,7 @@ def main():
         if not files:
             continue
         agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(files[0])):
+        for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
             if r["Counter_Name"] == counter:
                 agg[(r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
         for (name, grid), v in agg.items():
@@ -64,7 +65,7 @@ def main():
             e["hbm_bytes_per_launch"] = e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]
     cal = glob.glob(os.path.join(src, "cal_fetch", "*", "*_counter_collection.csv"))
     if cal:
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(cal[0]))
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(max(cal, key=os.path.getmtime)))
                 if r["Counter_Name"] == "FETCH_SIZE" and "k<4>" in r["Kernel_Name"]]
         true_bytes = 2097152 * 128
         summary["fetch_size_calibration"] = dict(
@@ -76,7 +77,7 @@ def main():
     instr = glob.glob(os.path.join(src, "pmc_instr", "*", "*_counter_collection.csv"))
     if instr:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
-        for r in csv.DictReader(open(instr[0])):
+        for r in csv.DictReader(open(max(instr, key=os.path.getmtime))):
             agg[(r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
         out = {}
         for (name, grid), cs in agg.items():
