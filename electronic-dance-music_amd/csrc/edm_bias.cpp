@@ -1039,9 +1039,10 @@ int edm_hip_bias_pair_list_upload(edm_hip_bias *b, long long npairs, const int *
   std::vector<int> it_idx((size_t)(npairs > 0 ? npairs : 1)), jt_idx((size_t)(npairs > 0 ? npairs : 1));
   {
     std::vector<long long> ci(it_off.begin(), it_off.end() - 1), cj(jt_off.begin(), jt_off.end() - 1);
+    // (the OTHER atom of every entry, grouped by atom: what the force pass walks -- contiguous per atom)
     for (long long p = 0; p < npairs; p++) {
-      it_idx[(size_t)ci[(size_t)h_pair_i[p]]++] = (int)p;
-      jt_idx[(size_t)cj[(size_t)h_pair_j[p]]++] = (int)p;
+      it_idx[(size_t)ci[(size_t)h_pair_i[p]]++] = h_pair_j[p];
+      jt_idx[(size_t)cj[(size_t)h_pair_j[p]]++] = h_pair_i[p];
     }
   }
   const size_t np1 = (size_t)(npairs > 0 ? npairs : 1), na1 = (size_t)(nall > 0 ? nall : 1);
@@ -1111,8 +1112,8 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   a.x = d_x;
   a.it_off = b->pl_it_off.p;
   a.jt_off = b->pl_jt_off.p;
-  a.it_idx = b->pl_it_idx.p;
-  a.jt_idx = b->pl_jt_idx.p;
+  a.it_partner = b->pl_it_idx.p;
+  a.jt_partner = b->pl_jt_idx.p;
   a.fdelta = d_fdelta;
   if (hill_step && npairs > 0 && !(b->pl_mask_valid && b->pl_mask_nlocal == nlocal && b->pl_mask_itype == itype &&
                                    b->pl_mask_jtype == jtype)) {

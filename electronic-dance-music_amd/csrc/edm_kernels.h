@@ -69,7 +69,8 @@ struct PairListArgs {
   int nlocal, nall;
   const double *x;              // [nall][3]
   const long long *it_off, *jt_off;   // [nall + 1] CSR offsets of the entries with pair_i == a / pair_j == a
-  const int *it_idx, *jt_idx;         // [npairs] entry indices, each atom's run in list order
+  const int *it_partner, *jt_partner; // [npairs] the OTHER atom of each of those entries (j of the entries with
+                                      // pair_i == a, i of the entries with pair_j == a), each atom's run in list order
   double *fdelta;               // out [nall][3]: bias force per atom (ghost atoms: zero)
   double *vs_r;                 // launch_pairlist_samples: out [2 * npairs] virtual-sample CVs
   int *vs_mask;                 // launch_pairlist_mask: out [2 * npairs] 1 = live sample

@@ -1019,18 +1019,17 @@ __device__ __forceinline__ bool pairlist_types_match(const PairListArgs &a, int 
   if (ti == a.jtype) return tj == a.itype;
   return false;
 }
-// One side of an atom's sum: entries idx[q], q = beg + sub, beg + sub + 16, ...; `as_i`: the atom is the entry's i
-// (partner = pair_j, the term is added and its energy counted), else its j (partner = pair_i, subtracted).  Four
-// entries per trip: their index, partner, type and position loads are requested together (an entry is a chain of
-// four dependent loads -- index -> partner -> position -> grid record -- and a lane walks a handful of entries), the
+// One side of an atom's sum: its entries q = beg + sub, beg + sub + 16, ... with partner[q] the other atom; `as_i`:
+// the atom is the entry's i (the term is added and its energy counted), else its j (subtracted).  Four
+// entries per trip: their partner, type and position loads are requested together (an entry is a chain of
+// three dependent loads -- partner -> position -> grid record -- and a lane walks a handful of entries), the
 // terms are still added in list order.
 template <bool FAST>
 __device__ __forceinline__ void pairlist_side(const Geom &g, const double *__restrict__ rec, const PairListArgs &a,
                                               double inv_dx, int atom, int ta, const double *xa, bool as_i,
-                                              const int *__restrict__ idx, long long beg, long long end, int sub,
+                                              const int *__restrict__ partner, long long beg, long long end, int sub,
                                               double &fx, double &fy, double &fz, double &e_acc) {
   constexpr int ILP = 4;
-  const int *__restrict__ partner_of = as_i ? a.pair_j : a.pair_i;
   for (long long q0 = beg + sub; q0 < end; q0 += 16 * ILP) {
     int other[ILP];
     bool ok[ILP];
@@ -1039,10 +1038,8 @@ __device__ __forceinline__ void pairlist_side(const Geom &g, const double *__res
     for (int u = 0; u < ILP; u++) {
       const long long q = q0 + 16 * u;
       ok[u] = q < end;
-      other[u] = ok[u] ? idx[q] : 0;
+      other[u] = ok[u] ? partner[q] : 0;   // (contiguous per atom: built when the list was uploaded)
     }
-#pragma unroll
-    for (int u = 0; u < ILP; u++) other[u] = ok[u] ? partner_of[other[u]] : 0;
 #pragma unroll
     for (int u = 0; u < ILP; u++) {
       const int to = ok[u] ? a.type[other[u]] : 0;
@@ -1111,8 +1108,8 @@ __global__ void __launch_bounds__(BLOCK) k_pairlist_forces(Geom g, const double 
       const int ta = a.type[atom];
       const double xa[3] = {a.x[3 * atom], a.x[3 * atom + 1], a.x[3 * atom + 2]};
       const long long ib = a.it_off[atom], ie = a.it_off[atom + 1], jb = a.jt_off[atom], je = a.jt_off[atom + 1];
-      pairlist_side<FAST>(g, rec, a, inv_dx, (int)atom, ta, xa, true, a.it_idx, ib, ie, sub, fx, fy, fz, e_acc);
-      pairlist_side<FAST>(g, rec, a, inv_dx, (int)atom, ta, xa, false, a.jt_idx, jb, je, sub, fx, fy, fz, e_acc);
+      pairlist_side<FAST>(g, rec, a, inv_dx, (int)atom, ta, xa, true, a.it_partner, ib, ie, sub, fx, fy, fz, e_acc);
+      pairlist_side<FAST>(g, rec, a, inv_dx, (int)atom, ta, xa, false, a.jt_partner, jb, je, sub, fx, fy, fz, e_acc);
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {   // fixed tree within the 16-lane group
