@@ -167,3 +167,39 @@ def test_remap_vs_oracle(oracle_lib):
         got = g.remap(q)
         want = np.array([o.remap(x) for x in q])
         assert np.array_equal(got, want), "case %d" % k
+
+
+@pytest.mark.parametrize("lammps", [0, 1], ids=["plumed_layout", "lammps_table"])
+def test_multi_write_of_a_skin_offset_subgrid_vs_oracle(lammps, oracle_lib, workdir):
+    """DimmedGrid::multi_write (grid.h:509-674) where it is NOT a node dump: the pair fix's grid reaches a skin beyond
+    the boundary on both sides (fix_edm_pair.cpp:96-104 -> edm_bias.cpp:142-154: grid [-0.3, 3.6], boundary [1, 3.3]), so
+    the rows box_min + k dx fall between nodes and are re-sampled by interpolation; the LAMMPS table prepends its
+    filler rows.  Hills near both walls (McGovern-De Pablo terms active).  Text equal to the oracle's up to last-digit
+    flips of the 8-decimal body (device exp vs libm), header and row structure exact."""
+    lo, hi, sp, sg = [-0.3], [3.6], [0.24375], [0.3]
+    g = H.Gauss.create(lo, hi, sp, [0], 1, sg)
+    o = B.Gauss.create(oracle_lib, lo, hi, sp, [0], 1, sg)
+    g.set_boundary([1.0], [3.3], [0])
+    o.set_boundary([1.0], [3.3], [0])
+    hx = np.zeros((30, 3))
+    hx[:, 0] = 1.0 + W.uniform(91, 30) * 2.3
+    hx[:3, 0] = [1.0, 3.3, 1.02]
+    hh = 0.2 + W.uniform(92, 30)
+    g.add_values(hx, hh)
+    for x, h in zip(hx, hh):
+        o.add_value(x[:1], float(h))
+    g.multi_write(str(workdir / "g.out"), lammps)
+    o.multi_write(str(workdir / "o.out"), lammps)
+    a, w = open(str(workdir / "g.out")).read().split("\n"), open(str(workdir / "o.out")).read().split("\n")
+    assert len(a) == len(w) and len(a) > 12
+    nhead = 7 if not lammps else 4
+    assert a[:nhead] == w[:nhead], "header"
+    flips = 0
+    for x, y in zip(a[nhead:], w[nhead:]):
+        if x == y:
+            continue
+        tx, ty = x.split(), y.split()
+        assert len(tx) == len(ty) and tx[0] == ty[0], (x, y)
+        assert np.allclose([float(t) for t in tx], [float(t) for t in ty], rtol=0, atol=1.01e-8), (x, y)
+        flips += 1
+    assert flips <= 2, "%d rows differ in a last digit" % flips
