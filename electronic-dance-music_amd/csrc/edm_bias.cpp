@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
@@ -925,6 +926,10 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
     set_error("pair_step: the pair-distance CV is 1-D (fix_edm_pair.cpp:52)");
     return EDM_HIP_ERR_ARG;
   }
+  static const bool host_trace = getenv("EDM_HIP_TRACE") != nullptr;
+  static double last_exit_us = 0;
+  const double t_in = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  if (host_trace && b->bias) b->bias->ht_ref_us = t_in;
   // pre_add_hill first, as fix_edm_pair does (:174): a pending overflow flush is part of the bias the
   // forces see
   int rc = do_pre_add_hill(b, est_hill_count < 0 ? n_samples : est_hill_count);
@@ -952,7 +957,15 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
   if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
   const double e = pair_forces_finish(b->bias, b->pending.nblk);
   if (energy) *energy = e;
-  return do_post_add_hill(b);
+  rc = do_post_add_hill(b);
+  if (host_trace) {
+    const double t_out = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (b->bias->ready_seq == 160)
+      fprintf(stderr, "[edm host] pair_step: %.2f us inside the call, %.2f us since the previous call returned\n", t_out - t_in,
+              t_in - last_exit_us);
+    last_exit_us = t_out;
+  }
+  return rc;
 }
 
 // The same step for a caller whose arrays live in HOST memory (the host-list fix edm_pair): staged through HBM with

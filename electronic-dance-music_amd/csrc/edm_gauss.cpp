@@ -1588,6 +1588,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   const double *st_added = reinterpret_cast<const double *>(stage + off_added);
   const double *st_pos = reinterpret_cast<const double *>(stage + off_pos);
   g->wait_polled = false;
+  static const bool host_trace = getenv("EDM_HIP_TRACE") != nullptr;   // development aid: host-side stamps
+  const auto ht_before_poll = std::chrono::steady_clock::now();
   if (polled) {
     // the limiter's workgroup flags the host-mapped region once it is complete: poll the word instead of waiting
     // for the stream's completion signal (bounded; falls back to the stream wait)
@@ -1610,6 +1612,12 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     }
   } else {
     EDM_HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (host_trace && g->ready_seq == 160) {
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[edm host] apply_hills: polling took %.2f us (entered the poll %.2f us after a reference point)\n",
+            std::chrono::duration<double, std::micro>(now - ht_before_poll).count(),
+            std::chrono::duration<double, std::micro>(ht_before_poll.time_since_epoch()).count() - g->ht_ref_us);
   }
   long long nh_act = nh;
   if (spec.limited) {

@@ -117,6 +117,7 @@ struct edm_hip_gauss {
   int *d_tickets = nullptr;              // three last-workgroup tickets (EDM_TICKET_INTS ints each), kept zero
   unsigned long long *d_ready = nullptr; // word the gather half of k_integrals_gather polls for ...
   unsigned long long ready_seq = 0;      // ... the sequence number of its launch
+  double ht_ref_us = 0;                  // development aid (EDM_HIP_TRACE): host clock at the entry of the step being traced
   // lookup replica of a 2-D / 3-D grid with a periodic boundary (see lookup_one / launch_build_faces): g.total
   // blocks of 128 bytes, 4x the node records -- memory spent so that a coordinate-CV sample reads 1 or 2 aligned
   // lines instead of 2.5 / 5.  faces_mode: -1 = automatic (grids beyond the L2s' reach), 0 = off, 1 = always.
