@@ -84,6 +84,7 @@ struct edm_hip_bias {
   DevBuf<int> vs_mask;
   bool force_sync = false;      // redo of a deferred step whose launch bound proved too small
   int debug_force_sync = 0;     // tests: never defer the count (every step takes the synchronous path)
+  int debug_no_one_launch = 0;  // tests: a fix edm_pair hill step keeps its two launches (forces + selection | integrals + gather)
   long long bound_redos = 0;    // steps redone because the accepted count exceeded the deferred launch bound
   PendingForces pending;        // pair forces of a fused step waiting for the launch of the step's selection
   // staging of the *_host entry points: device copies of the caller's host arrays, a second stream for the copy
@@ -806,6 +807,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     else {
       spec.sel_chain = &sel_args;
       spec.forces = &b->pending;
+      spec.allow_one_launch = !b->debug_no_one_launch;
     }
   }
   int rc = apply_hills(b->bias, spec, &oc, false);
@@ -1277,6 +1279,7 @@ int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
   G("mpi_size", b->mpi_size)
   // telemetry of the polled completion: batches released by the polled word / by the stream wait
   G("polled_batches", b->bias ? b->bias->polled_batches : 0)
+  G("fused_steps", b->bias ? b->bias->fused_steps : 0)
   G("poll_fallbacks", b->bias ? b->bias->poll_fallbacks : 0)
   G("bound_redos", b->bound_redos)
 #undef G
@@ -1296,6 +1299,7 @@ int edm_hip_bias_set(edm_hip_bias *b, const char *name, double value) {
   S("total_volume", b->total_volume, double)
   S("debug_virtual_ranks", b->debug_virtual_ranks, int)
   S("debug_force_sync", b->debug_force_sync, int)
+  S("debug_no_one_launch", b->debug_no_one_launch, int)
 #undef S
   set_error(std::string("unknown or read-only EDMBias member ") + name);
   return EDM_HIP_ERR_ARG;

@@ -719,6 +719,9 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
   if (g->d_dirty) (void)hipFree(g->d_dirty);
   if (g->d_tickets) (void)hipFree(g->d_tickets);
   if (g->d_ready) (void)hipFree(g->d_ready);
+  if (g->fs_rec) (void)hipFree(g->fs_rec);
+  if (g->rec_alt) (void)hipFree(g->rec_alt);
+  if (g->fs_counters) (void)hipFree(g->fs_counters);
   if (g->prof_ev) {
     for (int i = 0; i < 2 * edm_hip_gauss::PROF_RING; i++) (void)hipEventDestroy(g->prof_ev[i]);
     delete[] g->prof_ev;
@@ -808,6 +811,7 @@ int edm_hip_gauss_device_buffer(edm_hip_gauss *g, double **d_records, int *doubl
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
   g->faces_mode = 0;
   faces_touch(g);
+  g->rec_handed_out = true;   // (the pointer must stay the grid: no one-launch steps, whose output is the second buffer)
   if (d_records) *d_records = g->rec;
   if (doubles_per_node) *doubles_per_node = g->g.rec;
   if (nodes) *nodes = g->g.total;
@@ -1161,14 +1165,19 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hl.hx0 = p_hx0;
   hl.nh_dev = spec.d_nh;
   const Tables tabs = g->tables();
-  if (spec.sel_chain) {
-    // selection + preparation in one launch (and the step's pair forces with them, when they are pending)
-    int rc = select_prep_enqueue(g, *spec.sel_chain, hl, spec.forces);
-    if (rc) return rc;
-  } else if (spec.unpack_chain)
-    EDM_HIP_TRY(launch_unpack_prep(*spec.unpack_chain, q, hl, s));  // exchange packets -> global prepared list
-  else
-    EDM_HIP_TRY(launch_hill_prep(q, hl, s, spec.h_fetch_src, spec.h_fetch_src ? const_cast<double *>(spec.d_h) : nullptr));
+  // the launch that produces the prepared hill list (queued further down, once the gather plan is known: a short
+  // fix edm_pair step runs selection, forces, integrals, limiter and gather as ONE launch instead)
+  auto enqueue_preparation = [&]() -> int {
+    if (spec.sel_chain) {
+      // selection + preparation in one launch (and the step's pair forces with them, when they are pending)
+      int rc = select_prep_enqueue(g, *spec.sel_chain, hl, spec.forces);
+      if (rc) return rc;
+    } else if (spec.unpack_chain)
+      EDM_HIP_TRY(launch_unpack_prep(*spec.unpack_chain, q, hl, s));  // exchange packets -> global prepared list
+    else
+      EDM_HIP_TRY(launch_hill_prep(q, hl, s, spec.h_fetch_src, spec.h_fetch_src ? const_cast<double *>(spec.d_h) : nullptr));
+    return EDM_HIP_OK;
+  };
 
   HillHeights hh;
   hh.h = spec.d_h;
@@ -1293,6 +1302,14 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
   bool chain_post = false;
   bool gather_done = false;   // the gather rode in the integrals' launch (launch_integrals_gather)
+  static const bool one_launch_ok = !(getenv("EDM_HIP_ONE_LAUNCH") && getenv("EDM_HIP_ONE_LAUNCH")[0] == '0');
+  const bool one_launch = one_launch_ok && spec.allow_one_launch && chain_limit && spec.sel_chain && spec.forces && spec.forces->active && small &&
+                          rb_bytes + 128 <= g->h_stage_bytes && fused_post && !sharded && !g->rec_handed_out &&
+                          pair_step_fusable(q, spec.forces->n, *spec.sel_chain, hl, spec.d_h, plan);
+  if (!one_launch) {
+    int rcp = enqueue_preparation();
+    if (rcp) return rcp;
+  }
   if (sharded) {
     if (spec.shard_comm) {
       if (spec.shard_off < 0 || spec.shard_cnt < 0 || spec.shard_off + spec.shard_cnt > nh) {
@@ -1421,9 +1438,87 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         ps.rb_bytes = (long long)rb_bytes;
         rb_pushed = true;
       }
-      EDM_HIP_TRY(launch_integrals_gather(q, tabs, g->rec, hl, spec.d_h, spec.h_const, p_added, la, hh, plan, g->d_dirty, s,
-                                          chain_post ? &ps : nullptr));
+      size_t trace_wgs_fused = 0;
+      if (one_launch) {
+        // the whole step in one launch: selection (+ per-hill integrals), pair forces, bookkeeper, gather tiles
+        const SelectArgs &sa = *spec.sel_chain;
+        const size_t nsel = (size_t)((sa.n + 4095) / 4096);
+        if (!g->fs_counters) {
+          EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->fs_counters), sizeof(unsigned) * 32 * 2 * EDM_FS_SUB));
+          EDM_HIP_TRY(hipMemset(g->fs_counters, 0, sizeof(unsigned) * 32 * 2 * EDM_FS_SUB));
+          g->fs_sel_total = g->fs_k1_total = 0;
+        }
+        if (g->fs_rec_wgs < nsel) {
+          if (g->fs_rec) (void)hipFree(g->fs_rec);
+          g->fs_rec = nullptr;
+          g->fs_rec_wgs = 0;
+          EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->fs_rec), sizeof(double) * EDM_FS_CAP * EDM_FS_REC * (nsel + 64)));
+          g->fs_rec_wgs = nsel + 64;
+        }
+        if (!g->rec_alt) EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->rec_alt), sizeof(double) * grid_doubles));
+        PendingForces *pf = spec.forces;
+        hipEvent_t e0, e1;
+        profile_slot(g, &e0, &e1);
+        FusedStep fsd;
+        memset(&fsd, 0, sizeof(fsd));
+        fsd.wgrec = g->fs_rec;
+        fsd.sel_done = g->fs_counters;
+        fsd.k1_done = g->fs_counters + 32 * EDM_FS_SUB;
+        int nk1 = 0;
+        // (the targets are known only once the launcher has sized the grid: it fills nsel / nk1; the sums are advanced here)
+        fsd.sel_target = g->fs_sel_total;   // (sums so far: the launcher adds this launch's workgroup counts)
+        fsd.k1_target = g->fs_k1_total;
+        int nsel_launched = 0;
+        if (d_trace) {
+          (void)hipFree(d_trace);
+          d_trace = nullptr;
+          la.trace = nullptr;
+        }
+        if (tracing && g->ready_seq == 150) {
+          trace_wgs_fused = nsel + 2 * 256 + 8 + (size_t)((q.n[0] + 31) / 32);
+          EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_trace), trace_wgs_fused * 64));
+          EDM_HIP_TRY(hipMemset(d_trace, 0, trace_wgs_fused * 64));
+          la.trace = d_trace;
+        }
+        pf->active = false;
+        EDM_HIP_TRY(launch_pair_step(sa, q, tabs, g->rec, hl, spec.h_const, p_added, la, hh, plan, g->d_dirty, &ps, pf->d_r, pf->n,
+                                     pf->d_force, g->d_partials, fsd, s, e0, e1, &nk1, &nsel_launched, g->rec_alt));
+        pf->nblk = nk1;
+        g->fs_sel_total += (unsigned)nsel_launched;
+        g->fs_k1_total += (unsigned)nk1;
+        g->fused_steps++;
+      } else {
+        EDM_HIP_TRY(launch_integrals_gather(q, tabs, g->rec, hl, spec.d_h, spec.h_const, p_added, la, hh, plan, g->d_dirty, s,
+                                            chain_post ? &ps : nullptr));
+      }
       gather_done = true;
+      if (d_trace && one_launch) {
+        EDM_HIP_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned long long> tr(trace_wgs_fused * 8);
+        EDM_HIP_TRY(hipMemcpy(tr.data(), d_trace, trace_wgs_fused * 64, hipMemcpyDeviceToHost));
+        (void)hipFree(d_trace);
+        d_trace = nullptr;
+        unsigned long long t0 = ~0ull;
+        for (size_t w = 0; w < trace_wgs_fused; w++)
+          if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
+        const size_t nsel = (size_t)((spec.sel_chain->n + 4095) / 4096), nk1 = (size_t)spec.forces->nblk;
+        const size_t lo[4] = {0, nsel, nsel + nk1, nsel + nk1 + 1}, hi[4] = {nsel, nsel + nk1, nsel + nk1 + 1, trace_wgs_fused};
+        const char *role[4] = {"select   ", "forces   ", "bookkeep ", "tiles    "};
+        const char *names[4][8] = {{"start", "flags done", "published", "", "", "", "", "end"},
+                                   {"start", "", "", "", "", "", "", "end"},
+                                   {"start", "selection seen", "list written", "word published", "host released", "", "", "end"},
+                                   {"start", "selection seen", "terms parked", "heights known", "forces seen", "", "body end", "end"}};
+        for (int r = 0; r < 4; r++)
+          for (int k = 0; k < 8; k++) {
+            std::vector<double> v;
+            for (size_t w = lo[r]; w < hi[r] && w < trace_wgs_fused; w++)
+              if (tr[w * 8 + k]) v.push_back((double)(tr[w * 8 + k] - t0) * 0.01);
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[edm trace] %s %-16s n=%4zu  min %6.2f  med %6.2f  max %6.2f us\n", role[r], names[r][k], v.size(),
+                    v.front(), v[v.size() / 2], v.back());
+          }
+      }
       if (d_trace) {
         EDM_HIP_TRY(hipStreamSynchronize(s));
         std::vector<unsigned long long> tr(trace_wgs * 8);
@@ -1631,6 +1726,9 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       return EDM_HIP_ERR_OVERFLOW;
     }
     nh_act = res.nh;
+    // a one-launch step wrote the updated grid into the second buffer: it is the grid from here on (an error above
+    // means nothing was applied -- the tiles stood down -- and the buffers stay as they are)
+    if (one_launch) std::swap(g->rec, g->rec_alt);
   }
   if (out) {
     out->res = res;

@@ -24,6 +24,8 @@
 #include <limits.h>
 #include <string.h>
 
+#include <type_traits>
+
 // launch with the kernel's own begin/end timestamps in (ev0, ev1) when profiling is on: hipEventRecord
 // brackets would add the dispatch latency (~3 us) to a 10 us kernel
 #define EDM_LAUNCH_TIMED(kernel, grid, block, lds, s, ev0, ev1, ...)                                   \
@@ -1534,13 +1536,10 @@ __device__ __forceinline__ void hill_prep_one(const Geom &g, const HillList &h, 
   sample_position<DIM>(h, src, x);
   hill_prep_vals<DIM>(g, h, i, x);
 }
-// (x holds the sample's CV on entry and is remapped in place)
+// the prepared fields of one hill from its CV: x is remapped in place (gaussian_grid.h:206-224), c = centre node
+// (c[0] = INT_MIN: rejected, outside a wall), ht = the hill-only exponentials (t1, t3) of :310,:312 per dimension
 template <int DIM>
-__device__ __forceinline__ void hill_prep_vals(const Geom &g, const HillList &h, long long i, double *x) {
-  if (h.hx0) {
-#pragma unroll
-    for (int d = 0; d < DIM; d++) h.hx0[i * DIM + d] = x[d];
-  }
+__device__ __forceinline__ void hill_prep_compute(const Geom &g, double *x, int *c, double *ht) {
   remap<DIM>(g, x);
   bool ok = true;
 #pragma unroll
@@ -1548,18 +1547,35 @@ __device__ __forceinline__ void hill_prep_vals(const Geom &g, const HillList &h,
     if (!g.bper[d] && (x[d] < g.bmin[d] || x[d] > g.bmax[d])) ok = false;
 #pragma unroll
   for (int d = 0; d < DIM; d++) {
-    h.hx[i * DIM + d] = x[d];
-    h.hc[i * DIM + d] = ifloor((x[d] - g.min[d]) / g.dx[d]);
+    c[d] = ifloor((x[d] - g.min[d]) / g.dx[d]);
     double t1 = 0, t3 = 0;
     if (!g.bper[d]) {
       const double sg = g.sigma[d];
       t1 = exp(-((x[d] - g.bmin[d]) * (x[d] - g.bmin[d])) / (sg * sg));
       t3 = exp(-((x[d] - g.bmax[d]) * (x[d] - g.bmax[d])) / (sg * sg));
     }
-    h.ht[i * 2 * DIM + 2 * d] = t1;
-    h.ht[i * 2 * DIM + 2 * d + 1] = t3;
+    ht[2 * d] = t1;
+    ht[2 * d + 1] = t3;
   }
-  if (!ok) h.hc[i * DIM] = INT_MIN;
+  if (!ok) c[0] = INT_MIN;
+}
+// (x holds the sample's CV on entry and is remapped in place)
+template <int DIM>
+__device__ __forceinline__ void hill_prep_vals(const Geom &g, const HillList &h, long long i, double *x) {
+  if (h.hx0) {
+#pragma unroll
+    for (int d = 0; d < DIM; d++) h.hx0[i * DIM + d] = x[d];
+  }
+  int c[DIM];
+  double ht[2 * DIM];
+  hill_prep_compute<DIM>(g, x, c, ht);
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    h.hx[i * DIM + d] = x[d];
+    h.hc[i * DIM + d] = c[d];
+    h.ht[i * 2 * DIM + 2 * d] = ht[2 * d];
+    h.ht[i * 2 * DIM + 2 * d + 1] = ht[2 * d + 1];
+  }
 }
 
 template <int DIM>
@@ -1661,6 +1677,29 @@ __device__ __forceinline__ unsigned long long wait_for_word(const unsigned long 
     w = acquire(word);
     if ((w >> 40) == want && (!final || ((w >> 32) & 0xFF) != EDM_READY_BELOW)) return w;
     if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();   // 10 s at 100 MHz: never, short of a lost launch
+  }
+}
+
+// Cumulative completion counters of k_pair_step (FusedStep::sel_done / k1_done): EDM_FS_SUB sub-counters, one per
+// 128-byte line.  A finished workgroup adds one to sub-counter (id mod EDM_FS_SUB) -- no return value, nothing waits
+// for the add -- after its published stores have been acknowledged; a waiting workgroup's thread reads all the
+// sub-counters in one round trip and compares their sum with the launch's target (the sums only ever grow, 32-bit
+// wrap-around included, so nothing is reset between launches).
+__device__ __forceinline__ void counter_arrive(unsigned *sub, unsigned id) {
+  (void)__hip_atomic_fetch_add(sub + 32 * (id % EDM_FS_SUB), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wait_counter(const unsigned *sub, unsigned target) {
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    unsigned v[EDM_FS_SUB];
+#pragma unroll
+    for (int i = 0; i < EDM_FS_SUB; i++) v[i] = acquire(sub + 32 * i);
+    unsigned sum = 0;
+#pragma unroll
+    for (int i = 0; i < EDM_FS_SUB; i++) sum += v[i];
+    if (sum == target) return;
+    __builtin_amdgcn_s_sleep(4);
+    if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();   // 10 s: never, short of a lost launch
   }
 }
 
@@ -2159,52 +2198,17 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            const LimitTail &tail, LimitResult *res, long long nchunks,
                                            const double *chunk_sum, const double *chunk_max,
                                            const long long *nh_dev, long long mirror = 0, long long *k_out = nullptr,
-                                           int *err_out = nullptr, long long nh_known = -1);
+                                           int *err_out = nullptr, long long nh_known = -1,
+                                           const FusedStep *fsrc = nullptr, const unsigned short *fs_off = nullptr);
 
-// `la` (TPH == BLOCK only): the ordered limiter is chained onto the last workgroup to finish
-// (bid: this workgroup's index among the integrals workgroups -- blockIdx.x, except inside k_integrals_gather)
-// returns true (workgroup-uniform) in the workgroup that ran the chained limiter, once its results are out
+// The stencil walk of one hill by TPH cooperating threads (lt = this thread's index among them): the thread's share of
+// height * (expo + corr) * vol over the reference's stencil (gaussian_grid.h:227-281), summed in stencil order.  The
+// caller adds the shares up (wave_sum, then the waves in order): k_hill_integrals and the selection workgroups of
+// k_pair_step call this same walk, so the two paths yield the same bits.
 template <int DIM, int TPH, bool PERB>
-__device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables &t, const HillList &h,
-                                                    const double *__restrict__ heights, double h_const,
-                                                    double *__restrict__ added, const LimitArgs &la, unsigned bid) {
-  constexpr int NT = (TPH > BLOCK) ? TPH : BLOCK;  // workgroup size: 512 threads per hill for the 3-D stencil
-  __shared__ double s_red[NT / 64];
-  const int lane = threadIdx.x & 63;
-  const int lt = threadIdx.x % TPH;
-  const long long hill = (long long)bid * (NT / TPH) + (threadIdx.x / TPH);
-  // The hill's fields are requested BEFORE the hill count is known (the arrays hold h.nh entries, the launch bound:
-  // an entry beyond the true count is stale and masked below): one memory round trip instead of three dependent
-  // ones (count -> centre node -> the other fields).
-  int c_r[DIM];
-  double hx_r[DIM], ht_r[2 * DIM];
-  double height_r = h_const;
-#pragma unroll
-  for (int d = 0; d < DIM; d++) {
-    c_r[d] = INT_MIN;
-    hx_r[d] = 0;
-    ht_r[2 * d] = ht_r[2 * d + 1] = 0;
-  }
-  if (hill < h.nh) {
-#pragma unroll
-    for (int d = 0; d < DIM; d++) {
-      c_r[d] = h.hc[hill * DIM + d];
-      hx_r[d] = h.hx[hill * DIM + d];
-      ht_r[2 * d] = h.ht[hill * 2 * DIM + 2 * d];
-      ht_r[2 * d + 1] = h.ht[hill * 2 * DIM + 2 * d + 1];
-    }
-    if (heights) height_r = heights[hill];
-  }
-  const long long nh_eff = hill_count(h);
-  if (TPH == 64 && hill >= nh_eff) return false;  // (a whole workgroup shares one hill when TPH == BLOCK)
-  const bool live = hill < nh_eff;
-  // chained limiter (a workgroup per hill, launched against a bound on the hill count): only the workgroups that
-  // own a hill take a ticket -- workgroup 0 alone when there is none -- so the last arrival is one of a few hundred
-  // and a single counter (one atomic round trip) does
-  const unsigned ticket_blocks = (unsigned)(nh_eff > 0 ? nh_eff : 1);
-  if (TPH != 64 && la.enabled && bid >= ticket_blocks) return false;
-  TermConst<DIM> tc;
-  term_const<DIM>(g, tc);
+__device__ __forceinline__ double hill_stencil_partial(const Geom &g, const Tables &t, const TermConst<DIM> &tc,
+                                                       const int *c_r, const double *hx_r, const double *ht_r,
+                                                       double height_r, bool live, int lt) {
   double acc = 0;
   const int c0 = live ? c_r[0] : INT_MIN;
   if (c0 != INT_MIN) {
@@ -2284,6 +2288,132 @@ __device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables 
       for (int u = 0; u < ILP; u++) acc += term[u];
     }
   }
+  return acc;
+}
+
+// The serial stage behind the per-hill integrals, run by ONE workgroup once all of them are published: ordered
+// limiter (wave 0), read-back region to host-mapped memory, release of the host.  n_true_known >= 0: the caller
+// knows the batch's true hill count (else it is read from h.nh_dev); k1_done: see below.
+__device__ __forceinline__ void wait_counter(const unsigned *sub, unsigned target);
+template <int DIM, int NT>
+__device__ __forceinline__ void limiter_stage(const HillList &h, const double *__restrict__ heights, double h_const,
+                                              double *__restrict__ added, const LimitArgs &la, unsigned bid,
+                                              long long n_true_known, const unsigned *k1_done, unsigned k1_target) {
+  // wave 0 walks the limiter; with a read-back region (la.rb_dst) it stores its outputs to the device region and
+  // to its host-mapped copy alike, while the other waves copy what does not depend on the limiter -- per-hill
+  // bias and positions, by the true hill count -- so nothing is left to read back once the limiter is done.
+  // k_integrals_gather (la.ready_flag): the gather workgroups of the same launch wait for the limiter, so its
+  // outputs go to the device region only (agent scope), the word the gather polls follows as soon as wave 0's
+  // stores are acknowledged -- no host round trip in front of it -- and the copy to the host comes after.
+  const bool concurrent = la.ready_flag != nullptr;
+  const long long mirror = (la.rb_dst && !concurrent) ? (long long)(la.rb_dst - la.rb_src) : 0;
+  const long long nb = h.nh;   // the layout is sized by the launch bound
+  const long long n_true = n_true_known >= 0 ? n_true_known : (h.nh_dev ? *h.nh_dev : nb);   // (already on its way for hill_count(): no new round trip)
+  long long na = n_true;
+  if (na > nb) na = 0;         // (bound exceeded: the limiter reports it, nothing is read)
+  if (threadIdx.x < 64) {
+    long long k_first = 0;
+    int err = 0;
+    limit_wave<true>(h.nh, added, heights, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr,
+               nullptr, h.nh_dev, mirror, &k_first, &err, h.nh_dev ? n_true : -1);
+    if (concurrent) {
+      // the word carries what every gather workgroup needs first -- the error code and k, the first hill of the
+      // ordered tail -- so that seeing it is all the waiting workgroups have to do when there is no tail
+      __builtin_amdgcn_s_waitcnt(0);
+      if (threadIdx.x == 0) publish(la.ready_flag, ready_word(la.ready_seq, err, k_first));
+      if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 3] = wall_clock64();
+    }
+  } else if (concurrent && la.early_word && threadIdx.x >= NT - 64) {
+    // the last wave, beside the limiter's wave and the two that copy: does the batch stay below the limit
+    // whatever the order of the adds?
+    if (na <= 64 * 64 && la.cum_in >= 0) {
+      double part = 0;
+      for (long long i = threadIdx.x - (NT - 64); i < na; i += 64) part += fabs(acquire(&added[i]));
+      part = wave_sum(part);
+      if (threadIdx.x == NT - 64 && n_true <= nb && (la.cum_in + part) * (1.0 + 1e-9) < la.limit) {
+        // only over the PREVIOUS launch's word: the limiter's own word, should it already be there, must stay
+        unsigned long long seen = acquire(la.ready_flag);
+        if ((seen >> 40) != (la.ready_seq & 0xFFFFFFull))
+          (void)__hip_atomic_compare_exchange_strong(la.ready_flag, &seen, ready_word(la.ready_seq, EDM_READY_BELOW, na),
+                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else if (la.rb_dst) {
+    readback_copy_hills<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x - 64, (concurrent && la.early_word) ? NT - 128 : NT - 64);
+  }
+  if (la.rb_dst) {
+    if (concurrent) {
+      __syncthreads();
+      readback_copy_limiter<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x, NT);
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // every wave's stores into the host-mapped region have been acknowledged
+    __syncthreads();
+    // The flag is a RELAXED system-scope store on purpose.  A release at system scope would first write back the
+    // XCD's whole L2 (~35 us measured, the cost this design exists to avoid).  Ordering rests on the hardware
+    // instead: every store into the region above was itself a system-scope (write-through, uncached) store to
+    // host memory; s_waitcnt(0) + the barrier mean each wave has its acknowledgements; PCIe posted writes of one
+    // requester are not reordered, so the flag cannot overtake the data on the way to host memory.  The host
+    // reads the flag (volatile) and then the data behind an acquire fence.  Guarded twice over: the polled word
+    // is checked against byte-identical results of the stream-wait path (EDM_HIP_POLL=0) in
+    // test_polled_completion_equals_stream_wait, and a poll that does not see its word within 2 ms falls back
+    // to hipStreamSynchronize.
+    // (k_pair_step: the pair forces ride in this launch -- their partial energy sums must be in host memory before
+    //  the host is released)
+    if (k1_done) {
+      if (threadIdx.x == 0) wait_counter(k1_done, k1_target);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0 && la.done_flag)
+      __hip_atomic_store(la.done_flag, la.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// `la` (TPH == BLOCK only): the ordered limiter is chained onto the last workgroup to finish
+// (bid: this workgroup's index among the integrals workgroups -- blockIdx.x, except inside k_integrals_gather)
+// returns true (workgroup-uniform) in the workgroup that ran the chained limiter, once its results are out
+template <int DIM, int TPH, bool PERB>
+__device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables &t, const HillList &h,
+                                                    const double *__restrict__ heights, double h_const,
+                                                    double *__restrict__ added, const LimitArgs &la, unsigned bid) {
+  constexpr int NT = (TPH > BLOCK) ? TPH : BLOCK;  // workgroup size: 512 threads per hill for the 3-D stencil
+  __shared__ double s_red[NT / 64];
+  const int lane = threadIdx.x & 63;
+  const int lt = threadIdx.x % TPH;
+  const long long hill = (long long)bid * (NT / TPH) + (threadIdx.x / TPH);
+  // The hill's fields are requested BEFORE the hill count is known (the arrays hold h.nh entries, the launch bound:
+  // an entry beyond the true count is stale and masked below): one memory round trip instead of three dependent
+  // ones (count -> centre node -> the other fields).
+  int c_r[DIM];
+  double hx_r[DIM], ht_r[2 * DIM];
+  double height_r = h_const;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    c_r[d] = INT_MIN;
+    hx_r[d] = 0;
+    ht_r[2 * d] = ht_r[2 * d + 1] = 0;
+  }
+  if (hill < h.nh) {
+#pragma unroll
+    for (int d = 0; d < DIM; d++) {
+      c_r[d] = h.hc[hill * DIM + d];
+      hx_r[d] = h.hx[hill * DIM + d];
+      ht_r[2 * d] = h.ht[hill * 2 * DIM + 2 * d];
+      ht_r[2 * d + 1] = h.ht[hill * 2 * DIM + 2 * d + 1];
+    }
+    if (heights) height_r = heights[hill];
+  }
+  const long long nh_eff = hill_count(h);
+  if (TPH == 64 && hill >= nh_eff) return false;  // (a whole workgroup shares one hill when TPH == BLOCK)
+  const bool live = hill < nh_eff;
+  // chained limiter (a workgroup per hill, launched against a bound on the hill count): only the workgroups that
+  // own a hill take a ticket -- workgroup 0 alone when there is none -- so the last arrival is one of a few hundred
+  // and a single counter (one atomic round trip) does
+  const unsigned ticket_blocks = (unsigned)(nh_eff > 0 ? nh_eff : 1);
+  if (TPH != 64 && la.enabled && bid >= ticket_blocks) return false;
+  TermConst<DIM> tc;
+  term_const<DIM>(g, tc);
+  const double acc_part = hill_stencil_partial<DIM, TPH, PERB>(g, t, tc, c_r, hx_r, ht_r, height_r, live, lt);
+  double acc = acc_part;
   acc = wave_sum(acc);
   if (TPH == 64) {
     if (lane == 0) added[hill] = acc;
@@ -2299,67 +2429,7 @@ __device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables 
       if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 1] = wall_clock64();
       if (!last_block_done(la.ticket, ticket_blocks, bid, ticket_blocks <= 512)) return false;
       if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 2] = wall_clock64();
-      // wave 0 walks the limiter; with a read-back region (la.rb_dst) it stores its outputs to the device region and
-      // to its host-mapped copy alike, while the other waves copy what does not depend on the limiter -- per-hill
-      // bias and positions, by the true hill count -- so nothing is left to read back once the limiter is done.
-      // k_integrals_gather (la.ready_flag): the gather workgroups of the same launch wait for the limiter, so its
-      // outputs go to the device region only (agent scope), the word the gather polls follows as soon as wave 0's
-      // stores are acknowledged -- no host round trip in front of it -- and the copy to the host comes after.
-      const bool concurrent = la.ready_flag != nullptr;
-      const long long mirror = (la.rb_dst && !concurrent) ? (long long)(la.rb_dst - la.rb_src) : 0;
-      const long long nb = h.nh;   // the layout is sized by the launch bound
-      const long long n_true = h.nh_dev ? *h.nh_dev : nb;   // (already on its way for hill_count() above: no new round trip)
-      long long na = n_true;
-      if (na > nb) na = 0;         // (bound exceeded: the limiter reports it, nothing is read)
-      if (threadIdx.x < 64) {
-        long long k_first = 0;
-        int err = 0;
-        limit_wave<true>(h.nh, added, heights, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr,
-                   nullptr, h.nh_dev, mirror, &k_first, &err, h.nh_dev ? n_true : -1);
-        if (concurrent) {
-          // the word carries what every gather workgroup needs first -- the error code and k, the first hill of the
-          // ordered tail -- so that seeing it is all the waiting workgroups have to do when there is no tail
-          __builtin_amdgcn_s_waitcnt(0);
-          if (threadIdx.x == 0) publish(la.ready_flag, ready_word(la.ready_seq, err, k_first));
-          if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 3] = wall_clock64();
-        }
-      } else if (concurrent && la.early_word && threadIdx.x >= NT - 64) {
-        // the last wave, beside the limiter's wave and the two that copy: does the batch stay below the limit
-        // whatever the order of the adds?
-        if (na <= 64 * 64 && la.cum_in >= 0) {
-          double part = 0;
-          for (long long i = threadIdx.x - (NT - 64); i < na; i += 64) part += fabs(acquire(&added[i]));
-          part = wave_sum(part);
-          if (threadIdx.x == NT - 64 && n_true <= nb && (la.cum_in + part) * (1.0 + 1e-9) < la.limit) {
-            // only over the PREVIOUS launch's word: the limiter's own word, should it already be there, must stay
-            unsigned long long seen = acquire(la.ready_flag);
-            if ((seen >> 40) != (la.ready_seq & 0xFFFFFFull))
-              (void)__hip_atomic_compare_exchange_strong(la.ready_flag, &seen, ready_word(la.ready_seq, EDM_READY_BELOW, na),
-                                                         __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-      } else if (la.rb_dst) {
-        readback_copy_hills<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x - 64, (concurrent && la.early_word) ? NT - 128 : NT - 64);
-      }
-      if (la.rb_dst) {
-        if (concurrent) {
-          __syncthreads();
-          readback_copy_limiter<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x, NT);
-        }
-        __builtin_amdgcn_s_waitcnt(0);   // every wave's stores into the host-mapped region have been acknowledged
-        __syncthreads();
-        // The flag is a RELAXED system-scope store on purpose.  A release at system scope would first write back the
-        // XCD's whole L2 (~35 us measured, the cost this design exists to avoid).  Ordering rests on the hardware
-        // instead: every store into the region above was itself a system-scope (write-through, uncached) store to
-        // host memory; s_waitcnt(0) + the barrier mean each wave has its acknowledgements; PCIe posted writes of one
-        // requester are not reordered, so the flag cannot overtake the data on the way to host memory.  The host
-        // reads the flag (volatile) and then the data behind an acquire fence.  Guarded twice over: the polled word
-        // is checked against byte-identical results of the stream-wait path (EDM_HIP_POLL=0) in
-        // test_polled_completion_equals_stream_wait, and a poll that does not see its word within 2 ms falls back
-        // to hipStreamSynchronize.
-        if (threadIdx.x == 0 && la.done_flag)
-          __hip_atomic_store(la.done_flag, la.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+      limiter_stage<DIM, NT>(h, heights, h_const, added, la, bid, -1, nullptr, 0u);
       if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 4] = wall_clock64();
       __syncthreads();
       return true;
@@ -2566,6 +2636,57 @@ __device__ __forceinline__ void gather_post(const Geom &g, double *__restrict__ 
   }
 }
 
+// exclusive scan of the selection workgroups' counts into LDS (s_off[0 .. nsel], s_off[nsel] = total), by the whole
+// workgroup; returns the total.  Every thread takes PERC consecutive counts, requested together.
+// (offsets are kept as 16-bit values, saturated: a total beyond any launch bound -- 2048 -- makes the caller give up
+//  before it looks at them)
+__device__ __forceinline__ int fused_scan_counts(const int *counts, int nsel, unsigned short *s_off, int *s_ws) {
+  constexpr int PERC_MAX = EDM_FS_MAX_SEL / BLOCK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int PERC = (nsel + BLOCK - 1) / BLOCK;
+  const int blk0 = threadIdx.x * PERC;
+  int cj[PERC_MAX];
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < PERC_MAX; j++) {
+    cj[j] = (j < PERC && blk0 + j < nsel) ? acquire(&counts[blk0 + j]) : 0;
+    c += cj[j];
+  }
+  int inc = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) s_ws[wave] = inc;
+  __syncthreads();
+  int off = inc - c, total = 0;
+#pragma unroll
+  for (int w = 0; w < BLOCK / 64; w++) {
+    if (w < wave) off += s_ws[w];
+    total += s_ws[w];
+  }
+#pragma unroll
+  for (int j = 0; j < PERC_MAX; j++) {
+    if (j < PERC && blk0 + j < nsel) s_off[blk0 + j] = (unsigned short)(off < 65535 ? off : 65535);
+    off += cj[j];
+  }
+  if (threadIdx.x == 0) s_off[nsel] = (unsigned short)(total < 65535 ? total : 65535);
+  __syncthreads();
+  return total;
+}
+// record of hill e of the ordered list: last k with s_off[k] <= e (empty workgroups share their successor's offset
+// and are skipped); *blk_out = that selection workgroup
+__device__ __forceinline__ const double *fused_record(const FusedStep &fs, const unsigned short *s_off, int e, int *blk_out = nullptr) {
+  int lo = 0, hi = (int)fs.nsel;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)s_off[mid] <= e) lo = mid; else hi = mid;
+  }
+  if (blk_out) *blk_out = lo;
+  return fs.wgrec + ((size_t)lo * EDM_FS_CAP + (size_t)(e - (int)s_off[lo])) * EDM_FS_REC;
+}
+
 // PARTS (1 or 8; 8 on the 1-D grid only): the tile is BLOCK / PARTS nodes wide and thread (part, node)
 // accumulates every PARTS-th batch of the tile's hill list for its node; the parts are combined in LDS in a
 // fixed order.  A node's serial chain is its number of overlapping hills, and a tile's work lands on ONE CU:
@@ -2582,13 +2703,24 @@ __device__ __forceinline__ constexpr int tile_extent(int d) {
 // depend on the limiter -- are computed and parked in LDS, and only then does the workgroup wait for the limiter's
 // word (ready_flag == ready_seq), fetch k and the tail heights and accumulate.  Hills the limiter deferred (height 0)
 // are skipped at that point instead of at staging.
-template <int DIM, int MODE, int PARTS, bool PERB, bool DEFER = false>
+// FUSED (k_pair_step; implies DEFER): there is no prepared hill list yet when the tile starts -- it waits for the
+// selection workgroups (fs->sel_done), scans their counts and reads the hills' records from their slots, in list order;
+// it decides from the integrals in those records whether the limiter can bind at all (if not, nobody waits for the
+// limiter: base heights throughout); and it writes EVERY node of its tile -- rewritten or not -- to the grid's second
+// buffer rec_out, which becomes the grid once the step is known to have been applied: the K1 workgroups of the same
+// launch read `rec`, which nobody writes, so the tiles wait for none of them.  Boundary corrections are noted in the
+// workgroup's *s_dirty (LDS) instead of the device flag.
+template <int DIM, int MODE, int PARTS, bool PERB, bool DEFER = false, bool FUSED = false>
 __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t, double *__restrict__ rec,
                                                  const HillList &h, const HillHeights &hh, const GatherPlan &plan,
                                                  int use_list, int *__restrict__ dirty_flag, int coherent,
                                                  long long tile, const unsigned long long *ready_flag = nullptr,
-                                                 unsigned long long ready_seq = 0, unsigned long long *trace = nullptr) {
+                                                 unsigned long long ready_seq = 0, unsigned long long *trace = nullptr,
+                                                 const FusedStep *fs = nullptr, const int *sel_counts = nullptr,
+                                                 unsigned short *s_foff = nullptr, int *s_fws = nullptr,
+                                                 double *__restrict__ rec_out = nullptr, int *s_dirty = nullptr) {
   static_assert(!DEFER || (DIM == 1 && MODE == 0), "deferred heights: the 1-D in-place gather only");
+  static_assert(!FUSED || DEFER, "the fused step defers its heights");
   constexpr int R = (DIM == 1) ? 2 : 4;
   constexpr int NODES = BLOCK / PARTS;
   const int tnode = threadIdx.x % NODES;   // this thread's node within the tile
@@ -2620,6 +2752,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
 #pragma unroll
     for (int d = DIM - 1; d > 0; d--) flat = flat * g.n[d - 1] + p[d - 1];
   }
+  const bool in_grid0 = active;   // (before the boundary test below)
   NodeTerms<DIM> nt;
   bool node_interior = true;
   if (active) {
@@ -2634,7 +2767,16 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   // (limiter result and hill count in one round trip: the kernel is a chain of dependent loads)
   long long k_first_tail = hh.k;
   long long nh_eff = h.nh;
-  if (DEFER) {
+  __shared__ double s_fred[BLOCK / 64];
+  if (FUSED) {
+    if (threadIdx.x == 0) wait_counter(fs->sel_done, fs->sel_target);
+    __syncthreads();
+    if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
+    const long long n_true = fused_scan_counts(sel_counts, (int)fs->nsel, s_foff, s_fws);
+    if (n_true > h.nh) return;   // bound exceeded (or a selection workgroup out of slots): the bookkeeper reports it, nothing is applied
+    nh_eff = n_true;
+    k_first_tail = nh_eff;
+  } else if (DEFER) {
     nh_eff = hill_count(h);   // (the selection's count; the limiter's result is read after the wait below)
     k_first_tail = nh_eff;
   } else if (hh.res_dev) {
@@ -2663,9 +2805,9 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   for (int d = 0; d < DIM; d++) vol *= g.dx[d];
 
   double acc[1 + DIM];
-  if (in_place && active && part == 0) {
+  if (in_place && (active || (FUSED && in_grid0)) && part == 0) {
     // in-place: start from the stored record so the adds follow the reference's
-    // sequence V0 + h0*t0 + h1*t1 + ... exactly
+    // sequence V0 + h0*t0 + h1*t1 + ... exactly  (FUSED: also the nodes outside the boundary, which are only copied)
 #pragma unroll
     for (int j = 0; j <= DIM; j++) acc[j] = rec[flat * R + j];
   } else {
@@ -2685,12 +2827,15 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   __shared__ double s_t[PERB ? 1 : BLOCK][2 * DIM];  // (hill-side wall exponentials: none without walls)
   __shared__ double s_h1[BLOCK], s_h2[BLOCK];
   __shared__ int s_wcnt[BLOCK / 64];
-  __shared__ long long s_id[(MODE == 1 || DEFER) ? BLOCK : 1];
+  using id_t = typename std::conditional<FUSED, int, long long>::type;   // (FUSED: LDS is what limits the workgroups per CU)
+  __shared__ id_t s_id[(MODE == 1 || DEFER) ? BLOCK : 1];
   // DEFER: parked stencil terms of the first chunk, NTS per thread (value, derivative, multiplicity | nz << 30)
   constexpr int DEFER_ILP = 4;
-  constexpr int NTS = 8;
+  constexpr int NTS = FUSED ? 4 : 8;   // (a tile meets ~13 of the ~125 hills of a W1 step, 40 where the pairs are dense: 4 per part cover 32)
+  using tm_t = typename std::conditional<FUSED, short, int>::type;
+  constexpr int TM_NZ = FUSED ? 14 : 30;
   __shared__ double s_tv[DEFER ? NTS : 1][DEFER ? BLOCK : 1], s_td[DEFER ? NTS : 1][DEFER ? BLOCK : 1];
-  __shared__ int s_tm[DEFER ? NTS : 1][DEFER ? BLOCK : 1];
+  __shared__ tm_t s_tm[DEFER ? NTS : 1][DEFER ? BLOCK : 1];
   bool waited = !DEFER;   // (block-uniform) the limiter's result is known
   __shared__ double s_wpart[(MODE == 1) ? BLOCK / 64 : 1][(MODE == 1) ? BLOCK : 1];
   __shared__ double s_pacc[(PARTS > 1) ? PARTS - 1 : 1][(PARTS > 1) ? NODES : 1][1 + DIM];
@@ -2711,12 +2856,26 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     int c[DIM];
     double h1 = 0, h2 = 0;
     double hx_r[DIM], ht_r[2 * DIM];
+    double integ_abs = 0;   // FUSED: |integrated bias| of the hills this thread looked at (first chunk: of all its hills)
+    if (FUSED && cur < hend) {
+      const double *rp = fused_record(*fs, s_foff, (int)cur);
+      hx_r[0] = acquire(rp + 0);
+      ht_r[0] = acquire(rp + 1);
+      ht_r[1] = acquire(rp + 2);
+      const double ai = acquire(rp + 4);
+      c[0] = (int)acquire(reinterpret_cast<const long long *>(rp + 5));
+      integ_abs = fabs(ai);
+    }
+    if (FUSED && defer_chunk) {
+      for (long long e = cur + BLOCK; e < nh_eff; e += BLOCK) integ_abs += fabs(acquire(fused_record(*fs, s_foff, (int)e) + 4));
+    }
     if (cur < hend) {
       // 1-D: all of this hill's fields are requested together (one memory round trip; a tile overlaps a
       // good part of the hills).  2-D/3-D: a tile meets a few hills out of hundreds, so only the centre
       // node is fetched for the test and the rest follows for the hills that pass.
 #pragma unroll
       for (int d = 0; d < DIM; d++) {
+        if (FUSED) continue;
         c[d] = h.hc[cur * DIM + d];
         if (DIM == 1) {
           hx_r[d] = h.hx[cur * DIM + d];
@@ -2792,7 +2951,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       }
       s_h1[pos] = h1;
       s_h2[pos] = h2;
-      if (MODE == 1 || DEFER) s_id[pos] = cur;
+      if (MODE == 1 || DEFER) s_id[pos] = (id_t)cur;
     }
     __syncthreads();
     if (DEFER && defer_chunk) {
@@ -2816,16 +2975,30 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
             }
             s_tv[it * ILP + q][threadIdx.x] = v;
             s_td[it * ILP + q][threadIdx.x] = dv[0];
-            s_tm[it * ILP + q][threadIdx.x] = m | (nz ? (1 << 30) : 0);
+            s_tm[it * ILP + q][threadIdx.x] = (tm_t)(m | (nz ? (1 << TM_NZ) : 0));
           }
         }
       }
       // 2. the limiter's word (its workgroups were dispatched ahead of this one and wait for nobody)
-      if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
+      if (trace && threadIdx.x == 0) trace[FUSED ? 2 : 1] = wall_clock64();
       __shared__ unsigned long long s_word;
-      if (threadIdx.x == 0) s_word = wait_for_word(ready_flag, ready_seq, false);
+      if (FUSED) {
+        // ... unless the batch provably stays below the limit whatever the limiter does: the sum of the |integrals|
+        // (every thread holds those of hills tid, tid + BLOCK, ...) against the limit, with the margin of the early word
+        const double part = wave_sum(integ_abs);
+        if (lane == 0) s_fred[wave] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          double sum = 0;
+          for (int w = 0; w < BLOCK / 64; w++) sum += s_fred[w];
+          const bool below = fs->cum_in >= 0 && (fs->cum_in + sum) * (1.0 + 1e-9) < fs->limit;
+          s_word = below ? ready_word(ready_seq, EDM_READY_BELOW, nh_eff) : wait_for_word(ready_flag, ready_seq, true);
+        }
+      } else if (threadIdx.x == 0) {
+        s_word = wait_for_word(ready_flag, ready_seq, false);
+      }
       __syncthreads();
-      if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
+      if (trace && threadIdx.x == 0) trace[FUSED ? 3 : 2] = wall_clock64();
       waited = true;
       const unsigned long long word = s_word;
       const int state = (int)((word >> 32) & 0xFF);
@@ -2864,8 +3037,8 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
             const int mm = s_tm[DEFER ? it_acc * ILP + q : 0][DEFER ? threadIdx.x : 0];
             val[q] = s_tv[DEFER ? it_acc * ILP + q : 0][DEFER ? threadIdx.x : 0];
             dval[q][0] = s_td[DEFER ? it_acc * ILP + q : 0][DEFER ? threadIdx.x : 0];
-            mult[q] = mm & ((1 << 30) - 1);
-            nzq[q] = (mm >> 30) != 0;
+            mult[q] = mm & ((1 << TM_NZ) - 1);
+            nzq[q] = (mm >> TM_NZ) != 0;
           } else if (active && q0 + q < cnt) {
             int m = 1;
 #pragma unroll
@@ -2962,7 +3135,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     __syncthreads();
     if (part > 0) {
       if (any_corr && active) {
-        if (coherent) publish(dirty_flag, 1); else *dirty_flag = 1;
+        if (FUSED) *s_dirty = 1; else if (coherent) publish(dirty_flag, 1); else *dirty_flag = 1;
       }
       return;
     }
@@ -2973,7 +3146,15 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       touched |= (s_ptouch[q][tnode] != 0);
     }
   }
-  if (active && (touched || !in_place)) {
+  if (FUSED) {
+    if (in_grid0) {
+      double *dst = rec_out + flat * R;
+      publish(&dst[0], acc[0]);   // (the boundary duplication of the last tile reads node values)
+#pragma unroll
+      for (int j = 1; j <= DIM; j++) dst[j] = acc[j];
+      if (any_corr && active) *s_dirty = 1;
+    }
+  } else if (active && (touched || !in_place)) {
     double *dst = in_place ? rec + flat * R : plan.partial + ((long long)grp * g.total + flat) * R;
     if (coherent) {
       // the chained boundary duplication (another workgroup) reads node values and the flag
@@ -3022,6 +3203,195 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MOD
   }
   if (MODE == 0 && post.enabled)
     gather_post<DIM, PERB>(g, rec, h, hh, dirty_flag, post, gridDim.x * gridDim.y, blockIdx.x + gridDim.x * blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------
+// k_pair_step: a whole hill-depositing fix edm_pair step as one launch (roles and hand-over: FusedStep, edm_kernels.h)
+// ---------------------------------------------------------------------------
+// selection workgroup: the flags of its SEL_CHUNK samples (the samples' CVs are requested with the uniforms -- one
+// memory round trip for both), then every accepted sample is prepared and integrated right here
+static constexpr int FS_SPT = 16;                  // samples per thread of a k_pair_step selection workgroup
+static constexpr int FS_CHUNK = BLOCK * FS_SPT;   // 4096: half as many selection workgroups as k_select_prep's
+template <bool PERB>
+__device__ __forceinline__ void select_integral_body(const SelectArgs &a, const Geom &g, const Tables &t, const HillList &h,
+                                                     double h_const, const FusedStep &fs, unsigned bid,
+                                                     unsigned long long *trace) {
+  __shared__ int s_w[FS_SPT][BLOCK / 64];
+  __shared__ int s_loc[EDM_FS_CAP];
+  __shared__ double s_px[EDM_FS_CAP];
+  __shared__ double s_part[EDM_FS_CAP][BLOCK / 64];
+  __shared__ double s_prep[EDM_FS_CAP][3];
+  __shared__ int s_pc[EDM_FS_CAP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long base = (long long)bid * FS_CHUNK + threadIdx.x;
+  // every load of the workgroup's rows is requested before the first one is looked at: uniforms, CVs (used by the few
+  // accepted samples only -- asking for all of them costs bandwidth, asking afterwards would cost a round trip) and masks
+  bool fl[FS_SPT];
+  double xs[FS_SPT], uu[FS_SPT];
+  int mk[FS_SPT];
+  unsigned long long bal[FS_SPT];
+  const bool has_mask = a.apply_mask >= 0;
+#pragma unroll
+  for (int j = 0; j < FS_SPT; j++) {
+    const long long i = base + (long long)j * BLOCK;
+    const long long ic = i < a.n ? i : a.n - 1;
+    xs[j] = h.x[ic * h.x_stride];
+    mk[j] = has_mask ? a.mask[ic] : 0;
+  }
+  if (a.ru) {
+#pragma unroll
+    for (int j = 0; j < FS_SPT; j++) {
+      const long long i = base + (long long)j * BLOCK;
+      uu[j] = __builtin_nontemporal_load(&a.ru[i < a.n ? i : a.n - 1]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < FS_SPT; j++) uu[j] = device_uniform(a.rng, base + (long long)j * BLOCK);
+  }
+#pragma unroll
+  for (int j = 0; j < FS_SPT; j++) {
+    const long long i = base + (long long)j * BLOCK;
+    fl[j] = (i < a.n) && (!has_mask || (a.apply_mask & mk[j])) && (!a.use_thr || uu[j] < a.thr);   // sel_flag()
+  }
+#pragma unroll
+  for (int j = 0; j < FS_SPT; j++) {
+    bal[j] = __ballot(fl[j]);
+    if (lane == 0) s_w[j][wave] = __popcll(bal[j]);
+  }
+  __syncthreads();
+  int run = 0;   // accepted samples of the rows walked so far (the same in every thread)
+#pragma unroll
+  for (int j = 0; j < FS_SPT; j++) {
+    int before = 0, row = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) {
+      if (w < wave) before += s_w[j][w];
+      row += s_w[j][w];
+    }
+    if (fl[j]) {
+      const int pos = run + before + __popcll(bal[j] & ((1ull << lane) - 1ull));
+      if (pos < EDM_FS_CAP) {
+        s_loc[pos] = j * BLOCK + (int)threadIdx.x;
+        s_px[pos] = xs[j];
+      }
+    }
+    run += row;
+  }
+  if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
+  if (run > 0) {
+    __syncthreads();
+    // the workgroup's hills one after the other (the stencil walk of each is shared by all 256 threads exactly as in
+    // k_hill_integrals), their sums and the publication of the records side by side afterwards: thread j owns hill j
+    const int ndo = run < EDM_FS_CAP ? run : EDM_FS_CAP;
+    TermConst<1> tc;
+    term_const<1>(g, tc);
+    for (int j = 0; j < ndo; j++) {
+      double x[1] = {s_px[j]};
+      int c[1];
+      double ht[2];
+      hill_prep_compute<1>(g, x, c, ht);
+      double acc = hill_stencil_partial<1, BLOCK, PERB>(g, t, tc, c, x, ht, h_const, true, (int)threadIdx.x);
+      acc = wave_sum(acc);
+      if (lane == 0) s_part[j][wave] = acc;
+      if (threadIdx.x == 0) {
+        s_prep[j][0] = x[0];
+        s_prep[j][1] = ht[0];
+        s_prep[j][2] = ht[1];
+        s_pc[j] = c[0];
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ndo) {
+      const int j = threadIdx.x;
+      double r = 0;
+      for (int w = 0; w < BLOCK / 64; w++) r += s_part[j][w];
+      double *rp = fs.wgrec + ((size_t)bid * EDM_FS_CAP + (size_t)j) * EDM_FS_REC;
+      publish(rp + 0, s_prep[j][0]);
+      publish(rp + 1, s_prep[j][1]);
+      publish(rp + 2, s_prep[j][2]);
+      publish(rp + 3, s_px[j]);
+      publish(rp + 4, r);
+      publish(reinterpret_cast<long long *>(rp + 5), (long long)s_pc[j]);
+      publish(reinterpret_cast<long long *>(rp + 6), (long long)s_loc[j]);
+    }
+    // (more accepted samples than slots: an impossible count makes the whole step fall back, like a bound exceeded)
+    if (threadIdx.x == 0) publish(&a.counts[bid], run > EDM_FS_CAP ? (1 << 20) : run);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) counter_arrive(fs.sel_done, bid);
+  } else if (threadIdx.x == 0) {
+    publish(&a.counts[bid], 0);
+    __builtin_amdgcn_s_waitcnt(0);
+    counter_arrive(fs.sel_done, bid);
+  }
+  if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
+}
+
+// the bookkeeper: as soon as the selection is complete, wave 0 walks the ordered limiter straight off the selection
+// workgroups' records -- its outputs go to the device region and to its host-mapped copy alike -- while the other
+// waves write the ordered list out: canonical per-hill arrays (what every other path of the library leaves behind),
+// and the per-hill bias and positions of the read-back region, device and host copy.  Then the host is released
+// (once the pair forces' energy sums are in host memory) and the CV histogram updated.
+template <bool PERB>
+__device__ __forceinline__ void fused_bookkeeper(const SelectArgs &a, const HillList &h, double h_const,
+                                                 double *__restrict__ added, const LimitArgs &la, const PostArgs &post,
+                                                 const FusedStep &fs, unsigned bid, unsigned long long *trace,
+                                                 unsigned short *s_off, int *s_ws) {
+  if (threadIdx.x == 0) wait_counter(fs.sel_done, fs.sel_target);
+  __syncthreads();
+  if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
+  const long long n_true = fused_scan_counts(a.counts, (int)fs.nsel, s_off, s_ws);
+  const long long nb = h.nh;
+  const long long na = n_true <= nb ? n_true : 0;
+  const long long mirror = la.rb_dst ? (long long)(la.rb_dst - la.rb_src) : 0;
+  if (threadIdx.x < 64) {
+    long long k_first = 0;
+    int err = 0;
+    limit_wave<true>(nb, added, nullptr, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr, nullptr,
+                     h.nh_dev, mirror, &k_first, &err, n_true, &fs, s_off);
+    __builtin_amdgcn_s_waitcnt(0);
+    // (only a tile that could not rule the limiter out waits for this word)
+    if (threadIdx.x == 0) publish(la.ready_flag, ready_word(la.ready_seq, err, k_first));
+    if (trace && threadIdx.x == 0) trace[3] = wall_clock64();
+  } else {
+    auto put = [mirror](double *p, double v) {
+      publish(p, v);
+      if (mirror)
+        __hip_atomic_store(reinterpret_cast<double *>(reinterpret_cast<char *>(p) + mirror), v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    for (long long e = threadIdx.x - 64; e < na; e += BLOCK - 64) {
+      int blk;
+      const double *rp = fused_record(fs, s_off, (int)e, &blk);
+      const double hx = acquire(rp + 0), t1 = acquire(rp + 1), t3 = acquire(rp + 2), x0 = acquire(rp + 3), ai = acquire(rp + 4);
+      const long long c = acquire(reinterpret_cast<const long long *>(rp + 5));
+      const long long loc = acquire(reinterpret_cast<const long long *>(rp + 6));
+      publish(&h.hx[e], hx);
+      publish(&h.ht[2 * e], t1);
+      publish(&h.ht[2 * e + 1], t3);
+      publish(&h.hc[e], (int)c);
+      put(&h.hx0[e], x0);      // (both live in the read-back region: apply_hills' layout)
+      put(&added[e], ai);
+      a.sel[e] = (long long)blk * FS_CHUNK + loc;
+    }
+    if (threadIdx.x == 64) {
+      *a.count_host = n_true;
+      publish(a.count_dev, n_true);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+  __syncthreads();
+  if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
+  if (la.rb_dst) {
+    // release of the host: see limiter_stage (relaxed system-scope flag behind acknowledged system-scope stores)
+    if (threadIdx.x == 0) wait_counter(fs.k1_done, fs.k1_target);
+    __syncthreads();
+    if (threadIdx.x == 0 && la.done_flag)
+      __hip_atomic_store(la.done_flag, la.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (trace && threadIdx.x == 0) trace[4] = wall_clock64();
+  if (post.enabled && !la.res->error)
+    hist_batch<1>(post.hg, post.hist, h.nh, h.hx0, la.res, post.flags, post.flush_mode, threadIdx.x, BLOCK);
 }
 
 // One launch for the two halves of a short 1-D hill step that do not depend on each other: workgroups
@@ -3278,6 +3648,119 @@ hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, 
   else
     hipLaunchKernelGGL((k_integrals_gather<true>), dim3(nb_int + nb_tiles), dim3(BLOCK), 0, s, g, t, rec, h, heights, h_const,
                        added, la, hh, plan, dirty_flag, post, nb_int);
+  return hipGetLastError();
+}
+
+// the whole step (see FusedStep): selection + integrals | pair forces | bookkeeper | gather tiles
+template <bool PERB>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_pair_step(SelectArgs a, Geom g, Tables t, double *__restrict__ rec, HillList h,
+                                                     double h_const, double *__restrict__ added, LimitArgs la,
+                                                     HillHeights hh, GatherPlan plan, int *__restrict__ dirty_flag,
+                                                     PostArgs post, PairForcesArgs f, FusedStep fs,
+                                                     double *__restrict__ rec_next) {
+  extern __shared__ double2 lds_all[];
+  __shared__ unsigned short s_foff[EDM_FS_MAX_SEL + 1];
+  __shared__ int s_fws[BLOCK / 64];
+  unsigned long long *trace = la.trace ? la.trace + (size_t)blockIdx.x * 8 : nullptr;
+  if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
+  const unsigned b = blockIdx.x;
+  if (b < fs.nsel) {
+    select_integral_body<PERB>(a, g, t, h, h_const, fs, b, trace);
+  } else if (b < fs.nsel + fs.nk1) {
+    const unsigned kb = b - fs.nsel;
+    pair_forces_fast_body<false, BLOCK>(g, f.rec, f.n, f.r, f.force, f.block_energy, 0LL, 0, f.inv_dx, lds_all, kb, fs.nk1);
+    // (block_sum's barriers: every thread of the workgroup has read its grid records; thread 0's partial energy sum
+    //  must have reached host memory before the bookkeeper releases the host)
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_s_waitcnt(0);
+      counter_arrive(fs.k1_done, kb);
+    }
+  } else if (b == fs.nsel + fs.nk1) {
+    fused_bookkeeper<PERB>(a, h, h_const, added, la, post, fs, b, trace, s_foff, s_fws);
+  } else {
+    const unsigned tile = b - (fs.nsel + fs.nk1 + 1), ntile = gridDim.x - (fs.nsel + fs.nk1 + 1);
+    __shared__ int s_dirty, s_last;
+    if (threadIdx.x == 0) s_dirty = 0;   // (barriers inside the body lie between this and any thread's write)
+    hill_gather_body<1, 0, 8, PERB, true, true>(g, t, rec, h, hh, plan, 0, dirty_flag, post.enabled, tile, la.ready_flag,
+                                                la.ready_seq, trace, &fs, a.counts, s_foff, s_fws, rec_next, &s_dirty);
+    if (trace && threadIdx.x == 0) trace[6] = wall_clock64();
+    // last tile: boundary duplication (gaussian_grid.h:571-630) iff some tile of the step met a non-zero boundary
+    // correction.  The ticket carries that bit: every tile adds 1, and 0x10000 if it saw one, in ONE atomic round
+    // trip -- the last arrival learns both that it is the last and whether anybody was dirty.
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned mine = s_dirty ? 0x10001u : 1u;
+      const unsigned t0 = (unsigned)__hip_atomic_fetch_add(post.ticket, (int)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int last = 0;
+      if ((t0 & 0xFFFFu) == ntile - 1) {
+        __hip_atomic_store(post.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = ((t0 + mine) >> 16) ? 2 : 1;
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!PERB && s_last == 2 && threadIdx.x < 64) duplicate_boundary_wave(g, rec_next, post.dp, threadIdx.x);
+  }
+  if (trace && threadIdx.x == 0) trace[7] = wall_clock64();
+}
+
+bool pair_step_fusable(const Geom &g, long long n_pairs, const SelectArgs &a, const HillList &h, const double *heights,
+                       const GatherPlan &plan) {
+  if (!pair_forces_select_fusable(g, n_pairs, a.n) || !integrals_gather_fusable(g, h.nh, plan)) return false;
+  if (a.pack || heights || !h.x || h.pl_x || h.sel != a.sel || !h.hx0 || !h.nh_dev) return false;
+  // a selection workgroup hands on at most EDM_FS_CAP accepted samples (and works its hills off one after the other):
+  // only steps that expect a few per workgroup -- the stochastic regime, ~0.5 for W1 -- run as one launch
+  if (!a.use_thr || !(a.thr * (double)(a.n < FS_CHUNK ? a.n : FS_CHUNK) <= 4.0)) return false;
+  const long long nsel = (a.n + FS_CHUNK - 1) / FS_CHUNK;
+  return nsel <= EDM_FS_MAX_SEL;
+}
+hipError_t launch_pair_step(const SelectArgs &a, const Geom &g, const Tables &t, double *rec, const HillList &h,
+                            double h_const, double *added, const LimitArgs &chain, const HillHeights &hh,
+                            const GatherPlan &plan, int *dirty_flag, const PostSpec *post_chain, const double *pair_r,
+                            long long n_pairs, double *pair_force, double *pair_scratch, FusedStep fs, hipStream_t s,
+                            hipEvent_t ev0, hipEvent_t ev1, int *k1_blocks_out, int *sel_blocks_out, double *rec_next) {
+  if (!pair_step_fusable(g, n_pairs, a, h, nullptr, plan) || !chain.ready_flag || !hh.res_dev || !post_chain || !rec_next ||
+      rec_next == rec)
+    return hipErrorInvalidValue;
+  LimitArgs la = chain;
+  la.enabled = 1;
+  la.early_word = 0;   // (the tiles make that test themselves)
+  PostArgs post;
+  memset(&post, 0, sizeof(post));
+  post.enabled = 1;
+  post.ticket = post_chain->ticket;
+  post.dp = make_dup_plan(g);
+  post.hg = *post_chain->hist_geom;
+  post.hist = post_chain->hist;
+  post.flags = post_chain->flags;
+  post.flush_mode = post_chain->flush_mode;
+  post.skip_hist = 1;   // (the bookkeeper updates the histogram)
+  PairForcesArgs f;
+  f.rec = rec;
+  f.n = n_pairs;
+  f.r = pair_r;
+  f.force = pair_force;
+  f.block_energy = pair_scratch;
+  f.inv_dx = 1.0 / g.dx[0];
+  f.nsel = (unsigned)((a.n + FS_CHUNK - 1) / FS_CHUNK);
+  f.nk1 = (unsigned)pair_short_blocks(n_pairs);
+  fs.nsel = f.nsel;
+  fs.nk1 = f.nk1;
+  fs.sel_target += f.nsel;   // (the caller passes the sums before this launch)
+  fs.k1_target += f.nk1;
+  fs.limit = chain.limit;
+  fs.cum_in = chain.cum_in;
+  const unsigned nb_tiles = (unsigned)((g.n[0] + BLOCK / 8 - 1) / (BLOCK / 8));
+  const dim3 grid(fs.nsel + fs.nk1 + 1 + nb_tiles);
+  if (!g.bper[0])
+    EDM_LAUNCH_TIMED((k_pair_step<false>), grid, dim3(BLOCK), 256, s, ev0, ev1, a, g, t, rec, h, h_const, added, la, hh, plan,
+                     dirty_flag, post, f, fs, rec_next);
+  else
+    EDM_LAUNCH_TIMED((k_pair_step<true>), grid, dim3(BLOCK), 256, s, ev0, ev1, a, g, t, rec, h, h_const, added, la, hh, plan,
+                     dirty_flag, post, f, fs, rec_next);
+  if (k1_blocks_out) *k1_blocks_out = (int)f.nk1;
+  if (sel_blocks_out) *sel_blocks_out = (int)f.nsel;
   return hipGetLastError();
 }
 
@@ -3846,7 +4329,9 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            const LimitTail &tail, LimitResult *res, long long nchunks,
                                            const double *chunk_sum, const double *chunk_max,
                                            const long long *nh_dev, long long mirror, long long *k_out, int *err_out,
-                                           long long nh_known) {
+                                           long long nh_known, const FusedStep *fsrc, const unsigned short *fs_off) {
+  // (fsrc, k_pair_step: the per-hill bias is read from the selection workgroups' records, hill i found through the
+  //  scanned counts in LDS -- no ordered array has been written yet)
   // (k_out / err_out: the first tail hill and the error code, for a caller that hands them on in registers;
   //  nh_known >= 0: the caller has already read *nh_dev)
   // `mirror` != 0: the result and the tail's flags / h2 / added2 live in the packed read-back region, whose copy in
@@ -3933,7 +4418,11 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
   int stop = (int)ntail;
   bool stopped = false;
   // (the next slab's hills are requested before the current slab is walked: one memory round trip per slab hidden)
-  auto load_a = [&](long long i) { return (i < nh) ? (COHERENT ? acquire(&added[i]) : added[i]) : 0.0; };
+  auto load_a = [&](long long i) {
+    if (!(i < nh)) return 0.0;
+    if (fsrc) return acquire(fused_record(*fsrc, fs_off, (int)i) + 4);
+    return COHERENT ? acquire(&added[i]) : added[i];
+  };
   auto load_h = [&](long long i) { return (i < nh) ? (heights ? heights[i] : h_const) : 0.0; };
   double a_next = load_a(k + lane), h_next = load_h(k + lane);
   for (long long base = 0; base < ntail; base += 64) {
