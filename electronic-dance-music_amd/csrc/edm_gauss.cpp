@@ -231,6 +231,7 @@ edm::Tables edm_hip_gauss::tables() const {
     t.denom[d] = tab[d][0];
     t.dderiv[d] = tab[d][1];
   }
+  t.node1d = node_tab;
   return t;
 }
 
@@ -721,6 +722,7 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
   if (g->d_ready) (void)hipFree(g->d_ready);
   if (g->fs_rec) (void)hipFree(g->fs_rec);
   if (g->rec_alt) (void)hipFree(g->rec_alt);
+  if (g->node_tab) (void)hipFree(g->node_tab);
   if (g->fs_counters) (void)hipFree(g->fs_counters);
   if (g->prof_ev) {
     for (int i = 0; i < 2 * edm_hip_gauss::PROF_RING; i++) (void)hipEventDestroy(g->prof_ev[i]);
@@ -733,6 +735,20 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
 }
 
 // gaussian_grid.h:378-435.  libm erf/exp on the host: table bits equal the reference's.
+// Tables::node1d of a 1-D grid with walls, for the current geometry and boundary (dropped otherwise)
+static int node_table_rebuild(edm_hip_gauss *g) {
+  if (g->node_tab) (void)hipFree(g->node_tab);
+  g->node_tab = nullptr;
+  const Geom &q = g->g;
+  if (q.dim != 1 || q.bper[0] || !g->tab[0][0] || !g->tab[0][1]) return EDM_HIP_OK;
+  double *nt = nullptr;
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nt), sizeof(double) * 4 * (size_t)q.n[0]));
+  EDM_HIP_TRY(launch_build_node_table(q, g->tables(), nt, g->stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  g->node_tab = nt;
+  return EDM_HIP_OK;
+}
+
 int edm_hip_gauss_set_boundary(edm_hip_gauss *g, const double *min, const double *max, const int *periodic) {
   g->tiles_per_hill = 0;  // (cached bound: recomputed for the new geometry on demand)
   Geom &q = g->g;
@@ -768,7 +784,7 @@ int edm_hip_gauss_set_boundary(edm_hip_gauss *g, const double *min, const double
                             hipMemcpyHostToDevice));
     }
   }
-  return EDM_HIP_OK;
+  return node_table_rebuild(g);
 }
 
 int edm_hip_gauss_geometry(const edm_hip_gauss *g, edm_hip_geometry *out) {
@@ -1442,10 +1458,10 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       if (one_launch) {
         // the whole step in one launch: selection (+ per-hill integrals), pair forces, bookkeeper, gather tiles
         const SelectArgs &sa = *spec.sel_chain;
-        const size_t nsel = (size_t)((sa.n + 4095) / 4096);
+        const size_t nsel = (size_t)pair_step_sel_blocks(sa.n);
         if (!g->fs_counters) {
-          EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->fs_counters), sizeof(unsigned) * 32 * 2 * EDM_FS_SUB));
-          EDM_HIP_TRY(hipMemset(g->fs_counters, 0, sizeof(unsigned) * 32 * 2 * EDM_FS_SUB));
+          EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->fs_counters), sizeof(unsigned) * 32 * 3 * EDM_FS_SUB));
+          EDM_HIP_TRY(hipMemset(g->fs_counters, 0, sizeof(unsigned) * 32 * 3 * EDM_FS_SUB));
           g->fs_sel_total = g->fs_k1_total = 0;
         }
         if (g->fs_rec_wgs < nsel) {
@@ -1464,6 +1480,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         fsd.wgrec = g->fs_rec;
         fsd.sel_done = g->fs_counters;
         fsd.k1_done = g->fs_counters + 32 * EDM_FS_SUB;
+        fsd.int_done = g->fs_counters + 2 * 32 * EDM_FS_SUB;
+        fsd.int_target = g->fs_sel_total;   // (one arrival per selection workgroup on each of the two)
         int nk1 = 0;
         // (the targets are known only once the launcher has sized the grid: it fills nsel / nk1; the sums are advanced here)
         fsd.sel_target = g->fs_sel_total;   // (sums so far: the launcher adds this launch's workgroup counts)
@@ -1475,7 +1493,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
           la.trace = nullptr;
         }
         if (tracing && g->ready_seq == 150) {
-          trace_wgs_fused = nsel + 2 * 256 + 8 + (size_t)((q.n[0] + 31) / 32);
+          trace_wgs_fused = nsel + 4 * 256 + 8 + (size_t)((q.n[0] + 31) / 32);
           EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_trace), trace_wgs_fused * 64));
           EDM_HIP_TRY(hipMemset(d_trace, 0, trace_wgs_fused * 64));
           la.trace = d_trace;
@@ -1501,13 +1519,23 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         unsigned long long t0 = ~0ull;
         for (size_t w = 0; w < trace_wgs_fused; w++)
           if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
-        const size_t nsel = (size_t)((spec.sel_chain->n + 4095) / 4096), nk1 = (size_t)spec.forces->nblk;
+        const size_t nsel = (size_t)pair_step_sel_blocks(spec.sel_chain->n), nk1 = (size_t)spec.forces->nblk;
         const size_t lo[4] = {0, nsel, nsel + nk1, nsel + nk1 + 1}, hi[4] = {nsel, nsel + nk1, nsel + nk1 + 1, trace_wgs_fused};
         const char *role[4] = {"select   ", "forces   ", "bookkeep ", "tiles    "};
-        const char *names[4][8] = {{"start", "flags done", "published", "", "", "", "", "end"},
+        const char *names[4][8] = {{"start", "flags done", "published", "hills walked", "", "", "", "end"},
                                    {"start", "", "", "", "", "", "", "end"},
                                    {"start", "selection seen", "list written", "word published", "host released", "", "", "end"},
                                    {"start", "selection seen", "terms parked", "heights known", "forces seen", "", "body end", "end"}};
+        for (int kk = 1; kk <= 8; kk++) {   // selection workgroups by the number of samples they accepted
+          std::vector<double> v;
+          for (size_t w = 0; w < nsel; w++)
+            if (tr[w * 8 + 5] == (unsigned long long)kk && tr[w * 8 + 3]) v.push_back((double)(tr[w * 8 + 3] - tr[w * 8 + 1]) * 0.01);
+          if (v.empty()) continue;
+          std::sort(v.begin(), v.end());
+          fprintf(stderr, "[edm trace] select: %d hill(s) in the workgroup: n=%3zu  stencil walks took min %5.2f med %5.2f max %5.2f us\n", kk,
+                  v.size(), v.front(), v[v.size() / 2], v.back());
+        }
+        for (size_t w = 0; w < nsel; w++) tr[w * 8 + 5] = 0;
         for (int r = 0; r < 4; r++)
           for (int k = 0; k < 8; k++) {
             std::vector<double> v;
@@ -1987,8 +2015,14 @@ int edm_hip_gauss_reread(edm_hip_gauss *g, const char *filename) {
     g->rec = nullptr;
     EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->rec), sizeof(double) * (size_t)q.total * q.rec));
   }
+  if (g->rec_alt && q.total != g->g.total) {   // (the second buffer of the one-launch steps has the old size)
+    (void)hipFree(g->rec_alt);
+    g->rec_alt = nullptr;
+  }
   g->g = q;
   g->tiles_per_hill = 0;
+  int rcn = node_table_rebuild(g);
+  if (rcn) return rcn;
   return records_upload(g->g, g->rec, g->stream, gf.values.data(), gf.derivs.data());
 }
 int edm_hip_gauss_set_lookup_replica(edm_hip_gauss *g, int mode) {

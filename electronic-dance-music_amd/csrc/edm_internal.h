@@ -98,6 +98,7 @@ struct edm_hip_gauss {
   edm::Geom g;
   double *rec = nullptr;                 // device node records
   double *tab[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // denom, dderiv per dim
+  double *node_tab = nullptr;            // 1-D grid with walls: Tables::node1d (rebuilt with the boundary / the geometry)
   hipStream_t stream = nullptr;
   double *scratch = nullptr;             // lookup partial sums
   double *d_scalars = nullptr;           // small device result slots

@@ -13,7 +13,13 @@ namespace edm {
 struct Tables {
   const double *denom[3];
   const double *dderiv[3];
+  // 1-D grid with walls, optional: per node (t2, t4, 1 / bc_denom, inside ? 1 : 0) -- the node-only factors of a
+  // stencil term's VALUE (gaussian_grid.h:311,:313,:318), computed once by launch_build_node_table with the very
+  // code the kernels would run per stencil point (node_terms), so a walk that reads them yields the same bits
+  const double *node1d;
 };
+// out: 4 doubles per node of the 1-D grid (t.node1d is not read)
+hipError_t launch_build_node_table(const Geom &g, const Tables &t, double *out, hipStream_t s);
 
 // ---- lookup path (K1/K2/K8) ------------------------------------------------
 enum LookupMode {
@@ -277,12 +283,13 @@ hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, 
 #define EDM_FS_SUB 16        // sub-counters per set, 32 ints apart
 struct FusedStep {
   double *wgrec;             // [nsel][EDM_FS_CAP][EDM_FS_REC]
-  unsigned *sel_done, *k1_done;
-  unsigned sel_target, k1_target;   // sums the counters reach when this launch's workgroups are done (the launcher adds
+  unsigned *sel_done, *int_done, *k1_done;   // selection: accepted samples out | their integrals out; pair forces done
+  unsigned sel_target, int_target, k1_target;   // sums the counters reach when this launch's workgroups are done (the launcher adds
                                     // its workgroup counts to the sums the caller passes)
   unsigned nsel, nk1;
   double limit, cum_in;      // (the limiter's, for the tiles' own "cannot bind" test)
 };
+long long pair_step_sel_blocks(long long n_samples);   // selection workgroups of a k_pair_step launch
 bool pair_step_fusable(const Geom &g, long long n_pairs, const SelectArgs &a, const HillList &h, const double *heights,
                        const GatherPlan &plan);
 // h.nh is the launch bound; chain.ready_flag / ready_seq as for launch_integrals_gather; post_chain must be given

@@ -2042,6 +2042,25 @@ __device__ __forceinline__ void node_terms(const Geom &g, const Tables &t, const
   }
 }
 
+__global__ void __launch_bounds__(BLOCK) k_build_node_table(Geom g, Tables t, double *__restrict__ out) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= g.n[0]) return;
+  const int p[1] = {i};
+  NodeTerms<1> nt;
+  node_terms<1, false>(g, t, p, nt);
+  out[4 * (size_t)i + 0] = nt.t2[0];
+  out[4 * (size_t)i + 1] = nt.t4[0];
+  out[4 * (size_t)i + 2] = nt.inside ? nt.inv_dprod[0] : -nt.inv_dprod[0];   // (1 / bc_denom > 0: the sign says inside / outside)
+  out[4 * (size_t)i + 3] = 0.0;
+}
+hipError_t launch_build_node_table(const Geom &g, const Tables &t, double *out, hipStream_t s) {
+  if (g.dim != 1 || g.bper[0]) return hipErrorInvalidValue;
+  Tables tt = t;
+  tt.node1d = nullptr;
+  hipLaunchKernelGGL(k_build_node_table, dim3((unsigned)((g.n[0] + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, g, tt, out);
+  return hipGetLastError();
+}
+
 // One (node, hill) term: val multiplies the height for V, dval[d] for dV/ds_d.  Returns false when
 // the node is outside the hill's support (dp2 >= 8).  Same formulas as gaussian_grid.h:284-355 with
 // every division replaced by a multiplication with a node- or launch-constant reciprocal (values
@@ -2237,6 +2256,65 @@ __device__ __forceinline__ double hill_stencil_partial(const Geom &g, const Tabl
 #pragma unroll
     for (int d = 0; d < DIM; d++)
       if (g.periodic[d] && 2 * (g.msize[d] + 1) > g.n[d]) ball_ok = false;
+    if (DIM == 1 && !PERB && t.node1d) {
+      // 1-D grid with walls: the node-only factors of every stencil point come from the table built by
+      // launch_build_node_table (the same node_terms code ran there: same bits).  The walk is a serial instruction
+      // stream per thread and the length of that stream is what a hill step waits for: the per-point divisions, wall
+      // blends and the dependent read of the boundary table are gone, and the table rows of a trip's ILP points are
+      // requested TOGETHER, before the first one is used (three phases, no load inside a branch).
+      const double2 *tab2 = reinterpret_cast<const double2 *>(t.node1d);
+      const int m0 = g.msize[0], n0 = g.n[0];
+      const bool per0 = g.periodic[0] != 0;
+      for (unsigned s0 = (unsigned)lt; s0 < utotal; s0 += ILP * TPH) {
+        double term[ILP];
+        int pw[ILP];
+        bool ok[ILP];
+        double2 qa[ILP];
+        double qz[ILP];
+#pragma unroll
+        for (int u = 0; u < ILP; u++) {
+          const unsigned s = s0 + (unsigned)(u * TPH);
+          bool v = s < utotal;
+          int idx = (int)s - m0 + c[0];
+          const double e = ((g.min[0] + idx * g.dx[0]) - hx[0]) * tc.inv_sigma[0];
+          const double dp2_est = e * e;
+          if (idx >= n0) {
+            if (per0) idx %= n0; else v = false;
+          }
+          if (idx < 0) {
+            if (per0) idx += n0; else v = false;
+            if (idx < 0) v = false;
+          }
+          if (ball_ok && dp2_est > 8.0 * (1.0 + 1e-6)) v = false;
+          ok[u] = v;
+          pw[u] = v ? idx : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < ILP; u++) {
+          qa[u] = tab2[2 * (size_t)pw[u]];
+          qz[u] = t.node1d[4 * (size_t)pw[u] + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < ILP; u++) {
+          term[u] = 0;
+          if (!ok[u] || !(qz[u] > 0.0)) continue;
+          NodeTerms<DIM> nt;
+          nt.xx[0] = g.min[0] + g.dx[0] * (size_t)pw[u];
+          nt.t2[0] = qa[u].x;
+          nt.t4[0] = qa[u].y;
+          nt.inv_dprod[0] = qz[u];
+          nt.t6[0] = nt.t7[0] = nt.dden[0] = nt.dprod[0] = nt.inv_dprod2[0] = 0;   // (derivative only: not used here)
+          nt.inside = true;
+          double val, dval[DIM];
+          bool nz;
+          if (!pair_term<DIM, PERB>(g, tc, nt, hx, ht, val, dval, nz)) continue;
+          term[u] = height * val * vol;
+        }
+#pragma unroll
+        for (int u = 0; u < ILP; u++) acc += term[u];
+      }
+      return acc;
+    }
     for (unsigned s0 = (unsigned)lt; s0 < utotal; s0 += ILP * TPH) {
       double term[ILP];
 #pragma unroll
@@ -2858,16 +2936,11 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     double hx_r[DIM], ht_r[2 * DIM];
     double integ_abs = 0;   // FUSED: |integrated bias| of the hills this thread looked at (first chunk: of all its hills)
     if (FUSED && cur < hend) {
-      const double *rp = fused_record(*fs, s_foff, (int)cur);
-      hx_r[0] = acquire(rp + 0);
-      ht_r[0] = acquire(rp + 1);
-      ht_r[1] = acquire(rp + 2);
-      const double ai = acquire(rp + 4);
-      c[0] = (int)acquire(reinterpret_cast<const long long *>(rp + 5));
-      integ_abs = fabs(ai);
-    }
-    if (FUSED && defer_chunk) {
-      for (long long e = cur + BLOCK; e < nh_eff; e += BLOCK) integ_abs += fabs(acquire(fused_record(*fs, s_foff, (int)e) + 4));
+      // (the selection workgroup that accepted the sample published its position and went on to integrate the hill:
+      //  the prepared fields are recomputed here from the position -- hill_prep_compute, the same bits)
+      double xq[1] = {acquire(fused_record(*fs, s_foff, (int)cur) + 3)};
+      hill_prep_compute<1>(g, xq, c, ht_r);
+      hx_r[0] = xq[0];
     }
     if (cur < hend) {
       // 1-D: all of this hill's fields are requested together (one memory round trip; a tile overlaps a
@@ -2984,7 +3057,11 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       __shared__ unsigned long long s_word;
       if (FUSED) {
         // ... unless the batch provably stays below the limit whatever the limiter does: the sum of the |integrals|
-        // (every thread holds those of hills tid, tid + BLOCK, ...) against the limit, with the margin of the early word
+        // -- published by the selection workgroups while this tile computed its terms -- against the limit, with the
+        // margin of the early word
+        if (threadIdx.x == 0) wait_counter(fs->int_done, fs->int_target);
+        __syncthreads();
+        for (long long e = threadIdx.x; e < nh_eff; e += BLOCK) integ_abs += fabs(acquire(fused_record(*fs, s_foff, (int)e) + 4));
         const double part = wave_sum(integ_abs);
         if (lane == 0) s_fred[wave] = part;
         __syncthreads();
@@ -3210,8 +3287,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MOD
 // ---------------------------------------------------------------------------
 // selection workgroup: the flags of its SEL_CHUNK samples (the samples' CVs are requested with the uniforms -- one
 // memory round trip for both), then every accepted sample is prepared and integrated right here
-static constexpr int FS_SPT = 16;                  // samples per thread of a k_pair_step selection workgroup
-static constexpr int FS_CHUNK = BLOCK * FS_SPT;   // 4096: half as many selection workgroups as k_select_prep's
+static constexpr int FS_SPT = 4;                   // samples per thread of a k_pair_step selection workgroup
+static constexpr int FS_CHUNK = BLOCK * FS_SPT;   // samples per selection workgroup
 template <bool PERB>
 __device__ __forceinline__ void select_integral_body(const SelectArgs &a, const Geom &g, const Tables &t, const HillList &h,
                                                      double h_const, const FusedStep &fs, unsigned bid,
@@ -3224,10 +3301,11 @@ __device__ __forceinline__ void select_integral_body(const SelectArgs &a, const 
   __shared__ int s_pc[EDM_FS_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long base = (long long)bid * FS_CHUNK + threadIdx.x;
-  // every load of the workgroup's rows is requested before the first one is looked at: uniforms, CVs (used by the few
-  // accepted samples only -- asking for all of them costs bandwidth, asking afterwards would cost a round trip) and masks
+  // every load of the workgroup's rows is requested before the first one is looked at (uniforms, masks); the CVs of
+  // the few accepted samples follow afterwards -- one more round trip for the workgroups that found one, against 8 MB
+  // more for all of them to pull through HBM beside the pair forces' 16 MB
   bool fl[FS_SPT];
-  double xs[FS_SPT], uu[FS_SPT];
+  double uu[FS_SPT];
   int mk[FS_SPT];
   unsigned long long bal[FS_SPT];
   const bool has_mask = a.apply_mask >= 0;
@@ -3235,7 +3313,6 @@ __device__ __forceinline__ void select_integral_body(const SelectArgs &a, const 
   for (int j = 0; j < FS_SPT; j++) {
     const long long i = base + (long long)j * BLOCK;
     const long long ic = i < a.n ? i : a.n - 1;
-    xs[j] = h.x[ic * h.x_stride];
     mk[j] = has_mask ? a.mask[ic] : 0;
   }
   if (a.ru) {
@@ -3272,7 +3349,7 @@ __device__ __forceinline__ void select_integral_body(const SelectArgs &a, const 
       const int pos = run + before + __popcll(bal[j] & ((1ull << lane) - 1ull));
       if (pos < EDM_FS_CAP) {
         s_loc[pos] = j * BLOCK + (int)threadIdx.x;
-        s_px[pos] = xs[j];
+        s_px[pos] = h.x[(base + (long long)j * BLOCK) * h.x_stride];
       }
     }
     run += row;
@@ -3280,9 +3357,21 @@ __device__ __forceinline__ void select_integral_body(const SelectArgs &a, const 
   if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
   if (run > 0) {
     __syncthreads();
-    // the workgroup's hills one after the other (the stencil walk of each is shared by all 256 threads exactly as in
-    // k_hill_integrals), their sums and the publication of the records side by side afterwards: thread j owns hill j
     const int ndo = run < EDM_FS_CAP ? run : EDM_FS_CAP;
+    // stage A: WHICH samples were accepted and where they sit -- all the gather tiles need to start on their stencil
+    // terms -- goes out at once; the tiles are under way while this workgroup integrates its hills (stage B)
+    if ((int)threadIdx.x < ndo) {
+      double *rp = fs.wgrec + ((size_t)bid * EDM_FS_CAP + (size_t)threadIdx.x) * EDM_FS_REC;
+      publish(rp + 3, s_px[threadIdx.x]);
+      publish(reinterpret_cast<long long *>(rp + 6), (long long)s_loc[threadIdx.x]);
+    }
+    // (more accepted samples than slots: an impossible count makes the whole step fall back, like a bound exceeded)
+    if (threadIdx.x == 0) publish(&a.counts[bid], run > EDM_FS_CAP ? (1 << 20) : run);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) counter_arrive(fs.sel_done, bid);
+    // stage B: the workgroup's hills one after the other (the stencil walk of each is shared by all 256 threads exactly
+    // as in k_hill_integrals), their sums and the publication of the records side by side afterwards: thread j owns hill j
     TermConst<1> tc;
     term_const<1>(g, tc);
     for (int j = 0; j < ndo; j++) {
@@ -3300,6 +3389,10 @@ __device__ __forceinline__ void select_integral_body(const SelectArgs &a, const 
         s_pc[j] = c[0];
       }
     }
+    if (trace && threadIdx.x == 0) {
+      trace[3] = wall_clock64();
+      trace[5] = (unsigned long long)run;
+    }
     __syncthreads();
     if ((int)threadIdx.x < ndo) {
       const int j = threadIdx.x;
@@ -3309,20 +3402,17 @@ __device__ __forceinline__ void select_integral_body(const SelectArgs &a, const 
       publish(rp + 0, s_prep[j][0]);
       publish(rp + 1, s_prep[j][1]);
       publish(rp + 2, s_prep[j][2]);
-      publish(rp + 3, s_px[j]);
       publish(rp + 4, r);
       publish(reinterpret_cast<long long *>(rp + 5), (long long)s_pc[j]);
-      publish(reinterpret_cast<long long *>(rp + 6), (long long)s_loc[j]);
     }
-    // (more accepted samples than slots: an impossible count makes the whole step fall back, like a bound exceeded)
-    if (threadIdx.x == 0) publish(&a.counts[bid], run > EDM_FS_CAP ? (1 << 20) : run);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (threadIdx.x == 0) counter_arrive(fs.sel_done, bid);
+    if (threadIdx.x == 0) counter_arrive(fs.int_done, bid);
   } else if (threadIdx.x == 0) {
     publish(&a.counts[bid], 0);
     __builtin_amdgcn_s_waitcnt(0);
     counter_arrive(fs.sel_done, bid);
+    counter_arrive(fs.int_done, bid);
   }
   if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
 }
@@ -3344,6 +3434,8 @@ __device__ __forceinline__ void fused_bookkeeper(const SelectArgs &a, const Hill
   const long long nb = h.nh;
   const long long na = n_true <= nb ? n_true : 0;
   const long long mirror = la.rb_dst ? (long long)(la.rb_dst - la.rb_src) : 0;
+  if (threadIdx.x == 0) wait_counter(fs.int_done, fs.int_target);   // (the hills' integrals and prepared fields)
+  __syncthreads();
   if (threadIdx.x < 64) {
     long long k_first = 0;
     int err = 0;
@@ -3664,6 +3756,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
   unsigned long long *trace = la.trace ? la.trace + (size_t)blockIdx.x * 8 : nullptr;
   if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
   const unsigned b = blockIdx.x;
+  // the hill chain is what the step waits for; the pair forces only have to be done by the time the host is released:
+  // every role but K1 issues ahead of K1's waves where they share a SIMD
+  if (b < fs.nsel || b >= fs.nsel + fs.nk1) __builtin_amdgcn_s_setprio(3);
   if (b < fs.nsel) {
     select_integral_body<PERB>(a, g, t, h, h_const, fs, b, trace);
   } else if (b < fs.nsel + fs.nk1) {
@@ -3705,6 +3800,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
   if (trace && threadIdx.x == 0) trace[7] = wall_clock64();
 }
 
+long long pair_step_sel_blocks(long long n_samples) { return (n_samples + FS_CHUNK - 1) / FS_CHUNK; }
 bool pair_step_fusable(const Geom &g, long long n_pairs, const SelectArgs &a, const HillList &h, const double *heights,
                        const GatherPlan &plan) {
   if (!pair_forces_select_fusable(g, n_pairs, a.n) || !integrals_gather_fusable(g, h.nh, plan)) return false;
@@ -3748,6 +3844,7 @@ hipError_t launch_pair_step(const SelectArgs &a, const Geom &g, const Tables &t,
   fs.nsel = f.nsel;
   fs.nk1 = f.nk1;
   fs.sel_target += f.nsel;   // (the caller passes the sums before this launch)
+  fs.int_target += f.nsel;
   fs.k1_target += f.nk1;
   fs.limit = chain.limit;
   fs.cum_in = chain.cum_in;
