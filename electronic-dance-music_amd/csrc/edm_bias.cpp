@@ -84,7 +84,7 @@ struct edm_hip_bias {
   DevBuf<int> vs_mask;
   bool force_sync = false;      // redo of a deferred step whose launch bound proved too small
   int debug_force_sync = 0;     // tests: never defer the count (every step takes the synchronous path)
-  int debug_no_one_launch = 0;  // tests: a fix edm_pair hill step keeps its two launches (forces + selection | integrals + gather)
+  int debug_pair_step_mode = -1;  // tests: how a short fix edm_pair hill step is queued (see apply_hills); -1 = the library's choice
   long long bound_redos = 0;    // steps redone because the accepted count exceeded the deferred launch bound
   PendingForces pending;        // pair forces of a fused step waiting for the launch of the step's selection
   // staging of the *_host entry points: device copies of the caller's host arrays, a second stream for the copy
@@ -807,7 +807,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     else {
       spec.sel_chain = &sel_args;
       spec.forces = &b->pending;
-      spec.allow_one_launch = !b->debug_no_one_launch;
+      spec.pair_step_mode = b->debug_pair_step_mode;
     }
   }
   int rc = apply_hills(b->bias, spec, &oc, false);
@@ -1299,7 +1299,7 @@ int edm_hip_bias_set(edm_hip_bias *b, const char *name, double value) {
   S("total_volume", b->total_volume, double)
   S("debug_virtual_ranks", b->debug_virtual_ranks, int)
   S("debug_force_sync", b->debug_force_sync, int)
-  S("debug_no_one_launch", b->debug_no_one_launch, int)
+  S("debug_pair_step_mode", b->debug_pair_step_mode, int)
 #undef S
   set_error(std::string("unknown or read-only EDMBias member ") + name);
   return EDM_HIP_ERR_ARG;

@@ -126,7 +126,7 @@ struct edm_hip_gauss {
   bool rec_handed_out = false;           // edm_hip_gauss_device_buffer gave `rec` to the caller: the buffers must not change places
   size_t fs_rec_wgs = 0;
   unsigned *fs_counters = nullptr;       // 2 * EDM_FS_SUB sub-counters, 32 ints apart
-  unsigned fs_sel_total = 0, fs_k1_total = 0;
+  unsigned fs_sel_total = 0, fs_k1_total = 0, fs_int_total = 0;
   long long fused_steps = 0;             // steps that ran as one launch (telemetry / tests)
   double ht_ref_us = 0;                  // development aid (EDM_HIP_TRACE): host clock at the entry of the step being traced
   // lookup replica of a 2-D / 3-D grid with a periodic boundary (see lookup_one / launch_build_faces): g.total
@@ -191,7 +191,8 @@ struct ApplySpec {
   // with a deferred count: selection chained in front of the hill preparation (one launch for both)
   const SelectArgs *sel_chain = nullptr;
   PendingForces *forces = nullptr;   // launched together with sel_chain where possible
-  bool allow_one_launch = true;      // ... and, for a short 1-D step, with everything else of the step (k_pair_step)
+  int pair_step_mode = -1;           // ... and, for a short 1-D step, with everything else of the step (k_pair_step): see apply_hills;
+                                     // -1 = the library's choice
   // multi-GPU packed exchange: the hill list is unpacked from the gathered packets (replaces preparation)
   const UnpackArgs *unpack_chain = nullptr;
   // sharded application of a dense batch on a replicated grid (multi-GPU): this rank gathers only its own

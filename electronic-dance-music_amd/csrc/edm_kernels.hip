@@ -3370,6 +3370,10 @@ __device__ __forceinline__ void select_integral_body(const SelectArgs &a, const 
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (threadIdx.x == 0) counter_arrive(fs.sel_done, bid);
+    if (fs.phase == 1) {   // (front launch of a split step: the integrator workgroups of the back launch take it from here)
+      if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
+      return;
+    }
     // stage B: the workgroup's hills one after the other (the stencil walk of each is shared by all 256 threads exactly
     // as in k_hill_integrals), their sums and the publication of the records side by side afterwards: thread j owns hill j
     TermConst<1> tc;
@@ -3412,7 +3416,47 @@ __device__ __forceinline__ void select_integral_body(const SelectArgs &a, const 
     publish(&a.counts[bid], 0);
     __builtin_amdgcn_s_waitcnt(0);
     counter_arrive(fs.sel_done, bid);
-    counter_arrive(fs.int_done, bid);
+    if (fs.phase != 1) counter_arrive(fs.int_done, bid);
+  }
+  if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
+}
+
+// integrator workgroup i of the back launch of a split step: the integrated bias (and the prepared fields) of hill i
+// of the ordered list -- a workgroup per hill, the walk of k_hill_integrals -- into the hill's record
+template <bool PERB>
+__device__ __forceinline__ void fused_integrator(const SelectArgs &a, const Geom &g, const Tables &t, const HillList &h,
+                                                 double h_const, const FusedStep &fs, unsigned i, unsigned long long *trace,
+                                                 unsigned short *s_off, int *s_ws) {
+  __shared__ double s_red[BLOCK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) wait_counter(fs.sel_done, fs.sel_target);   // (the front launch: complete before this one began)
+  __syncthreads();
+  const long long n_true = fused_scan_counts(a.counts, (int)fs.nsel, s_off, s_ws);
+  if ((long long)i >= n_true || n_true > h.nh) {
+    if (threadIdx.x == 0) counter_arrive(fs.int_done, i);
+    return;
+  }
+  double *rp = const_cast<double *>(fused_record(fs, s_off, (int)i));
+  double x[1] = {acquire(rp + 3)};
+  int c[1];
+  double ht[2];
+  hill_prep_compute<1>(g, x, c, ht);
+  TermConst<1> tc;
+  term_const<1>(g, tc);
+  double acc = hill_stencil_partial<1, BLOCK, PERB>(g, t, tc, c, x, ht, h_const, true, (int)threadIdx.x);
+  acc = wave_sum(acc);
+  if (lane == 0) s_red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = 0;
+    for (int w = 0; w < BLOCK / 64; w++) r += s_red[w];
+    publish(rp + 0, x[0]);
+    publish(rp + 1, ht[0]);
+    publish(rp + 2, ht[1]);
+    publish(rp + 4, r);
+    publish(reinterpret_cast<long long *>(rp + 5), (long long)c[0]);
+    __builtin_amdgcn_s_waitcnt(0);
+    counter_arrive(fs.int_done, i);
   }
   if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
 }
@@ -3755,14 +3799,18 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
   __shared__ int s_fws[BLOCK / 64];
   unsigned long long *trace = la.trace ? la.trace + (size_t)blockIdx.x * 8 : nullptr;
   if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
+  // roles of this launch, in workgroup order: selection | pair forces | integrators | bookkeeper | tiles
+  // (phase 0: the whole step -- no integrators, the selection workgroups integrate their own hills; phase 1, the front
+  //  launch of a split step: selection + pair forces; phase 2, its back launch: integrators + bookkeeper + tiles)
+  const unsigned n_sel = fs.phase == 2 ? 0u : fs.nsel, n_k1 = fs.phase == 2 ? 0u : fs.nk1, n_int = fs.phase == 2 ? fs.n_int : 0u;
   const unsigned b = blockIdx.x;
   // the hill chain is what the step waits for; the pair forces only have to be done by the time the host is released:
   // every role but K1 issues ahead of K1's waves where they share a SIMD
-  if (b < fs.nsel || b >= fs.nsel + fs.nk1) __builtin_amdgcn_s_setprio(3);
-  if (b < fs.nsel) {
+  if (b < n_sel || b >= n_sel + n_k1) __builtin_amdgcn_s_setprio(3);
+  if (b < n_sel) {
     select_integral_body<PERB>(a, g, t, h, h_const, fs, b, trace);
-  } else if (b < fs.nsel + fs.nk1) {
-    const unsigned kb = b - fs.nsel;
+  } else if (b < n_sel + n_k1) {
+    const unsigned kb = b - n_sel;
     pair_forces_fast_body<false, BLOCK>(g, f.rec, f.n, f.r, f.force, f.block_energy, 0LL, 0, f.inv_dx, lds_all, kb, fs.nk1);
     // (block_sum's barriers: every thread of the workgroup has read its grid records; thread 0's partial energy sum
     //  must have reached host memory before the bookkeeper releases the host)
@@ -3770,10 +3818,12 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
       __builtin_amdgcn_s_waitcnt(0);
       counter_arrive(fs.k1_done, kb);
     }
-  } else if (b == fs.nsel + fs.nk1) {
+  } else if (b < n_sel + n_k1 + n_int) {
+    fused_integrator<PERB>(a, g, t, h, h_const, fs, b - (n_sel + n_k1), trace, s_foff, s_fws);
+  } else if (b == n_sel + n_k1 + n_int) {
     fused_bookkeeper<PERB>(a, h, h_const, added, la, post, fs, b, trace, s_foff, s_fws);
   } else {
-    const unsigned tile = b - (fs.nsel + fs.nk1 + 1), ntile = gridDim.x - (fs.nsel + fs.nk1 + 1);
+    const unsigned tile = b - (n_sel + n_k1 + n_int + 1), ntile = gridDim.x - (n_sel + n_k1 + n_int + 1);
     __shared__ int s_dirty, s_last;
     if (threadIdx.x == 0) s_dirty = 0;   // (barriers inside the body lie between this and any thread's write)
     hill_gather_body<1, 0, 8, PERB, true, true>(g, t, rec, h, hh, plan, 0, dirty_flag, post.enabled, tile, la.ready_flag,
@@ -3815,7 +3865,8 @@ hipError_t launch_pair_step(const SelectArgs &a, const Geom &g, const Tables &t,
                             double h_const, double *added, const LimitArgs &chain, const HillHeights &hh,
                             const GatherPlan &plan, int *dirty_flag, const PostSpec *post_chain, const double *pair_r,
                             long long n_pairs, double *pair_force, double *pair_scratch, FusedStep fs, hipStream_t s,
-                            hipEvent_t ev0, hipEvent_t ev1, int *k1_blocks_out, int *sel_blocks_out, double *rec_next) {
+                            hipEvent_t ev0, hipEvent_t ev1, int *k1_blocks_out, int *sel_blocks_out, double *rec_next,
+                            int phase) {
   if (!pair_step_fusable(g, n_pairs, a, h, nullptr, plan) || !chain.ready_flag || !hh.res_dev || !post_chain || !rec_next ||
       rec_next == rec)
     return hipErrorInvalidValue;
@@ -3843,13 +3894,18 @@ hipError_t launch_pair_step(const SelectArgs &a, const Geom &g, const Tables &t,
   f.nk1 = (unsigned)pair_short_blocks(n_pairs);
   fs.nsel = f.nsel;
   fs.nk1 = f.nk1;
-  fs.sel_target += f.nsel;   // (the caller passes the sums before this launch)
-  fs.int_target += f.nsel;
+  fs.phase = phase;
+  fs.n_int = (unsigned)h.nh;   // (back launch of a split step: a workgroup per hill of the launch bound)
+  // the caller passes the sums the counters stand at BEFORE the step's first launch (phase 0 or 1); every launch is told
+  // the sums that mean "complete": the front launch's workgroups arrive on sel_done / k1_done, the integrators of a
+  // back launch -- or the selection workgroups of a whole-step launch -- on int_done
+  fs.sel_target += f.nsel;
   fs.k1_target += f.nk1;
+  fs.int_target += (phase == 2) ? fs.n_int : f.nsel;
   fs.limit = chain.limit;
   fs.cum_in = chain.cum_in;
   const unsigned nb_tiles = (unsigned)((g.n[0] + BLOCK / 8 - 1) / (BLOCK / 8));
-  const dim3 grid(fs.nsel + fs.nk1 + 1 + nb_tiles);
+  const dim3 grid(phase == 1 ? fs.nsel + fs.nk1 : phase == 2 ? fs.n_int + 1 + nb_tiles : fs.nsel + fs.nk1 + 1 + nb_tiles);
   if (!g.bper[0])
     EDM_LAUNCH_TIMED((k_pair_step<false>), grid, dim3(BLOCK), 256, s, ev0, ev1, a, g, t, rec, h, h_const, added, la, hh, plan,
                      dirty_flag, post, f, fs, rec_next);

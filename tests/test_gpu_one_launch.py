@@ -1,6 +1,7 @@
-"""A hill-depositing fix edm_pair step as ONE launch (k_pair_step: selection with per-hill integrals | pair forces |
-bookkeeper | gather tiles) against the same step as two launches (k_pair_forces_select, k_integrals_gather): every
-result bit for bit -- energies, forces, grid, gradient, histogram, controller state, HILLS log.  The reference loop
+"""A hill-depositing fix edm_pair step through k_pair_step -- as ONE launch (selection with per-hill integrals | pair
+forces | bookkeeper | gather tiles) and split in two at the point where the accepted samples are known (selection + pair
+forces | a workgroup per hill, bookkeeper, gather tiles) -- against the same step as round 2 queued it
+(k_pair_forces_select, then k_integrals_gather): every result bit for bit -- energies, forces, grid, gradient, histogram, controller state, HILLS log.  The reference loop
 both replace is fix_edm_pair.cpp:174-246 over edm_bias.cpp:401-583."""
 import numpy as np
 import pytest
@@ -38,11 +39,11 @@ CASES = {
 }
 
 
-def run(tag, case, workdir, one_launch):
+def run(tag, case, workdir, mode):
     cfg = str(workdir / (tag + ".edm"))
     open(cfg, "w").write(BASE + case["cfg"] + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
     b = H.Bias(cfg)
-    b.set("debug_no_one_launch", 0 if one_launch else 1)
+    b.set("debug_pair_step_mode", mode)   # 0: forces+selection | integrals+gather; 1: one launch; 2: k_pair_step split in two
     b.setup(1.0, 1.0)
     b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
     n = case["n"]
@@ -68,11 +69,12 @@ def run(tag, case, workdir, one_launch):
     return out
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("name", list(CASES))
-def test_one_launch_equals_two_launches(name, workdir):
+def test_one_launch_equals_two_launches(name, mode, workdir):
     case = CASES[name]
-    one = run("one", case, workdir, True)
-    two = run("two", case, workdir, False)
+    one = run("one", case, workdir, mode)
+    two = run("two", case, workdir, 0)
     # (a step that finds the overflow buffer still filled after its flush adds no new hills: edm_bias.cpp:534-535)
     want = 1 if name == "limiter_binds" else case["steps"] - 1
     assert one["fused"] >= want and two["fused"] == 0, (one["fused"], two["fused"])
@@ -88,7 +90,8 @@ def test_one_launch_equals_two_launches(name, workdir):
         assert one["redos"] >= 1 and two["redos"] == 0
 
 
-def test_one_launch_against_oracle(workdir, oracle_lib):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_one_launch_against_oracle(mode, workdir, oracle_lib):
     """The one-launch step against the oracle executing the reference's per-pair loop (pre_add_hill, update_force per
     pair, add_hill per sample, post_add_hill)."""
     text = BASE + "hill_density 50\nbias_per_step 0.3\nbias_spacing 0.001\nbias_sigma 0.05\n"
@@ -97,6 +100,7 @@ def test_one_launch_against_oracle(workdir, oracle_lib):
         cfgs[tag] = str(workdir / (tag + ".edm"))
         open(cfgs[tag], "w").write(text + "hills_filename %s/H_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
     b = H.Bias(cfgs["gpu"])
+    b.set("debug_pair_step_mode", mode)
     ob = B.Bias(oracle_lib, cfgs["ora"])
     for x in (b, ob):
         x.setup(1.0, 1.0)
