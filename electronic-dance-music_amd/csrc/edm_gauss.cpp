@@ -1318,13 +1318,13 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
   bool chain_post = false;
   bool gather_done = false;   // the gather rode in the integrals' launch (launch_integrals_gather)
-  // how a short fix edm_pair hill step is queued: 0 = k_pair_forces_select, then k_integrals_gather (round 2's way);
-  // 1 = everything in one k_pair_step launch; 2 = k_pair_step split at the point where the accepted samples are known
-  // (front: selection + pair forces; back: a workgroup per hill integrates, bookkeeper, tiles).  EDM_HIP_PAIR_STEP_MODE
-  // in the environment overrides the built-in choice, spec.pair_step_mode (tests) both.
-  static const int mode_env = getenv("EDM_HIP_PAIR_STEP_MODE") ? atoi(getenv("EDM_HIP_PAIR_STEP_MODE")) : 2;
+  // how a short fix edm_pair hill step is queued: 0 = k_pair_forces_select, then k_integrals_gather -- the default: on
+  // the MI355X the two ways take the same time, and this one keeps the pair forces in a launch
+  // of their own size; 1 = everything in ONE k_pair_step launch.  EDM_HIP_PAIR_STEP_MODE in the environment overrides
+  // the built-in choice, spec.pair_step_mode (tests) both.
+  static const int mode_env = getenv("EDM_HIP_PAIR_STEP_MODE") ? atoi(getenv("EDM_HIP_PAIR_STEP_MODE")) : 0;
   const int pair_step_mode = spec.pair_step_mode >= 0 ? spec.pair_step_mode : mode_env;
-  const bool one_launch = pair_step_mode != 0 && chain_limit && spec.sel_chain && spec.forces && spec.forces->active && small &&
+  const bool one_launch = pair_step_mode == 1 && chain_limit && spec.sel_chain && spec.forces && spec.forces->active && small &&
                           rb_bytes + 128 <= g->h_stage_bytes && fused_post && !sharded && !g->rec_handed_out &&
                           pair_step_fusable(q, spec.forces->n, *spec.sel_chain, hl, spec.d_h, plan);
   if (!one_launch) {
@@ -1497,27 +1497,16 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
           d_trace = nullptr;
           la.trace = nullptr;
         }
-        const bool split = pair_step_mode == 2;   // front launch: selection + forces; back launch: integrators + bookkeeper + tiles
         if (tracing && g->ready_seq == 150) {
-          trace_wgs_fused = (split ? (size_t)nh : nsel + 4 * 256) + 8 + (size_t)((q.n[0] + 31) / 32);
+          trace_wgs_fused = nsel + 4 * 256 + 8 + (size_t)((q.n[0] + 31) / 32);
           EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_trace), trace_wgs_fused * 64));
           EDM_HIP_TRY(hipMemset(d_trace, 0, trace_wgs_fused * 64));
           la.trace = d_trace;
         }
         pf->active = false;
-        if (split) {
-          LimitArgs la_front = la;
-          la_front.trace = nullptr;   // (the stamps are taken in the back launch)
-          EDM_HIP_TRY(launch_pair_step(sa, q, tabs, g->rec, hl, spec.h_const, p_added, la_front, hh, plan, g->d_dirty, &ps, pf->d_r,
-                                       pf->n, pf->d_force, g->d_partials, fsd, s, e0, e1, &nk1, &nsel_launched, g->rec_alt, 1));
-          EDM_HIP_TRY(launch_pair_step(sa, q, tabs, g->rec, hl, spec.h_const, p_added, la, hh, plan, g->d_dirty, &ps, pf->d_r, pf->n,
-                                       pf->d_force, g->d_partials, fsd, s, nullptr, nullptr, &nk1, &nsel_launched, g->rec_alt, 2));
-          g->fs_int_total += (unsigned)nh;
-        } else {
-          EDM_HIP_TRY(launch_pair_step(sa, q, tabs, g->rec, hl, spec.h_const, p_added, la, hh, plan, g->d_dirty, &ps, pf->d_r, pf->n,
-                                       pf->d_force, g->d_partials, fsd, s, e0, e1, &nk1, &nsel_launched, g->rec_alt, 0));
-          g->fs_int_total += (unsigned)nsel_launched;
-        }
+        EDM_HIP_TRY(launch_pair_step(sa, q, tabs, g->rec, hl, spec.h_const, p_added, la, hh, plan, g->d_dirty, &ps, pf->d_r, pf->n,
+                                     pf->d_force, g->d_partials, fsd, s, e0, e1, &nk1, &nsel_launched, g->rec_alt));
+        g->fs_int_total += (unsigned)nsel_launched;
         pf->nblk = nk1;
         g->fs_sel_total += (unsigned)nsel_launched;
         g->fs_k1_total += (unsigned)nk1;
@@ -1536,13 +1525,11 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         unsigned long long t0 = ~0ull;
         for (size_t w = 0; w < trace_wgs_fused; w++)
           if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
-        const bool split_t = pair_step_mode == 2;
-        const size_t nsel = split_t ? 0 : (size_t)pair_step_sel_blocks(spec.sel_chain->n);
-        const size_t nk1 = split_t ? (size_t)nh : (size_t)spec.forces->nblk;   // (split: the second group are the integrators)
+        const size_t nsel = (size_t)pair_step_sel_blocks(spec.sel_chain->n), nk1 = (size_t)spec.forces->nblk;
         const size_t lo[4] = {0, nsel, nsel + nk1, nsel + nk1 + 1}, hi[4] = {nsel, nsel + nk1, nsel + nk1 + 1, trace_wgs_fused};
-        const char *role[4] = {"select   ", split_t ? "integrate" : "forces   ", "bookkeep ", "tiles    "};
+        const char *role[4] = {"select   ", "forces   ", "bookkeep ", "tiles    "};
         const char *names[4][8] = {{"start", "flags done", "published", "hills walked", "", "", "", "end"},
-                                   {"start", "", "published", "", "", "", "", "end"},
+                                   {"start", "", "", "", "", "", "", "end"},
                                    {"start", "selection seen", "list written", "word published", "host released", "", "", "end"},
                                    {"start", "selection seen", "terms parked", "heights known", "forces seen", "", "body end", "end"}};
         for (int kk = 1; kk <= 8; kk++) {   // selection workgroups by the number of samples they accepted

@@ -287,8 +287,6 @@ struct FusedStep {
   unsigned sel_target, int_target, k1_target;   // sums the counters reach when this launch's workgroups are done (the launcher adds
                                     // its workgroup counts to the sums the caller passes)
   unsigned nsel, nk1;
-  int phase;                 // 0: the whole step in this launch; 1 / 2: front (selection + forces) / back launch of a split step
-  unsigned n_int;            // phase 2: integrator workgroups (one per hill of the launch bound)
   double limit, cum_in;      // (the limiter's, for the tiles' own "cannot bind" test)
 };
 long long pair_step_sel_blocks(long long n_samples);   // selection workgroups of a k_pair_step launch
@@ -299,8 +297,7 @@ hipError_t launch_pair_step(const SelectArgs &a, const Geom &g, const Tables &t,
                             double h_const, double *added, const LimitArgs &chain, const HillHeights &hh,
                             const GatherPlan &plan, int *dirty_flag, const PostSpec *post_chain, const double *pair_r,
                             long long n_pairs, double *pair_force, double *pair_scratch, FusedStep fs, hipStream_t s,
-                            hipEvent_t ev0, hipEvent_t ev1, int *k1_blocks_out, int *sel_blocks_out, double *rec_next,
-                            int phase);
+                            hipEvent_t ev0, hipEvent_t ev1, int *k1_blocks_out, int *sel_blocks_out, double *rec_next);
 
 // pieces of launch_hill_gather_correct_and_apply for the sharded multi-GPU application: the correction pass
 // alone (writes partial buffer [plan.groups], zeroed first) and dst[i] += sum of `groups` partial buffers

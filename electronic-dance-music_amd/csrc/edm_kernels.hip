@@ -1736,9 +1736,30 @@ __device__ __forceinline__ void select_prep_body(const SelectArgs &a, const Geom
     bool fl[SEL_PER_THREAD];
     unsigned long long bal[SEL_PER_THREAD];
     bool any = false;
+    // sel_flag() of the thread's eight samples with every load requested before the first one is looked at (as a
+    // loop over sel_flag the loads sat behind each other's compare: eight dependent round trips instead of one)
+    double uu[SEL_PER_THREAD];
+    int mk[SEL_PER_THREAD];
+    const bool has_mask = a.apply_mask >= 0;
 #pragma unroll
     for (int j = 0; j < SEL_PER_THREAD; j++) {
-      fl[j] = sel_flag(base + (long long)j * BLOCK, a.n, a.ru, a.thr, a.use_thr, a.mask, a.apply_mask, a.rng);
+      const long long i = base + (long long)j * BLOCK;
+      mk[j] = has_mask ? a.mask[i < a.n ? i : a.n - 1] : 0;
+    }
+    if (a.ru) {
+#pragma unroll
+      for (int j = 0; j < SEL_PER_THREAD; j++) {
+        const long long i = base + (long long)j * BLOCK;
+        uu[j] = a.ru[i < a.n ? i : a.n - 1];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SEL_PER_THREAD; j++) uu[j] = device_uniform(a.rng, base + (long long)j * BLOCK);
+    }
+#pragma unroll
+    for (int j = 0; j < SEL_PER_THREAD; j++) {
+      const long long i = base + (long long)j * BLOCK;
+      fl[j] = (i < a.n) && (!has_mask || (a.apply_mask & mk[j])) && (!a.use_thr || uu[j] < a.thr);
       any |= fl[j];
     }
 #pragma unroll
@@ -2681,6 +2702,9 @@ struct PostArgs {
   char *rb_dst;
   long long rb_bytes;
 };
+template <bool PERB>
+__device__ __forceinline__ void tile_ticket_duplicate(const Geom &g, double *__restrict__ rec, const PostArgs &post,
+                                                      unsigned ntile, const int *s_dirty, int *s_last);
 
 // boundary duplication (K6) and the histogram updates (K7) by the last gather workgroup to finish
 // (a few hundred workgroups that finish spread over microseconds: one counter, one atomic round trip -- the
@@ -3212,7 +3236,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     __syncthreads();
     if (part > 0) {
       if (any_corr && active) {
-        if (FUSED) *s_dirty = 1; else if (coherent) publish(dirty_flag, 1); else *dirty_flag = 1;
+        if (s_dirty) *s_dirty = 1; else if (coherent) publish(dirty_flag, 1); else *dirty_flag = 1;
       }
       return;
     }
@@ -3238,7 +3262,9 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       publish(&dst[0], acc[0]);
 #pragma unroll
       for (int j = 1; j <= DIM; j++) dst[j] = acc[j];
-      if (any_corr) publish(dirty_flag, 1);
+      if (any_corr) {
+        if (s_dirty) *s_dirty = 1; else publish(dirty_flag, 1);
+      }
     } else {
 #pragma unroll
       for (int j = 0; j <= DIM; j++) dst[j] = acc[j];
@@ -3370,10 +3396,6 @@ __device__ __forceinline__ void select_integral_body(const SelectArgs &a, const 
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (threadIdx.x == 0) counter_arrive(fs.sel_done, bid);
-    if (fs.phase == 1) {   // (front launch of a split step: the integrator workgroups of the back launch take it from here)
-      if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
-      return;
-    }
     // stage B: the workgroup's hills one after the other (the stencil walk of each is shared by all 256 threads exactly
     // as in k_hill_integrals), their sums and the publication of the records side by side afterwards: thread j owns hill j
     TermConst<1> tc;
@@ -3416,47 +3438,7 @@ __device__ __forceinline__ void select_integral_body(const SelectArgs &a, const 
     publish(&a.counts[bid], 0);
     __builtin_amdgcn_s_waitcnt(0);
     counter_arrive(fs.sel_done, bid);
-    if (fs.phase != 1) counter_arrive(fs.int_done, bid);
-  }
-  if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
-}
-
-// integrator workgroup i of the back launch of a split step: the integrated bias (and the prepared fields) of hill i
-// of the ordered list -- a workgroup per hill, the walk of k_hill_integrals -- into the hill's record
-template <bool PERB>
-__device__ __forceinline__ void fused_integrator(const SelectArgs &a, const Geom &g, const Tables &t, const HillList &h,
-                                                 double h_const, const FusedStep &fs, unsigned i, unsigned long long *trace,
-                                                 unsigned short *s_off, int *s_ws) {
-  __shared__ double s_red[BLOCK / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) wait_counter(fs.sel_done, fs.sel_target);   // (the front launch: complete before this one began)
-  __syncthreads();
-  const long long n_true = fused_scan_counts(a.counts, (int)fs.nsel, s_off, s_ws);
-  if ((long long)i >= n_true || n_true > h.nh) {
-    if (threadIdx.x == 0) counter_arrive(fs.int_done, i);
-    return;
-  }
-  double *rp = const_cast<double *>(fused_record(fs, s_off, (int)i));
-  double x[1] = {acquire(rp + 3)};
-  int c[1];
-  double ht[2];
-  hill_prep_compute<1>(g, x, c, ht);
-  TermConst<1> tc;
-  term_const<1>(g, tc);
-  double acc = hill_stencil_partial<1, BLOCK, PERB>(g, t, tc, c, x, ht, h_const, true, (int)threadIdx.x);
-  acc = wave_sum(acc);
-  if (lane == 0) s_red[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double r = 0;
-    for (int w = 0; w < BLOCK / 64; w++) r += s_red[w];
-    publish(rp + 0, x[0]);
-    publish(rp + 1, ht[0]);
-    publish(rp + 2, ht[1]);
-    publish(rp + 4, r);
-    publish(reinterpret_cast<long long *>(rp + 5), (long long)c[0]);
-    __builtin_amdgcn_s_waitcnt(0);
-    counter_arrive(fs.int_done, i);
+    counter_arrive(fs.int_done, bid);
   }
   if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
 }
@@ -3556,10 +3538,21 @@ __global__ void __launch_bounds__(BLOCK) k_integrals_gather(Geom g, Tables t, do
     return;
   }
   const unsigned tile = blockIdx.x - nb_int, ntile = gridDim.x - nb_int;
+  // (chained bookkeeping that is only the boundary duplication: boundary corrections are noted in LDS and travel in
+  //  the ticket, see tile_ticket_duplicate)
+  __shared__ int s_dirty, s_last;
+  const bool ticket_dirty = post.enabled && post.skip_hist && !post.rb_dst && ntile < 0xFFFFu;
+  if (threadIdx.x == 0) s_dirty = 0;
   hill_gather_body<1, 0, 8, PERB, true>(g, t, rec, h, hh, plan, 0, dirty_flag, post.enabled, tile, la.ready_flag, la.ready_seq,
-                                        la.trace ? la.trace + (size_t)blockIdx.x * 8 : nullptr);
+                                        la.trace ? la.trace + (size_t)blockIdx.x * 8 : nullptr, nullptr, nullptr, nullptr, nullptr,
+                                        nullptr, ticket_dirty ? &s_dirty : nullptr);
   EDM_STAMP(6);
   if (!post.enabled) return;
+  if (ticket_dirty) {
+    tile_ticket_duplicate<PERB>(g, rec, post, ntile, &s_dirty, &s_last);
+    EDM_STAMP(7);
+    return;
+  }
   // (the bookkeeping reads the limiter's result: a workgroup whose tile met no hill has not waited for it yet)
   __syncthreads();
   if (threadIdx.x == 0) (void)wait_for_word(la.ready_flag, la.ready_seq);
@@ -3787,6 +3780,29 @@ hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, 
   return hipGetLastError();
 }
 
+// Tail of a 1-D gather tile whose launch chains the boundary duplication (gaussian_grid.h:571-630, due iff some tile of
+// the batch met a non-zero boundary correction).  The ticket carries that bit: every tile adds 1, and 0x10000 if it
+// saw one (*s_dirty, LDS), in ONE atomic round trip -- the last arrival learns both that it is the last and whether
+// anybody was dirty (a separate flag word cost the last tile a second dependent round trip).
+template <bool PERB>
+__device__ __forceinline__ void tile_ticket_duplicate(const Geom &g, double *__restrict__ rec, const PostArgs &post,
+                                                      unsigned ntile, const int *s_dirty, int *s_last) {
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned mine = *s_dirty ? 0x10001u : 1u;
+    const unsigned t0 = (unsigned)__hip_atomic_fetch_add(post.ticket, (int)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int last = 0;
+    if ((t0 & 0xFFFFu) == ntile - 1) {
+      __hip_atomic_store(post.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = ((t0 + mine) >> 16) ? 2 : 1;
+    }
+    *s_last = last;
+  }
+  __syncthreads();
+  if (!PERB && *s_last == 2 && threadIdx.x < 64) duplicate_boundary_wave(g, rec, post.dp, threadIdx.x);
+}
+
 // the whole step (see FusedStep): selection + integrals | pair forces | bookkeeper | gather tiles
 template <bool PERB>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_pair_step(SelectArgs a, Geom g, Tables t, double *__restrict__ rec, HillList h,
@@ -3799,10 +3815,8 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
   __shared__ int s_fws[BLOCK / 64];
   unsigned long long *trace = la.trace ? la.trace + (size_t)blockIdx.x * 8 : nullptr;
   if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
-  // roles of this launch, in workgroup order: selection | pair forces | integrators | bookkeeper | tiles
-  // (phase 0: the whole step -- no integrators, the selection workgroups integrate their own hills; phase 1, the front
-  //  launch of a split step: selection + pair forces; phase 2, its back launch: integrators + bookkeeper + tiles)
-  const unsigned n_sel = fs.phase == 2 ? 0u : fs.nsel, n_k1 = fs.phase == 2 ? 0u : fs.nk1, n_int = fs.phase == 2 ? fs.n_int : 0u;
+  // roles, in workgroup order: selection | pair forces | bookkeeper | tiles
+  const unsigned n_sel = fs.nsel, n_k1 = fs.nk1;
   const unsigned b = blockIdx.x;
   // the hill chain is what the step waits for; the pair forces only have to be done by the time the host is released:
   // every role but K1 issues ahead of K1's waves where they share a SIMD
@@ -3818,34 +3832,16 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
       __builtin_amdgcn_s_waitcnt(0);
       counter_arrive(fs.k1_done, kb);
     }
-  } else if (b < n_sel + n_k1 + n_int) {
-    fused_integrator<PERB>(a, g, t, h, h_const, fs, b - (n_sel + n_k1), trace, s_foff, s_fws);
-  } else if (b == n_sel + n_k1 + n_int) {
+  } else if (b == n_sel + n_k1) {
     fused_bookkeeper<PERB>(a, h, h_const, added, la, post, fs, b, trace, s_foff, s_fws);
   } else {
-    const unsigned tile = b - (n_sel + n_k1 + n_int + 1), ntile = gridDim.x - (n_sel + n_k1 + n_int + 1);
+    const unsigned tile = b - (n_sel + n_k1 + 1), ntile = gridDim.x - (n_sel + n_k1 + 1);
     __shared__ int s_dirty, s_last;
     if (threadIdx.x == 0) s_dirty = 0;   // (barriers inside the body lie between this and any thread's write)
     hill_gather_body<1, 0, 8, PERB, true, true>(g, t, rec, h, hh, plan, 0, dirty_flag, post.enabled, tile, la.ready_flag,
                                                 la.ready_seq, trace, &fs, a.counts, s_foff, s_fws, rec_next, &s_dirty);
     if (trace && threadIdx.x == 0) trace[6] = wall_clock64();
-    // last tile: boundary duplication (gaussian_grid.h:571-630) iff some tile of the step met a non-zero boundary
-    // correction.  The ticket carries that bit: every tile adds 1, and 0x10000 if it saw one, in ONE atomic round
-    // trip -- the last arrival learns both that it is the last and whether anybody was dirty.
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned mine = s_dirty ? 0x10001u : 1u;
-      const unsigned t0 = (unsigned)__hip_atomic_fetch_add(post.ticket, (int)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int last = 0;
-      if ((t0 & 0xFFFFu) == ntile - 1) {
-        __hip_atomic_store(post.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = ((t0 + mine) >> 16) ? 2 : 1;
-      }
-      s_last = last;
-    }
-    __syncthreads();
-    if (!PERB && s_last == 2 && threadIdx.x < 64) duplicate_boundary_wave(g, rec_next, post.dp, threadIdx.x);
+    tile_ticket_duplicate<PERB>(g, rec_next, post, ntile, &s_dirty, &s_last);
   }
   if (trace && threadIdx.x == 0) trace[7] = wall_clock64();
 }
@@ -3865,8 +3861,7 @@ hipError_t launch_pair_step(const SelectArgs &a, const Geom &g, const Tables &t,
                             double h_const, double *added, const LimitArgs &chain, const HillHeights &hh,
                             const GatherPlan &plan, int *dirty_flag, const PostSpec *post_chain, const double *pair_r,
                             long long n_pairs, double *pair_force, double *pair_scratch, FusedStep fs, hipStream_t s,
-                            hipEvent_t ev0, hipEvent_t ev1, int *k1_blocks_out, int *sel_blocks_out, double *rec_next,
-                            int phase) {
+                            hipEvent_t ev0, hipEvent_t ev1, int *k1_blocks_out, int *sel_blocks_out, double *rec_next) {
   if (!pair_step_fusable(g, n_pairs, a, h, nullptr, plan) || !chain.ready_flag || !hh.res_dev || !post_chain || !rec_next ||
       rec_next == rec)
     return hipErrorInvalidValue;
@@ -3894,18 +3889,15 @@ hipError_t launch_pair_step(const SelectArgs &a, const Geom &g, const Tables &t,
   f.nk1 = (unsigned)pair_short_blocks(n_pairs);
   fs.nsel = f.nsel;
   fs.nk1 = f.nk1;
-  fs.phase = phase;
-  fs.n_int = (unsigned)h.nh;   // (back launch of a split step: a workgroup per hill of the launch bound)
-  // the caller passes the sums the counters stand at BEFORE the step's first launch (phase 0 or 1); every launch is told
-  // the sums that mean "complete": the front launch's workgroups arrive on sel_done / k1_done, the integrators of a
-  // back launch -- or the selection workgroups of a whole-step launch -- on int_done
+  // the caller passes the sums the counters stand at before this launch; the launch is told the sums that mean
+  // "complete": every selection workgroup arrives once on sel_done and once on int_done, every K1 workgroup on k1_done
   fs.sel_target += f.nsel;
+  fs.int_target += f.nsel;
   fs.k1_target += f.nk1;
-  fs.int_target += (phase == 2) ? fs.n_int : f.nsel;
   fs.limit = chain.limit;
   fs.cum_in = chain.cum_in;
   const unsigned nb_tiles = (unsigned)((g.n[0] + BLOCK / 8 - 1) / (BLOCK / 8));
-  const dim3 grid(phase == 1 ? fs.nsel + fs.nk1 : phase == 2 ? fs.n_int + 1 + nb_tiles : fs.nsel + fs.nk1 + 1 + nb_tiles);
+  const dim3 grid(fs.nsel + fs.nk1 + 1 + nb_tiles);
   if (!g.bper[0])
     EDM_LAUNCH_TIMED((k_pair_step<false>), grid, dim3(BLOCK), 256, s, ev0, ev1, a, g, t, rec, h, h_const, added, la, hh, plan,
                      dirty_flag, post, f, fs, rec_next);

@@ -1,7 +1,6 @@
-"""A hill-depositing fix edm_pair step through k_pair_step -- as ONE launch (selection with per-hill integrals | pair
-forces | bookkeeper | gather tiles) and split in two at the point where the accepted samples are known (selection + pair
-forces | a workgroup per hill, bookkeeper, gather tiles) -- against the same step as round 2 queued it
-(k_pair_forces_select, then k_integrals_gather): every result bit for bit -- energies, forces, grid, gradient, histogram, controller state, HILLS log.  The reference loop
+"""A hill-depositing fix edm_pair step as ONE launch (k_pair_step, opt-in: selection with per-hill integrals | pair
+forces | bookkeeper | gather tiles, the grid written to its second buffer) against the same step as the library queues
+it by default (k_pair_forces_select, then k_integrals_gather): every result bit for bit -- energies, forces, grid, gradient, histogram, controller state, HILLS log.  The reference loop
 both replace is fix_edm_pair.cpp:174-246 over edm_bias.cpp:401-583."""
 import numpy as np
 import pytest
@@ -43,7 +42,7 @@ def run(tag, case, workdir, mode):
     cfg = str(workdir / (tag + ".edm"))
     open(cfg, "w").write(BASE + case["cfg"] + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
     b = H.Bias(cfg)
-    b.set("debug_pair_step_mode", mode)   # 0: forces+selection | integrals+gather; 1: one launch; 2: k_pair_step split in two
+    b.set("debug_pair_step_mode", mode)   # 0: forces+selection | integrals+gather (the default); 1: one launch
     b.setup(1.0, 1.0)
     b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
     n = case["n"]
@@ -69,7 +68,7 @@ def run(tag, case, workdir, mode):
     return out
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1])
 @pytest.mark.parametrize("name", list(CASES))
 def test_one_launch_equals_two_launches(name, mode, workdir):
     case = CASES[name]
@@ -90,7 +89,7 @@ def test_one_launch_equals_two_launches(name, mode, workdir):
         assert one["redos"] >= 1 and two["redos"] == 0
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1])
 def test_one_launch_against_oracle(mode, workdir, oracle_lib):
     """The one-launch step against the oracle executing the reference's per-pair loop (pre_add_hill, update_force per
     pair, add_hill per sample, post_add_hill)."""
