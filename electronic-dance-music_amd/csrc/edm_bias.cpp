@@ -903,11 +903,16 @@ int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_str
     if (rc) return rc;
   }
   // add_hills behind it on the same stream (:401-411): pre_add_hill, the samples, post_add_hill
+  // (the force kernel is ALREADY queued: a polled batch of the overflow flush inside pre_add_hill is behind it on the
+  //  stream and shows it complete just as a polled batch of new hills does -- a step whose new hills are skipped,
+  //  edm_bias.cpp:534-535, must not fall back to a stream wait for that: 20-30 us of idle GPU per step on W4)
+  if (b->bias) b->bias->wait_polled = false;
   int rc = do_pre_add_hill(b, est_hill_count < 0 ? n : est_hill_count);
   if (rc) return rc;
   if (!b->b_outofbounds) {
-    b->bias->wait_polled = false;
+    const bool flush_polled = b->bias->wait_polled;
     rc = process_new_hills(b, n, d_x, x_stride, d_runiform, apply_mask);
+    if (flush_polled) b->bias->wait_polled = true;   // (whatever the new hills did: the forces were seen complete)
     if (rc) return rc;
     if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
     const double e = pair_forces_finish(b->bias, nblk);
@@ -1146,9 +1151,13 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     b->pl_mask_itype = itype;
     b->pl_mask_jtype = jtype;
   }
-  int nblk = 0;
+  // the force pass is queued like the pair forces of edm_hip_bias_pair_step: in the launch of the step's selection
+  // where there is one, else on its own ahead of anything of the step that writes the grid
   b->bias->wait_polled = false;
-  EDM_HIP_TRY(launch_pairlist_forces(b->bias->g, b->bias->rec, a, b->bias->d_partials, s, &nblk));
+  b->pending = PendingForces();
+  b->pending.active = true;
+  b->pending.list = true;
+  b->pending.pl = a;
   if (hill_step && npairs > 0) {
     // add_hill(r, u) for the two virtual samples of every list entry, in list order; dead ones are masked out.
     // The CV of an accepted sample is recomputed from the positions when its hill is prepared; only the paths
@@ -1167,8 +1176,11 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     rc = process_new_hills(b, 2 * npairs, sample_r, 1, nullptr, 1);
     b->d_mask = saved_mask;
     b->pl_view_x = nullptr;
-    if (rc) return rc;
   }
+  int rcf = pending_forces_flush(b->bias, &b->pending);   // (no hill launch carried it: nothing has touched the grid)
+  if (rc) return rc;
+  if (rcf) return rcf;
+  const int nblk = b->pending.nblk;
   // (a polled hill batch has shown the stream past the force pass queued ahead of it)
   if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(s));
   double e = 0;

@@ -1021,10 +1021,19 @@ int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x
 int pending_forces_flush(const edm_hip_gauss *g, PendingForces *pf) {
   if (!pf || !pf->active) return EDM_HIP_OK;
   pf->active = false;
+  if (pf->list) {
+    EDM_HIP_TRY(launch_pairlist_forces(g->g, g->rec, pf->pl, g->d_partials, g->stream, &pf->nblk));
+    return EDM_HIP_OK;
+  }
   return pair_forces_enqueue(g, pf->n, pf->d_r, pf->d_force, &pf->nblk);
 }
 int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a, const HillList &h, PendingForces *pf) {
-  if (pf && pf->active && pair_forces_select_fusable(g->g, pf->n, a.n)) {
+  if (pf && pf->active && pf->list && g->g.dim == 1 && a.n > 0 && pf->pl.nall > 0) {
+    pf->active = false;
+    EDM_HIP_TRY(launch_pairlist_forces_select(a, g->g, h, g->rec, pf->pl, g->d_partials, g->stream, &pf->nblk));
+    return EDM_HIP_OK;
+  }
+  if (pf && pf->active && !pf->list && pair_forces_select_fusable(g->g, pf->n, a.n)) {
     hipEvent_t e0, e1;
     profile_slot(g, &e0, &e1);
     pf->active = false;
@@ -1324,7 +1333,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   // the built-in choice, spec.pair_step_mode (tests) both.
   static const int mode_env = getenv("EDM_HIP_PAIR_STEP_MODE") ? atoi(getenv("EDM_HIP_PAIR_STEP_MODE")) : 0;
   const int pair_step_mode = spec.pair_step_mode >= 0 ? spec.pair_step_mode : mode_env;
-  const bool one_launch = pair_step_mode == 1 && chain_limit && spec.sel_chain && spec.forces && spec.forces->active && small &&
+  const bool one_launch = pair_step_mode == 1 && chain_limit && spec.sel_chain && spec.forces && spec.forces->active &&
+                          !spec.forces->list && small &&
                           rb_bytes + 128 <= g->h_stage_bytes && fused_post && !sharded && !g->rec_handed_out &&
                           pair_step_fusable(q, spec.forces->n, *spec.sel_chain, hl, spec.d_h, plan);
   if (!one_launch) {

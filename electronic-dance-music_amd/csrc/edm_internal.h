@@ -163,6 +163,9 @@ struct PendingForces {
   const double *d_r = nullptr;
   double *d_force = nullptr;
   int nblk = 0;              // K1 workgroups launched (partial energy sums to add up)
+  // ... or the force pass over a device-resident neighbour list (fix edm_pair gpu_list), queued the same way
+  bool list = false;
+  PairListArgs pl;
 };
 struct ApplySpec {
   long long nh = 0;

@@ -199,6 +199,9 @@ bool pair_forces_select_fusable(const Geom &g, long long n_pairs, long long n_sa
 hipError_t launch_pair_forces_select(const SelectArgs &a, const Geom &g, const HillList &h, const double *rec, long long n,
                                      const double *r, double *force, double *scratch, hipStream_t s, hipEvent_t ev0,
                                      hipEvent_t ev1, int *blocks_out);
+// the force pass over a device-resident neighbour list and the selection (+ preparation) of the same step as ONE launch
+hipError_t launch_pairlist_forces_select(const SelectArgs &a, const Geom &g, const HillList &h, const double *rec,
+                                         const PairListArgs &pl, double *partials, hipStream_t s, int *blocks_out);
 struct LimitArgs;
 struct PostSpec;
 struct LimitResult;

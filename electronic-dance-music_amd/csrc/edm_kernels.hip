@@ -1097,14 +1097,17 @@ __device__ __forceinline__ void pairlist_side(const Geom &g, const double *__res
     }
   }
 }
+// (body of the pass for workgroup `bid` of `nblk`: shared by the plain launch and by the launch that also carries the
+//  step's selection)
 template <bool FAST>
-__global__ void __launch_bounds__(BLOCK) k_pairlist_forces(Geom g, const double *__restrict__ rec, PairListArgs a,
-                                                           double *__restrict__ partials, double inv_dx) {
+__device__ __forceinline__ void pairlist_forces_body(const Geom &g, const double *__restrict__ rec, const PairListArgs &a,
+                                                     double *__restrict__ partials, double inv_dx, unsigned bid,
+                                                     unsigned nblk) {
   __shared__ double lds[BLOCK / 64];
   const int sub = threadIdx.x & 15;
   double e_acc = 0;
-  const long long astride = ((long long)gridDim.x * BLOCK) >> 4;
-  for (long long atom = ((long long)blockIdx.x * BLOCK + threadIdx.x) >> 4; atom < a.nall; atom += astride) {
+  const long long astride = ((long long)nblk * BLOCK) >> 4;
+  for (long long atom = ((long long)bid * BLOCK + threadIdx.x) >> 4; atom < a.nall; atom += astride) {
     double fx = 0, fy = 0, fz = 0;
     if (atom < a.nlocal) {   // (ghost atoms never appear as i and receive nothing as j: newton off)
       const int ta = a.type[atom];
@@ -1126,7 +1129,12 @@ __global__ void __launch_bounds__(BLOCK) k_pairlist_forces(Geom g, const double 
     }
   }
   const double se = block_sum(e_acc, lds);
-  if (threadIdx.x == 0) partials[blockIdx.x] = se;
+  if (threadIdx.x == 0) partials[bid] = se;
+}
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK) k_pairlist_forces(Geom g, const double *__restrict__ rec, PairListArgs a,
+                                                           double *__restrict__ partials, double inv_dx) {
+  pairlist_forces_body<FAST>(g, rec, a, partials, inv_dx, blockIdx.x, gridDim.x);
 }
 
 // which virtual samples of the list are live (static between list uploads) + their number
@@ -1884,6 +1892,39 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_select(SelectArgs a, Geom
   else
     pair_forces_fast_body<false, BLOCK>(g, f.rec, f.n, f.r, f.force, f.block_energy, 0LL, 0, f.inv_dx, lds_all,
                                         blockIdx.x, f.nk1);
+}
+
+// The same pairing for fix edm_pair on a device-resident neighbour list: workgroups [0, nsel) run the selection over
+// the list's virtual add_hill samples (+ hill preparation in the last of them), the rest the force pass
+// (k_pairlist_forces' body).  The selection reads the live-sample mask and the uniforms' stream, the force pass the
+// positions and the grid; the 2.26 M-sample selection of the 32 k-atom melt (14 us on its own) hides behind the pass.
+template <bool FAST>
+__global__ void __launch_bounds__(BLOCK) k_pairlist_forces_select(SelectArgs a, Geom g, HillList h, PairListArgs pl,
+                                                                  const double *__restrict__ rec,
+                                                                  double *__restrict__ partials, double inv_dx,
+                                                                  unsigned nsel) {
+  if (blockIdx.x < nsel)
+    select_prep_body<1>(a, g, h, blockIdx.x, nsel);
+  else
+    pairlist_forces_body<FAST>(g, rec, pl, partials, inv_dx, blockIdx.x - nsel, gridDim.x - nsel);
+}
+hipError_t launch_pairlist_forces_select(const SelectArgs &a, const Geom &g, const HillList &h, const double *rec,
+                                         const PairListArgs &pl, double *partials, hipStream_t s, int *blocks_out) {
+  if (g.dim != 1 || pl.nall <= 0 || a.n <= 0) return hipErrorInvalidValue;
+  const long long threads = (long long)pl.nall * 16;
+  long long nb = (threads + BLOCK - 1) / BLOCK;
+  if (nb > MAX_BLOCKS) nb = MAX_BLOCKS;
+  const unsigned nsel = (unsigned)((a.n + SEL_CHUNK - 1) / SEL_CHUNK);
+  const bool fast = (g.interp && !g.periodic[0] && !g.bper[0] && g.n[0] >= 2);
+  const double inv_dx = 1.0 / g.dx[0];
+  if (fast)
+    hipLaunchKernelGGL(k_pairlist_forces_select<true>, dim3(nsel + (unsigned)nb), dim3(BLOCK), 0, s, a, g, h, pl, rec, partials,
+                       inv_dx, nsel);
+  else
+    hipLaunchKernelGGL(k_pairlist_forces_select<false>, dim3(nsel + (unsigned)nb), dim3(BLOCK), 0, s, a, g, h, pl, rec, partials,
+                       inv_dx, nsel);
+  if (blocks_out) *blocks_out = (int)nb;
+  return hipGetLastError();
 }
 
 size_t select_stage_ints(long long n) { return (size_t)((n + SEL_CHUNK - 1) / SEL_CHUNK) * SEL_CHUNK; }
