@@ -646,6 +646,26 @@ def main():
     ms_step_device_rng = (time.perf_counter() - t_r) / args.steps * 1e3
     b.set_device_rng(False, 0)
 
+    # the same step queued as ONE launch (k_pair_step, opt-in: selection with per-hill integrals | pair forces |
+    # bookkeeper | gather tiles in one grid); informational: the default keeps the two launches
+    one_launch = None
+    guard.stage("one_launch_step")
+    if dist is None:
+        b.set("debug_pair_step_mode", 1)
+        fused0 = b.get("fused_steps")
+        for _ in range(3):
+            step()
+        barrier()
+        t_o = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        one_launch = dict(ms_per_step=(time.perf_counter() - t_o) / args.steps * 1e3,
+                          steps_run_as_one_launch=int(b.get("fused_steps") - fused0), steps=args.steps + 3,
+                          note="edm_hip_bias_pair_step with the whole step in one k_pair_step launch "
+                               "(EDM_HIP_PAIR_STEP_MODE=1); bit-identical results (tests/test_gpu_one_launch.py)")
+        b.set("debug_pair_step_mode", -1)
+
     # BASELINE configs[1] end to end from POSITIONS: 32k atoms at the LJ-melt density, half neighbour list within
     # r_c + skin = 2.8 resident on the GPU (fix edm_pair ... gpu_list), every step deposits hills; informational
     lj = None
@@ -743,6 +763,7 @@ def main():
             "evals_only_million_per_s": npairs / t_eval / 1e6,
             "ms_per_step_device_rng": ms_step_device_rng,
             "lj_melt_32k_from_positions": lj,
+            "one_launch_step": one_launch,
             "energy_last_step": energy,
             # (batches released by the polled completion word / by the stream-wait fallback, whole run of this object)
             "polled_batches": b.get("polled_batches"),
