@@ -2377,28 +2377,55 @@ __device__ __forceinline__ double hill_stencil_partial(const Geom &g, const Tabl
       }
       return acc;
     }
+    // The stencil offset of point s = lt + k * TPH is kept as a running mixed-radix number (digit d in base
+    // 2 * msize[d] + 1) and advanced by the digits of TPH per point: the two 32-bit divisions per point that decoding s
+    // afresh costs (~50 of a 3-D point's ~170 instructions) are paid once per thread.  Same points, same order.
+    unsigned dig[DIM], inc[DIM], wd[DIM];
+    {
+      unsigned r0 = (unsigned)lt, r1 = (unsigned)TPH;
+#pragma unroll
+      for (int d = 0; d < DIM; d++) {
+        wd[d] = (unsigned)(2 * g.msize[d] + 1);
+        if (d < DIM - 1) {
+          dig[d] = r0 % wd[d];
+          r0 /= wd[d];
+          inc[d] = r1 % wd[d];
+          r1 /= wd[d];
+        } else {
+          dig[d] = r0;   // (the last digit is not reduced: s < utotal bounds it)
+          inc[d] = r1;
+        }
+      }
+    }
     for (unsigned s0 = (unsigned)lt; s0 < utotal; s0 += ILP * TPH) {
       double term[ILP];
 #pragma unroll
       for (int u = 0; u < ILP; u++) {
         term[u] = 0;
         const unsigned s = s0 + (unsigned)(u * TPH);
+        unsigned offd[DIM];
+        {
+          // this point's digits, then the state moves on to the next point (whether or not this one is used)
+          unsigned carry = 0;
+#pragma unroll
+          for (int d = 0; d < DIM; d++) {
+            offd[d] = dig[d];
+            unsigned nd = dig[d] + inc[d] + carry;
+            carry = 0;
+            if (d < DIM - 1 && nd >= wd[d]) {
+              nd -= wd[d];
+              carry = 1;
+            }
+            dig[d] = nd;
+          }
+        }
         if (s >= utotal) continue;
         int p[DIM];
-        unsigned rest = s;
         bool skip = false;
         double dp2_est = 0;
 #pragma unroll
         for (int d = 0; d < DIM; d++) {
-          const unsigned w = (unsigned)(2 * g.msize[d] + 1);
-          int off;
-          if (d < DIM - 1) {
-            const unsigned qq = rest / w;
-            off = (int)(rest - qq * w);
-            rest = qq;
-          } else {
-            off = (int)rest;
-          }
+          const int off = (int)offd[d];
           int idx = off - g.msize[d] + c[d];
           {
             // distance to this (un-wrapped) stencil point; most of the stencil box lies outside dp2 < 8
