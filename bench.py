@@ -598,8 +598,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # K1 is stamped on every 4th step of the timed region (a stamp costs the stream ~6 us, a tenth of a step)
-    TIMED_EVERY = 4
+    # K1's launch is stamped (dispatch begin / end timestamps) on a few steps of the timed region -- 2 of 20, 10 of 200:
+    # a stamped launch costs the stream ~15 us (an unstamped step takes ~31 us; every 4th step stamped, round 1's
+    # choice, added 3.5 us to EVERY step of the average), so a sparse sample keeps `ms_per_step` what the step costs.
+    # (EDM_BENCH_TIMED_EVERY overrides; the first stamped launch of a process pays for switching the queue's profiling
+    #  on -- spent here on two extra warm-up steps, outside the timed region)
+    n_stamps = min(10, max(2, args.steps // 10))
+    TIMED_EVERY = int(os.environ.get("EDM_BENCH_TIMED_EVERY", "0")) or max(1, args.steps // n_stamps)
+    g.profile_enable(1)
+    for _ in range(2):
+        step()
+    g.profile_read(reset=True)
     g.profile_enable(TIMED_EVERY)
     g.profile_read(reset=True)
     barrier()
@@ -621,6 +630,11 @@ def main():
     # the CPU baseline).  The headline numbers are complete at this point: if an extra ever failed to finish -- the
     # multi-rank ones run collectives -- rank 0 still prints the line, marked, instead of losing the measurement.
     headline = headline_dict(args, world, npairs, elapsed, k_ms, k_launches, TIMED_EVERY)
+    if b.get("fused_steps") > 0:   # (EDM_HIP_PAIR_STEP_MODE=1 in the environment: the stamped launch was the whole step)
+        headline["roofline"]["kernel"] = ("k_pair_step (the WHOLE step in one launch: selection + per-hill integrals | K1 | "
+                                          "bookkeeper | gather tiles; only K1's 16 B per pair are counted)")
+        headline["roofline"]["traffic"] = pmc_traffic("edm::k_pair_step")
+        headline["roofline"]["kernel_us_rocprof"] = rocprof_avg_us("edm::k_pair_step")
     # second quantity of the metric (BASELINE.json: "... + hill-adds/sec", target: strong scaling at 8 GPUs): the
     # all-samples hill mode, 1,048,576 hills per step in total split over the GPUs (a collective: every rank runs it);
     # part of the measured line, not of the guarded extras
@@ -649,22 +663,33 @@ def main():
     # the same step queued as ONE launch (k_pair_step, opt-in: selection with per-hill integrals | pair forces |
     # bookkeeper | gather tiles in one grid); informational: the default keeps the two launches
     one_launch = None
-    guard.stage("one_launch_step")
+    guard.stage("step_modes")
     if dist is None:
-        b.set("debug_pair_step_mode", 1)
-        fused0 = b.get("fused_steps")
-        for _ in range(3):
-            step()
-        barrier()
-        t_o = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        one_launch = dict(ms_per_step=(time.perf_counter() - t_o) / args.steps * 1e3,
-                          steps_run_as_one_launch=int(b.get("fused_steps") - fused0), steps=args.steps + 3,
-                          note="edm_hip_bias_pair_step with the whole step in one k_pair_step launch "
-                               "(EDM_HIP_PAIR_STEP_MODE=1); bit-identical results (tests/test_gpu_one_launch.py)")
+        # both ways of queueing the step, WITHOUT the dispatch stamps of the timed region above (a stamped launch costs
+        # the stream ~6 us), alternating so that drift hits both alike
+        modes = {0: [], 1: []}
+        fused = 0
+        for rep in range(4):
+            for m in (0, 1):
+                b.set("debug_pair_step_mode", m)
+                f0 = b.get("fused_steps")
+                for _ in range(3):
+                    step()
+                barrier()
+                t_o = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                barrier()
+                modes[m].append((time.perf_counter() - t_o) / args.steps * 1e3)
+                if m == 1:
+                    fused += int(b.get("fused_steps") - f0)
         b.set("debug_pair_step_mode", -1)
+        one_launch = dict(ms_per_step=min(modes[1]), ms_per_step_runs=modes[1],
+                          two_launches_ms_per_step=min(modes[0]), two_launches_ms_per_step_runs=modes[0],
+                          steps_run_as_one_launch=fused, steps_per_run=args.steps,
+                          note="edm_hip_bias_pair_step unstamped, alternating EDM_HIP_PAIR_STEP_MODE 0 (k_pair_forces_select, "
+                               "k_integrals_gather) and 1 (the whole step in one k_pair_step launch); bit-identical results "
+                               "(tests/test_gpu_one_launch.py)")
 
     # BASELINE configs[1] end to end from POSITIONS: 32k atoms at the LJ-melt density, half neighbour list within
     # r_c + skin = 2.8 resident on the GPU (fix edm_pair ... gpu_list), every step deposits hills; informational

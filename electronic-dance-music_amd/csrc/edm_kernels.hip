@@ -22,6 +22,7 @@
 
 #include <hip/hip_ext.h>
 #include <limits.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -3881,11 +3882,17 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
   extern __shared__ double2 lds_all[];
   __shared__ unsigned short s_foff[EDM_FS_MAX_SEL + 1];
   __shared__ int s_fws[BLOCK / 64];
-  unsigned long long *trace = la.trace ? la.trace + (size_t)blockIdx.x * 8 : nullptr;
-  if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
-  // roles, in workgroup order: selection | pair forces | bookkeeper | tiles
+  // roles, in DISPATCH order: selection | bookkeeper | tiles | pair forces.  The bookkeeper and the tiles wait for
+  // selection workgroups only, which are dispatched ahead of them; K1 waits for nobody and nobody but the bookkeeper's
+  // release of the host waits for K1 -- so it goes last: behind it in the queue the tiles would get their slots only as
+  // K1's workgroups retire (stamps: tiles starting at 15 us, the kernel ending with them at 32 us).
+  // (below, `b` is the workgroup's index in the order selection | pair forces | bookkeeper | tiles the roles are written in)
   const unsigned n_sel = fs.nsel, n_k1 = fs.nk1;
-  const unsigned b = blockIdx.x;
+  const unsigned n_rest = gridDim.x - n_sel - n_k1;   // bookkeeper + tiles
+  const unsigned b = blockIdx.x < n_sel ? blockIdx.x
+                                        : (blockIdx.x < n_sel + n_rest ? blockIdx.x + n_k1 : blockIdx.x - n_rest);
+  unsigned long long *trace = la.trace ? la.trace + (size_t)b * 8 : nullptr;
+  if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
   // the hill chain is what the step waits for; the pair forces only have to be done by the time the host is released:
   // every role but K1 issues ahead of K1's waves where they share a SIMD
   if (b < n_sel || b >= n_sel + n_k1) __builtin_amdgcn_s_setprio(3);
