@@ -18,6 +18,7 @@ def _gpu():
     yield
 
 BASE = ("tempering 0\nhill_prefactor 0.5\ndimension 1\nbox_low 0\nbox_high 2.8\n")
+TEMPERED = ("tempering 1\nbias_factor 5\nglobal_tempering 0.05\nhill_prefactor 0.5\ndimension 1\nbox_low 0\nbox_high 2.8\n")
 
 # (a step runs as one launch when its selection workgroups -- 4096 samples each -- expect at most four accepted samples:
 #  hill_density * 4096 / n <= 4)
@@ -32,6 +33,10 @@ CASES = {
     "w1_full": dict(cfg="hill_density 250\nbias_per_step 0.5\nbias_spacing 0.00025\nbias_sigma 0.025\n", n=1 << 20, ns=None, steps=4),
     # more than one 256-hill chunk per tile (the launch bound allows 2048 hills)
     "many_hills": dict(cfg="hill_density 400\nbias_per_step 2.0\nbias_spacing 0.001\nbias_sigma 0.05\n", n=500_000, ns=None, steps=3),
+    # globally tempered heights (the prefactor shrinks with the accumulated bias, edm_bias.cpp:419-424: a new constant height
+    # every step) on the production grid, walls included
+    "global_tempering": dict(base=TEMPERED, cfg="hill_density 120\nbias_per_step 0.9\nbias_spacing 0.00025\nbias_sigma 0.025\n",
+                             n=300_000, ns=None, steps=6),
     # one selection workgroup accepts more samples than it has slots for: the whole step falls back (synchronous redo)
     "slots_overflow": dict(cfg="hill_density 60\nbias_per_step 0.6\nbias_spacing 0.001\nbias_sigma 0.05\n", n=100_000, ns=None, steps=4,
                            clustered=True),
@@ -40,7 +45,7 @@ CASES = {
 
 def run(tag, case, workdir, mode):
     cfg = str(workdir / (tag + ".edm"))
-    open(cfg, "w").write(BASE + case["cfg"] + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+    open(cfg, "w").write(case.get("base", BASE) + case["cfg"] + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
     b = H.Bias(cfg)
     b.set("debug_pair_step_mode", mode)   # 0: forces+selection | integrals+gather (the default); 1: one launch
     b.setup(1.0, 1.0)
