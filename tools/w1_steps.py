@@ -1,0 +1,37 @@
+"""Development aid: only the W1 step loop of bench.py (fix edm_pair, BASELINE configs[1]), for a kernel trace:
+   EDM_HIP_PAIR_STEP_MODE=2 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/w1 -o w1 -- python3 tools/w1_steps.py"""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import edm_amd.hip as H
+import edm_amd.workloads as W
+from bench import make_bias
+
+H.require_gpu()
+tmpdir = tempfile.mkdtemp()
+npairs = 1 << 20
+b = H.Bias(make_bias(H, tmpdir, "gpu", 0))
+b.setup(1.0, 1.0)
+b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+b.set_hill_log(False)
+hills0 = np.zeros((4096, 1))
+hills0[:, 0] = W.pair_distances(4096, 2)
+b.gauss.add_values(hills0, 1e-3)
+d_r = H.DeviceArray.from_host(W.pair_distances(npairs, 1))
+d_u = H.DeviceArray.from_host(W.uniform(3, npairs))
+d_f = H.DeviceArray.zeros((npairs,))
+est = 2 * npairs
+for _ in range(10):
+    b.pair_step_device(d_r, d_f, npairs, d_r, d_u, npairs, est)
+H.synchronize()
+steps = int(os.environ.get("W1_STEPS", "200"))
+t = time.perf_counter()
+for _ in range(steps):
+    b.pair_step_device(d_r, d_f, npairs, d_r, d_u, npairs, est)
+H.synchronize()
+print("ms_per_step", (time.perf_counter() - t) / steps * 1e3, "fused", b.get("fused_steps"), "split", b.get("split_steps"))
