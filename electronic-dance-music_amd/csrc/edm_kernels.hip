@@ -16,8 +16,10 @@
 //   K8     block/wave reductions           fixed-order energy and bias sums
 // A short hill step is three launches: sel -> K3 (+K4, read-back) -> K5 (+K6, K7), each stage's small serial
 // tail run by the last workgroup to finish (last_block_done); in a fix edm_pair step K1 rides in the first launch
-// (k_pair_forces_select).  The host is released by a word K3's last workgroup stores behind the read-back region in
-// host-mapped memory: it polls that word, not the stream.
+// (k_pair_forces_select; the force pass over a device-resident neighbour list likewise, k_pairlist_forces_select).  The
+// host is released by a word K3's last workgroup stores behind the read-back region in host-mapped memory: it polls
+// that word, not the stream.  k_pair_step (opt-in, EDM_HIP_PAIR_STEP_MODE=1) is the same step as ONE launch with the
+// roles side by side -- bit-identical and, on the MI355X, no faster: DESIGN.md section 5 has the stamps.
 #include "edm_kernels.h"
 
 #include <hip/hip_ext.h>
