@@ -34,4 +34,4 @@ t = time.perf_counter()
 for _ in range(steps):
     b.pair_step_device(d_r, d_f, npairs, d_r, d_u, npairs, est)
 H.synchronize()
-print("ms_per_step", (time.perf_counter() - t) / steps * 1e3, "fused", b.get("fused_steps"), "split", b.get("split_steps"))
+print("ms_per_step", (time.perf_counter() - t) / steps * 1e3, "fused", b.get("fused_steps"))
