@@ -1027,7 +1027,43 @@ int pending_forces_flush(const edm_hip_gauss *g, PendingForces *pf) {
   }
   return pair_forces_enqueue(g, pf->n, pf->d_r, pf->d_force, &pf->nblk);
 }
-int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a, const HillList &h, PendingForces *pf) {
+int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a_in, const HillList &h, PendingForces *pf) {
+  SelectArgs a = a_in;
+  // development aid (EDM_HIP_TRACE=select): stamps of one k_pair_forces_select launch to stderr
+  static const bool tracing = getenv("EDM_HIP_TRACE") && !strcmp(getenv("EDM_HIP_TRACE"), "select");
+  static int launches = 0;
+  unsigned long long *d_trace = nullptr;
+  size_t trace_wgs = 0;
+  if (tracing && pf && pf->active && !pf->list && ++launches == 150) {
+    trace_wgs = (size_t)((a.n + 2047) / 2048) + 1024;
+    if (hipMalloc(reinterpret_cast<void **>(&d_trace), trace_wgs * 64) == hipSuccess) {
+      (void)hipMemset(d_trace, 0, trace_wgs * 64);
+      a.trace = d_trace;
+    }
+  }
+  struct TraceDump {
+    const edm_hip_gauss *g; unsigned long long *d; size_t wgs, nsel;
+    ~TraceDump() {
+      if (!d) return;
+      (void)hipStreamSynchronize(g->stream);
+      std::vector<unsigned long long> tr(wgs * 8);
+      (void)hipMemcpy(tr.data(), d, wgs * 64, hipMemcpyDeviceToHost);
+      (void)hipFree(d);
+      unsigned long long t0 = ~0ull;
+      for (size_t w = 0; w < wgs; w++) if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
+      const char *names[8] = {"start", "published", "ticket (not last)", "ticket (last)", "list prepared", "", "", "end"};
+      for (int role = 0; role < 2; role++)
+        for (int k = 0; k < 8; k++) {
+          std::vector<double> v;
+          for (size_t w = role ? nsel : 0; w < (role ? wgs : nsel); w++)
+            if (tr[w * 8 + k]) v.push_back((double)(tr[w * 8 + k] - t0) * 0.01);
+          if (v.empty()) continue;
+          std::sort(v.begin(), v.end());
+          fprintf(stderr, "[edm trace] %s %-18s n=%4zu  min %6.2f  med %6.2f  max %6.2f us\n", role ? "forces   " : "selection",
+                  names[k], v.size(), v.front(), v[v.size() / 2], v.back());
+        }
+    }
+  } dump{g, d_trace, trace_wgs, (size_t)((a.n + 2047) / 2048)};
   if (pf && pf->active && pf->list && g->g.dim == 1 && a.n > 0 && pf->pl.nall > 0) {
     pf->active = false;
     EDM_HIP_TRY(launch_pairlist_forces_select(a, g->g, h, g->rec, pf->pl, g->d_partials, g->stream, &pf->nblk));

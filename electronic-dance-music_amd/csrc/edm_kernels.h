@@ -173,6 +173,7 @@ struct SelectArgs {
   int *ticket;            // zero-initialised device int, left at zero
   double *pack;           // multi-GPU: instead of sel/prep, write this rank's exchange packet
                           // [count, x_0 .. x_{bound-1}] (bound = h.nh, dim doubles per position)
+  unsigned long long *trace;   // development aid (EDM_HIP_TRACE): 8 wall-clock stamps per workgroup of k_pair_forces_select, or NULL
 };
 // receive side of the packed exchange (see k_unpack_prep)
 #define EDM_MAX_RANKS 16

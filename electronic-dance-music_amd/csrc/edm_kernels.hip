@@ -1797,7 +1797,12 @@ __device__ __forceinline__ void select_prep_body(const SelectArgs &a, const Geom
       if (threadIdx.x == 0) publish(&a.counts[bid], run);
     }
   }
-  if (!last_block_done(a.ticket, nblk, bid)) return;
+  if (a.trace && threadIdx.x == 0) a.trace[(size_t)bid * 8 + 1] = wall_clock64();
+  if (!last_block_done(a.ticket, nblk, bid)) {
+    if (a.trace && threadIdx.x == 0) a.trace[(size_t)bid * 8 + 2] = wall_clock64();
+    return;
+  }
+  if (a.trace && threadIdx.x == 0) a.trace[(size_t)bid * 8 + 3] = wall_clock64();
 
   // scan of the per-workgroup counts: every thread takes PERC consecutive workgroups and requests their
   // counts together (one memory round trip per BLOCK * PERC workgroups; 512 workgroups = one pass), the
@@ -1862,6 +1867,7 @@ __device__ __forceinline__ void select_prep_body(const SelectArgs &a, const Geom
     if (threadIdx.x == 0) s_carry = carry + pass_total;
     __syncthreads();
   }
+  if (a.trace && threadIdx.x == 0) a.trace[(size_t)bid * 8 + 4] = wall_clock64();
   if (threadIdx.x == 0) {
     const long long total = s_carry;
     *a.count_host = total;
@@ -1890,11 +1896,19 @@ struct PairForcesArgs {
 };
 __global__ void __launch_bounds__(BLOCK) k_pair_forces_select(SelectArgs a, Geom g, HillList h, PairForcesArgs f) {
   extern __shared__ double2 lds_all[];
+  if (a.trace && threadIdx.x == 0) {
+    const size_t slot = blockIdx.x >= f.nk1 ? blockIdx.x - f.nk1 : f.nsel + blockIdx.x;   // (selection first, then K1)
+    a.trace[slot * 8] = wall_clock64();
+  }
   if (blockIdx.x >= f.nk1)
     select_prep_body<1>(a, g, h, blockIdx.x - f.nk1, f.nsel);
   else
     pair_forces_fast_body<false, BLOCK>(g, f.rec, f.n, f.r, f.force, f.block_energy, 0LL, 0, f.inv_dx, lds_all,
                                         blockIdx.x, f.nk1);
+  if (a.trace && threadIdx.x == 0) {
+    const size_t slot = blockIdx.x >= f.nk1 ? blockIdx.x - f.nk1 : f.nsel + blockIdx.x;
+    a.trace[slot * 8 + 7] = wall_clock64();
+  }
 }
 
 // The same pairing for fix edm_pair on a device-resident neighbour list: workgroups [0, nsel) run the selection over
