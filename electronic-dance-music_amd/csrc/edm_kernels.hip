@@ -1663,30 +1663,42 @@ __device__ __forceinline__ T acquire(const T *p) {
 }
 
 // The word the limiter's workgroup of k_integrals_gather publishes and the gather's workgroups poll:
-// [sequence number of the launch : 24][state : 8][k, first hill of the ordered tail : 32].  It may be published twice:
+// [sequence number of the launch : 40][state : 8][k, first hill of the ordered tail (< 2^16: chained batches hold at most
+// 2048 hills) : 16].  It may be published twice:
 //   state EDM_READY_BELOW -- (early, optional) the batch provably stays below the limit: the limiter will change no
 //                            height, every hill keeps its base height.  Published by a wave that adds the per-hill
 //                            integrals up while the limiter's wave is still walking them -- one round trip after
 //                            the last integral instead of the limiter's three -- with a margin far above the sum's
 //                            rounding (a near-tie waits for the limiter).
-//   state = limiter error (0 = none) -- the limiter's outputs are published, k is valid
-#define EDM_READY_BELOW 0xFD
+//   state EDM_READY_FINAL | limiter error (0 = none) -- the limiter's outputs are published, k is valid
+// Every publication is an atomic MAX: sequence numbers grow with the launches and FINAL > BELOW, so the limiter's own
+// word always stands whichever of the two arrives first, and the early wave needs no look at the word before it
+// writes (a compare-and-swap over the word it had read first cost it a dependent round trip, 1.2 us on the path of
+// every tile).
+#define EDM_READY_BELOW 0x01
+#define EDM_READY_FINAL 0x80
 __device__ __forceinline__ unsigned long long ready_word(unsigned long long seq, int state, long long k) {
-  return ((seq & 0xFFFFFFull) << 40) | ((unsigned long long)(state & 0xFF) << 32) | (unsigned long long)(unsigned)k;
+  return ((seq & 0xFFFFFFFFFFull) << 24) | ((unsigned long long)(state & 0xFF) << 16) | (unsigned long long)((unsigned)k & 0xFFFFu);
+}
+__device__ __forceinline__ unsigned long long ready_seq_of(unsigned long long w) { return w >> 24; }
+__device__ __forceinline__ int ready_state_of(unsigned long long w) { return (int)((w >> 16) & 0xFF); }
+__device__ __forceinline__ long long ready_k_of(unsigned long long w) { return (long long)(w & 0xFFFFull); }
+__device__ __forceinline__ void ready_publish(unsigned long long *word, unsigned long long w) {
+  (void)__hip_atomic_fetch_max(word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one thread waits until a word of launch `seq` is there (final: the limiter's own) and returns it (a few hundred
 // workgroups poll the same word: spaced ~0.2 us apart so that the polls do not crowd the round trips of the
 // workgroup that will store it)
 __device__ __forceinline__ unsigned long long wait_for_word(const unsigned long long *word, unsigned long long seq,
                                                             bool final = true) {
-  const unsigned long long want = seq & 0xFFFFFFull;
+  const unsigned long long want = seq & 0xFFFFFFFFFFull;
   unsigned long long w = acquire(word);
-  if ((w >> 40) == want && (!final || ((w >> 32) & 0xFF) != EDM_READY_BELOW)) return w;
+  if (ready_seq_of(w) == want && (!final || (ready_state_of(w) & EDM_READY_FINAL))) return w;
   const unsigned long long t0 = wall_clock64();
   for (;;) {
     __builtin_amdgcn_s_sleep(7);   // ~450 cycles
     w = acquire(word);
-    if ((w >> 40) == want && (!final || ((w >> 32) & 0xFF) != EDM_READY_BELOW)) return w;
+    if (ready_seq_of(w) == want && (!final || (ready_state_of(w) & EDM_READY_FINAL))) return w;
     if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();   // 10 s at 100 MHz: never, short of a lost launch
   }
 }
@@ -2504,7 +2516,7 @@ __device__ __forceinline__ void limiter_stage(const HillList &h, const double *_
       // the word carries what every gather workgroup needs first -- the error code and k, the first hill of the
       // ordered tail -- so that seeing it is all the waiting workgroups have to do when there is no tail
       __builtin_amdgcn_s_waitcnt(0);
-      if (threadIdx.x == 0) publish(la.ready_flag, ready_word(la.ready_seq, err, k_first));
+      if (threadIdx.x == 0) ready_publish(la.ready_flag, ready_word(la.ready_seq, EDM_READY_FINAL | err, k_first));
       if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 3] = wall_clock64();
     }
   } else if (concurrent && la.early_word && threadIdx.x >= NT - 64) {
@@ -2514,13 +2526,8 @@ __device__ __forceinline__ void limiter_stage(const HillList &h, const double *_
       double part = 0;
       for (long long i = threadIdx.x - (NT - 64); i < na; i += 64) part += fabs(acquire(&added[i]));
       part = wave_sum(part);
-      if (threadIdx.x == NT - 64 && n_true <= nb && (la.cum_in + part) * (1.0 + 1e-9) < la.limit) {
-        // only over the PREVIOUS launch's word: the limiter's own word, should it already be there, must stay
-        unsigned long long seen = acquire(la.ready_flag);
-        if ((seen >> 40) != (la.ready_seq & 0xFFFFFFull))
-          (void)__hip_atomic_compare_exchange_strong(la.ready_flag, &seen, ready_word(la.ready_seq, EDM_READY_BELOW, na),
-                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (threadIdx.x == NT - 64 && n_true <= nb && (la.cum_in + part) * (1.0 + 1e-9) < la.limit)
+        ready_publish(la.ready_flag, ready_word(la.ready_seq, EDM_READY_BELOW, na));   // (cannot displace the limiter's own word)
     }
   } else if (la.rb_dst) {
     readback_copy_hills<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x - 64, (concurrent && la.early_word) ? NT - 128 : NT - 64);
@@ -3187,12 +3194,12 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       if (trace && threadIdx.x == 0) trace[FUSED ? 3 : 2] = wall_clock64();
       waited = true;
       const unsigned long long word = s_word;
-      const int state = (int)((word >> 32) & 0xFF);
+      const int state = ready_state_of(word);
       if (state == EDM_READY_BELOW) {
         k_first_tail = nh_eff;   // no hill is touched by the limiter: base heights throughout
       } else {
-        if (state) return;  // limiter overflow / bound exceeded: the host handles it, nothing is applied
-        k_first_tail = (long long)(unsigned)(word & 0xFFFFFFFFull);
+        if (state & ~EDM_READY_FINAL) return;  // limiter overflow / bound exceeded: the host handles it, nothing is applied
+        k_first_tail = ready_k_of(word);
       }
       // 3. heights of the staged hills
       if ((int)threadIdx.x < cnt) {
@@ -3554,7 +3561,7 @@ __device__ __forceinline__ void fused_bookkeeper(const SelectArgs &a, const Hill
                      h.nh_dev, mirror, &k_first, &err, n_true, &fs, s_off);
     __builtin_amdgcn_s_waitcnt(0);
     // (only a tile that could not rule the limiter out waits for this word)
-    if (threadIdx.x == 0) publish(la.ready_flag, ready_word(la.ready_seq, err, k_first));
+    if (threadIdx.x == 0) ready_publish(la.ready_flag, ready_word(la.ready_seq, EDM_READY_FINAL | err, k_first));
     if (trace && threadIdx.x == 0) trace[3] = wall_clock64();
   } else {
     auto put = [mirror](double *p, double v) {
@@ -3610,11 +3617,19 @@ __global__ void __launch_bounds__(BLOCK) k_integrals_gather(Geom g, Tables t, do
                                                             const double *__restrict__ heights, double h_const,
                                                             double *__restrict__ added, LimitArgs la, HillHeights hh,
                                                             GatherPlan plan, int *__restrict__ dirty_flag, PostArgs post,
-                                                            unsigned nb_int) {
-#define EDM_STAMP(k) do { if (la.trace && threadIdx.x == 0) la.trace[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+                                                            unsigned nb_int, unsigned tiles_first) {
+  // Dispatch order.  The tiles wait for the limiter's word, so they must never keep the integrals' workgroups off the
+  // machine: with the integrals first that holds by construction, but the launch is sized by a BOUND on the hill count
+  // (628 integrals workgroups for ~125 hills) and the tiles -- whose terms are the longest stretch of the launch --
+  // then start 2-4 us late, behind hundreds of workgroups that exit at once.  When the tiles cannot fill the machine
+  // (host-checked against two resident workgroups per CU) they go first.
+  // (`wg`: this workgroup's index in the order integrals | tiles, which the stamps and the rest of the code use)
+  const unsigned ntile_all = gridDim.x - nb_int;
+  const unsigned wg = tiles_first ? (blockIdx.x < ntile_all ? nb_int + blockIdx.x : blockIdx.x - ntile_all) : blockIdx.x;
+#define EDM_STAMP(k) do { if (la.trace && threadIdx.x == 0) la.trace[(size_t)wg * 8 + (k)] = wall_clock64(); } while (0)
   EDM_STAMP(0);
-  if (blockIdx.x < nb_int) {
-    const bool ran_limiter = hill_integrals_body<1, BLOCK, PERB>(g, t, h, heights, h_const, added, la, blockIdx.x);
+  if (wg < nb_int) {
+    const bool ran_limiter = hill_integrals_body<1, BLOCK, PERB>(g, t, h, heights, h_const, added, la, wg);
     // the CV histogram needs the limiter's flags and the hills' positions, nothing of the gather: the limiter's
     // workgroup updates it while the gather applies heights (edm_bias.cpp:601-610)
     if (ran_limiter && post.enabled && !la.res->error)
@@ -3622,14 +3637,14 @@ __global__ void __launch_bounds__(BLOCK) k_integrals_gather(Geom g, Tables t, do
     EDM_STAMP(7);
     return;
   }
-  const unsigned tile = blockIdx.x - nb_int, ntile = gridDim.x - nb_int;
+  const unsigned tile = wg - nb_int, ntile = ntile_all;
   // (chained bookkeeping that is only the boundary duplication: boundary corrections are noted in LDS and travel in
   //  the ticket, see tile_ticket_duplicate)
   __shared__ int s_dirty, s_last;
   const bool ticket_dirty = post.enabled && post.skip_hist && !post.rb_dst && ntile < 0xFFFFu;
   if (threadIdx.x == 0) s_dirty = 0;
   hill_gather_body<1, 0, 8, PERB, true>(g, t, rec, h, hh, plan, 0, dirty_flag, post.enabled, tile, la.ready_flag, la.ready_seq,
-                                        la.trace ? la.trace + (size_t)blockIdx.x * 8 : nullptr, nullptr, nullptr, nullptr, nullptr,
+                                        la.trace ? la.trace + (size_t)wg * 8 : nullptr, nullptr, nullptr, nullptr, nullptr,
                                         nullptr, ticket_dirty ? &s_dirty : nullptr);
   EDM_STAMP(6);
   if (!post.enabled) return;
@@ -3856,12 +3871,16 @@ hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, 
   }
   const unsigned nb_int = (unsigned)h.nh;
   const unsigned nb_tiles = (unsigned)((g.n[0] + BLOCK / 8 - 1) / (BLOCK / 8));
+  // tiles first iff the waiting tiles can never fill the machine: the kernel keeps two workgroups per CU resident at
+  // the very least (157 registers: three waves per SIMD; 59 KB of LDS: two per CU), so with 64 slots to spare the
+  // integrals' workgroups -- which wait for nobody -- always find room to run through
+  const unsigned tiles_first = ((size_t)nb_tiles + 64 <= (size_t)2 * cu_count()) ? 1u : 0u;
   if (!g.bper[0])
     hipLaunchKernelGGL((k_integrals_gather<false>), dim3(nb_int + nb_tiles), dim3(BLOCK), 0, s, g, t, rec, h, heights, h_const,
-                       added, la, hh, plan, dirty_flag, post, nb_int);
+                       added, la, hh, plan, dirty_flag, post, nb_int, tiles_first);
   else
     hipLaunchKernelGGL((k_integrals_gather<true>), dim3(nb_int + nb_tiles), dim3(BLOCK), 0, s, g, t, rec, h, heights, h_const,
-                       added, la, hh, plan, dirty_flag, post, nb_int);
+                       added, la, hh, plan, dirty_flag, post, nb_int, tiles_first);
   return hipGetLastError();
 }
 
