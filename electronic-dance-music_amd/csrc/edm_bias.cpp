@@ -838,6 +838,10 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   } else {
     b->hills_added += (int)k;
   }
+  if (oc.plain_fast) {   // every hill of the tail was added in full (and there is no log to write): nothing to replay
+    b->hills_added += ntail;
+    return EDM_HIP_OK;
+  }
   // ordered tail: the log lines, and the overflow appends of edm_bias.cpp:498-523
   for (int j = 0; j < ntail; j++) {
     const double *p = &oc.pos[(size_t)(k - first + j) * dim];

@@ -1168,6 +1168,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     out->total_added = 0;
     out->flags.clear(); out->h2.clear(); out->a2.clear(); out->pos.clear(); out->added.clear(); out->heights.clear();
     out->first = nh;
+    out->plain_fast = false;
   }
   if (nh <= 0) return EDM_HIP_OK;
   hipStream_t s = g->stream;
@@ -1763,16 +1764,42 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   const double *st_added = reinterpret_cast<const double *>(stage + off_added);
   const double *st_pos = reinterpret_cast<const double *>(stage + off_pos);
   g->wait_polled = false;
+  bool plain_fast = false;
+  LimitResult header_res;
+  memset(&header_res, 0, sizeof(header_res));
   static const bool host_trace = getenv("EDM_HIP_TRACE") != nullptr;   // development aid: host-side stamps
   const auto ht_before_poll = std::chrono::steady_clock::now();
   if (polled) {
     // the limiter's workgroup flags the host-mapped region once it is complete: poll the word instead of waiting
     // for the stream's completion signal (bounded; falls back to the stream wait)
     volatile unsigned long long *w = reinterpret_cast<volatile unsigned long long *>(g->h_stage + g->h_stage_bytes - 128);
+    // ... or, sooner, its header line: the limiter's wave writes the 64-byte result to the host with ONE instruction,
+    // the batch's number in its last two words (LimitResult).  If that line says every hill was added in full and the
+    // caller wants neither positions nor per-hill bias, nothing else of the region is needed and the call returns
+    // ~3 us before the acknowledgements of the region's other stores would let the completion word out.
+    volatile unsigned long long *hd = reinterpret_cast<volatile unsigned long long *>(stage);
+    static const bool header_env = !(getenv("EDM_HIP_FAST_HEADER") && getenv("EDM_HIP_FAST_HEADER")[0] == '0');   // (A/B and tests)
+    bool header_may_do = header_env && spec.limited && !spec.flush_mode && !spec.fetch_all && out != nullptr;
     const unsigned long long want = g->done_seq;
     const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
     bool seen = false;
     for (unsigned spin = 0;; spin++) {
+      if (header_may_do && hd[7] == want && hd[6] == want) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        unsigned long long line[8];
+        for (int i = 0; i < 8; i++) line[i] = hd[i];
+        if (line[6] == want && line[7] == want) {
+          LimitResult hr;
+          memcpy(&hr, line, sizeof(hr));
+          if (hr.all_plain && !hr.error) {
+            header_res = hr;
+            plain_fast = true;
+            seen = true;
+            break;
+          }
+        }
+        header_may_do = false;   // (the limiter changed something: the rest of the region is needed)
+      }
       if (w[0] == want) { seen = true; break; }
       __builtin_ia32_pause();
       if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
@@ -1796,7 +1823,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   }
   long long nh_act = nh;
   if (spec.limited) {
-    res = *hres;
+    res = plain_fast ? header_res : *hres;
     if (res.error == 2) {
       if (out) out->res = res;
       return EDM_APPLY_BOUND_EXCEEDED;  // deferred count above the launch bound: nothing was applied
@@ -1825,7 +1852,9 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     const long long first = spec.fetch_all ? 0 : k;
     out->first = first;
     const long long need = nh_act - first;
-    if (small) {
+    if (plain_fast) {
+      out->plain_fast = true;   // (flags 1, undo heights 0, undo bias 0 throughout; positions and per-hill bias not asked for)
+    } else if (small) {
       out->flags.assign(st_flags, st_flags + ntail);
       out->h2.assign(st_h2, st_h2 + ntail);
       out->a2.assign(st_a2, st_a2 + ntail);

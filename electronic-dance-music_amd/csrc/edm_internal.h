@@ -221,6 +221,9 @@ struct ApplyOutcome {
   long long first = 0;
   std::vector<double> pos, added;
   std::vector<double> heights;     // per-hill base heights of [first, nh) when spec.d_h was given
+  // the batch was released by its header line alone (see LimitResult): every hill was added in full, nothing deferred,
+  // nobody asked for positions / per-hill bias -- flags, h2, a2, pos, added above are EMPTY (they would read 1, 0, 0)
+  bool plain_fast = false;
 };
 // prep -> integrals -> (limiter) -> ordered gather -> boundary duplication.
 // Leaves per-hill `added` in g->ws.added and the tail arrays in g->ws.tail_*.

@@ -330,7 +330,17 @@ struct LimitResult {
   int stop;                // flush mode: tail-relative index where the flush stopped, or n_tail
   int n_deferred;          // new-hill mode: hills (whole or remainder) to append to the overflow buffer
   int error;               // 1 = tail longer than EDM_TAIL_CAP, 2 = deferred count exceeded the launch bound
+  // The rest completes an aligned 64-byte line.  In the packed read-back region this struct is the header; the
+  // limiter's wave stores the WHOLE line to the host copy with ONE instruction (eight lanes of 8 bytes: one 64-byte
+  // write), the batch's sequence number in the last two words -- so the host may take the header the moment both show
+  // the number it waits for, without waiting for the acknowledgement of every other store into the region (~3 us on
+  // PCIe).  all_plain (new hills only): every hill of the batch was added in full -- no undo, nothing deferred -- so
+  // flags, undo heights and undo bias need not be read at all (they are 1, 0, 0).
+  int all_plain;
+  int pad0;
+  unsigned long long seq_head, seq_tail;
 };
+static_assert(sizeof(LimitResult) == 64, "the limiter's result is one 64-byte line");
 // flags per tail hill: bit0 = applied (an 'h'/'b' hill was added), bit1 = undo hill
 // added too ('u'/'v'), bit2 = deferred to the overflow buffer
 struct LimitTail {

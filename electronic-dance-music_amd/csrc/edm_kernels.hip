@@ -2309,7 +2309,8 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            const double *chunk_sum, const double *chunk_max,
                                            const long long *nh_dev, long long mirror = 0, long long *k_out = nullptr,
                                            int *err_out = nullptr, long long nh_known = -1,
-                                           const FusedStep *fsrc = nullptr, const unsigned short *fs_off = nullptr);
+                                           const FusedStep *fsrc = nullptr, const unsigned short *fs_off = nullptr,
+                                           LimitResult *out_local = nullptr);
 
 // The stencil walk of one hill by TPH cooperating threads (lt = this thread's index among them): the thread's share of
 // height * (expo + corr) * vol over the reference's stencil (gaussian_grid.h:227-281), summed in stencil order.  The
@@ -2487,6 +2488,21 @@ __device__ __forceinline__ double hill_stencil_partial(const Geom &g, const Tabl
   return acc;
 }
 
+// The limiter's result -- the header of the packed read-back region -- to its host copy as ONE 64-byte write: lanes 0..7
+// of the calling wave (which all hold the same result) store 8 bytes each with a single instruction, the batch's sequence
+// number in the last two words.  See LimitResult.
+__device__ __forceinline__ void header_line_to_host(unsigned long long *host_line, const LimitResult &r, unsigned long long seq) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long piece = seq;   // lanes 6, 7: seq_head, seq_tail
+  if (lane == 0) piece = (unsigned long long)__double_as_longlong(r.cum_out);
+  if (lane == 1) piece = (unsigned long long)r.k;
+  if (lane == 2) piece = (unsigned long long)r.nh;
+  if (lane == 3) piece = (unsigned long long)(unsigned)r.n_tail | ((unsigned long long)(unsigned)r.stop << 32);
+  if (lane == 4) piece = (unsigned long long)(unsigned)r.n_deferred | ((unsigned long long)(unsigned)r.error << 32);
+  if (lane == 5) piece = (unsigned long long)(unsigned)r.all_plain;
+  if (lane < 8) __hip_atomic_store(host_line + lane, piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The serial stage behind the per-hill integrals, run by ONE workgroup once all of them are published: ordered
 // limiter (wave 0), read-back region to host-mapped memory, release of the host.  n_true_known >= 0: the caller
 // knows the batch's true hill count (else it is read from h.nh_dev); k1_done: see below.
@@ -2510,8 +2526,16 @@ __device__ __forceinline__ void limiter_stage(const HillList &h, const double *_
   if (threadIdx.x < 64) {
     long long k_first = 0;
     int err = 0;
+    LimitResult rl;
     limit_wave<true>(h.nh, added, heights, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr,
-               nullptr, h.nh_dev, mirror, &k_first, &err, h.nh_dev ? n_true : -1);
+               nullptr, h.nh_dev, mirror, &k_first, &err, h.nh_dev ? n_true : -1, nullptr, nullptr, &rl);
+    if (la.rb_dst && la.done_flag) {
+      // (the device copy of the header carries the number too: the copy of the region that follows must not put a
+      //  stale one over the line the host may be looking at)
+      if (threadIdx.x == 6) publish(&la.res->seq_head, la.done_seq);
+      if (threadIdx.x == 7) publish(&la.res->seq_tail, la.done_seq);
+      header_line_to_host(reinterpret_cast<unsigned long long *>(la.rb_dst), rl, la.done_seq);
+    }
     if (concurrent) {
       // the word carries what every gather workgroup needs first -- the error code and k, the first hill of the
       // ordered tail -- so that seeing it is all the waiting workgroups have to do when there is no tail
@@ -4584,7 +4608,10 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            const LimitTail &tail, LimitResult *res, long long nchunks,
                                            const double *chunk_sum, const double *chunk_max,
                                            const long long *nh_dev, long long mirror, long long *k_out, int *err_out,
-                                           long long nh_known, const FusedStep *fsrc, const unsigned short *fs_off) {
+                                           long long nh_known, const FusedStep *fsrc, const unsigned short *fs_off,
+                                           LimitResult *out_local) {
+  // (out_local: the result as every lane of the wave holds it -- the walk is uniform -- for a caller that writes the
+  //  header line to the host in one instruction)
   // (fsrc, k_pair_step: the per-hill bias is read from the selection workgroups' records, hill i found through the
   //  scanned counts in LDS -- no ordered array has been written yet)
   // (k_out / err_out: the first tail hill and the error code, for a caller that hands them on in registers;
@@ -4611,6 +4638,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
       __hip_atomic_store(reinterpret_cast<long long *>(reinterpret_cast<char *>(p) + mirror), v, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
   };
+  int plain_l = flush_mode ? 0 : 1;   // new hills: so far every hill was added in full
   auto put_result = [&](double cum_out, long long k_, long long nh_, int n_tail, int stop_, int n_def_, int error) {
     put_f64(&res->cum_out, cum_out);
     put_i64(&res->k, k_);
@@ -4619,6 +4647,18 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
     put_i32(&res->stop, stop_);
     put_i32(&res->n_deferred, n_def_);
     put_i32(&res->error, error);
+    put_i32(&res->all_plain, (error == 0 && n_def_ == 0) ? plain_l : 0);
+  };
+  auto keep_local = [&](double cum_out, long long k_, long long nh_, int n_tail, int stop_, int n_def_, int error) {
+    if (!out_local) return;
+    out_local->cum_out = cum_out;
+    out_local->k = k_;
+    out_local->nh = nh_;
+    out_local->n_tail = n_tail;
+    out_local->stop = stop_;
+    out_local->n_deferred = n_def_;
+    out_local->error = error;
+    out_local->all_plain = (error == 0 && n_def_ == 0) ? plain_l : 0;
   };
   long long nh = nh_bound;
   if (k_out) *k_out = 0;
@@ -4627,6 +4667,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
     nh = nh_known >= 0 ? nh_known : *nh_dev;
     if (nh > nh_bound) {  // the batch was queued with too small a bound: nothing is applied
       if (threadIdx.x == 0) put_result(cum_in, 0, nh, 0, 0, 0, 2);
+      keep_local(cum_in, 0, nh, 0, 0, 0, 2);
       if (err_out) *err_out = 2;
       return;
     }
@@ -4662,6 +4703,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
   const long long ntail = nh - k;
   if (ntail > EDM_TAIL_CAP) {
     if (lane == 0) put_result(cum, k, nh, 0, 0, 0, 1);
+    keep_local(cum, k, nh, 0, 0, 0, 1);
     if (err_out) *err_out = 1;
     return;
   }
@@ -4751,6 +4793,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
       cum = after;
       start = j1 + 1;
     }
+    if (__ballot(lane < lim && o_fl != 1) != 0ull) plain_l = 0;
     if (lane < lim) {
       const long long ti = base + lane;
       if (COHERENT) publish(&tail.h1[ti], o_h1); else tail.h1[ti] = o_h1;
@@ -4761,6 +4804,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
     }
   }
   if (lane == 0) put_result(cum, k, nh, (int)ntail, stop, n_def, 0);
+  keep_local(cum, k, nh, (int)ntail, stop, n_def, 0);
   if (k_out) *k_out = k;
 }
 
