@@ -598,12 +598,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # K1's launch is stamped (dispatch begin / end timestamps) on a few steps of the timed region -- 2 of 20, 10 of 200:
+    # K1's launch is stamped (dispatch begin / end timestamps) on a few steps of the timed region -- 1 of 20, 10 of 200:
     # a stamped launch costs the stream ~15 us (an unstamped step takes ~31 us; every 4th step stamped, round 1's
     # choice, added 3.5 us to EVERY step of the average), so a sparse sample keeps `ms_per_step` what the step costs.
     # (EDM_BENCH_TIMED_EVERY overrides; the first stamped launch of a process pays for switching the queue's profiling
     #  on -- spent here on two extra warm-up steps, outside the timed region)
-    n_stamps = min(10, max(2, args.steps // 10))
+    n_stamps = min(10, max(1, args.steps // 20))
     TIMED_EVERY = int(os.environ.get("EDM_BENCH_TIMED_EVERY", "0")) or max(1, args.steps // n_stamps)
     g.profile_enable(1)
     for _ in range(2):
