@@ -1297,6 +1297,7 @@ int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
   G("polled_batches", b->bias ? b->bias->polled_batches : 0)
   G("fused_steps", b->bias ? b->bias->fused_steps : 0)
   G("poll_fallbacks", b->bias ? b->bias->poll_fallbacks : 0)
+  G("header_releases", b->bias ? b->bias->header_releases : 0)
   G("bound_redos", b->bound_redos)
 #undef G
   set_error(std::string("unknown EDMBias member ") + name);

@@ -1794,6 +1794,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
           if (hr.all_plain && !hr.error) {
             header_res = hr;
             plain_fast = true;
+            g->header_releases++;
             seen = true;
             break;
           }

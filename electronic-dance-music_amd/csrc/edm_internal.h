@@ -111,6 +111,7 @@ struct edm_hip_gauss {
   unsigned long long done_seq = 0;       // sequence number of the last polled read-back (see PostSpec::done_flag)
   long long polled_batches = 0;          // hill batches whose completion was seen through the polled word ...
   long long poll_fallbacks = 0;          // ... and batches whose poll ran out (the stream wait took over)
+  long long header_releases = 0;         // polled batches released by their header line alone (see LimitResult)
   bool wait_polled = false;              // the last apply_hills saw its results through the polled words: the
                                          // stream was NOT synchronised (its last kernel may still be retiring)
   int *d_dirty = nullptr;

@@ -70,6 +70,29 @@ def main(workdir):
     gv, gd = b.gauss.download()
     feed(gv, gd, b.hist.values, [b.get("cum_bias"), b.get("overflow_right"), b.get("hills_added")])
     del b
+    # 1-D pair CV, no HILLS log, limiter far away: the steps whose host call returns on the limiter's HEADER LINE alone
+    # (EDM_HIP_FAST_HEADER=0 makes them wait for the completion word like every other polled batch)
+    cfg = os.path.join(workdir, "p3.edm")
+    open(cfg, "w").write("tempering 0\nhill_prefactor 0.5\nhill_density 120\nbias_per_step 50\ndimension 1\nbox_low 0\n"
+                         "box_high 2.8\nbias_spacing 0.00025\nbias_sigma 0.025\nhills_filename %s/HILLS_p3\n"
+                         "histogram_filename %s/HIST_p3\n" % (workdir, workdir))
+    b = H.Bias(cfg)
+    b.setup(1.0, 1.0)
+    b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    b.set_hill_log(False)
+    n = 200_000
+    for step in range(12):
+        r = W.pair_distances(n, 1500 + step)
+        d_r = H.DeviceArray.from_host(r)
+        d_u = H.DeviceArray.from_host(W.uniform(1550 + step, n))
+        d_f = H.DeviceArray.zeros((n,))
+        e = b.pair_step_device(d_r, d_f, n, d_r, d_u, n, est=n)
+        v, dv = b.gauss.get_value_deriv(probe)
+        feed([e], v, dv, d_f.to_host(), [b.get("cum_bias"), b.get("hills_added"), b.get("overflow_right")])
+    gv, gd = b.gauss.download()
+    feed(gv, gd, b.hist.values)
+    print("HEADER_RELEASES", int(b.get("header_releases")))
+    del b
     print("DIGEST", dig.hexdigest())
 
 

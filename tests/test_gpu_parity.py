@@ -909,19 +909,27 @@ def test_polled_completion_equals_stream_wait(workdir):
 
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "poll_worker.py")
     digests = []
-    for tag, val in (("polled", None), ("waited", "0")):
+    releases = []
+    # polled (short unlogged batches the limiter leaves alone are released by their header line), polled without the
+    # header-line release, and every batch waiting for its stream
+    for tag, poll, header in (("polled", None, None), ("polled_no_header", None, "0"), ("waited", "0", None)):
         d = workdir / tag
         d.mkdir()
         env = dict(os.environ)
         env.pop("EDM_HIP_POLL", None)
-        if val is not None:
-            env["EDM_HIP_POLL"] = val
+        env.pop("EDM_HIP_FAST_HEADER", None)
+        if poll is not None:
+            env["EDM_HIP_POLL"] = poll
+        if header is not None:
+            env["EDM_HIP_FAST_HEADER"] = header
         res = subprocess.run([sys.executable, worker, str(d)], env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
         lines = [ln for ln in res.stdout.splitlines() if ln.startswith("DIGEST ")]
         assert lines, res.stdout[-2000:]
         digests.append(lines[-1])
-    assert digests[0] == digests[1]
+        releases.append(int([ln for ln in res.stdout.splitlines() if ln.startswith("HEADER_RELEASES ")][-1].split()[1]))
+    assert digests[0] == digests[1] == digests[2]
+    assert releases[0] >= 10 and releases[1] == 0 and releases[2] == 0, releases
 
 
 def test_polled_completion_is_what_releases_short_batches(workdir):
