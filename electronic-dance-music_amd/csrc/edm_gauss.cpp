@@ -1468,6 +1468,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         la.done_flag = reinterpret_cast<unsigned long long *>(g->d_stage + g->h_stage_bytes - 128);
         la.done_seq = ++g->done_seq;
         polled = true;
+        // (the 128 bytes in front of the completion word: the limiter's result as one line, see the poll below)
+        if (rb_bytes + 256 <= g->h_stage_bytes) la.fast_line = reinterpret_cast<unsigned long long *>(g->d_stage + g->h_stage_bytes - 256);
       }
     }
     hh.res_dev = dres;
@@ -1777,20 +1779,20 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     // the batch's number in its last two words (LimitResult).  If that line says every hill was added in full and the
     // caller wants neither positions nor per-hill bias, nothing else of the region is needed and the call returns
     // ~3 us before the acknowledgements of the region's other stores would let the completion word out.
-    volatile unsigned long long *hd = reinterpret_cast<volatile unsigned long long *>(stage);
+    volatile unsigned long long *hd = reinterpret_cast<volatile unsigned long long *>(g->h_stage + g->h_stage_bytes - 256);
     static const bool header_env = !(getenv("EDM_HIP_FAST_HEADER") && getenv("EDM_HIP_FAST_HEADER")[0] == '0');   // (A/B and tests)
-    bool header_may_do = header_env && spec.limited && !spec.flush_mode && !spec.fetch_all && out != nullptr;
+    bool header_may_do = header_env && spec.limited && !spec.flush_mode && !spec.fetch_all && out != nullptr &&
+                         rb_bytes + 256 <= g->h_stage_bytes;
     const unsigned long long want = g->done_seq;
     const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
     bool seen = false;
     for (unsigned spin = 0;; spin++) {
-      if (header_may_do && hd[7] == want && hd[6] == want) {
+      if (header_may_do && hd[0] == want && hd[7] == want) {
         std::atomic_thread_fence(std::memory_order_acquire);
         unsigned long long line[8];
         for (int i = 0; i < 8; i++) line[i] = hd[i];
-        if (line[6] == want && line[7] == want) {
-          LimitResult hr;
-          memcpy(&hr, line, sizeof(hr));
+        LimitResult hr;
+        if (edm_header_line_decode(line, want, &hr)) {
           if (hr.all_plain && !hr.error) {
             header_res = hr;
             plain_fast = true;

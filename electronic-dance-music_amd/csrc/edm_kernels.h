@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime_api.h>
+#include <string.h>
 
 #include "edm_common.h"
 
@@ -330,16 +331,30 @@ struct LimitResult {
   int stop;                // flush mode: tail-relative index where the flush stopped, or n_tail
   int n_deferred;          // new-hill mode: hills (whole or remainder) to append to the overflow buffer
   int error;               // 1 = tail longer than EDM_TAIL_CAP, 2 = deferred count exceeded the launch bound
-  // The rest completes an aligned 64-byte line.  In the packed read-back region this struct is the header; the
-  // limiter's wave stores the WHOLE line to the host copy with ONE instruction (eight lanes of 8 bytes: one 64-byte
-  // write), the batch's sequence number in the last two words -- so the host may take the header the moment both show
-  // the number it waits for, without waiting for the acknowledgement of every other store into the region (~3 us on
-  // PCIe).  all_plain (new hills only): every hill of the batch was added in full -- no undo, nothing deferred -- so
-  // flags, undo heights and undo bias need not be read at all (they are 1, 0, 0).
+  // new hills only: every hill of the batch was added in full -- no undo, nothing deferred -- so flags, undo heights
+  // and undo bias need not be read at all (they are 1, 0, 0)
   int all_plain;
   int pad0;
-  unsigned long long seq_head, seq_tail;
+  unsigned long long reserved[2];   // (the header of the packed read-back region is one 64-byte line)
 };
+// The limiter's wave also sends its result to a line of its own in host memory (LimitArgs::fast_line) as ONE 64-byte
+// store (header_line_to_host in edm_kernels.hip):
+// eight words [seq | cum_out | k | nh | n_tail, stop | n_deferred, error | all_plain | seq], the batch's number first
+// and last.  The host may take that line the moment both show the number it waits for, without waiting for the
+// acknowledgement of every other store into the region (~3 us on PCIe).
+inline bool edm_header_line_decode(const unsigned long long line[8], unsigned long long want, LimitResult *out) {
+  if (line[0] != want || line[7] != want) return false;
+  memset(out, 0, sizeof(*out));
+  memcpy(&out->cum_out, &line[1], 8);
+  out->k = (long long)line[2];
+  out->nh = (long long)line[3];
+  out->n_tail = (int)(unsigned)(line[4] & 0xFFFFFFFFull);
+  out->stop = (int)(unsigned)(line[4] >> 32);
+  out->n_deferred = (int)(unsigned)(line[5] & 0xFFFFFFFFull);
+  out->error = (int)(unsigned)(line[5] >> 32);
+  out->all_plain = (int)(unsigned)(line[6] & 0xFFFFFFFFull);
+  return true;
+}
 static_assert(sizeof(LimitResult) == 64, "the limiter's result is one 64-byte line");
 // flags per tail hill: bit0 = applied (an 'h'/'b' hill was added), bit1 = undo hill
 // added too ('u'/'v'), bit2 = deferred to the overflow buffer
@@ -370,6 +385,9 @@ struct LimitArgs {
   char *rb_dst;
   unsigned long long *done_flag;
   unsigned long long done_seq;
+  // optional, with done_flag: 64 bytes of host-mapped memory that receive the limiter's result as one store the moment
+  // the limiter's wave has it (see edm_header_line_decode)
+  unsigned long long *fast_line;
   // k_integrals_gather: device word the gather workgroups of the same launch poll for ready_seq
   unsigned long long *ready_flag;
   unsigned long long ready_seq;

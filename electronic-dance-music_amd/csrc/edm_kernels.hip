@@ -2488,18 +2488,20 @@ __device__ __forceinline__ double hill_stencil_partial(const Geom &g, const Tabl
   return acc;
 }
 
-// The limiter's result -- the header of the packed read-back region -- to its host copy as ONE 64-byte write: lanes 0..7
-// of the calling wave (which all hold the same result) store 8 bytes each with a single instruction, the batch's sequence
-// number in the last two words.  See LimitResult.
+// The limiter's result to a 64-byte line of its own in host-mapped memory (LimitArgs::fast_line) as ONE write: lanes 0..7
+// of the calling wave (which all hold the same result) store 8 bytes each with a single instruction --
+//   [seq | cum_out | k | nh | n_tail, stop | n_deferred, error | all_plain | seq]
+// -- the batch's sequence number in the FIRST and the LAST word, so that a reader who finds both has the line whole even
+// if the write travelled as two halves (edm_header_line_decode in edm_kernels.h).
 __device__ __forceinline__ void header_line_to_host(unsigned long long *host_line, const LimitResult &r, unsigned long long seq) {
   const int lane = threadIdx.x & 63;
-  unsigned long long piece = seq;   // lanes 6, 7: seq_head, seq_tail
-  if (lane == 0) piece = (unsigned long long)__double_as_longlong(r.cum_out);
-  if (lane == 1) piece = (unsigned long long)r.k;
-  if (lane == 2) piece = (unsigned long long)r.nh;
-  if (lane == 3) piece = (unsigned long long)(unsigned)r.n_tail | ((unsigned long long)(unsigned)r.stop << 32);
-  if (lane == 4) piece = (unsigned long long)(unsigned)r.n_deferred | ((unsigned long long)(unsigned)r.error << 32);
-  if (lane == 5) piece = (unsigned long long)(unsigned)r.all_plain;
+  unsigned long long piece = seq;   // lanes 0 and 7
+  if (lane == 1) piece = (unsigned long long)__double_as_longlong(r.cum_out);
+  if (lane == 2) piece = (unsigned long long)r.k;
+  if (lane == 3) piece = (unsigned long long)r.nh;
+  if (lane == 4) piece = (unsigned long long)(unsigned)r.n_tail | ((unsigned long long)(unsigned)r.stop << 32);
+  if (lane == 5) piece = (unsigned long long)(unsigned)r.n_deferred | ((unsigned long long)(unsigned)r.error << 32);
+  if (lane == 6) piece = (unsigned long long)(unsigned)r.all_plain;
   if (lane < 8) __hip_atomic_store(host_line + lane, piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -2529,13 +2531,7 @@ __device__ __forceinline__ void limiter_stage(const HillList &h, const double *_
     LimitResult rl;
     limit_wave<true>(h.nh, added, heights, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr,
                nullptr, h.nh_dev, mirror, &k_first, &err, h.nh_dev ? n_true : -1, nullptr, nullptr, &rl);
-    if (la.rb_dst && la.done_flag) {
-      // (the device copy of the header carries the number too: the copy of the region that follows must not put a
-      //  stale one over the line the host may be looking at)
-      if (threadIdx.x == 6) publish(&la.res->seq_head, la.done_seq);
-      if (threadIdx.x == 7) publish(&la.res->seq_tail, la.done_seq);
-      header_line_to_host(reinterpret_cast<unsigned long long *>(la.rb_dst), rl, la.done_seq);
-    }
+    if (la.fast_line) header_line_to_host(la.fast_line, rl, la.done_seq);
     if (concurrent) {
       // the word carries what every gather workgroup needs first -- the error code and k, the first hill of the
       // ordered tail -- so that seeing it is all the waiting workgroups have to do when there is no tail
