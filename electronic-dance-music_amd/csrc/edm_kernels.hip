@@ -3577,12 +3577,20 @@ __device__ __forceinline__ void fused_bookkeeper(const SelectArgs &a, const Hill
   if (threadIdx.x < 64) {
     long long k_first = 0;
     int err = 0;
+    LimitResult rl;
     limit_wave<true>(nb, added, nullptr, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr, nullptr,
-                     h.nh_dev, mirror, &k_first, &err, n_true, &fs, s_off);
+                     h.nh_dev, mirror, &k_first, &err, n_true, &fs, s_off, &rl);
     __builtin_amdgcn_s_waitcnt(0);
     // (only a tile that could not rule the limiter out waits for this word)
     if (threadIdx.x == 0) ready_publish(la.ready_flag, ready_word(la.ready_seq, EDM_READY_FINAL | err, k_first));
     if (trace && threadIdx.x == 0) trace[3] = wall_clock64();
+    if (la.fast_line) {
+      // the result as one line for a host that needs nothing else (see header_line_to_host) -- once the pair forces of
+      // this launch are complete too: the host reads their energy sums the moment it is released
+      if (threadIdx.x == 0) wait_counter(fs.k1_done, fs.k1_target);
+      __builtin_amdgcn_wave_barrier();
+      header_line_to_host(la.fast_line, rl, la.done_seq);
+    }
   } else {
     auto put = [mirror](double *p, double v) {
       publish(p, v);
