@@ -1181,14 +1181,28 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     b->d_mask = saved_mask;
     b->pl_view_x = nullptr;
   }
+  // (a step without hills: the force pass goes alone, its workgroups tag their partial energy sums and the host looks at
+  //  the slots instead of waiting for the stream, see edm_hip_gauss_pair_forces)
+  unsigned long long tag = 0;
+  if (b->pending.active && !hill_step && forces_poll_enabled()) {
+    tag = ++b->bias->force_seq;
+    b->pending.pl.partial_tag = tag;
+  }
   int rcf = pending_forces_flush(b->bias, &b->pending);   // (no hill launch carried it: nothing has touched the grid)
   if (rc) return rc;
   if (rcf) return rcf;
   const int nblk = b->pending.nblk;
+  double e = 0;
+  if (tag && poll_tagged_partials(b->bias, nblk, tag, &e)) {
+    b->bias->polled_forces++;
+    if (energy) *energy = e;
+    if (ncalls) *ncalls = 0;
+    return EDM_HIP_OK;
+  }
   // (a polled hill batch has shown the stream past the force pass queued ahead of it)
   if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(s));
-  double e = 0;
-  for (int k = 0; k < nblk; k++) e += b->bias->h_partials[k];
+  e = 0;
+  for (int k = 0; k < nblk; k++) e += b->bias->h_partials[tag ? 2 * k : k];
   if (energy) *energy = e;
   if (ncalls) *ncalls = hill_step ? b->pl_calls : 0;
   return hill_step ? do_post_add_hill(b) : EDM_HIP_OK;
@@ -1298,6 +1312,7 @@ int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
   G("fused_steps", b->bias ? b->bias->fused_steps : 0)
   G("poll_fallbacks", b->bias ? b->bias->poll_fallbacks : 0)
   G("header_releases", b->bias ? b->bias->header_releases : 0)
+  G("polled_forces", b->bias ? b->bias->polled_forces : 0)
   G("bound_redos", b->bound_redos)
 #undef G
   set_error(std::string("unknown EDMBias member ") + name);

@@ -897,9 +897,27 @@ int edm_hip_gauss_update_forces(const edm_hip_gauss *g, long long n, const doubl
                                 int f_stride, const int *d_mask, int apply_mask, double *energy) {
   if (energy) *energy = 0;
   int nblk = 0;
-  int rc = edm::update_forces_enqueue(g, n, d_x, x_stride, d_f, f_stride, d_mask, apply_mask, &nblk);
+  // (a forces-only call: the workgroups tag their partial energy sums and the host looks at the slots instead of
+  //  waiting for the stream, see edm_hip_gauss_pair_forces)
+  const bool poll = n > 0 && edm::forces_poll_enabled();
+  edm_hip_gauss *gm = const_cast<edm_hip_gauss *>(g);
+  const unsigned long long tag = poll ? ++gm->force_seq : 0ull;
+  int rc = edm::update_forces_enqueue(g, n, d_x, x_stride, d_f, f_stride, d_mask, apply_mask, &nblk, tag);
   if (rc) return rc;
   if (n <= 0) return EDM_HIP_OK;
+  if (poll) {
+    double e = 0;
+    if (edm::poll_tagged_partials(g, nblk, tag, &e)) {
+      gm->polled_forces++;
+      if (energy) *energy = e;
+      return EDM_HIP_OK;
+    }
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));   // (the poll ran out: the slots are complete now)
+    e = 0;
+    for (int i = 0; i < nblk; i++) e += g->h_partials[2 * i];
+    if (energy) *energy = e;
+    return EDM_HIP_OK;
+  }
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
   const double e = edm::pair_forces_finish(g, nblk);
   if (energy) *energy = e;
@@ -910,6 +928,34 @@ int edm_hip_gauss_pair_forces(const edm_hip_gauss *g, long long n, const double 
                               double *energy) {
   if (energy) *energy = 0;
   int nblk = 0;
+  if (g->g.dim == 1 && n > 0 && edm::forces_poll_enabled()) {
+    // a forces-only call (every fix edm_pair step between two hill steps): the workgroups tag their partial energy
+    // sums, the host looks at the slots instead of waiting for the stream -- the wait's wake-up alone is ~7 us of a
+    // 20 us call.  (The force array is complete when every workgroup's sum is: a workgroup stores its forces first.)
+    edm_hip_gauss *gm = const_cast<edm_hip_gauss *>(g);
+    hipEvent_t e0, e1;
+    profile_slot(g, &e0, &e1);
+    int tagged = 0;
+    const unsigned long long tag = ++gm->force_seq;
+    EDM_HIP_TRY(edm::launch_pair_forces(g->g, g->rec, n, d_r, d_force, g->d_partials, nullptr, g->stream, e0, e1, &nblk, tag, &tagged));
+    if (tagged) {
+      double e = 0;
+      if (edm::poll_tagged_partials(g, nblk, tag, &e)) {
+        gm->polled_forces++;
+        if (energy) *energy = e;
+        return EDM_HIP_OK;
+      }
+      EDM_HIP_TRY(hipStreamSynchronize(g->stream));   // (the poll ran out: the slots are complete now)
+      e = 0;
+      for (int i = 0; i < nblk; i++) e += g->h_partials[2 * i];
+      if (energy) *energy = e;
+      return EDM_HIP_OK;
+    }
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    const double e = edm::pair_forces_finish(g, nblk);
+    if (energy) *energy = e;
+    return EDM_HIP_OK;
+  }
   int rc = edm::pair_forces_enqueue(g, n, d_r, d_force, &nblk);
   if (rc) return rc;
   if (n <= 0) return EDM_HIP_OK;
@@ -1001,7 +1047,7 @@ int pair_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_r, 
 }
 // K2 (any dimension, strided rows, group mask) without the host wait; finish with pair_forces_finish()
 int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride, double *d_f, int f_stride,
-                          const int *d_mask, int apply_mask, int *nblk) {
+                          const int *d_mask, int apply_mask, int *nblk, unsigned long long tag) {
   *nblk = 0;
   if (n <= 0) return EDM_HIP_OK;
   if (apply_mask >= 0 && !d_mask) {
@@ -1010,6 +1056,7 @@ int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x
   }
   LookupArgs a{};
   a.n = n; a.x = d_x; a.x_stride = x_stride; a.f = d_f; a.f_stride = f_stride; a.mask = d_mask; a.apply_mask = apply_mask;
+  a.partial_tag = tag;   // (0: plain partial sums for a caller that waits for the stream)
   hipEvent_t e0, e1;
   profile_slot(g, &e0, &e1);
   const double *faces = nullptr;
@@ -1081,6 +1128,36 @@ int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a_in, const Hi
   if (rc) return rc;
   EDM_HIP_TRY(launch_select_prep(a, g->g, h, g->stream));
   return EDM_HIP_OK;
+}
+// forces-only calls poll their workgroups' tagged sums unless EDM_HIP_POLL=0
+bool forces_poll_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("EDM_HIP_POLL");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
+}
+// waits (bounded: 2 ms) until every one of the nblk slots {sum, tag} in the host-mapped partial-sum array carries `tag`,
+// and adds the sums up in workgroup order; false when the poll ran out
+bool poll_tagged_partials(const edm_hip_gauss *g, int nblk, unsigned long long tag, double *energy) {
+  const volatile unsigned long long *slots = reinterpret_cast<const volatile unsigned long long *>(g->h_partials);
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+  double e = 0;
+  unsigned spin = 0;
+  for (int i = 0; i < nblk; i++) {
+    while (slots[2 * i + 1] != tag) {
+      __builtin_ia32_pause();
+      if ((++spin & 255) == 255 && std::chrono::steady_clock::now() > t_end) return false;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    unsigned long long bits = slots[2 * i];
+    double v;
+    memcpy(&v, &bits, 8);
+    e += v;
+  }
+  *energy = e;
+  return true;
 }
 double pair_forces_finish(const edm_hip_gauss *g, int nblk) {
   double e = 0;

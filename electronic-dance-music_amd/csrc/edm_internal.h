@@ -112,6 +112,8 @@ struct edm_hip_gauss {
   long long polled_batches = 0;          // hill batches whose completion was seen through the polled word ...
   long long poll_fallbacks = 0;          // ... and batches whose poll ran out (the stream wait took over)
   long long header_releases = 0;         // polled batches released by their header line alone (see LimitResult)
+  unsigned long long force_seq = 0;      // tag of the last forces-only launch whose partial sums the host polled for
+  long long polled_forces = 0;           // forces-only calls that returned on their workgroups' tagged sums (telemetry)
   bool wait_polled = false;              // the last apply_hills saw its results through the polled words: the
                                          // stream was NOT synchronised (its last kernel may still be retiring)
   int *d_dirty = nullptr;
@@ -236,9 +238,11 @@ inline void faces_touch(edm_hip_gauss *g) {   // the node records were written b
 }
 int pair_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_r, double *d_force, int *nblk);
 int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x, int x_stride, double *d_f, int f_stride,
-                          const int *d_mask, int apply_mask, int *nblk);
+                          const int *d_mask, int apply_mask, int *nblk, unsigned long long tag = 0);
 double pair_forces_finish(const edm_hip_gauss *g, int nblk);
 // queues pending forces on their own (no-op when none are pending)
+bool forces_poll_enabled();
+bool poll_tagged_partials(const edm_hip_gauss *g, int nblk, unsigned long long tag, double *energy);
 int pending_forces_flush(const edm_hip_gauss *g, PendingForces *pf);
 // selection (+ preparation / packing) of a step, in one launch with the pending forces where possible
 int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a, const HillList &h, PendingForces *pf);

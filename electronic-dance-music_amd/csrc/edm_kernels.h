@@ -39,6 +39,9 @@ struct LookupArgs {
   long long *flat;    // INDEX
   const int *mask;
   int apply_mask;
+  // FORCES, optional: every workgroup stores {partial energy sum, partial_tag} as one 16-byte system-scope store at
+  // scratch[2 * workgroup] (host-mapped memory the host polls, see launch_pair_forces); 0 = plain partial sums
+  unsigned long long partial_tag;
 };
 
 // energy_out: device double receiving the (deterministic, fixed-order) sum of V;
@@ -81,6 +84,7 @@ struct PairListArgs {
   double *fdelta;               // out [nall][3]: bias force per atom (ghost atoms: zero)
   double *vs_r;                 // launch_pairlist_samples: out [2 * npairs] virtual-sample CVs
   int *vs_mask;                 // launch_pairlist_mask: out [2 * npairs] 1 = live sample
+  unsigned long long partial_tag;   // launch_pairlist_forces, optional: tagged partial energy sums (see launch_pair_forces)
 };
 // partials[0 .. blocks): energy partial sums (launch_pairlist_forces) / live-sample counts (launch_pairlist_mask)
 #define EDM_PAIRLIST_MAX_BLOCKS 1024
@@ -92,9 +96,13 @@ hipError_t launch_pairlist_mask(const PairListArgs &a, double *partials, hipStre
 // vs_r[2 e + slot] = r_e for every entry: only for the paths that read sample positions as a plain array (the
 // synchronous multi-GPU exchange, target heights)
 hipError_t launch_pairlist_samples(const PairListArgs &a, hipStream_t s);
+// tag != 0 (honoured by the specialised 1-D kernels: *tagged_out = 1): every workgroup stores {partial sum, tag} as one
+// 16-byte system-scope store at scratch[2 * workgroup] -- scratch then is host-mapped memory the host polls instead of
+// waiting for the stream (energy_out must be NULL)
 hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, const double *r,
                               double *force, double *scratch, double *energy_out, hipStream_t s,
-                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int *blocks_out = nullptr);
+                              hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int *blocks_out = nullptr,
+                              unsigned long long tag = 0, int *tagged_out = nullptr);
 
 // ---- record layout conversion ---------------------------------------------------
 hipError_t launch_pack(const Geom &g, double *rec, const double *values, const double *derivs, hipStream_t s);

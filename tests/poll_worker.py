@@ -91,6 +91,16 @@ def main(workdir):
         feed([e], v, dv, d_f.to_host(), [b.get("cum_bias"), b.get("hills_added"), b.get("overflow_right")])
     gv, gd = b.gauss.download()
     feed(gv, gd, b.hist.values)
+    # forces-only calls in between (every step of a fix edm_pair run that deposits no hills): the host returns on the
+    # workgroups' tagged partial sums instead of waiting for the stream -- short arrays and the LDS-staged long-array kernel
+    for m, seed in ((n, 1600), (4001, 1601), (1_700_000, 1602)):
+        rr = W.pair_distances(m, seed)
+        d_rr = H.DeviceArray.from_host(rr)
+        d_ff = H.DeviceArray.zeros((m,))
+        for _ in range(3):
+            e = b.pair_forces_device(d_rr, d_ff, m)
+        feed([e], d_ff.to_host())
+    print("POLLED_FORCES", int(b.get("polled_forces")))
     print("HEADER_RELEASES", int(b.get("header_releases")))
     del b
     print("DIGEST", dig.hexdigest())

@@ -910,6 +910,7 @@ def test_polled_completion_equals_stream_wait(workdir):
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "poll_worker.py")
     digests = []
     releases = []
+    polled_forces = []
     # polled (short unlogged batches the limiter leaves alone are released by their header line), polled without the
     # header-line release, and every batch waiting for its stream
     for tag, poll, header in (("polled", None, None), ("polled_no_header", None, "0"), ("waited", "0", None)):
@@ -928,8 +929,10 @@ def test_polled_completion_equals_stream_wait(workdir):
         assert lines, res.stdout[-2000:]
         digests.append(lines[-1])
         releases.append(int([ln for ln in res.stdout.splitlines() if ln.startswith("HEADER_RELEASES ")][-1].split()[1]))
+        polled_forces.append(int([ln for ln in res.stdout.splitlines() if ln.startswith("POLLED_FORCES ")][-1].split()[1]))
     assert digests[0] == digests[1] == digests[2]
     assert releases[0] >= 10 and releases[1] == 0 and releases[2] == 0, releases
+    assert polled_forces[0] >= 9 and polled_forces[2] == 0, polled_forces   # (forces-only calls: tagged sums / stream wait)
 
 
 def test_polled_completion_is_what_releases_short_batches(workdir):
