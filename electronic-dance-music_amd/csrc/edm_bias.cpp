@@ -902,8 +902,12 @@ int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_str
     return EDM_HIP_ERR_STATE;
   }
   int nblk = 0;
+  unsigned long long ftag = 0;
   if (!b->b_outofbounds) {   // update_forces (:279-280) -- queued, not waited for
-    int rc = update_forces_enqueue(b->bias, n, d_x, x_stride, d_f, f_stride, b->d_mask, apply_mask, &nblk);
+    // (tagged partial energy sums: should no polled hill batch follow, the host looks at the slots instead of waiting
+    //  for the stream, see edm_hip_gauss_pair_forces)
+    if (n > 0 && forces_poll_enabled()) ftag = ++b->bias->force_seq;
+    int rc = update_forces_enqueue(b->bias, n, d_x, x_stride, d_f, f_stride, b->d_mask, apply_mask, &nblk, ftag);
     if (rc) return rc;
   }
   // add_hills behind it on the same stream (:401-411): pre_add_hill, the samples, post_add_hill
@@ -918,8 +922,14 @@ int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_str
     rc = process_new_hills(b, n, d_x, x_stride, d_runiform, apply_mask);
     if (flush_polled) b->bias->wait_polled = true;   // (whatever the new hills did: the forces were seen complete)
     if (rc) return rc;
-    if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
-    const double e = pair_forces_finish(b->bias, nblk);
+    double e = 0;
+    if (ftag && !b->bias->wait_polled && poll_tagged_partials(b->bias, nblk, ftag, &e)) {
+      b->bias->polled_forces++;
+    } else {
+      if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
+      e = 0;
+      for (int k = 0; k < nblk; k++) e += b->bias->h_partials[ftag ? 2 * k : k];
+    }
     if (energy) *energy = e;
   }
   return do_post_add_hill(b);
@@ -960,13 +970,23 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
     b->pending.d_force = d_force;
   }
   rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
-  int rcf = pending_forces_flush(b->bias, &b->pending);  // (no hills this step: nothing has touched the grid)
+  // (no hills this step, or they were skipped: the force kernel goes alone -- with tagged partial sums the host can
+  //  look at instead of waiting for the stream, see edm_hip_gauss_pair_forces)
+  unsigned long long tag = 0;
+  if (b->pending.active && forces_poll_enabled()) tag = b->pending.tag = ++b->bias->force_seq;
+  int rcf = pending_forces_flush(b->bias, &b->pending);
   if (rc) return rc;
   if (rcf) return rcf;
-  // (a polled hill batch has shown the stream's last kernel past its read-back: the force kernel, earlier on the
-  //  stream, is complete and its partial sums are in host memory)
-  if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
-  const double e = pair_forces_finish(b->bias, b->pending.nblk);
+  double e = 0;
+  if (tag && b->pending.tagged && poll_tagged_partials(b->bias, b->pending.nblk, tag, &e)) {
+    b->bias->polled_forces++;
+  } else {
+    // (a polled hill batch has shown the stream's last kernel past its read-back: the force kernel, earlier on the
+    //  stream, is complete and its partial sums are in host memory)
+    if ((tag && b->pending.tagged) || !b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
+    e = 0;
+    for (int k = 0; k < b->pending.nblk; k++) e += b->bias->h_partials[(tag && b->pending.tagged) ? 2 * k : k];
+  }
   if (energy) *energy = e;
   rc = do_post_add_hill(b);
   if (host_trace) {
@@ -1184,7 +1204,7 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   // (a step without hills: the force pass goes alone, its workgroups tag their partial energy sums and the host looks at
   //  the slots instead of waiting for the stream, see edm_hip_gauss_pair_forces)
   unsigned long long tag = 0;
-  if (b->pending.active && !hill_step && forces_poll_enabled()) {
+  if (b->pending.active && forces_poll_enabled()) {   // (no hills this step, or the step's new hills were skipped)
     tag = ++b->bias->force_seq;
     b->pending.pl.partial_tag = tag;
   }
@@ -1195,14 +1215,12 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   double e = 0;
   if (tag && poll_tagged_partials(b->bias, nblk, tag, &e)) {
     b->bias->polled_forces++;
-    if (energy) *energy = e;
-    if (ncalls) *ncalls = 0;
-    return EDM_HIP_OK;
+  } else {
+    // (a polled hill batch has shown the stream past the force pass queued ahead of it)
+    if (tag || !b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(s));
+    e = 0;
+    for (int k = 0; k < nblk; k++) e += b->bias->h_partials[tag ? 2 * k : k];
   }
-  // (a polled hill batch has shown the stream past the force pass queued ahead of it)
-  if (!b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(s));
-  e = 0;
-  for (int k = 0; k < nblk; k++) e += b->bias->h_partials[tag ? 2 * k : k];
   if (energy) *energy = e;
   if (ncalls) *ncalls = hill_step ? b->pl_calls : 0;
   return hill_step ? do_post_add_hill(b) : EDM_HIP_OK;

@@ -1072,6 +1072,19 @@ int pending_forces_flush(const edm_hip_gauss *g, PendingForces *pf) {
     EDM_HIP_TRY(launch_pairlist_forces(g->g, g->rec, pf->pl, g->d_partials, g->stream, &pf->nblk));
     return EDM_HIP_OK;
   }
+  if (pf->tag) {
+    if (g->g.dim != 1) {
+      set_error("pair_forces: the pair-distance CV is 1-D (fix_edm_pair.cpp:52)");
+      return EDM_HIP_ERR_ARG;
+    }
+    hipEvent_t e0, e1;
+    profile_slot(g, &e0, &e1);
+    int tagged = 0;
+    EDM_HIP_TRY(launch_pair_forces(g->g, g->rec, pf->n, pf->d_r, pf->d_force, g->d_partials, nullptr, g->stream, e0, e1,
+                                   &pf->nblk, pf->tag, &tagged));
+    pf->tagged = tagged != 0;
+    return EDM_HIP_OK;
+  }
   return pair_forces_enqueue(g, pf->n, pf->d_r, pf->d_force, &pf->nblk);
 }
 int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a_in, const HillList &h, PendingForces *pf) {

@@ -166,6 +166,8 @@ struct PendingForces {
   const double *d_r = nullptr;
   double *d_force = nullptr;
   int nblk = 0;              // K1 workgroups launched (partial energy sums to add up)
+  unsigned long long tag = 0;   // != 0: when the forces are launched on their own, with tagged partial sums (launch_pair_forces)
+  bool tagged = false;       // ... and the launch honoured it (the specialised 1-D kernels do)
   // ... or the force pass over a device-resident neighbour list (fix edm_pair gpu_list), queued the same way
   bool list = false;
   PairListArgs pl;
