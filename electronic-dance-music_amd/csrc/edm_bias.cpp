@@ -431,7 +431,8 @@ static int flush_overflow(edm_hip_bias *b, double max_bias, double *bias_added) 
   spec.cum_in = 0;
   spec.hist_g = &b->hist->g;
   spec.hist_values = b->hist->values;
-  spec.fetch_all = true;
+  const bool log_all = b->hill_log && b->hills_fp;
+  spec.fetch_all = log_all;     // (per-hill bias only for the HILLS log; without one the limiter's header line is enough)
   spec.fetch_heights = false;   // (the heights came from the host's own overflow records)
   ApplyOutcome oc;
   int rc = apply_hills(b->bias, spec, &oc, false);
@@ -441,11 +442,11 @@ static int flush_overflow(edm_hip_bias *b, double max_bias, double *bias_added) 
   for (long long i = 0; i < nrun; i++) {
     double *rec = &b->overflow[(b->overflow_left + (size_t)i) * w];
     b->hills_added++;
-    log_hill(b, rec, rec[b->dim], oc.added[(size_t)i], 'b');
+    if (log_all) log_hill(b, rec, rec[b->dim], oc.added[(size_t)i], 'b');
     if (i == stop) {
-      const double h2 = oc.h2[(size_t)i];
+      const double h2 = oc.plain_fast ? oc.res.h2_stop : oc.h2[(size_t)i];
       rec[b->dim] = -h2;                      // the remaining part stays buffered (:341)
-      log_hill(b, rec, h2, oc.a2[(size_t)i], 'v');
+      if (log_all) log_hill(b, rec, h2, oc.a2[(size_t)i], 'v');
       b->hills_added++;
     }
   }

@@ -1871,7 +1871,9 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     // ~3 us before the acknowledgements of the region's other stores would let the completion word out.
     volatile unsigned long long *hd = reinterpret_cast<volatile unsigned long long *>(g->h_stage + g->h_stage_bytes - 256);
     static const bool header_env = !(getenv("EDM_HIP_FAST_HEADER") && getenv("EDM_HIP_FAST_HEADER")[0] == '0');   // (A/B and tests)
-    bool header_may_do = header_env && spec.limited && !spec.flush_mode && !spec.fetch_all && out != nullptr &&
+    // (A flush of the overflow buffer: the line carries the stop index and that hill's undo height -- all the host's
+    // replay needs when there is no log.)
+    bool header_may_do = header_env && spec.limited && !spec.fetch_all && out != nullptr &&
                          rb_bytes + 256 <= g->h_stage_bytes;
     const unsigned long long want = g->done_seq;
     const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
@@ -1883,7 +1885,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         for (int i = 0; i < 8; i++) line[i] = hd[i];
         LimitResult hr;
         if (edm_header_line_decode(line, want, &hr)) {
-          if (hr.all_plain && !hr.error) {
+          if ((hr.all_plain || spec.flush_mode) && !hr.error) {
             header_res = hr;
             plain_fast = true;
             g->header_releases++;
@@ -1946,7 +1948,9 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     out->first = first;
     const long long need = nh_act - first;
     if (plain_fast) {
-      out->plain_fast = true;   // (flags 1, undo heights 0, undo bias 0 throughout; positions and per-hill bias not asked for)
+      // (new hills: flags 1, undo heights 0, undo bias 0 throughout; a flush: res.stop / res.h2_stop; positions and
+      // per-hill bias not asked for)
+      out->plain_fast = true;
     } else if (small) {
       out->flags.assign(st_flags, st_flags + ntail);
       out->h2.assign(st_h2, st_h2 + ntail);

@@ -343,24 +343,27 @@ struct LimitResult {
   // and undo bias need not be read at all (they are 1, 0, 0)
   int all_plain;
   int pad0;
-  unsigned long long reserved[2];   // (the header of the packed read-back region is one 64-byte line)
+  double h2_stop;                   // flush mode: the undo height of the hill the flush stopped at (0 if it ran through) -- all a
+                                    // host without a HILLS log needs of the tail arrays
+  unsigned long long reserved;      // (the header of the packed read-back region is one 64-byte line)
 };
 // The limiter's wave also sends its result to a line of its own in host memory (LimitArgs::fast_line) as ONE 64-byte
 // store (header_line_to_host in edm_kernels.hip):
-// eight words [seq | cum_out | k | nh | n_tail, stop | n_deferred, error | all_plain | seq], the batch's number first
-// and last.  The host may take that line the moment both show the number it waits for, without waiting for the
+// eight words [seq | cum_out | k, nh | n_tail, stop | n_deferred, error | all_plain | h2_stop | seq], the batch's number
+// first and last.  The host may take that line the moment both show the number it waits for, without waiting for the
 // acknowledgement of every other store into the region (~3 us on PCIe).
 inline bool edm_header_line_decode(const unsigned long long line[8], unsigned long long want, LimitResult *out) {
   if (line[0] != want || line[7] != want) return false;
   memset(out, 0, sizeof(*out));
   memcpy(&out->cum_out, &line[1], 8);
-  out->k = (long long)line[2];
-  out->nh = (long long)line[3];
-  out->n_tail = (int)(unsigned)(line[4] & 0xFFFFFFFFull);
-  out->stop = (int)(unsigned)(line[4] >> 32);
-  out->n_deferred = (int)(unsigned)(line[5] & 0xFFFFFFFFull);
-  out->error = (int)(unsigned)(line[5] >> 32);
-  out->all_plain = (int)(unsigned)(line[6] & 0xFFFFFFFFull);
+  out->k = (long long)(line[2] & 0xFFFFFFFFull);        // (chained batches: at most 2048 hills)
+  out->nh = (long long)(line[2] >> 32);
+  out->n_tail = (int)(unsigned)(line[3] & 0xFFFFFFFFull);
+  out->stop = (int)(unsigned)(line[3] >> 32);
+  out->n_deferred = (int)(unsigned)(line[4] & 0xFFFFFFFFull);
+  out->error = (int)(unsigned)(line[4] >> 32);
+  out->all_plain = (int)(unsigned)(line[5] & 0xFFFFFFFFull);
+  memcpy(&out->h2_stop, &line[6], 8);
   return true;
 }
 static_assert(sizeof(LimitResult) == 64, "the limiter's result is one 64-byte line");

@@ -2516,18 +2516,18 @@ __device__ __forceinline__ double hill_stencil_partial(const Geom &g, const Tabl
 
 // The limiter's result to a 64-byte line of its own in host-mapped memory (LimitArgs::fast_line) as ONE write: lanes 0..7
 // of the calling wave (which all hold the same result) store 8 bytes each with a single instruction --
-//   [seq | cum_out | k | nh | n_tail, stop | n_deferred, error | all_plain | seq]
+//   [seq | cum_out | k, nh | n_tail, stop | n_deferred, error | all_plain | h2_stop | seq]
 // -- the batch's sequence number in the FIRST and the LAST word, so that a reader who finds both has the line whole even
 // if the write travelled as two halves (edm_header_line_decode in edm_kernels.h).
 __device__ __forceinline__ void header_line_to_host(unsigned long long *host_line, const LimitResult &r, unsigned long long seq) {
   const int lane = threadIdx.x & 63;
   unsigned long long piece = seq;   // lanes 0 and 7
   if (lane == 1) piece = (unsigned long long)__double_as_longlong(r.cum_out);
-  if (lane == 2) piece = (unsigned long long)r.k;
-  if (lane == 3) piece = (unsigned long long)r.nh;
-  if (lane == 4) piece = (unsigned long long)(unsigned)r.n_tail | ((unsigned long long)(unsigned)r.stop << 32);
-  if (lane == 5) piece = (unsigned long long)(unsigned)r.n_deferred | ((unsigned long long)(unsigned)r.error << 32);
-  if (lane == 6) piece = (unsigned long long)(unsigned)r.all_plain;
+  if (lane == 2) piece = (unsigned long long)(unsigned)r.k | ((unsigned long long)(unsigned)r.nh << 32);
+  if (lane == 3) piece = (unsigned long long)(unsigned)r.n_tail | ((unsigned long long)(unsigned)r.stop << 32);
+  if (lane == 4) piece = (unsigned long long)(unsigned)r.n_deferred | ((unsigned long long)(unsigned)r.error << 32);
+  if (lane == 5) piece = (unsigned long long)(unsigned)r.all_plain;
+  if (lane == 6) piece = (unsigned long long)__double_as_longlong(r.h2_stop);
   if (lane < 8) __hip_atomic_store(host_line + lane, piece, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -4669,6 +4669,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                          __HIP_MEMORY_SCOPE_SYSTEM);
   };
   int plain_l = flush_mode ? 0 : 1;   // new hills: so far every hill was added in full
+  double h2_stop_l = 0;               // flush: undo height of the hill the flush stopped at
   auto put_result = [&](double cum_out, long long k_, long long nh_, int n_tail, int stop_, int n_def_, int error) {
     put_f64(&res->cum_out, cum_out);
     put_i64(&res->k, k_);
@@ -4689,6 +4690,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
     out_local->n_deferred = n_def_;
     out_local->error = error;
     out_local->all_plain = (error == 0 && n_def_ == 0) ? plain_l : 0;
+    out_local->h2_stop = h2_stop_l;
   };
   long long nh = nh_bound;
   if (k_out) *k_out = 0;
@@ -4811,6 +4813,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
         if (flush_mode) {
           stop = (int)(base + j1);
           stopped = true;
+          h2_stop_l = h2;
         }
       }
       if (lane == j1) {
