@@ -2841,10 +2841,13 @@ struct PostArgs {
   const char *rb_src;
   char *rb_dst;
   long long rb_bytes;
+  // tile_ticket_duplicate: tiles [0, tk_lo_end) and [tk_hi_begin, ntile) take the ticket (both zero: every tile)
+  unsigned tk_lo_end, tk_hi_begin;
 };
+static void dup_ticket_tiles_1d(const Geom &g, PostArgs &post, unsigned ntile, unsigned tile_nodes);
 template <bool PERB>
 __device__ __forceinline__ void tile_ticket_duplicate(const Geom &g, double *__restrict__ rec, const PostArgs &post,
-                                                      unsigned ntile, const int *s_dirty, int *s_last);
+                                                      unsigned ntile, unsigned tile, const int *s_dirty, int *s_last);
 
 // boundary duplication (K6) and the histogram updates (K7) by the last gather workgroup to finish
 // (a few hundred workgroups that finish spread over microseconds: one counter, one atomic round trip -- the
@@ -3705,7 +3708,7 @@ __global__ void __launch_bounds__(BLOCK) k_integrals_gather(Geom g, Tables t, do
   EDM_STAMP(6);
   if (!post.enabled) return;
   if (ticket_dirty) {
-    tile_ticket_duplicate<PERB>(g, rec, post, ntile, &s_dirty, &s_last);
+    tile_ticket_duplicate<PERB>(g, rec, post, ntile, tile, &s_dirty, &s_last);
     EDM_STAMP(7);
     return;
   }
@@ -3931,6 +3934,7 @@ hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, 
   // the very least (157 registers: three waves per SIMD; 59 KB of LDS: two per CU), so with 64 slots to spare the
   // integrals' workgroups -- which wait for nobody -- always find room to run through
   const unsigned tiles_first = ((size_t)nb_tiles + 64 <= (size_t)2 * cu_count()) ? 1u : 0u;
+  if (post.enabled) dup_ticket_tiles_1d(g, post, nb_tiles, BLOCK / 8);
   if (!g.bper[0])
     hipLaunchKernelGGL((k_integrals_gather<false>), dim3(nb_int + nb_tiles), dim3(BLOCK), 0, s, g, t, rec, h, heights, h_const,
                        added, la, hh, plan, dirty_flag, post, nb_int, tiles_first);
@@ -3944,9 +3948,18 @@ hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, 
 // the batch met a non-zero boundary correction).  The ticket carries that bit: every tile adds 1, and 0x10000 if it
 // saw one (*s_dirty, LDS), in ONE atomic round trip -- the last arrival learns both that it is the last and whether
 // anybody was dirty (a separate flag word cost the last tile a second dependent round trip).
+// Only tiles that can matter take it (dup_ticket_tiles_1d, host): those holding a node a wall blend reaches -- no other
+// node can meet a boundary correction -- or a node the duplication reads or writes.  Where the walls sit on the grid's
+// first and last node (the usual fix edm_pair set-up, W1 included) there is nothing to duplicate and nobody takes it:
+// the launch ends with the last tile's stores instead of two dependent round trips later.
 template <bool PERB>
 __device__ __forceinline__ void tile_ticket_duplicate(const Geom &g, double *__restrict__ rec, const PostArgs &post,
-                                                      unsigned ntile, const int *s_dirty, int *s_last) {
+                                                      unsigned ntile, unsigned tile, const int *s_dirty, int *s_last) {
+  const bool everyone = post.tk_lo_end == 0 && post.tk_hi_begin == 0;
+  if (!everyone) {
+    if (PERB || (tile >= post.tk_lo_end && tile < post.tk_hi_begin)) return;   // (uniform over the workgroup)
+    ntile = post.tk_lo_end + (ntile - post.tk_hi_begin);
+  }
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -4007,7 +4020,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8
     hill_gather_body<1, 0, 8, PERB, true, true>(g, t, rec, h, hh, plan, 0, dirty_flag, post.enabled, tile, la.ready_flag,
                                                 la.ready_seq, trace, &fs, a.counts, s_foff, s_fws, rec_next, &s_dirty);
     if (trace && threadIdx.x == 0) trace[6] = wall_clock64();
-    tile_ticket_duplicate<PERB>(g, rec_next, post, ntile, &s_dirty, &s_last);
+    tile_ticket_duplicate<PERB>(g, rec_next, post, ntile, tile, &s_dirty, &s_last);
   }
   if (trace && threadIdx.x == 0) trace[7] = wall_clock64();
 }
@@ -4064,6 +4077,7 @@ hipError_t launch_pair_step(const SelectArgs &a, const Geom &g, const Tables &t,
   fs.cum_in = chain.cum_in;
   const unsigned nb_tiles = (unsigned)((g.n[0] + BLOCK / 8 - 1) / (BLOCK / 8));
   const dim3 grid(fs.nsel + fs.nk1 + 1 + nb_tiles);
+  dup_ticket_tiles_1d(g, post, nb_tiles, BLOCK / 8);
   if (!g.bper[0])
     EDM_LAUNCH_TIMED((k_pair_step<false>), grid, dim3(BLOCK), 256, s, ev0, ev1, a, g, t, rec, h, h_const, added, la, hh, plan,
                      dirty_flag, post, f, fs, rec_next);
@@ -4464,6 +4478,42 @@ static DupPlan make_dup_plan(const Geom &g) {
     dp.hi[d] = hi;
   }
   return dp;
+}
+
+// Which 1-D gather tiles (tile_nodes nodes each) take the duplication ticket: see tile_ticket_duplicate.  A node can
+// meet a non-zero boundary correction only where a wall blend is non-zero (pair_term: corr = (..) t2 + (..) t4, and
+// node_terms: t2 != 0 only for bmin <= x < bmin + EDM_BC_MAR sigma, t4 != 0 only for bmax - EDM_BC_MAR sigma < x <= bmax);
+// the duplication copies node lo -> lo - 1 and hi -> hi + 1 where those exist (duplicate_boundary_lanes).  Ranges are
+// widened by two nodes against rounding in the node positions.  EDM_HIP_DUP_TICKET_ALL=1: every tile (A/B, tests).
+static void dup_ticket_tiles_1d(const Geom &g, PostArgs &post, unsigned ntile, unsigned tile_nodes) {
+  post.tk_lo_end = post.tk_hi_begin = 0;   // every tile
+  static const bool all_env = getenv("EDM_HIP_DUP_TICKET_ALL") && getenv("EDM_HIP_DUP_TICKET_ALL")[0] == '1';
+  if (all_env || g.dim != 1 || ntile == 0 || ntile >= 0xFFFFu) return;
+  if (g.bper[0]) {   // no walls: no corrections, nothing to duplicate
+    post.tk_hi_begin = ntile;
+    return;
+  }
+  const DupPlan &dp = post.dp;
+  const long long n = g.n[0];
+  const bool lo_copy = dp.lo[0] > 0 && dp.lo[0] < (unsigned long long)n;
+  const bool hi_copy = dp.hi[0] + 1 < (unsigned long long)n;
+  if (!lo_copy && !hi_copy) {   // the walls sit on the grid's end nodes: nobody needs to know who was dirty
+    post.tk_hi_begin = ntile;
+    return;
+  }
+  const double reach = EDM_BC_MAR * g.sigma[0];
+  long long a1 = (long long)ceil((g.bmin[0] + reach - g.min[0]) / g.dx[0]) + 2;    // last node of the lower set
+  long long b0 = (long long)floor((g.bmax[0] - reach - g.min[0]) / g.dx[0]) - 2;   // first node of the upper set
+  if (lo_copy && (long long)dp.lo[0] + 2 > a1) a1 = (long long)dp.lo[0] + 2;
+  if ((long long)dp.hi[0] - 2 < b0) b0 = (long long)dp.hi[0] - 2;
+  if (a1 < 0) a1 = 0;
+  if (b0 < 0) b0 = 0;
+  if (a1 > n - 1) a1 = n - 1;
+  if (b0 > n - 1) b0 = n - 1;
+  const unsigned lo_end = (unsigned)(a1 / tile_nodes) + 1, hi_begin = (unsigned)(b0 / tile_nodes);
+  if (lo_end >= hi_begin || lo_end >= ntile) return;   // the two sets meet: every tile
+  post.tk_lo_end = lo_end;
+  post.tk_hi_begin = hi_begin;
 }
 
 hipError_t launch_hills_ordered(const Geom &g, const Tables &t, double *rec, const HillList &h, const OrderedParams &op,

@@ -103,6 +103,31 @@ def main(workdir):
     print("POLLED_FORCES", int(b.get("polled_forces")))
     print("HEADER_RELEASES", int(b.get("header_releases")))
     del b
+    # 1-D pair CV whose walls lie INSIDE the rank's grid (a sub-domain with skin): hills at both walls meet boundary
+    # corrections, and the duplication behind the gather copies the wall nodes outwards (gaussian_grid.h:571-630).  Only
+    # the tiles near the walls take the ticket that decides it (EDM_HIP_DUP_TICKET_ALL=1: every tile, the old way).
+    for tag, limit in (("p4", 50.0), ("p5", 0.2)):
+        cfg = os.path.join(workdir, tag + ".edm")
+        open(cfg, "w").write("tempering 0\nhill_prefactor 0.5\nhill_density 150\nbias_per_step %g\ndimension 1\nbox_low 0.9\n"
+                             "box_high 2.7\nbias_spacing 0.0005\nbias_sigma 0.03\nhills_filename %s/HILLS_%s\n"
+                             "histogram_filename %s/HIST_%s\n" % (limit, workdir, tag, workdir, tag))
+        b = H.Bias(cfg)
+        b.setup(1.0, 1.0)
+        b.subdivide([0.5], [3.0], [0.0], [3.5], [0], [0.3])
+        b.set_hill_log(tag == "p5")
+        n = 120_000
+        for step in range(6):
+            r = W.pair_distances(n, 1700 + step)
+            d_r = H.DeviceArray.from_host(r)
+            d_u = H.DeviceArray.from_host(W.uniform(1750 + step, n))
+            d_f = H.DeviceArray.zeros((n,))
+            e = b.pair_step_device(d_r, d_f, n, d_r, d_u, n, est=n)
+            feed([e], d_f.to_host(), [b.get("cum_bias"), b.get("hills_added"), b.get("overflow_right")])
+        gv, gd = b.gauss.download()
+        feed(gv, gd, b.hist.values)
+        geo = b.gauss.geometry
+        print("WALLS_INSIDE", tag, float(geo.min[0]), float(geo.max[0]), float(np.abs(gv).max()))
+        del b
     print("DIGEST", dig.hexdigest())
 
 

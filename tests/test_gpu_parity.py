@@ -913,16 +913,21 @@ def test_polled_completion_equals_stream_wait(workdir):
     polled_forces = []
     # polled (short unlogged batches the limiter leaves alone are released by their header line), polled without the
     # header-line release, and every batch waiting for its stream
-    for tag, poll, header in (("polled", None, None), ("polled_no_header", None, "0"), ("waited", "0", None)):
+    # ... and with every gather tile taking the boundary-duplication ticket instead of the tiles near the walls only
+    for tag, poll, header, dup_all in (("polled", None, None, None), ("polled_no_header", None, "0", None), ("waited", "0", None, None),
+                                       ("dup_ticket_all", None, None, "1")):
         d = workdir / tag
         d.mkdir()
         env = dict(os.environ)
         env.pop("EDM_HIP_POLL", None)
         env.pop("EDM_HIP_FAST_HEADER", None)
+        env.pop("EDM_HIP_DUP_TICKET_ALL", None)
         if poll is not None:
             env["EDM_HIP_POLL"] = poll
         if header is not None:
             env["EDM_HIP_FAST_HEADER"] = header
+        if dup_all is not None:
+            env["EDM_HIP_DUP_TICKET_ALL"] = dup_all
         res = subprocess.run([sys.executable, worker, str(d)], env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
         lines = [ln for ln in res.stdout.splitlines() if ln.startswith("DIGEST ")]
@@ -930,7 +935,7 @@ def test_polled_completion_equals_stream_wait(workdir):
         digests.append(lines[-1])
         releases.append(int([ln for ln in res.stdout.splitlines() if ln.startswith("HEADER_RELEASES ")][-1].split()[1]))
         polled_forces.append(int([ln for ln in res.stdout.splitlines() if ln.startswith("POLLED_FORCES ")][-1].split()[1]))
-    assert digests[0] == digests[1] == digests[2]
+    assert digests[0] == digests[1] == digests[2] == digests[3]
     assert releases[0] >= 10 and releases[1] == 0 and releases[2] == 0, releases
     assert polled_forces[0] >= 9 and polled_forces[2] == 0, polled_forces   # (forces-only calls: tagged sums / stream wait)
 
