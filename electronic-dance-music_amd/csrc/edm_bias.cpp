@@ -960,6 +960,7 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
     if (n > 0) EDM_HIP_TRY(hipMemset(d_force, 0, sizeof(double) * (size_t)n));
     return do_post_add_hill(b);
   }
+  ht_mark(b->bias, 0);
   // forces (queued, not waited for), then the new hills behind them on the same stream: one host wait
   // (where the step's selection runs as a chained launch, the force kernel rides in that launch)
   b->pending = PendingForces();
@@ -971,6 +972,7 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
     b->pending.d_force = d_force;
   }
   rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
+  ht_mark(b->bias, 7);
   // (no hills this step, or they were skipped: the force kernel goes alone -- with tagged partial sums the host can
   //  look at instead of waiting for the stream, see edm_hip_gauss_pair_forces)
   unsigned long long tag = 0;
@@ -989,12 +991,18 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
     for (int k = 0; k < b->pending.nblk; k++) e += b->bias->h_partials[(tag && b->pending.tagged) ? 2 * k : k];
   }
   if (energy) *energy = e;
+  ht_mark(b->bias, 8);
   rc = do_post_add_hill(b);
   if (host_trace) {
     const double t_out = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (b->bias->ready_seq == 160)
+    if (b->bias->ready_seq == 160) {
       fprintf(stderr, "[edm host] pair_step: %.2f us inside the call, %.2f us since the previous call returned\n", t_out - t_in,
               t_in - last_exit_us);
+      const double *m = b->bias->ht_marks;
+      fprintf(stderr, "[edm host] marks (us after entry): pre_add_hill done %.2f | first launch %.2f -> %.2f | second launch %.2f -> %.2f | "
+              "poll %.2f -> %.2f | new hills processed %.2f | energy summed %.2f | exit %.2f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6],
+              m[7], m[8], t_out - t_in);
+    }
     last_exit_us = t_out;
   }
   return rc;

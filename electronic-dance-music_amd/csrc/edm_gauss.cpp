@@ -22,6 +22,14 @@
 
 namespace edm {
 
+// development aid (EDM_HIP_TRACE): host clock, microseconds after the traced step's entry, at marked place `slot`
+void ht_mark(edm_hip_gauss *g, int slot) {
+  static const bool on = getenv("EDM_HIP_TRACE") != nullptr;
+  if (!on || !g || slot < 0 || slot >= 12) return;
+  g->ht_marks[slot] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() - g->ht_ref_us;
+}
+
+
 static thread_local std::string g_last_error;
 
 void set_error(const std::string &msg) { g_last_error = msg; }
@@ -1133,8 +1141,10 @@ int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a_in, const Hi
     hipEvent_t e0, e1;
     profile_slot(g, &e0, &e1);
     pf->active = false;
+    ht_mark(const_cast<edm_hip_gauss *>(g), 1);
     EDM_HIP_TRY(launch_pair_forces_select(a, g->g, h, g->rec, pf->n, pf->d_r, pf->d_force, g->d_partials, g->stream, e0, e1,
                                           &pf->nblk));
+    ht_mark(const_cast<edm_hip_gauss *>(g), 2);
     return EDM_HIP_OK;
   }
   int rc = pending_forces_flush(g, pf);
@@ -1651,8 +1661,10 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         g->fs_k1_total += (unsigned)nk1;
         g->fused_steps++;
       } else {
+        ht_mark(g, 3);
         EDM_HIP_TRY(launch_integrals_gather(q, tabs, g->rec, hl, spec.d_h, spec.h_const, p_added, la, hh, plan, g->d_dirty, s,
                                             chain_post ? &ps : nullptr));
+        ht_mark(g, 4);
       }
       gather_done = true;
       if (d_trace && one_launch) {
@@ -1715,7 +1727,35 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         }
       }
     } else {
+      static const bool tracing_nd = getenv("EDM_HIP_TRACE") != nullptr;   // development aid: stamps of one launch to stderr
+      static int traced_launches = 0;
+      unsigned long long *d_trace = nullptr;
+      if (tracing_nd && ++traced_launches >= 40 && traced_launches <= 43) {
+        EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_trace), (size_t)nh * 64));
+        EDM_HIP_TRY(hipMemset(d_trace, 0, (size_t)nh * 64));
+        la.trace = d_trace;
+      }
       EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s, &la));
+      if (d_trace) {
+        EDM_HIP_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned long long> tr((size_t)nh * 8);
+        EDM_HIP_TRY(hipMemcpy(tr.data(), d_trace, (size_t)nh * 64, hipMemcpyDeviceToHost));
+        (void)hipFree(d_trace);
+        unsigned long long t0 = ~0ull;
+        for (size_t w = 0; w < (size_t)nh; w++)
+          if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
+        const char *names_i[8] = {"start", "integral done", "last wg: ticket", "rows known", "limiter stage done", "walk begins", "stretches laid out", "end"};
+        fprintf(stderr, "[edm trace] k_hill_integrals<%d>, launch bound %lld hills, flush %d\n", dim, nh, spec.flush_mode);
+        for (int k = 0; k < 8; k++) {
+          std::vector<double> v;
+          for (size_t w = 0; w < (size_t)nh; w++)
+            if (tr[w * 8 + k]) v.push_back((double)(tr[w * 8 + k] - t0) * 0.01);
+          if (v.empty()) continue;
+          std::sort(v.begin(), v.end());
+          fprintf(stderr, "[edm trace] integrals %-18s n=%4zu  min %6.2f  med %6.2f  max %6.2f us\n", names_i[k], v.size(), v.front(),
+                  v[v.size() / 2], v.back());
+        }
+      }
     }
   } else if (spec.limited || want_total) {
     EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s));
@@ -1861,6 +1901,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   memset(&header_res, 0, sizeof(header_res));
   static const bool host_trace = getenv("EDM_HIP_TRACE") != nullptr;   // development aid: host-side stamps
   const auto ht_before_poll = std::chrono::steady_clock::now();
+  ht_mark(g, 5);
   if (polled) {
     // the limiter's workgroup flags the host-mapped region once it is complete: poll the word instead of waiting
     // for the stream's completion signal (bounded; falls back to the stream wait)
@@ -1916,6 +1957,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
             std::chrono::duration<double, std::micro>(now - ht_before_poll).count(),
             std::chrono::duration<double, std::micro>(ht_before_poll.time_since_epoch()).count() - g->ht_ref_us);
   }
+  ht_mark(g, 6);
   long long nh_act = nh;
   if (spec.limited) {
     res = plain_fast ? header_res : *hres;

@@ -132,6 +132,7 @@ struct edm_hip_gauss {
   unsigned fs_sel_total = 0, fs_k1_total = 0, fs_int_total = 0;
   long long fused_steps = 0;             // steps that ran as one launch (telemetry / tests)
   double ht_ref_us = 0;                  // development aid (EDM_HIP_TRACE): host clock at the entry of the step being traced
+  double ht_marks[12] = {0};             // ... and at marked places of that step (ht_mark), printed by the step's entry point
   // lookup replica of a 2-D / 3-D grid with a periodic boundary (see lookup_one / launch_build_faces): g.total
   // blocks of 128 bytes, 4x the node records -- memory spent so that a coordinate-CV sample reads 1 or 2 aligned
   // lines instead of 2.5 / 5.  faces_mode: -1 = automatic (grids beyond the L2s' reach), 0 = off, 1 = always.
@@ -172,6 +173,8 @@ struct PendingForces {
   bool list = false;
   PairListArgs pl;
 };
+void ht_mark(edm_hip_gauss *g, int slot);   // development aid, edm_gauss.cpp
+
 struct ApplySpec {
   long long nh = 0;
   const double *d_x = nullptr;     // sample positions
