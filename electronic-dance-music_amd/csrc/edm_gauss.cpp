@@ -240,6 +240,8 @@ edm::Tables edm_hip_gauss::tables() const {
     t.dderiv[d] = tab[d][1];
   }
   t.node1d = node_tab;
+  t.ball = ball;
+  t.nball = nball;
   return t;
 }
 
@@ -731,6 +733,7 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
   if (g->fs_rec) (void)hipFree(g->fs_rec);
   if (g->rec_alt) (void)hipFree(g->rec_alt);
   if (g->node_tab) (void)hipFree(g->node_tab);
+  if (g->ball) (void)hipFree(g->ball);
   if (g->fs_counters) (void)hipFree(g->fs_counters);
   if (g->prof_ev) {
     for (int i = 0; i < 2 * edm_hip_gauss::PROF_RING; i++) (void)hipEventDestroy(g->prof_ev[i]);
@@ -739,6 +742,58 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
   g->ws.release();
   if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
+  return EDM_HIP_OK;
+}
+
+// Tables::ball for the current spacing, sigma and stencil half-widths (see edm_kernels.h); checked before every hill
+// batch, rebuilt when one of them changed (creation, re-read of a file with another spacing)
+static int ball_list_ensure(edm_hip_gauss *g) {
+  const Geom &q = g->g;
+  double key[10] = {(double)q.dim, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int d = 0; d < q.dim; d++) {
+    key[1 + d] = q.dx[d];
+    key[4 + d] = q.sigma[d];
+    key[7 + d] = (double)q.msize[d];
+  }
+  if (memcmp(key, g->ball_key, sizeof(key)) == 0) return EDM_HIP_OK;
+  memcpy(g->ball_key, key, sizeof(key));
+  if (g->ball) {
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    (void)hipFree(g->ball);
+  }
+  g->ball = nullptr;
+  g->nball = 0;
+  static const bool off = getenv("EDM_HIP_BALL_LIST") && getenv("EDM_HIP_BALL_LIST")[0] == '0';   // (A/B, tests)
+  if (off || q.dim < 2) return EDM_HIP_OK;
+  long long box = 1;
+  for (int d = 0; d < q.dim; d++) {
+    if (q.msize[d] < 0 || q.msize[d] > 127) return EDM_HIP_OK;
+    box *= 2 * q.msize[d] + 1;
+  }
+  if (box > (1LL << 22)) return EDM_HIP_OK;
+  std::vector<std::pair<double, int>> cand;
+  const int m0 = q.msize[0], m1 = q.msize[1], m2 = q.dim > 2 ? q.msize[2] : 0;
+  for (int o2 = -m2; o2 <= m2; o2++)
+    for (int o1 = -m1; o1 <= m1; o1++)
+      for (int o0 = -m0; o0 <= m0; o0++) {
+        const int o[3] = {o0, o1, o2};
+        double sum = 0;
+        for (int d = 0; d < q.dim; d++) {
+          const int a = o[d] < 0 ? -o[d] : o[d];
+          const double e = (a > 1 ? (double)(a - 1) : 0.0) * q.dx[d] / q.sigma[d];
+          sum += e * e;
+        }
+        if (sum <= EDM_GAUSS_SUPPORT * (1.0 + 1e-6) + 1e-9)
+          cand.push_back(std::make_pair(sum, (o0 + 128) | ((o1 + 128) << 8) | ((o2 + 128) << 16)));
+      }
+  // inner offsets first (stable: ties keep stencil order): the cheap rejects of the outer shell share their waves
+  std::stable_sort(cand.begin(), cand.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first < b.first; });
+  if (cand.empty() || (long long)cand.size() * 2 > box) return EDM_HIP_OK;   // (no gain over the box walk)
+  std::vector<int> packed(cand.size());
+  for (size_t i = 0; i < cand.size(); i++) packed[i] = cand[i].second;
+  EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->ball), sizeof(int) * packed.size()));
+  EDM_HIP_TRY(hipMemcpy(g->ball, packed.data(), sizeof(int) * packed.size(), hipMemcpyHostToDevice));
+  g->nball = (int)packed.size();
   return EDM_HIP_OK;
 }
 
@@ -1326,6 +1381,10 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   hl.ht = ws.ht.p;
   hl.hx0 = p_hx0;
   hl.nh_dev = spec.d_nh;
+  {
+    int rcb = ball_list_ensure(g);
+    if (rcb) return rcb;
+  }
   const Tables tabs = g->tables();
   // the launch that produces the prepared hill list (queued further down, once the gather plan is known: a short
   // fix edm_pair step runs selection, forces, integrals, limiter and gather as ONE launch instead)
@@ -2056,6 +2115,10 @@ int edm_hip_gauss_hill_integrals(const edm_hip_gauss *gc, long long n, const dou
   hl.nh = n; hl.x = d_x; hl.x_stride = x_stride; hl.sel = nullptr;
   hl.hx = ws.hx.p; hl.hc = ws.hc.p; hl.ht = ws.ht.p; hl.hx0 = nullptr; hl.nh_dev = nullptr;
   EDM_HIP_TRY(launch_hill_prep(q, hl, g->stream));
+  {
+    int rcb = ball_list_ensure(g);
+    if (rcb) return rcb;
+  }
   EDM_HIP_TRY(launch_hill_integrals(q, g->tables(), hl, d_h, h_const, d_added, g->stream));
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
   return EDM_HIP_OK;

@@ -98,6 +98,9 @@ struct edm_hip_gauss {
   edm::Geom g;
   double *rec = nullptr;                 // device node records
   double *tab[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // denom, dderiv per dim
+  int *ball = nullptr;                   // 2-D / 3-D: Tables::ball (rebuilt when spacing, sigma or stencil half-widths change)
+  int nball = 0;
+  double ball_key[10] = {0};             // (dim, dx, sigma, msize the list was built for)
   double *node_tab = nullptr;            // 1-D grid with walls: Tables::node1d (rebuilt with the boundary / the geometry)
   hipStream_t stream = nullptr;
   double *scratch = nullptr;             // lookup partial sums

@@ -18,6 +18,12 @@ struct Tables {
   // stencil term's VALUE (gaussian_grid.h:311,:313,:318), computed once by launch_build_node_table with the very
   // code the kernels would run per stencil point (node_terms), so a walk that reads them yields the same bits
   const double *node1d;
+  // 2-D / 3-D, optional: the stencil offsets that can lie inside a hill's support (dp2 < 8, gaussian_grid.h:299)
+  // whatever the hill's position within its cell -- offsets o with sum_d (max(0, |o_d| - 1) dx_d / sigma_d)^2 <= 8,
+  // |o_d| <= msize_d, packed (o_0 + 128) | (o_1 + 128) << 8 | (o_2 + 128) << 16 and ordered by that sum (inner
+  // first): the per-hill integral walks this list instead of the (2 msize + 1)^DIM box (built by the host, edm_gauss.cpp)
+  const int *ball;
+  int nball;
 };
 // out: 4 doubles per node of the 1-D grid (t.node1d is not read)
 hipError_t launch_build_node_table(const Geom &g, const Tables &t, double *out, hipStream_t s);

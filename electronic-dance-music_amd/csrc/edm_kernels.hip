@@ -2437,123 +2437,30 @@ __device__ __forceinline__ double hill_stencil_partial(const Geom &g, const Tabl
       return acc;
     }
     if constexpr (DIM > 1 && TPH >= BLOCK) {
-      // 2-D / 3-D, a workgroup per hill: only the stencil points inside the hill's support (dp2 < 8, :299) are dealt out.
-      // The box the reference walks holds (2 msize + 1)^DIM points of which the support's ball covers 20 % in 2-D and
-      // 6 % in 3-D; dealt out point by point, every wave met a few support points in most of its trips and walked the
-      // full 24 trips of a 23^3 box as a serial instruction stream -- 16 us per hill however few hills a step had.
-      // Here the box is cut into ROWS along dimension 0; each row's stretch inside the ball (one spare node either
-      // side; pair_term makes the exact test) is computed once, the stretches are laid end to end by a scan over the
-      // rows, and the points of that list -- ~800 of 12 167 for W4 -- go round the threads.  Same terms; a thread's
-      // terms are added in list order, the threads' sums as before.
-      constexpr int ROW_CAP = 2304, RPT_MAX = (ROW_CAP + TPH - 1) / TPH;
-      unsigned wdr[DIM];
-      unsigned nrows = 1;
-#pragma unroll
-      for (int d = 0; d < DIM; d++) {
-        wdr[d] = (unsigned)(2 * g.msize[d] + 1);
-        if (d > 0) nrows *= wdr[d];
-      }
-      if (ball_ok && nrows <= (unsigned)ROW_CAP && total < (1LL << 31)) {
-        __shared__ int s_off[ROW_CAP + 1];
-        __shared__ short s_lo[ROW_CAP];
-        __shared__ int s_wsum[TPH / 64];
+      if (t.ball && ball_ok) {
+        // 2-D / 3-D, a workgroup per hill: only stencil points that can lie inside the hill's support (dp2 < 8, :299) are
+        // dealt out -- the host's list of such offsets (Tables::ball: one coalesced load per point, no decode, nothing
+        // shared between the threads; pair_term makes the exact test).  The box the reference walks holds
+        // (2 msize + 1)^DIM points of which the support's ball covers 20 % in 2-D and 6 % in 3-D; dealt out point by
+        // point, every wave met a few support points in most of its trips and walked all 24 trips of W4's 23^3 box as
+        // a serial instruction stream: 16 us per hill however few hills a step had, 7 us this way (a point is ~350
+        // dependent fp64 instructions and the hill's waves share one CU).  Same terms; a thread's terms are added in
+        // list order, the threads' sums as before.
         const double thr = 8.0 * (1.0 + 1e-6);
-        const unsigned rpt = (nrows + TPH - 1) / TPH;
-        int cnt[RPT_MAX];
-        short lo[RPT_MAX];
-        int mysum = 0;
-#pragma unroll
-        for (int q = 0; q < RPT_MAX; q++) {
-          cnt[q] = 0;
-          lo[q] = 0;
-          const unsigned r = (unsigned)lt * rpt + (unsigned)q;
-          if ((unsigned)q < rpt && r < nrows) {
-            unsigned rr = r;
-            double d2 = 0;
-            bool valid = true;
-#pragma unroll
-            for (int d = 1; d < DIM; d++) {
-              unsigned od = rr;
-              if (d < DIM - 1) {
-                od = rr % wdr[d];
-                rr /= wdr[d];
-              }
-              const int idx = (int)od - g.msize[d] + c[d];
-              const double e = ((g.min[d] + idx * g.dx[d]) - hx[d]) * tc.inv_sigma[d];
-              d2 += e * e;
-              if (!g.periodic[d] && (idx < 0 || idx >= g.n[d])) valid = false;
-              if (g.periodic[d] && idx + g.n[d] < 0) valid = false;   // (reference: undefined)
-            }
-            if (valid && d2 <= thr) {
-              const double xr = sqrt(thr - d2) * g.sigma[0];
-              const int ilo = (int)floor((hx[0] - xr - g.min[0]) / g.dx[0]) - 1;
-              const int ihi = (int)ceil((hx[0] + xr - g.min[0]) / g.dx[0]) + 1;
-              int olo = ilo + g.msize[0] - c[0], ohi = ihi + g.msize[0] - c[0];
-              if (olo < 0) olo = 0;
-              if (ohi > (int)wdr[0] - 1) ohi = (int)wdr[0] - 1;
-              if (ohi >= olo) {
-                cnt[q] = ohi - olo + 1;
-                lo[q] = (short)olo;
-              }
-            }
-          }
-          mysum += cnt[q];
-        }
-        if (trace && lt == 0) trace[3] = wall_clock64();
-        int incl = mysum;
-        const int lane_ = lt & 63, wave_ = lt >> 6;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int up = __shfl_up(incl, o, 64);
-          if (lane_ >= o) incl += up;
-        }
-        if (lane_ == 63) s_wsum[wave_] = incl;
-        __syncthreads();
-        int run = incl - mysum, npts = 0;
-#pragma unroll
-        for (int w = 0; w < TPH / 64; w++) {
-          if (w < wave_) run += s_wsum[w];
-          npts += s_wsum[w];
-        }
-#pragma unroll
-        for (int q = 0; q < RPT_MAX; q++) {
-          const unsigned r = (unsigned)lt * rpt + (unsigned)q;
-          if ((unsigned)q < rpt && r < nrows) {
-            s_off[r] = run;
-            s_lo[r] = lo[q];
-          }
-          run += cnt[q];
-        }
-        if (lt == 0) s_off[nrows] = npts;
-        __syncthreads();
-        if (trace && lt == 0) trace[6] = wall_clock64();
-        for (int j = lt; j < npts; j += TPH) {
-          // the last row whose stretch starts at or before j (empty rows share their successor's start and are skipped)
-          int a = 0, b = (int)nrows;
-          while (b - a > 1) {
-            const int mid = (a + b) >> 1;
-            if (s_off[mid] <= j) a = mid; else b = mid;
-          }
-          unsigned rr = (unsigned)a;
+        for (int j = lt; j < t.nball; j += TPH) {
+          const int pk = t.ball[j];
           int p[DIM];
           bool skip = false;
           double dp2_est = 0;
 #pragma unroll
           for (int d = 0; d < DIM; d++) {
-            unsigned od;
-            if (d == 0) {
-              od = (unsigned)((int)s_lo[a] + (j - s_off[a]));
-            } else if (d < DIM - 1) {
-              od = rr % wdr[d];
-              rr /= wdr[d];
-            } else {
-              od = rr;
-            }
-            int idx = (int)od - g.msize[d] + c[d];
+            int idx = ((pk >> (8 * d)) & 255) - 128 + c[d];
             const double e = ((g.min[d] + idx * g.dx[d]) - hx[d]) * tc.inv_sigma[d];
             dp2_est += e * e;
+            // (ball_ok: the stencil is narrower than the grid, so a periodic index is less than one period out)
             if (idx >= g.n[d]) {
-              if (g.periodic[d]) idx %= g.n[d]; else skip = true;
+              if (g.periodic[d]) idx -= g.n[d]; else skip = true;
+              if (idx >= g.n[d]) idx %= g.n[d];
             }
             if (idx < 0) {
               if (g.periodic[d]) idx += g.n[d]; else skip = true;
@@ -2855,8 +2762,10 @@ hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList 
     const unsigned nb = (unsigned)h.nh;
     switch (g.dim) {
       case 1: EDM_INTEGRALS(1, BLOCK, BLOCK, nb); break;
-      case 2: EDM_INTEGRALS(2, BLOCK, BLOCK, nb); break;
-      default: EDM_INTEGRALS(3, 2 * BLOCK, 2 * BLOCK, nb); break;
+      // (2-D / 3-D: the support's points are dealt out one or two per thread -- the walk is a serial instruction stream
+      //  of ~300 dependent fp64 instructions per point, and a hill step waits for it)
+      case 2: EDM_INTEGRALS(2, 2 * BLOCK, 2 * BLOCK, nb); break;
+      default: EDM_INTEGRALS(3, 4 * BLOCK, 4 * BLOCK, nb); break;
     }
   } else {
     const unsigned nb = (unsigned)((h.nh + (BLOCK / 64) - 1) / (BLOCK / 64));
