@@ -1457,6 +1457,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   plan.tile_list = nullptr;
   plan.tile_parity = 0;
   plan.tile_bound = 0;
+  plan.tiles_marked = 0;
   const long long ntiles = gather_tiles(q);
   if (fused) {
     // planned above
@@ -1794,7 +1795,12 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         EDM_HIP_TRY(hipMemset(d_trace, 0, (size_t)nh * 64));
         la.trace = d_trace;
       }
-      EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s, &la));
+      // a culled gather follows (2-D / 3-D, short list on a big grid): its tile list is built by extra workgroups of
+      // this launch instead of a launch of its own (the list needs the prepared hills, nothing of the integrals)
+      MarkArgs mark{plan.tile_flags, plan.tile_list, ntiles, plan.tile_parity};
+      const bool mark_here = dim > 1 && plan.tile_flags && plan.tile_list && plan.groups == 1 && !sharded && !fused && !spec.ordered;
+      EDM_HIP_TRY(launch_hill_integrals(q, tabs, hl, spec.d_h, spec.h_const, p_added, s, &la, mark_here ? &mark : nullptr));
+      if (mark_here) plan.tiles_marked = 1;
       if (d_trace) {
         EDM_HIP_TRY(hipStreamSynchronize(s));
         std::vector<unsigned long long> tr((size_t)nh * 8);

@@ -233,8 +233,19 @@ struct HillHeights {
                           // (sharded multi-GPU application); 0 otherwise
 };
 // per-hill integrated bias for the BASE heights (the value add_value returns)
+// `mark` (workgroup-per-hill launches of a 2-D / 3-D grid only): extra workgroups of the same launch list the tiles the
+// hills touch for the culled gather that follows (k_mark_tiles' body: it needs the prepared hills, nothing of the
+// integrals) -- one launch and its ~6-9 us of dependent atomics less per hill batch
+long long mark_tiles_threads(const Geom &g, long long nh);   // threads k_mark_tiles' body needs for nh hills
+struct MarkArgs {
+  int *flags;        // GatherPlan::tile_flags
+  int *list;         // GatherPlan::tile_list
+  long long ntiles;
+  int parity;
+};
 hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList &h, const double *heights,
-                                 double h_const, double *added, hipStream_t s, const LimitArgs *chain = nullptr);
+                                 double h_const, double *added, hipStream_t s, const LimitArgs *chain = nullptr,
+                                 const MarkArgs *mark = nullptr);
 
 struct GatherPlan {
   int groups;             // hill groups (partial buffers) -- 1 = accumulate in place
@@ -246,6 +257,7 @@ struct GatherPlan {
                           // zeroes the counter of the NEXT batch, so no memset precedes it); kept zero in between
   int tile_parity;        // which counter this batch uses
   long long tile_bound;   // launch bound for culled gathers
+  int tiles_marked;       // the tile list of this batch was built by an earlier launch (launch_hill_integrals with `mark`)
   // fused mode (dense batches on small grids): the gather runs BEFORE the limiter with the base
   // heights, writes per-group deltas and, as a by-product, the per-(hill, tile) pieces of each
   // hill's integrated bias into `slots` [nh][slots_per_hill]; a correction pass then fixes up the

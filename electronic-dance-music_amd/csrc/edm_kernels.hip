@@ -2723,12 +2723,21 @@ __device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables 
   }
   return false;
 }
+template <int DIM>
+__device__ __forceinline__ void mark_tiles_body(const Geom &g, const HillList &h, int *__restrict__ flags,
+                                                int *__restrict__ list, long long ntiles, int parity, long long id);
+// (workgroups [0, nb_int): the integrals; the rest, if any: the tile list of the culled gather that follows -- MarkArgs)
 template <int DIM, int TPH, bool PERB>
 __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(Geom g, Tables t, HillList h,
                                                                                 const double *__restrict__ heights,
                                                                                 double h_const,
                                                                                 double *__restrict__ added,
-                                                                                LimitArgs la) {
+                                                                                LimitArgs la, MarkArgs mk, unsigned nb_int) {
+  if (blockIdx.x >= nb_int) {
+    constexpr int NT = (TPH > BLOCK) ? TPH : BLOCK;
+    mark_tiles_body<DIM>(g, h, mk.flags, mk.list, mk.ntiles, mk.parity, (long long)(blockIdx.x - nb_int) * NT + threadIdx.x);
+    return;
+  }
   if (la.trace && threadIdx.x == 0) la.trace[(size_t)blockIdx.x * 8] = wall_clock64();
   (void)hill_integrals_body<DIM, TPH, PERB>(g, t, h, heights, h_const, added, la, blockIdx.x);
   if (la.trace && threadIdx.x == 0) la.trace[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
@@ -2737,8 +2746,15 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
 bool hill_integrals_can_chain_limit(long long nh) { return nh > 0 && nh <= 2048; }
 
 hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList &h, const double *heights,
-                                 double h_const, double *added, hipStream_t s, const LimitArgs *chain) {
+                                 double h_const, double *added, hipStream_t s, const LimitArgs *chain,
+                                 const MarkArgs *mark) {
   if (h.nh <= 0) return hipSuccess;
+  MarkArgs mk;
+  memset(&mk, 0, sizeof(mk));
+  if (mark) {
+    if (h.nh > 2048 || g.dim < 2 || !mark->flags || !mark->list) return hipErrorInvalidValue;
+    mk = *mark;
+  }
   LimitArgs la;
   memset(&la, 0, sizeof(la));
   if (chain) {
@@ -2752,12 +2768,15 @@ hipError_t launch_hill_integrals(const Geom &g, const Tables &t, const HillList 
 #define EDM_INTEGRALS(D, TPHV, NTV, NB)                                                                            \
   do {                                                                                                             \
     if (perb)                                                                                                      \
-      hipLaunchKernelGGL((k_hill_integrals<D, TPHV, true>), dim3(NB), dim3(NTV), 0, s, g, t, h, heights, h_const,  \
-                         added, la);                                                                               \
+      hipLaunchKernelGGL((k_hill_integrals<D, TPHV, true>), dim3((NB) + nmark(NTV)), dim3(NTV), 0, s, g, t, h,    \
+                         heights, h_const, added, la, mk, (unsigned)(NB));                                        \
     else                                                                                                           \
-      hipLaunchKernelGGL((k_hill_integrals<D, TPHV, false>), dim3(NB), dim3(NTV), 0, s, g, t, h, heights, h_const, \
-                         added, la);                                                                               \
+      hipLaunchKernelGGL((k_hill_integrals<D, TPHV, false>), dim3((NB) + nmark(NTV)), dim3(NTV), 0, s, g, t, h,   \
+                         heights, h_const, added, la, mk, (unsigned)(NB));                                        \
   } while (0)
+  // marking workgroups behind the integrals' (which wait for nobody and are what the step waits for)
+  const long long mark_threads = mark ? mark_tiles_threads(g, h.nh) : 0;
+  auto nmark = [mark_threads](int nt) { return (unsigned)((mark_threads + nt - 1) / nt); };
   if (h.nh <= 2048) {
     const unsigned nb = (unsigned)h.nh;
     switch (g.dim) {
@@ -3796,11 +3815,12 @@ __global__ void __launch_bounds__(BLOCK) k_reduce_partials(Geom g, double *__res
 // (hill, stencil-corner offset); a tile is appended by whoever flips its flag first (wave-aggregated
 // append), and the gather workgroup that later owns the tile clears the flag again, so `flags` is all
 // zero between batches and nothing has to be memset or compacted.
+// (id: this thread's index among the marking threads -- whole waves, see the wave-aggregated append)
 template <int DIM>
-__global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *__restrict__ flags,
-                                                      int *__restrict__ list, long long ntiles, int parity) {
+__device__ __forceinline__ void mark_tiles_body(const Geom &g, const HillList &h, int *__restrict__ flags,
+                                                int *__restrict__ list, long long ntiles, int parity, long long id) {
   int *count = list + ntiles + parity;
-  if (blockIdx.x == 0 && threadIdx.x == 0) list[ntiles + (1 - parity)] = 0;  // the next batch's counter
+  if (id == 0) list[ntiles + (1 - parity)] = 0;  // the next batch's counter
   int ntile[DIM], steps[DIM];
   long long combos = 1;
 #pragma unroll
@@ -3813,7 +3833,6 @@ __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *_
     steps[d] = (2 * g.msize[d]) / T + 2 + ((g.periodic[d] && g.n[d] % T != 0) ? 4 : 0);
     combos *= steps[d];
   }
-  const long long id = (long long)blockIdx.x * BLOCK + threadIdx.x;
   const long long i = id / combos;
   bool emit = false;
   long long tflat = 0;
@@ -3879,6 +3898,11 @@ __global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *_
     if (emit) list[base + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (int)tflat;
   }
 }
+template <int DIM>
+__global__ void __launch_bounds__(BLOCK) k_mark_tiles(Geom g, HillList h, int *__restrict__ flags,
+                                                      int *__restrict__ list, long long ntiles, int parity) {
+  mark_tiles_body<DIM>(g, h, flags, list, ntiles, parity, (long long)blockIdx.x * BLOCK + threadIdx.x);
+}
 long long mark_tiles_threads(const Geom &g, long long nh) {
   long long combos = 1;
   for (int d = 0; d < g.dim; d++) {
@@ -3911,8 +3935,9 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
   long long launch_tiles = ntiles;
   if (plan.tile_flags && plan.tile_list && plan.groups == 1) {
     const long long mt = mark_tiles_threads(g, h.nh);
-    hipLaunchKernelGGL(k_mark_tiles<DIM>, dim3((unsigned)((mt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, g, h, plan.tile_flags,
-                       plan.tile_list, ntiles, plan.tile_parity);
+    if (!plan.tiles_marked)
+      hipLaunchKernelGGL(k_mark_tiles<DIM>, dim3((unsigned)((mt + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, g, h, plan.tile_flags,
+                         plan.tile_list, ntiles, plan.tile_parity);
     use_list = 1;
     launch_tiles = plan.tile_bound < ntiles ? plan.tile_bound : ntiles;
   }
