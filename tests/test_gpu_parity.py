@@ -1017,3 +1017,28 @@ def test_pair_step_host_equals_device_arrays(pinned, workdir):
     for k in (1, 2, 3):
         assert np.array_equal(state[0][k], state[1][k])
     assert state[0][1].max() > 0 and state[0][0][-1][2][2] > 0
+
+
+def test_ball_list_equals_box_walk():
+    """2-D / 3-D per-hill integrals walk the host's list of the stencil offsets that can lie inside the support
+    (Tables::ball) instead of the reference's (2 minisize + 1)^D box (gaussian_grid.h:227-281): the same terms in another
+    order, so the two walks agree to rounding -- periodic and walled boundaries, hills on walls, seams and nodes."""
+    import json
+    import subprocess
+    import sys
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ball_worker.py")
+    res = {}
+    for tag, val in (("list", None), ("box", "0")):
+        env = dict(os.environ)
+        env.pop("EDM_HIP_BALL_LIST", None)
+        if val is not None:
+            env["EDM_HIP_BALL_LIST"] = val
+        r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("INTEGRALS ")][-1]
+        res[tag] = {k: np.array([float.fromhex(v) for v in vs]) for k, vs in json.loads(line[len("INTEGRALS "):]).items()}
+    for name in res["list"]:
+        a, b = res["list"][name], res["box"][name]
+        assert a.shape == b.shape and np.abs(b).max() > 0, name
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-14 * np.abs(b).max()), (name, np.abs(a - b).max())
