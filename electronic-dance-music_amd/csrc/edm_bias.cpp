@@ -87,6 +87,7 @@ struct edm_hip_bias {
   int debug_pair_step_mode = -1;  // tests: how a short fix edm_pair hill step is queued (see apply_hills); -1 = the library's choice
   long long bound_redos = 0;    // steps redone because the accepted count exceeded the deferred launch bound
   PendingForces pending;        // pair forces of a fused step waiting for the launch of the step's selection
+  PendingForces *flush_forces = nullptr;   // fix edm step: the pending force kernel an overflow flush may carry (else NULL)
   // staging of the *_host entry points: device copies of the caller's host arrays, a second stream for the copy
   // that runs against the direction of the others, and the event that orders it behind the force kernel
   DevBuf<double> hs_r, hs_f, hs_x, hs_u;
@@ -434,6 +435,7 @@ static int flush_overflow(edm_hip_bias *b, double max_bias, double *bias_added) 
   const bool log_all = b->hill_log && b->hills_fp;
   spec.fetch_all = log_all;     // (per-hill bias only for the HILLS log; without one the limiter's header line is enough)
   spec.fetch_heights = false;   // (the heights came from the host's own overflow records)
+  spec.forces = b->flush_forces;   // (fix edm step: its pending force kernel can share the preparation's launch)
   ApplyOutcome oc;
   int rc = apply_hills(b->bias, spec, &oc, false);
   if (rc) return rc;
@@ -904,19 +906,50 @@ int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_str
   }
   int nblk = 0;
   unsigned long long ftag = 0;
+  bool lookup_pending = false;
   if (!b->b_outofbounds) {   // update_forces (:279-280) -- queued, not waited for
     // (tagged partial energy sums: should no polled hill batch follow, the host looks at the slots instead of waiting
     //  for the stream, see edm_hip_gauss_pair_forces)
     if (n > 0 && forces_poll_enabled()) ftag = ++b->bias->force_seq;
-    int rc = update_forces_enqueue(b->bias, n, d_x, x_stride, d_f, f_stride, b->d_mask, apply_mask, &nblk, ftag);
-    if (rc) return rc;
+    if (n > 0 && b->dim > 1) {
+      // 2-D / 3-D: kept pending until the overflow flush queues its preparation -- the two share a launch
+      // (launch_lookup_prep); whoever queues anything else first launches it on its own (pending_forces_flush)
+      if (apply_mask >= 0 && !b->d_mask) {
+        set_error("update_forces: apply_mask >= 0 needs a mask");
+        return EDM_HIP_ERR_ARG;
+      }
+      b->pending = PendingForces();
+      b->pending.active = true;
+      b->pending.lookup = true;
+      b->pending.la = LookupArgs{};
+      b->pending.la.n = n;
+      b->pending.la.x = d_x;
+      b->pending.la.x_stride = x_stride;
+      b->pending.la.f = d_f;
+      b->pending.la.f_stride = f_stride;
+      b->pending.la.mask = b->d_mask;
+      b->pending.la.apply_mask = apply_mask;
+      b->pending.la.partial_tag = ftag;
+      lookup_pending = true;
+    } else {
+      int rc = update_forces_enqueue(b->bias, n, d_x, x_stride, d_f, f_stride, b->d_mask, apply_mask, &nblk, ftag);
+      if (rc) return rc;
+    }
   }
   // add_hills behind it on the same stream (:401-411): pre_add_hill, the samples, post_add_hill
   // (the force kernel is ALREADY queued: a polled batch of the overflow flush inside pre_add_hill is behind it on the
   //  stream and shows it complete just as a polled batch of new hills does -- a step whose new hills are skipped,
   //  edm_bias.cpp:534-535, must not fall back to a stream wait for that: 20-30 us of idle GPU per step on W4)
   if (b->bias) b->bias->wait_polled = false;
+  b->flush_forces = lookup_pending ? &b->pending : nullptr;
   int rc = do_pre_add_hill(b, est_hill_count < 0 ? n : est_hill_count);
+  b->flush_forces = nullptr;
+  if (lookup_pending) {
+    // (no flush this step, or one that could not carry it: the force kernel goes now, ahead of the new hills)
+    int rcf = pending_forces_flush(b->bias, &b->pending);
+    nblk = b->pending.nblk;
+    if (!rc) rc = rcf;
+  }
   if (rc) return rc;
   if (!b->b_outofbounds) {
     const bool flush_polled = b->bias->wait_polled;
@@ -1340,6 +1373,7 @@ int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
   G("poll_fallbacks", b->bias ? b->bias->poll_fallbacks : 0)
   G("header_releases", b->bias ? b->bias->header_releases : 0)
   G("polled_forces", b->bias ? b->bias->polled_forces : 0)
+  G("lookup_prep_launches", b->bias ? b->bias->lookup_prep_launches : 0)
   G("bound_redos", b->bound_redos)
 #undef G
   set_error(std::string("unknown EDMBias member ") + name);

@@ -1131,6 +1131,15 @@ int update_forces_enqueue(const edm_hip_gauss *g, long long n, const double *d_x
 int pending_forces_flush(const edm_hip_gauss *g, PendingForces *pf) {
   if (!pf || !pf->active) return EDM_HIP_OK;
   pf->active = false;
+  if (pf->lookup) {
+    hipEvent_t e0, e1;
+    profile_slot(g, &e0, &e1);
+    const double *faces = nullptr;
+    int rcf = faces_prepare(const_cast<edm_hip_gauss *>(g), &faces);
+    if (rcf) return rcf;
+    EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, pf->la, g->d_partials, nullptr, g->stream, e0, e1, &pf->nblk, faces));
+    return EDM_HIP_OK;
+  }
   if (pf->list) {
     EDM_HIP_TRY(launch_pairlist_forces(g->g, g->rec, pf->pl, g->d_partials, g->stream, &pf->nblk));
     return EDM_HIP_OK;
@@ -1393,10 +1402,30 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       // selection + preparation in one launch (and the step's pair forces with them, when they are pending)
       int rc = select_prep_enqueue(g, *spec.sel_chain, hl, spec.forces);
       if (rc) return rc;
-    } else if (spec.unpack_chain)
+    } else if (spec.unpack_chain) {
+      int rc = pending_forces_flush(g, spec.forces);
+      if (rc) return rc;
       EDM_HIP_TRY(launch_unpack_prep(*spec.unpack_chain, q, hl, s));  // exchange packets -> global prepared list
-    else
-      EDM_HIP_TRY(launch_hill_prep(q, hl, s, spec.h_fetch_src, spec.h_fetch_src ? const_cast<double *>(spec.d_h) : nullptr));
+    } else {
+      PendingForces *pf = spec.forces;
+      double *fetch_dst = spec.h_fetch_src ? const_cast<double *>(spec.d_h) : nullptr;
+      static const bool fuse_env = !(getenv("EDM_HIP_LOOKUP_PREP") && getenv("EDM_HIP_LOOKUP_PREP")[0] == '0');   // (A/B, tests)
+      if (pf && pf->active && pf->lookup && fuse_env && pf->la.n > 0 && lookup_prep_fusable(q, hl)) {
+        // fix edm step: the pending force kernel (K2) and this list's preparation share a launch
+        pf->active = false;
+        hipEvent_t e0, e1;
+        profile_slot(g, &e0, &e1);
+        const double *faces = nullptr;
+        int rcf = faces_prepare(g, &faces);
+        if (rcf) return rcf;
+        EDM_HIP_TRY(launch_lookup_prep(q, g->rec, pf->la, g->d_partials, s, e0, e1, &pf->nblk, faces, hl, spec.h_fetch_src, fetch_dst));
+        g->lookup_prep_launches++;
+        return EDM_HIP_OK;
+      }
+      int rc = pending_forces_flush(g, pf);   // (a pending force kernel goes ahead of everything this batch queues)
+      if (rc) return rc;
+      EDM_HIP_TRY(launch_hill_prep(q, hl, s, spec.h_fetch_src, fetch_dst));
+    }
     return EDM_HIP_OK;
   };
 

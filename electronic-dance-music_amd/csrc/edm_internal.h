@@ -98,6 +98,7 @@ struct edm_hip_gauss {
   edm::Geom g;
   double *rec = nullptr;                 // device node records
   double *tab[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // denom, dderiv per dim
+  long long lookup_prep_launches = 0;    // fix edm steps whose force kernel shared a launch with the flush's preparation
   int *ball = nullptr;                   // 2-D / 3-D: Tables::ball (rebuilt when spacing, sigma or stencil half-widths change)
   int nball = 0;
   double ball_key[10] = {0};             // (dim, dx, sigma, msize the list was built for)
@@ -175,6 +176,10 @@ struct PendingForces {
   // ... or the force pass over a device-resident neighbour list (fix edm_pair gpu_list), queued the same way
   bool list = false;
   PairListArgs pl;
+  // ... or K2, the coordinate-CV force kernel of a fix edm step (edm_hip_bias_step): it can share a launch with the
+  // preparation of the overflow flush's hill list (launch_lookup_prep); `la.partial_tag` as for `tag` above
+  bool lookup = false;
+  LookupArgs la;
 };
 void ht_mark(edm_hip_gauss *g, int slot);   // development aid, edm_gauss.cpp
 

@@ -166,6 +166,11 @@ struct HillList {
 };
 hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s, const double *fetch_src = nullptr,
                             double *fetch_dst = nullptr);
+// fix edm step on a 2-D / 3-D grid: K2 (forces, four lanes per atom) and the preparation of a hill list in one launch
+bool lookup_prep_fusable(const Geom &g, const HillList &h);
+hipError_t launch_lookup_prep(const Geom &g, const double *rec, const LookupArgs &a, double *scratch, hipStream_t s,
+                              hipEvent_t ev0, hipEvent_t ev1, int *blocks_out, const double *faces, const HillList &h,
+                              const double *fetch_src, double *fetch_dst);
 
 // --- chained launches for short hill steps (see last_block_done in edm_kernels.hip) ---
 // a ticket = zero-initialised device ints: top counter + FAN sub-counters, one 128-byte line each

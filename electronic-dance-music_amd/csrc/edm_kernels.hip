@@ -531,16 +531,17 @@ __device__ __forceinline__ void corner_terms(const Geom &g, const double4 &r, co
 // enough to sit in L2): lane q loads corner q (and q + 4) at its node's address -- a quad covers the 64-byte corner
 // pairs of two grid rows per instruction, 32 lines per wave-instruction instead of 64, a quarter of the load
 // instructions per sample.
-template <int DIM, int MODE, bool REPLICA = true>
-__global__ void __launch_bounds__(BLOCK) k_lookup_quad(Geom g, const double *__restrict__ faces, LookupArgs a,
-                                                       double *__restrict__ block_energy) {
+// (body for workgroup `bid` of `nb`: shared by the plain launch and by the launch that also prepares a hill list)
+template <int DIM, int MODE, bool REPLICA>
+__device__ __forceinline__ void lookup_quad_body(const Geom &g, const double *__restrict__ faces, const LookupArgs &a,
+                                                 double *__restrict__ block_energy, unsigned bid, unsigned nb) {
   static_assert(DIM == 2 || DIM == 3, "the replica serves 2-D and 3-D grids");
   __shared__ double lds[BLOCK / 64];
   const int q = threadIdx.x & 3;
   const int b0 = q & 1, b1 = q >> 1;
   double e_acc = 0;
-  const long long stride = (long long)gridDim.x * (BLOCK / 4);
-  for (long long i = (long long)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2); i < a.n; i += stride) {
+  const long long stride = (long long)nb * (BLOCK / 4);
+  for (long long i = (long long)bid * (BLOCK / 4) + (threadIdx.x >> 2); i < a.n; i += stride) {
     if (MODE == LOOKUP_FORCES && !(a.apply_mask < 0 || (a.mask[i] & a.apply_mask))) continue;   // (uniform over the quad)
     double xx[DIM];
 #pragma unroll
@@ -649,8 +650,13 @@ __global__ void __launch_bounds__(BLOCK) k_lookup_quad(Geom g, const double *__r
   }
   double r = block_sum(e_acc, lds);
   if (threadIdx.x == 0) {
-    if (a.partial_tag) store_partial_tagged(block_energy, blockIdx.x, r, a.partial_tag); else block_energy[blockIdx.x] = r;
+    if (a.partial_tag) store_partial_tagged(block_energy, bid, r, a.partial_tag); else block_energy[bid] = r;
   }
+}
+template <int DIM, int MODE, bool REPLICA = true>
+__global__ void __launch_bounds__(BLOCK) k_lookup_quad(Geom g, const double *__restrict__ faces, LookupArgs a,
+                                                       double *__restrict__ block_energy) {
+  lookup_quad_body<DIM, MODE, REPLICA>(g, faces, a, block_energy, blockIdx.x, gridDim.x);
 }
 
 template <int DIM>
@@ -1615,17 +1621,37 @@ __device__ __forceinline__ void hill_prep_vals(const Geom &g, const HillList &h,
   }
 }
 
+// (body for workgroup `bid` of `nb`)
+template <int DIM>
+__device__ __forceinline__ void hill_prep_body(const Geom &g, const HillList &h, const double *__restrict__ fetch_src,
+                                               double *__restrict__ fetch_dst, unsigned bid, unsigned nb) {
+  const long long stride = (long long)nb * BLOCK;
+  const long long nh = hill_count(h);
+  for (long long i = (long long)bid * BLOCK + threadIdx.x; i < nh; i += stride) {
+    if (fetch_dst) fetch_dst[i] = fetch_src[i];
+    hill_prep_one<DIM>(g, h, i, h.sel ? h.sel[i] : i);
+  }
+}
 template <int DIM>
 // (fetch_src/fetch_dst, optional: the per-hill heights of an overflow flush sit in host-mapped memory next to the
 //  positions; this kernel brings them over while it prepares the hills -- no separate upload)
 __global__ void __launch_bounds__(BLOCK) k_hill_prep(Geom g, HillList h, const double *__restrict__ fetch_src,
                                                      double *__restrict__ fetch_dst) {
-  const long long stride = (long long)gridDim.x * BLOCK;
-  const long long nh = hill_count(h);
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < nh; i += stride) {
-    if (fetch_dst) fetch_dst[i] = fetch_src[i];
-    hill_prep_one<DIM>(g, h, i, h.sel ? h.sel[i] : i);
-  }
+  hill_prep_body<DIM>(g, h, fetch_src, fetch_dst, blockIdx.x, gridDim.x);
+}
+// fix edm step on a 2-D / 3-D grid: the force kernel (K2 on four lanes per atom) and the preparation of the overflow
+// flush's hill list in ONE launch -- workgroups [0, nb_prep) prepare (they read positions and heights from host-mapped
+// memory: dispatched first, done long before the lookups), the rest evaluate forces.  Neither touches what the other
+// reads or writes (the flush's gather, which writes the grid, is a later launch): one launch and its 5 us less per step.
+template <int DIM, bool REPLICA>
+__global__ void __launch_bounds__(BLOCK) k_lookup_quad_prep(Geom g, const double *__restrict__ faces, LookupArgs a,
+                                                            double *__restrict__ block_energy, HillList h,
+                                                            const double *__restrict__ fetch_src,
+                                                            double *__restrict__ fetch_dst, unsigned nb_prep) {
+  if (blockIdx.x < nb_prep)
+    hill_prep_body<DIM>(g, h, fetch_src, fetch_dst, blockIdx.x, nb_prep);
+  else
+    lookup_quad_body<DIM, LOOKUP_FORCES, REPLICA>(g, faces, a, block_energy, blockIdx.x - nb_prep, gridDim.x - nb_prep);
 }
 
 // ---------------------------------------------------------------------------
@@ -2026,6 +2052,32 @@ hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s, con
     case 2: hipLaunchKernelGGL(k_hill_prep<2>, dim3(b), dim3(BLOCK), 0, s, g, h, fetch_src, fetch_dst); break;
     default: hipLaunchKernelGGL(k_hill_prep<3>, dim3(b), dim3(BLOCK), 0, s, g, h, fetch_src, fetch_dst); break;
   }
+  return hipGetLastError();
+}
+
+bool lookup_prep_fusable(const Geom &g, const HillList &h) {
+  return g.dim > 1 && g.interp && g.rec == 4 && h.nh > 0;
+}
+hipError_t launch_lookup_prep(const Geom &g, const double *rec, const LookupArgs &a, double *scratch, hipStream_t s,
+                              hipEvent_t ev0, hipEvent_t ev1, int *blocks_out, const double *faces, const HillList &h,
+                              const double *fetch_src, double *fetch_dst) {
+  if (!lookup_prep_fusable(g, h) || a.n <= 0) return hipErrorInvalidValue;
+  long long qb = (a.n * 4 + BLOCK - 1) / BLOCK;
+  if (qb > MAX_BLOCKS) qb = MAX_BLOCKS;
+  const unsigned nb = (unsigned)(qb < 1 ? 1 : qb), nb_prep = (unsigned)blocks_for(h.nh);
+  const dim3 grid(nb_prep + nb);
+  if (g.dim == 2) {
+    if (faces)
+      EDM_LAUNCH_TIMED((k_lookup_quad_prep<2, true>), grid, dim3(BLOCK), 0, s, ev0, ev1, g, faces, a, scratch, h, fetch_src, fetch_dst, nb_prep);
+    else
+      EDM_LAUNCH_TIMED((k_lookup_quad_prep<2, false>), grid, dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, h, fetch_src, fetch_dst, nb_prep);
+  } else {
+    if (faces)
+      EDM_LAUNCH_TIMED((k_lookup_quad_prep<3, true>), grid, dim3(BLOCK), 0, s, ev0, ev1, g, faces, a, scratch, h, fetch_src, fetch_dst, nb_prep);
+    else
+      EDM_LAUNCH_TIMED((k_lookup_quad_prep<3, false>), grid, dim3(BLOCK), 0, s, ev0, ev1, g, rec, a, scratch, h, fetch_src, fetch_dst, nb_prep);
+  }
+  if (blocks_out) *blocks_out = (int)nb;
   return hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ def main(workdir):
     dig.update(open(os.path.join(workdir, "BIAS_p1"), "rb").read())
     dig.update(open(os.path.join(workdir, "HILLS_p1_0"), "rb").read())
     del b
+    print("SECTION", 1, dig.hexdigest()[:16])
 
     # 2-D periodic coordinate CV through edm_hip_bias_step (flush + new hills every step)
     cfg = os.path.join(workdir, "p2.edm")
@@ -69,7 +70,11 @@ def main(workdir):
         feed([e], d_f.to_host())
     gv, gd = b.gauss.download()
     feed(gv, gd, b.hist.values, [b.get("cum_bias"), b.get("overflow_right"), b.get("hills_added")])
+    # (steps with an overflow flush: the force kernel rides in the launch that prepares the flush's hill list,
+    #  EDM_HIP_LOOKUP_PREP=0: a launch of its own, ahead of it)
+    print("LOOKUP_PREP", int(b.get("lookup_prep_launches")))
     del b
+    print("SECTION", 2, dig.hexdigest()[:16])
     # 1-D pair CV, no HILLS log, limiter far away: the steps whose host call returns on the limiter's HEADER LINE alone
     # (EDM_HIP_FAST_HEADER=0 makes them wait for the completion word like every other polled batch)
     cfg = os.path.join(workdir, "p3.edm")
@@ -103,6 +108,7 @@ def main(workdir):
     print("POLLED_FORCES", int(b.get("polled_forces")))
     print("HEADER_RELEASES", int(b.get("header_releases")))
     del b
+    print("SECTION", 3, dig.hexdigest()[:16])
     # 1-D pair CV whose walls lie INSIDE the rank's grid (a sub-domain with skin): hills at both walls meet boundary
     # corrections, and the duplication behind the gather copies the wall nodes outwards (gaussian_grid.h:571-630).  Only
     # the tiles near the walls take the ticket that decides it (EDM_HIP_DUP_TICKET_ALL=1: every tile, the old way).
@@ -128,6 +134,8 @@ def main(workdir):
         geo = b.gauss.geometry
         print("WALLS_INSIDE", tag, float(geo.min[0]), float(geo.max[0]), float(np.abs(gv).max()))
         del b
+        print("SECTION", tag, dig.hexdigest()[:16])
+    print("SECTION", 4, dig.hexdigest()[:16])
     print("DIGEST", dig.hexdigest())
 
 
