@@ -1020,7 +1020,11 @@ __device__ __forceinline__ void pair_forces_fast_body(const Geom &g, const doubl
   }
   double s = block_sum(e_acc, red);
   if (threadIdx.x == 0) {
-    if (tag) store_partial_tagged(block_energy, bid, s, tag); else block_energy[bid] = s;
+    // (untagged: a system-scope store -- written through to the host-mapped array now.  Inside k_pair_step the host is
+    //  released by a workgroup of the SAME launch once this workgroup has arrived on k1_done: a plain store could still
+    //  sit in this XCD's L2 then, and the host would add up last step's sum)
+    if (tag) store_partial_tagged(block_energy, bid, s, tag);
+    else __hip_atomic_store(&block_energy[bid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
