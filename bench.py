@@ -434,11 +434,11 @@ def coordinate_cv_measure(H, W, tmpdir):
             bb.step_device(d_x, 3, d_fs, 3, natoms, d_uu, -1, natoms)
         H.synchronize()
         t4 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(40):
             bb.step_device(d_x, 3, d_fs, 3, natoms, d_uu, -1, natoms)
         H.synchronize()
-        t_step = (time.perf_counter() - t4) / 20
-        hills_step = bb.get("hills_added") / 23.0
+        t_step = (time.perf_counter() - t4) / 40
+        hills_step = bb.get("hills_added") / 43.0
         del bb
         kname = "edm::k_lookup_quad<%d" % dim
         nd[tag] = dict(workload="BASELINE configs[%d]: fix edm coordinate CV, %s periodic bias grid, %d atoms at random positions"
