@@ -944,16 +944,20 @@ int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_str
   b->flush_forces = lookup_pending ? &b->pending : nullptr;
   int rc = do_pre_add_hill(b, est_hill_count < 0 ? n : est_hill_count);
   b->flush_forces = nullptr;
-  if (lookup_pending) {
-    // (no flush this step, or one that could not carry it: the force kernel goes now, ahead of the new hills)
-    int rcf = pending_forces_flush(b->bias, &b->pending);
-    nblk = b->pending.nblk;
-    if (!rc) rc = rcf;
+  if (rc) {
+    if (lookup_pending) (void)pending_forces_flush(b->bias, &b->pending);
+    return rc;
   }
-  if (rc) return rc;
   if (!b->b_outofbounds) {
     const bool flush_polled = b->bias->wait_polled;
+    // (no flush this step, or one that could not carry the force kernel: it is still pending, and the new hills'
+    //  selection can carry it -- select_prep_enqueue; whatever is left pending after that goes on its own)
     rc = process_new_hills(b, n, d_x, x_stride, d_runiform, apply_mask);
+    if (lookup_pending) {
+      int rcf = pending_forces_flush(b->bias, &b->pending);
+      nblk = b->pending.nblk;
+      if (!rc) rc = rcf;
+    }
     if (flush_polled) b->bias->wait_polled = true;   // (whatever the new hills did: the forces were seen complete)
     if (rc) return rc;
     double e = 0;

@@ -1201,7 +1201,21 @@ int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a_in, const Hi
     EDM_HIP_TRY(launch_pairlist_forces_select(a, g->g, h, g->rec, pf->pl, g->d_partials, g->stream, &pf->nblk));
     return EDM_HIP_OK;
   }
-  if (pf && pf->active && !pf->list && pair_forces_select_fusable(g->g, pf->n, a.n)) {
+  static const bool lookup_fuse_env = !(getenv("EDM_HIP_LOOKUP_PREP") && getenv("EDM_HIP_LOOKUP_PREP")[0] == '0');   // (A/B, tests)
+  if (pf && pf->active && pf->lookup && lookup_fuse_env && !a.pack && g->g.dim > 1 && g->g.interp && g->g.rec == 4 &&
+      pf->la.n > 0 && a.n > 0) {
+    // fix edm step without an overflow flush: the pending force kernel (K2) and the step's selection share a launch
+    pf->active = false;
+    hipEvent_t e0, e1;
+    profile_slot(g, &e0, &e1);
+    const double *faces = nullptr;
+    int rcf = faces_prepare(const_cast<edm_hip_gauss *>(g), &faces);
+    if (rcf) return rcf;
+    EDM_HIP_TRY(launch_lookup_select(g->g, g->rec, pf->la, g->d_partials, g->stream, e0, e1, &pf->nblk, faces, a, h));
+    const_cast<edm_hip_gauss *>(g)->lookup_prep_launches++;
+    return EDM_HIP_OK;
+  }
+  if (pf && pf->active && !pf->list && !pf->lookup && pair_forces_select_fusable(g->g, pf->n, a.n)) {
     hipEvent_t e0, e1;
     profile_slot(g, &e0, &e1);
     pf->active = false;
@@ -1393,6 +1407,14 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   {
     int rcb = ball_list_ensure(g);
     if (rcb) return rcb;
+  }
+  // a force kernel still pending (fix edm step) will read the lookup replica: settle the replica's state NOW -- built
+  // if it is due -- before the gather plan below decides whether this batch's gather keeps it current (building it
+  // later, when the kernel is launched, would leave a replica of the grid as it was BEFORE this batch flagged current)
+  if (spec.forces && spec.forces->active && spec.forces->lookup) {
+    const double *faces_now = nullptr;
+    int rcf = faces_prepare(g, &faces_now);
+    if (rcf) return rcf;
   }
   const Tables tabs = g->tables();
   // the launch that produces the prepared hill list (queued further down, once the gather plan is known: a short

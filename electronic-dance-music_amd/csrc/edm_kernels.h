@@ -168,6 +168,11 @@ hipError_t launch_hill_prep(const Geom &g, const HillList &h, hipStream_t s, con
                             double *fetch_dst = nullptr);
 // fix edm step on a 2-D / 3-D grid: K2 (forces, four lanes per atom) and the preparation of a hill list in one launch
 bool lookup_prep_fusable(const Geom &g, const HillList &h);
+// ... or, without a flush, K2 and the step's selection + preparation (k_select_prep's body) in one launch
+struct SelectArgs;
+hipError_t launch_lookup_select(const Geom &g, const double *rec, const LookupArgs &la, double *scratch, hipStream_t s,
+                                hipEvent_t ev0, hipEvent_t ev1, int *blocks_out, const double *faces, const SelectArgs &a,
+                                const HillList &h);
 hipError_t launch_lookup_prep(const Geom &g, const double *rec, const LookupArgs &a, double *scratch, hipStream_t s,
                               hipEvent_t ev0, hipEvent_t ev1, int *blocks_out, const double *faces, const HillList &h,
                               const double *fetch_src, double *fetch_dst);

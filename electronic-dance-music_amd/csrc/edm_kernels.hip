@@ -1948,6 +1948,41 @@ template <int DIM>
 __global__ void __launch_bounds__(BLOCK) k_select_prep(SelectArgs a, Geom g, HillList h) {
   select_prep_body<DIM>(a, g, h, blockIdx.x, gridDim.x);
 }
+// fix edm step on a 2-D / 3-D grid without an overflow flush: the force kernel (K2 on four lanes per atom) and the
+// step's selection + hill preparation in ONE launch -- workgroups [0, nsel) select (their serial tail is the longest
+// chain: dispatched first), the rest evaluate forces.  The selection reads positions, mask and uniforms, the lookups the
+// grid; the gather that writes the grid is a later launch.
+template <int DIM, bool REPLICA>
+__global__ void __launch_bounds__(BLOCK) k_lookup_quad_select(Geom g, const double *__restrict__ faces, LookupArgs la,
+                                                              double *__restrict__ block_energy, SelectArgs a, HillList h,
+                                                              unsigned nsel) {
+  if (blockIdx.x < nsel)
+    select_prep_body<DIM>(a, g, h, blockIdx.x, nsel);
+  else
+    lookup_quad_body<DIM, LOOKUP_FORCES, REPLICA>(g, faces, la, block_energy, blockIdx.x - nsel, gridDim.x - nsel);
+}
+hipError_t launch_lookup_select(const Geom &g, const double *rec, const LookupArgs &la, double *scratch, hipStream_t s,
+                                hipEvent_t ev0, hipEvent_t ev1, int *blocks_out, const double *faces, const SelectArgs &a,
+                                const HillList &h) {
+  if (!(g.dim > 1 && g.interp && g.rec == 4) || la.n <= 0 || a.n <= 0) return hipErrorInvalidValue;
+  long long qb = (la.n * 4 + BLOCK - 1) / BLOCK;
+  if (qb > MAX_BLOCKS) qb = MAX_BLOCKS;
+  const unsigned nb = (unsigned)(qb < 1 ? 1 : qb), nsel = (unsigned)((a.n + SEL_CHUNK - 1) / SEL_CHUNK);
+  const dim3 grid(nsel + nb);
+  if (g.dim == 2) {
+    if (faces)
+      EDM_LAUNCH_TIMED((k_lookup_quad_select<2, true>), grid, dim3(BLOCK), 0, s, ev0, ev1, g, faces, la, scratch, a, h, nsel);
+    else
+      EDM_LAUNCH_TIMED((k_lookup_quad_select<2, false>), grid, dim3(BLOCK), 0, s, ev0, ev1, g, rec, la, scratch, a, h, nsel);
+  } else {
+    if (faces)
+      EDM_LAUNCH_TIMED((k_lookup_quad_select<3, true>), grid, dim3(BLOCK), 0, s, ev0, ev1, g, faces, la, scratch, a, h, nsel);
+    else
+      EDM_LAUNCH_TIMED((k_lookup_quad_select<3, false>), grid, dim3(BLOCK), 0, s, ev0, ev1, g, rec, la, scratch, a, h, nsel);
+  }
+  if (blocks_out) *blocks_out = (int)nb;
+  return hipGetLastError();
+}
 
 // One launch for the two independent streaming passes of a fix edm_pair hill step: workgroups [0, nsel) run the
 // selection (+ hill preparation in the last of them), the rest evaluate the pair forces (K1, arrays read from

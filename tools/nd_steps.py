@@ -23,7 +23,9 @@ cfgp = os.path.join(tmpdir, "nd.edm")
 with open(cfgp, "w") as fh:
     fh.write("tempering 0\nhill_prefactor %g\nhill_density 250\n%sdimension %d\nbox_low %s\nbox_high %s\n"
              "bias_spacing %s\nbias_sigma %s\nhills_filename %s/HILLS\nhistogram_filename %s/HIST\n" % (
-                 0.02 if dim == 3 else 0.5, "bias_per_step 0.008\n" if dim == 3 else "", dim,
+                 0.02 if dim == 3 else 0.5,
+                 ("bias_per_step %s\n" % os.environ["ND_BIAS_PER_STEP"]) if os.environ.get("ND_BIAS_PER_STEP") else
+                 ("bias_per_step 0.008\n" if dim == 3 else ""), dim,
                  " ".join("0" for _ in range(dim)), " ".join("64" for _ in range(dim)),
                  " ".join("%.10g" % v for v in c["spacing"]), " ".join("%.10g" % v for v in c["sigma"]), tmpdir, tmpdir))
 bb = H.Bias(cfgp)
@@ -39,4 +41,5 @@ t = time.perf_counter()
 for _ in range(steps):
     bb.step_device(d_x, 3, d_fs, 3, natoms, d_uu, -1, natoms)
 H.synchronize()
-print("dim", dim, "ms_per_step", (time.perf_counter() - t) / steps * 1e3, "overflow_right", bb.get("overflow_right"))
+print("dim", dim, "ms_per_step", (time.perf_counter() - t) / steps * 1e3, "overflow_right", bb.get("overflow_right"), "hills", bb.get("hills_added"),
+      "shared launches", bb.get("lookup_prep_launches"))
