@@ -2527,9 +2527,9 @@ __device__ __forceinline__ double hill_stencil_partial(const Geom &g, const Tabl
       }
       return acc;
     }
-    if constexpr (DIM > 1 && TPH >= BLOCK) {
+    if constexpr (DIM > 1) {
       if (t.ball && ball_ok) {
-        // 2-D / 3-D, a workgroup per hill: only stencil points that can lie inside the hill's support (dp2 < 8, :299) are
+        // 2-D / 3-D (a workgroup per hill, or a wave per hill on long lists): only stencil points that can lie inside the hill's support (dp2 < 8, :299) are
         // dealt out -- the host's list of such offsets (Tables::ball: one coalesced load per point, no decode, nothing
         // shared between the threads; pair_term makes the exact test).  The box the reference walks holds
         // (2 msize + 1)^DIM points of which the support's ball covers 20 % in 2-D and 6 % in 3-D; dealt out point by

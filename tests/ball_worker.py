@@ -36,6 +36,11 @@ def main():
         h = 0.5 + W.uniform(4100 + dim, nh)
         a = g.hill_integrals(x, h)
         out[name] = [float(v).hex() for v in a]
+        # ... and a list long enough for the wave-per-hill launch (more than 2048 hills)
+        nl = 2600
+        xl = W.uniform(4200 + dim, nl * dim).reshape(nl, dim) * (np.array(hi) - np.array(lo)) + np.array(lo)
+        al = g.hill_integrals(xl, 0.75)
+        out[name + "_long"] = [float(v).hex() for v in al]
         del g
     print("INTEGRALS " + json.dumps(out))
 
