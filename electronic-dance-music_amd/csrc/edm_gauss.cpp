@@ -1390,6 +1390,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     p_added = reinterpret_cast<double *>(base + off_added);
     p_hx0 = reinterpret_cast<double *>(base + off_pos);
   }
+  if (out) out->d_added = p_added;
 
   HillList hl;
   hl.nh = nh;
@@ -2152,10 +2153,23 @@ int edm_hip_gauss_add_values(edm_hip_gauss *g, long long n, const double *d_x, i
   spec.h_const = h_const;
   ApplyOutcome outc;
   const bool want = (d_added != nullptr) || (total_added != nullptr);
+  // A short batch whose total is wanted goes through the chained limiter with a limit nothing reaches: integrals +
+  // "limiter" + tile list in one launch and the total on the limiter's header line, polled -- instead of integrals,
+  // a sum launch, a tile-list launch, and a copy behind a stream wait.  (The total is then the limiter's ordered sum.)
+  static const bool chain_env = !(getenv("EDM_HIP_ADD_VALUES_CHAIN") && getenv("EDM_HIP_ADD_VALUES_CHAIN")[0] == '0');   // (A/B, tests)
+  const bool chained = want && chain_env && hill_integrals_can_chain_limit(n);
+  if (chained) {
+    spec.limited = true;
+    spec.limit = std::numeric_limits<double>::infinity();
+    spec.cum_in = 0;
+    spec.flush_mode = 0;
+    spec.fetch_heights = false;
+  }
   int rc = apply_hills(g, spec, &outc, want);
   if (rc) return rc;
-  if (d_added) EDM_HIP_TRY(hipMemcpy(d_added, g->ws.added.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice));
-  if (total_added) *total_added = outc.total_added;
+  // (hipMemcpy on the null stream: ordered behind the object's stream, on which the integrals ran)
+  if (d_added) EDM_HIP_TRY(hipMemcpy(d_added, outc.d_added ? outc.d_added : g->ws.added.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice));
+  if (total_added) *total_added = chained ? outc.res.cum_out : outc.total_added;
   return EDM_HIP_OK;
 }
 

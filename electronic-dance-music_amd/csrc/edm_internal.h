@@ -240,6 +240,7 @@ struct ApplyOutcome {
   // the batch was released by its header line alone (see LimitResult): every hill was added in full, nothing deferred,
   // nobody asked for positions / per-hill bias -- flags, h2, a2, pos, added above are EMPTY (they would read 1, 0, 0)
   bool plain_fast = false;
+  const double *d_added = nullptr;   // where the batch's per-hill bias_added lies on the device (valid until the next batch)
 };
 // prep -> integrals -> (limiter) -> ordered gather -> boundary duplication.
 // Leaves per-hill `added` in g->ws.added and the tail arrays in g->ws.tail_*.

@@ -1036,16 +1036,30 @@ def test_ball_list_equals_box_walk():
 
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ball_worker.py")
     res = {}
-    for tag, val in (("list", None), ("box", "0")):
+    for tag, var, val in (("list", None, None), ("box", "EDM_HIP_BALL_LIST", "0"), ("unchained", "EDM_HIP_ADD_VALUES_CHAIN", "0")):
         env = dict(os.environ)
         env.pop("EDM_HIP_BALL_LIST", None)
-        if val is not None:
-            env["EDM_HIP_BALL_LIST"] = val
+        env.pop("EDM_HIP_ADD_VALUES_CHAIN", None)
+        if var is not None:
+            env[var] = val
         r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("INTEGRALS ")][-1]
-        res[tag] = {k: np.array([float.fromhex(v) for v in vs]) for k, vs in json.loads(line[len("INTEGRALS "):]).items()}
+        raw = json.loads(line[len("INTEGRALS "):])
+        res[tag] = {k: (vs if k.endswith("_grid") else np.array([float.fromhex(v) for v in vs])) for k, vs in raw.items()}
     for name in res["list"]:
+        if name.endswith("_grid"):
+            continue
         a, b = res["list"][name], res["box"][name]
         assert a.shape == b.shape and np.abs(b).max() > 0, name
         assert np.allclose(a, b, rtol=1e-12, atol=1e-14 * np.abs(b).max()), (name, np.abs(a - b).max())
+    # a short add_values batch through the chained limiter launch (limit nothing reaches) against the launches of the
+    # unlimited path: the same per-hill bias and the same grid bit for bit, the total to rounding (another summation order)
+    for name in res["list"]:
+        a, u = res["list"][name], res["unchained"][name]
+        if name.endswith("_grid"):
+            assert a == u, name
+        elif name.endswith("_addv_total"):
+            assert abs(a[0] - u[0]) <= 1e-13 * abs(u[0]), name
+        else:
+            assert np.array_equal(a, u), name
