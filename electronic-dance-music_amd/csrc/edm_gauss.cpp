@@ -1861,7 +1861,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         unsigned long long t0 = ~0ull;
         for (size_t w = 0; w < (size_t)nh; w++)
           if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
-        const char *names_i[8] = {"start", "integral done", "last wg: ticket", "rows known", "limiter stage done", "walk begins", "stretches laid out", "end"};
+        const char *names_i[8] = {"start", "integral done", "last wg: ticket", "", "limiter stage done", "walk begins", "", "end"};
         fprintf(stderr, "[edm trace] k_hill_integrals<%d>, launch bound %lld hills, flush %d\n", dim, nh, spec.flush_mode);
         for (int k = 0; k < 8; k++) {
           std::vector<double> v;

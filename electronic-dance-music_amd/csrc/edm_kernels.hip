@@ -2438,8 +2438,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
 template <int DIM, int TPH, bool PERB>
 __device__ __forceinline__ double hill_stencil_partial(const Geom &g, const Tables &t, const TermConst<DIM> &tc,
                                                        const int *c_r, const double *hx_r, const double *ht_r,
-                                                       double height_r, bool live, int lt,
-                                                       unsigned long long *trace = nullptr) {
+                                                       double height_r, bool live, int lt) {
   double acc = 0;
   const int c0 = live ? c_r[0] : INT_MIN;
   if (c0 != INT_MIN) {
@@ -2789,7 +2788,7 @@ __device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables 
   term_const<DIM>(g, tc);
   unsigned long long *wtrace = (TPH != 64 && la.enabled && la.trace) ? la.trace + (size_t)bid * 8 : nullptr;
   if (wtrace && threadIdx.x == 0) wtrace[5] = wall_clock64();
-  const double acc_part = hill_stencil_partial<DIM, TPH, PERB>(g, t, tc, c_r, hx_r, ht_r, height_r, live, lt, wtrace);
+  const double acc_part = hill_stencil_partial<DIM, TPH, PERB>(g, t, tc, c_r, hx_r, ht_r, height_r, live, lt);
   double acc = acc_part;
   acc = wave_sum(acc);
   if (TPH == 64) {
