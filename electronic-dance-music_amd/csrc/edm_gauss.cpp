@@ -1510,6 +1510,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   plan.tile_parity = 0;
   plan.tile_bound = 0;
   plan.tiles_marked = 0;
+  static const int compact_env = getenv("EDM_HIP_COMPACT_WAVES") ? atoi(getenv("EDM_HIP_COMPACT_WAVES")) : 1;   // (A/B)
+  plan.compact_waves = compact_env;
   const long long ntiles = gather_tiles(q);
   if (fused) {
     // planned above

@@ -267,6 +267,7 @@ struct GatherPlan {
                           // zeroes the counter of the NEXT batch, so no memset precedes it); kept zero in between
   int tile_parity;        // which counter this batch uses
   long long tile_bound;   // launch bound for culled gathers
+  int compact_waves;      // 2-D / 3-D: a wave owns a compact block of its tile (hill_gather_body), not 64 consecutive nodes
   int tiles_marked;       // the tile list of this batch was built by an earlier launch (launch_hill_integrals with `mark`)
   // fused mode (dense batches on small grids): the gather runs BEFORE the limiter with the base
   // heights, writes per-group deltas and, as a by-product, the per-(hill, tile) pieces of each

@@ -3136,6 +3136,22 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   {
     long long rest = tile;
     int lrest = tnode;
+    // 2-D / 3-D: a WAVE owns a compact block of the tile -- 8 x 8 of the 16 x 16 nodes, 4 x 4 x 4 of the 8 x 8 x 4 --
+    // instead of 64 consecutive nodes (a 16 x 4 strip, an 8 x 8 x 1 slab): a wave runs a hill's terms whenever ONE of
+    // its nodes lies inside the hill's support, and a compact block meets fewer supports than a flat one (by the
+    // blocks' Minkowski sums with the support ball: 84 instead of 108 wave-visits per 3-D hill of W4).  Which thread
+    // owns which node changes nothing in a node's sum.
+    int loc[3] = {0, 0, 0};
+    if (DIM == 2 && PARTS == 1 && plan.compact_waves) {
+      const int w = tnode >> 6, l = tnode & 63;
+      loc[0] = (l & 7) + 8 * (w & 1);
+      loc[1] = (l >> 3) + 8 * (w >> 1);
+    } else if (DIM == 3 && PARTS == 1 && plan.compact_waves) {
+      const int w = tnode >> 6, l = tnode & 63;
+      loc[0] = (l & 3) + 4 * (w & 1);
+      loc[1] = ((l >> 2) & 3) + 4 * (w >> 1);
+      loc[2] = l >> 4;
+    }
 #pragma unroll
     for (int d = 0; d < DIM; d++) {
       const int T = tile_extent<DIM, PARTS>(d);
@@ -3143,10 +3159,12 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       tcoord[d] = (int)(rest % nt_d);
       t0[d] = tcoord[d] * T;
       rest /= nt_d;
-      p[d] = t0[d] + (lrest % T);
+      p[d] = t0[d] + ((DIM > 1 && PARTS == 1 && plan.compact_waves) ? loc[d] : (lrest % T));
       lrest /= T;
     }
   }
+  static_assert(DIM == 1 || (BLOCK == 256 && Tile<2>::T[0] == 16 && Tile<2>::T[1] == 16 && Tile<3>::T[0] == 8 &&
+                             Tile<3>::T[1] == 8 && Tile<3>::T[2] == 4), "the waves' blocks assume these tiles");
   bool active = true;
 #pragma unroll
   for (int d = 0; d < DIM; d++)
@@ -4030,6 +4048,16 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
                          plan.tile_list, ntiles, plan.tile_parity);
     use_list = 1;
     launch_tiles = plan.tile_bound < ntiles ? plan.tile_bound : ntiles;
+    // ... and never more workgroups than a few per CU: the workgroups stride over the list, and DISPATCHING a
+    // workgroup that finds nothing to do is not free -- the bound is several times the list's length (it is taken on
+    // the launch bound of the hill count), 18 000 workgroups for a list of 9 000 tiles on W4, and the launch's
+    // duration followed the launched count, not the list (PMC: busy cycles 1.0 M at 410 workgroups, 5.4 M at 18 000)
+    static const long long cap_env = getenv("EDM_HIP_GATHER_WGS") ? atoll(getenv("EDM_HIP_GATHER_WGS")) : 0;   // (A/B)
+    // (four per CU = what is resident at once at the kernel's 120-128 registers: every workgroup starts at once and
+    //  strides; measured on W4: 512 -> 0.127, 768 -> 0.115, 1024 -> 0.110, 1536 -> 0.115, 2048 -> 0.113, unbounded
+    //  0.124 ms per step; the 2-D gather, whose bound is closer to its list, does not care)
+    const long long cap = cap_env > 0 ? cap_env : (long long)4 * cu_count();
+    if (launch_tiles > cap) launch_tiles = cap;
   }
   bool perb = true;
   for (int d = 0; d < DIM; d++)
