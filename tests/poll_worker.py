@@ -72,8 +72,32 @@ def main(workdir):
     feed(gv, gd, b.hist.values, [b.get("cum_bias"), b.get("overflow_right"), b.get("hills_added")])
     # (steps with an overflow flush: the force kernel rides in the launch that prepares the flush's hill list,
     #  EDM_HIP_LOOKUP_PREP=0: a launch of its own, ahead of it)
-    print("LOOKUP_PREP", int(b.get("lookup_prep_launches")))
+    nshared = int(b.get("lookup_prep_launches"))
     del b
+    # ... a 3-D grid with a group mask, device-drawn acceptance numbers, and the limiter far away (no flush: the force
+    # kernel rides in the launch of the step's selection) for three steps, then binding (flushes carry it)
+    for tag, limit, seed in (("p2m_free", 1000.0, 5), ("p2m_bound", 0.05, 6)):
+        cfg = os.path.join(workdir, tag + ".edm")
+        open(cfg, "w").write("tempering 0\nhill_prefactor 0.5\nhill_density 80\nbias_per_step %g\ndimension 3\nbox_low 0 0 0\n"
+                             "box_high 6 6 6\nbias_spacing 0.1 0.1 0.1\nbias_sigma 0.2 0.2 0.2\nhills_filename %s/HILLS_%s\n"
+                             "histogram_filename %s/HIST_%s\n" % (limit, workdir, tag, workdir, tag))
+        b = H.Bias(cfg)
+        b.setup(1.0, 1.0)
+        b.subdivide([0, 0, 0], [6, 6, 6], [0, 0, 0], [6, 6, 6], [1, 1, 1], [0, 0, 0])
+        na = 24000
+        b.set_mask(1 + (np.arange(na) % 3 == 0).astype(np.int32))   # groups 1 and 2
+        d_f = H.DeviceArray.zeros((na, 3))
+        for step in range(4):
+            x = W.uniform(1400 + 10 * seed + step, 3 * na).reshape(na, 3) * 6.0
+            d_x = H.DeviceArray.from_host(x)
+            d_u = H.DeviceArray.from_host(W.uniform(1450 + 10 * seed + step, na))
+            e = b.step_device(d_x, 3, d_f, 3, na, d_u, 2, na)
+            feed([e], d_f.to_host(), [b.get("cum_bias"), b.get("overflow_right"), b.get("hills_added")])
+        gv, gd = b.gauss.download()
+        feed(gv, gd, b.hist.values)
+        nshared += int(b.get("lookup_prep_launches"))
+        del b
+    print("LOOKUP_PREP", nshared)
     print("SECTION", 2, dig.hexdigest()[:16])
     # 1-D pair CV, no HILLS log, limiter far away: the steps whose host call returns on the limiter's HEADER LINE alone
     # (EDM_HIP_FAST_HEADER=0 makes them wait for the completion word like every other polled batch)
