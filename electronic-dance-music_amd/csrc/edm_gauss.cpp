@@ -22,6 +22,8 @@
 
 namespace edm {
 
+static constexpr long long EDM_TAG_CAP_HOST = 1024;   // = EDM_TAG_CAP of edm_kernels.hip
+
 // development aid (EDM_HIP_TRACE): host clock, microseconds after the traced step's entry, at marked place `slot`
 void ht_mark(edm_hip_gauss *g, int slot) {
   static const bool on = getenv("EDM_HIP_TRACE") != nullptr;
@@ -42,7 +44,7 @@ int hip_fail(hipError_t e, const char *what) {
 void HillWorkspace::release() {
   gath.release(); slots.release(); heights.release(); hx.release(); hx0.release(); ht.release(); added.release(); partial.release(); scratch.release();
   tail_h1.release(); tail_h2.release(); tail_a2.release(); tail_cum.release();
-  hc.release(); tail_flags.release(); tile_flags.release(); tile_list.release(); result.release(); rb.release();
+  hc.release(); tail_flags.release(); tile_flags.release(); tile_list.release(); result.release(); rb.release(); tagged.release();
 }
 
 // grid.h:190-213
@@ -1671,6 +1673,13 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     la.flush_mode = spec.flush_mode;
     la.tail = LimitTail{ws.tail_h1.p, p_h2, p_a2, ws.tail_cum.p, p_flags};
     la.res = dres;
+    // the hills' workgroups hand their integrals to the limiter's workgroup as tagged 16-byte stores (LimitArgs::tagged)
+    static const bool tagged_env = !(getenv("EDM_HIP_TAGGED_INTEGRALS") && getenv("EDM_HIP_TAGGED_INTEGRALS")[0] == '0');   // (A/B, tests)
+    if (tagged_env && nh <= EDM_TAG_CAP_HOST) {
+      EDM_HIP_TRY(ws.tagged.reserve_zeroed(2 * (size_t)EDM_TAG_CAP_HOST));
+      la.tagged = ws.tagged.p;
+      la.tag_seq = ++ws.tag_seq;
+    }
     if (small && rb_bytes + 128 <= g->h_stage_bytes) {
       // ... and so does the read-back: everything the host reads is final once the limiter has run, so the
       // same workgroup copies the packed region into host-mapped memory and flags it; the host polls the flag

@@ -63,6 +63,8 @@ struct HillWorkspace {
   int tile_parity = 0;      // which of tile_list's two counters the next culled gather uses
   DevBuf<char> result;      // LimitResult
   DevBuf<char> rb;          // packed read-back region of small batches (one D2H instead of six)
+  DevBuf<double> tagged;    // LimitArgs::tagged: {integral, batch number} per hill (zero-filled when allocated)
+  unsigned long long tag_seq = 0;
   void release();
 };
 

@@ -432,6 +432,12 @@ struct LimitArgs {
   unsigned long long *ready_flag;
   unsigned long long ready_seq;
   int early_word;   // the last wave of the limiter's workgroup may publish EDM_READY_BELOW ahead of the limiter
+  // optional (a workgroup per hill, launch wider than the hill count): every hill's workgroup stores {integral, tag_seq}
+  // as ONE 16-byte agent-scope store into tagged[2 * hill], takes no ticket and is done; the first workgroup WITHOUT a
+  // hill polls the slots and runs the limiter on what it has read -- one dependent round trip between the last integral
+  // and the limiter instead of three (store acknowledged -> ticket -> reload).  NULL: the last-arrival ticket.
+  double *tagged;
+  unsigned long long tag_seq;
   // development aid (EDM_HIP_TRACE=1): 8 wall-clock stamps (10 ns units) per workgroup of k_integrals_gather, or NULL
   unsigned long long *trace;
 };

@@ -68,6 +68,27 @@ __device__ __forceinline__ void store_partial_tagged(double *base, unsigned bid,
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(d) : "memory");
 }
 
+// {value, tag} as ONE 16-byte store / load at agent scope (LimitArgs::tagged): the reader that finds the tag has the value
+#define EDM_TAG_CAP 1024   // hills a polling limiter workgroup keeps in LDS
+__device__ __forceinline__ void store_tagged_agent(double *base, long long idx, double v, unsigned long long tag) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  v4i d;
+  d.x = __double2loint(v);
+  d.y = __double2hiint(v);
+  d.z = (int)(unsigned)(tag & 0xFFFFFFFFull);
+  d.w = (int)(unsigned)(tag >> 32);
+  double *p = base + 2 * (size_t)idx;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(d) : "memory");
+}
+__device__ __forceinline__ bool load_tagged_agent(const double *base, long long idx, unsigned long long tag, double *v) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  v4i d;
+  const double *p = base + 2 * (size_t)idx;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(d) : "v"(p) : "memory");
+  *v = __hiloint2double(d.y, d.x);
+  return ((unsigned long long)(unsigned)d.z | ((unsigned long long)(unsigned)d.w << 32)) == tag;
+}
+
 // number of hills of a batch (resolves a deferred count)
 __device__ __forceinline__ long long hill_count(const HillList &h) {
   long long n = h.nh;
@@ -2401,14 +2422,14 @@ __device__ __forceinline__ void readback_copy_limiter(const char *rb_src, char *
 // the limiter-independent part of the same region: per-hill bias and original positions of hills [0, na)
 template <int DIM>
 __device__ __forceinline__ void readback_copy_hills(const char *rb_src, char *rb_dst, long long nb, long long na, int me,
-                                                    int nthr) {
+                                                    int nthr, const double *s_added = nullptr) {
   const long long off_flags = 64, off_h2 = off_flags + ((4 * nb + 7) & ~7LL), off_a2 = off_h2 + 8 * nb,
                   off_added = off_a2 + 8 * nb, off_pos = off_added + 8 * nb;
   const long long *src = reinterpret_cast<const long long *>(rb_src);
   long long *dst = reinterpret_cast<long long *>(rb_dst);
   for (long long w = me; w < na * DIM; w += nthr) {
     const bool has_a = w < na;
-    const long long va = has_a ? acquire(&src[off_added / 8 + w]) : 0;
+    const long long va = has_a ? (s_added ? __double_as_longlong(s_added[w]) : acquire(&src[off_added / 8 + w])) : 0;
     const long long vp = acquire(&src[off_pos / 8 + w]);
     if (has_a) __hip_atomic_store(&dst[off_added / 8 + w], va, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&dst[off_pos / 8 + w], vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2429,7 +2450,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            const long long *nh_dev, long long mirror = 0, long long *k_out = nullptr,
                                            int *err_out = nullptr, long long nh_known = -1,
                                            const FusedStep *fsrc = nullptr, const unsigned short *fs_off = nullptr,
-                                           LimitResult *out_local = nullptr);
+                                           LimitResult *out_local = nullptr, const double *s_added = nullptr);
 
 // The stencil walk of one hill by TPH cooperating threads (lt = this thread's index among them): the thread's share of
 // height * (expo + corr) * vol over the reference's stencil (gaussian_grid.h:227-281), summed in stencil order.  The
@@ -2675,7 +2696,8 @@ __device__ __forceinline__ void wait_counter(const unsigned *sub, unsigned targe
 template <int DIM, int NT>
 __device__ __forceinline__ void limiter_stage(const HillList &h, const double *__restrict__ heights, double h_const,
                                               double *__restrict__ added, const LimitArgs &la, unsigned bid,
-                                              long long n_true_known, const unsigned *k1_done, unsigned k1_target) {
+                                              long long n_true_known, const unsigned *k1_done, unsigned k1_target,
+                                              const double *s_added = nullptr) {
   // wave 0 walks the limiter; with a read-back region (la.rb_dst) it stores its outputs to the device region and
   // to its host-mapped copy alike, while the other waves copy what does not depend on the limiter -- per-hill
   // bias and positions, by the true hill count -- so nothing is left to read back once the limiter is done.
@@ -2693,7 +2715,7 @@ __device__ __forceinline__ void limiter_stage(const HillList &h, const double *_
     int err = 0;
     LimitResult rl;
     limit_wave<true>(h.nh, added, heights, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr,
-               nullptr, h.nh_dev, mirror, &k_first, &err, h.nh_dev ? n_true : -1, nullptr, nullptr, &rl);
+               nullptr, h.nh_dev, mirror, &k_first, &err, h.nh_dev ? n_true : -1, nullptr, nullptr, &rl, s_added);
     if (la.fast_line) header_line_to_host(la.fast_line, rl, la.done_seq);
     if (concurrent) {
       // the word carries what every gather workgroup needs first -- the error code and k, the first hill of the
@@ -2707,13 +2729,14 @@ __device__ __forceinline__ void limiter_stage(const HillList &h, const double *_
     // whatever the order of the adds?
     if (na <= 64 * 64 && la.cum_in >= 0) {
       double part = 0;
-      for (long long i = threadIdx.x - (NT - 64); i < na; i += 64) part += fabs(acquire(&added[i]));
+      for (long long i = threadIdx.x - (NT - 64); i < na; i += 64) part += fabs(s_added ? s_added[i] : acquire(&added[i]));
       part = wave_sum(part);
       if (threadIdx.x == NT - 64 && n_true <= nb && (la.cum_in + part) * (1.0 + 1e-9) < la.limit)
         ready_publish(la.ready_flag, ready_word(la.ready_seq, EDM_READY_BELOW, na));   // (cannot displace the limiter's own word)
     }
   } else if (la.rb_dst) {
-    readback_copy_hills<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x - 64, (concurrent && la.early_word) ? NT - 128 : NT - 64);
+    readback_copy_hills<DIM>(la.rb_src, la.rb_dst, nb, na, (int)threadIdx.x - 64, (concurrent && la.early_word) ? NT - 128 : NT - 64,
+                             s_added);
   }
   if (la.rb_dst) {
     if (concurrent) {
@@ -2748,8 +2771,9 @@ __device__ __forceinline__ void limiter_stage(const HillList &h, const double *_
 template <int DIM, int TPH, bool PERB>
 __device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables &t, const HillList &h,
                                                     const double *__restrict__ heights, double h_const,
-                                                    double *__restrict__ added, const LimitArgs &la, unsigned bid) {
-  constexpr int NT = (TPH > BLOCK) ? TPH : BLOCK;  // workgroup size: 512 threads per hill for the 3-D stencil
+                                                    double *__restrict__ added, const LimitArgs &la, unsigned bid,
+                                                    unsigned nwg) {
+  constexpr int NT = (TPH > BLOCK) ? TPH : BLOCK;  // workgroup size: 512 / 1024 threads per hill for the 2-D / 3-D stencil
   __shared__ double s_red[NT / 64];
   const int lane = threadIdx.x & 63;
   const int lt = threadIdx.x % TPH;
@@ -2783,7 +2807,48 @@ __device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables 
   // own a hill take a ticket -- workgroup 0 alone when there is none -- so the last arrival is one of a few hundred
   // and a single counter (one atomic round trip) does
   const unsigned ticket_blocks = (unsigned)(nh_eff > 0 ? nh_eff : 1);
-  if (TPH != 64 && la.enabled && bid >= ticket_blocks) return false;
+  // ... or none at all (LimitArgs::tagged): the launch is wider than the hill count, so its first workgroup WITHOUT a
+  // hill can be the limiter's -- the hills' workgroups store {integral, batch number} as one 16-byte store and are
+  // done; that workgroup polls the slots and runs the limiter on what it has read.  Between the last integral and the
+  // limiter lies one round trip (store -> poll) instead of three (store acknowledged -> ticket -> reload).
+  const bool tagged = TPH != 64 && la.enabled && la.tagged != nullptr && nh_eff >= 1 && nh_eff < (long long)nwg &&
+                      nh_eff <= EDM_TAG_CAP;
+  if constexpr (TPH != 64) {
+    if (tagged && bid == (unsigned)nh_eff) {
+      __shared__ double s_val[EDM_TAG_CAP];
+      const int n = (int)nh_eff;
+      constexpr int PER = (EDM_TAG_CAP + NT - 1) / NT;
+      bool have[PER];
+#pragma unroll
+      for (int q = 0; q < PER; q++) have[q] = !((int)threadIdx.x + q * NT < n);
+      const unsigned long long t0 = wall_clock64();
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+          if (have[q]) continue;
+          const int i = (int)threadIdx.x + q * NT;
+          double v;
+          if (load_tagged_agent(la.tagged, i, la.tag_seq, &v)) {
+            s_val[i] = v;
+            publish(&added[i], v);   // (the device array later launches and the read-back read)
+            have[q] = true;
+          } else {
+            ok = false;
+          }
+        }
+        if (__syncthreads_and(ok ? 1 : 0)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();   // 10 s at 100 MHz: never, short of a lost workgroup
+      }
+      if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 2] = wall_clock64();
+      limiter_stage<DIM, NT>(h, heights, h_const, added, la, bid, -1, nullptr, 0u, s_val);
+      if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 4] = wall_clock64();
+      __syncthreads();
+      return true;
+    }
+  }
+  if (TPH != 64 && la.enabled && (tagged ? bid > (unsigned)nh_eff : bid >= ticket_blocks)) return false;
   TermConst<DIM> tc;
   term_const<DIM>(g, tc);
   unsigned long long *wtrace = (TPH != 64 && la.enabled && la.trace) ? la.trace + (size_t)bid * 8 : nullptr;
@@ -2799,7 +2864,13 @@ __device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables 
     if (threadIdx.x == 0 && live) {
       double r = 0;
       for (int w = 0; w < NT / 64; w++) r += s_red[w];
-      if (la.enabled) publish(&added[hill], r); else added[hill] = r;
+      if (tagged) store_tagged_agent(la.tagged, hill, r, la.tag_seq);
+      else if (la.enabled) publish(&added[hill], r);
+      else added[hill] = r;
+    }
+    if (tagged) {
+      if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 1] = wall_clock64();
+      return false;
     }
     if (la.enabled) {
       if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 1] = wall_clock64();
@@ -2829,7 +2900,7 @@ __global__ void __launch_bounds__((TPH > BLOCK) ? TPH : BLOCK) k_hill_integrals(
     return;
   }
   if (la.trace && threadIdx.x == 0) la.trace[(size_t)blockIdx.x * 8] = wall_clock64();
-  (void)hill_integrals_body<DIM, TPH, PERB>(g, t, h, heights, h_const, added, la, blockIdx.x);
+  (void)hill_integrals_body<DIM, TPH, PERB>(g, t, h, heights, h_const, added, la, blockIdx.x, nb_int);
   if (la.trace && threadIdx.x == 0) la.trace[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
 }
 
@@ -3866,7 +3937,7 @@ __global__ void __launch_bounds__(BLOCK) k_integrals_gather(Geom g, Tables t, do
 #define EDM_STAMP(k) do { if (la.trace && threadIdx.x == 0) la.trace[(size_t)wg * 8 + (k)] = wall_clock64(); } while (0)
   EDM_STAMP(0);
   if (wg < nb_int) {
-    const bool ran_limiter = hill_integrals_body<1, BLOCK, PERB>(g, t, h, heights, h_const, added, la, wg);
+    const bool ran_limiter = hill_integrals_body<1, BLOCK, PERB>(g, t, h, heights, h_const, added, la, wg, nb_int);
     // the CV histogram needs the limiter's flags and the hills' positions, nothing of the gather: the limiter's
     // workgroup updates it while the gather applies heights (edm_bias.cpp:601-610)
     if (ran_limiter && post.enabled && !la.res->error)
@@ -4885,7 +4956,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            const double *chunk_sum, const double *chunk_max,
                                            const long long *nh_dev, long long mirror, long long *k_out, int *err_out,
                                            long long nh_known, const FusedStep *fsrc, const unsigned short *fs_off,
-                                           LimitResult *out_local) {
+                                           LimitResult *out_local, const double *s_added) {
   // (out_local: the result as every lane of the wave holds it -- the walk is uniform -- for a caller that writes the
   //  header line to the host in one instruction)
   // (fsrc, k_pair_step: the per-hill bias is read from the selection workgroups' records, hill i found through the
@@ -4996,6 +5067,7 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
   auto load_a = [&](long long i) {
     if (!(i < nh)) return 0.0;
     if (fsrc) return acquire(fused_record(*fsrc, fs_off, (int)i) + 4);
+    if (s_added) return s_added[i];   // (LDS: the polling limiter workgroup has the integrals already)
     return COHERENT ? acquire(&added[i]) : added[i];
   };
   auto load_h = [&](long long i) { return (i < nh) ? (heights ? heights[i] : h_const) : 0.0; };
