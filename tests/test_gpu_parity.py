@@ -917,7 +917,8 @@ def test_polled_completion_equals_stream_wait(workdir):
     # ... and with the fix edm step's force kernel in a launch of its own instead of the flush preparation's
     lookup_prep = []
     for tag, poll, header, dup_all in (("polled", None, None, None), ("polled_no_header", None, "0", None), ("waited", "0", None, None),
-                                       ("dup_ticket_all", None, None, "1"), ("lookup_alone", None, None, None)):
+                                       ("dup_ticket_all", None, None, "1"), ("lookup_alone", None, None, None),
+                                       ("integrals_ticket", None, None, None)):
         d = workdir / tag
         d.mkdir()
         env = dict(os.environ)
@@ -925,8 +926,11 @@ def test_polled_completion_equals_stream_wait(workdir):
         env.pop("EDM_HIP_FAST_HEADER", None)
         env.pop("EDM_HIP_DUP_TICKET_ALL", None)
         env.pop("EDM_HIP_LOOKUP_PREP", None)
+        env.pop("EDM_HIP_TAGGED_INTEGRALS", None)
         if tag == "lookup_alone":
             env["EDM_HIP_LOOKUP_PREP"] = "0"
+        if tag == "integrals_ticket":   # (the per-hill integrals behind a last-arrival ticket, not as tagged stores)
+            env["EDM_HIP_TAGGED_INTEGRALS"] = "0"
         if poll is not None:
             env["EDM_HIP_POLL"] = poll
         if header is not None:
@@ -941,7 +945,7 @@ def test_polled_completion_equals_stream_wait(workdir):
         releases.append(int([ln for ln in res.stdout.splitlines() if ln.startswith("HEADER_RELEASES ")][-1].split()[1]))
         polled_forces.append(int([ln for ln in res.stdout.splitlines() if ln.startswith("POLLED_FORCES ")][-1].split()[1]))
         lookup_prep.append(int([ln for ln in res.stdout.splitlines() if ln.startswith("LOOKUP_PREP ")][-1].split()[1]))
-    assert digests[0] == digests[1] == digests[2] == digests[3] == digests[4]
+    assert digests[0] == digests[1] == digests[2] == digests[3] == digests[4] == digests[5]
     assert lookup_prep[0] >= 8 and lookup_prep[4] == 0, lookup_prep
     assert releases[0] >= 10 and releases[1] == 0 and releases[2] == 0, releases
     assert polled_forces[0] >= 9 and polled_forces[2] == 0, polled_forces   # (forces-only calls: tagged sums / stream wait)
