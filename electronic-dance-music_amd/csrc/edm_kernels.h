@@ -438,6 +438,8 @@ struct LimitArgs {
   // and the limiter instead of three (store acknowledged -> ticket -> reload).  NULL: the last-arrival ticket.
   double *tagged;
   unsigned long long tag_seq;
+  // host-side hint: the hill count the batch is expected to have (<= the launch bound h.nh); 0: unknown
+  long long expected_hills;
   // development aid (EDM_HIP_TRACE=1): 8 wall-clock stamps (10 ns units) per workgroup of k_integrals_gather, or NULL
   unsigned long long *trace;
 };

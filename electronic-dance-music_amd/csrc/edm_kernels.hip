@@ -4198,7 +4198,13 @@ hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, 
   // tiles first iff the waiting tiles can never fill the machine: the kernel keeps two workgroups per CU resident at
   // the very least (157 registers: three waves per SIMD; 59 KB of LDS: two per CU), so with 64 slots to spare the
   // integrals' workgroups -- which wait for nobody -- always find room to run through
-  const unsigned tiles_first = ((size_t)nb_tiles + 64 <= (size_t)2 * cu_count()) ? 1u : 0u;
+  // ... and the hills' workgroups must find room beside them: a launch whose tiles and expected hills together exceed
+  // the two-per-CU residency dispatches the integrals first (the neighbour-list melt: 351 tiles + ~250 hills against
+  // 512 slots -- tiles first, 86 hills waited for a slot until the first ones had finished: integrals done at 11 us
+  // instead of 6; a launch bound without a hint counts as its own expectation)
+  const long long live = (chain.expected_hills > 0 && chain.expected_hills < h.nh) ? chain.expected_hills : h.nh;
+  const unsigned tiles_first = ((size_t)nb_tiles + 64 <= (size_t)2 * cu_count() &&
+                                (long long)nb_tiles + live + live / 4 <= (long long)2 * cu_count()) ? 1u : 0u;
   if (post.enabled) dup_ticket_tiles_1d(g, post, nb_tiles, BLOCK / 8);
   if (!g.bper[0])
     hipLaunchKernelGGL((k_integrals_gather<false>), dim3(nb_int + nb_tiles), dim3(BLOCK), 0, s, g, t, rec, h, heights, h_const,
