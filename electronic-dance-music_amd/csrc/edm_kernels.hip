@@ -3325,7 +3325,9 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   __shared__ id_t s_id[(MODE == 1 || DEFER) ? BLOCK : 1];
   // DEFER: parked stencil terms of the first chunk, NTS per thread (value, derivative, multiplicity | nz << 30)
   constexpr int DEFER_ILP = 4;
-  constexpr int NTS = FUSED ? 4 : 8;   // (a tile meets ~13 of the ~125 hills of a W1 step, 40 where the pairs are dense: 4 per part cover 32)
+  // (a tile meets ~13 of the ~125 hills of a W1 step, 40 where the pairs are dense: 4 per part cover 32.  Eight cost
+  //  20 KB more LDS and 30 registers -- two workgroups per CU instead of three -- and bought the W1 step nothing)
+  constexpr int NTS = 4;
   using tm_t = typename std::conditional<FUSED, short, int>::type;
   constexpr int TM_NZ = FUSED ? 14 : 30;
   __shared__ double s_tv[DEFER ? NTS : 1][DEFER ? BLOCK : 1], s_td[DEFER ? NTS : 1][DEFER ? BLOCK : 1];
@@ -4195,16 +4197,17 @@ hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, 
   }
   const unsigned nb_int = (unsigned)h.nh;
   const unsigned nb_tiles = (unsigned)((g.n[0] + BLOCK / 8 - 1) / (BLOCK / 8));
-  // tiles first iff the waiting tiles can never fill the machine: the kernel keeps two workgroups per CU resident at
-  // the very least (157 registers: three waves per SIMD; 59 KB of LDS: two per CU), so with 64 slots to spare the
-  // integrals' workgroups -- which wait for nobody -- always find room to run through
+  // tiles first iff the waiting tiles can never fill the machine: the kernel keeps three workgroups per CU resident
+  // (139 registers: three waves per SIMD; 47 KB of LDS), so with 64 slots to spare the integrals' workgroups -- which
+  // wait for nobody -- always find room to run through
   // ... and the hills' workgroups must find room beside them: a launch whose tiles and expected hills together exceed
-  // the two-per-CU residency dispatches the integrals first (the neighbour-list melt: 351 tiles + ~250 hills against
-  // 512 slots -- tiles first, 86 hills waited for a slot until the first ones had finished: integrals done at 11 us
-  // instead of 6; a launch bound without a hint counts as its own expectation)
+  // the residency dispatches the integrals first (the neighbour-list melt at two workgroups per CU: 351 tiles + ~250
+  // hills against 512 slots -- tiles first, 86 hills waited for a slot until the first ones had finished: integrals
+  // done at 11 us instead of 6; a launch bound without a hint counts as its own expectation)
   const long long live = (chain.expected_hills > 0 && chain.expected_hills < h.nh) ? chain.expected_hills : h.nh;
-  const unsigned tiles_first = ((size_t)nb_tiles + 64 <= (size_t)2 * cu_count() &&
-                                (long long)nb_tiles + live + live / 4 <= (long long)2 * cu_count()) ? 1u : 0u;
+  constexpr int PER_CU = 3;   // (47 KB of LDS, 139 registers)
+  const unsigned tiles_first = ((size_t)nb_tiles + 64 <= (size_t)PER_CU * cu_count() &&
+                                (long long)nb_tiles + live + live / 4 <= (long long)PER_CU * cu_count()) ? 1u : 0u;
   if (post.enabled) dup_ticket_tiles_1d(g, post, nb_tiles, BLOCK / 8);
   if (!g.bper[0])
     hipLaunchKernelGGL((k_integrals_gather<false>), dim3(nb_int + nb_tiles), dim3(BLOCK), 0, s, g, t, rec, h, heights, h_const,
