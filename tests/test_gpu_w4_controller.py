@@ -91,3 +91,21 @@ def test_w4_limited_steps_vs_equivalent_oracle(oracle_lib, workdir):
     assert np.abs(foldd - od).max() <= 1e-10 * np.abs(od).max(), "folded bias gradient differs from the oracle's grid"
     # locality on the big grid: bias only within the stencil reach of some logged hill position
     assert (v != 0).sum() < 6 * 300 * 23 ** 3
+
+
+def test_w4_controller_with_a_narrow_gather_launch():
+    """The culled gather's launch is capped at a few workgroups per CU and its workgroups stride over the tile list: the
+    same controller test with the launch only SEVEN workgroups wide (EDM_HIP_GATHER_WGS, read once per process), i.e.
+    every workgroup walking hundreds of tiles, must pass unchanged."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("EDM_TEST_CHILD"):
+        pytest.skip("child run")
+    env = dict(os.environ)
+    env["EDM_HIP_GATHER_WGS"] = "7"
+    env["EDM_TEST_CHILD"] = "1"
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q"], env=env,
+                         capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]

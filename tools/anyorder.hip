@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdio.h>
+#include <chrono>
 
 __global__ void spin(unsigned long long *out, unsigned long long ticks) {
   const unsigned long long t0 = wall_clock64();
@@ -12,6 +13,11 @@ __global__ void spin(unsigned long long *out, unsigned long long ticks) {
     out[0] = t0;
     out[1] = wall_clock64();
   }
+}
+
+struct BigArg { double a[88]; };
+__global__ void spin_big(unsigned long long *out, unsigned long long ticks, BigArg b) {
+  if (ticks == 12345ull && threadIdx.x == 0) out[0] = (unsigned long long)b.a[3];
 }
 
 int main() {
@@ -30,6 +36,24 @@ int main() {
       hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
       printf("flags %d: A %.1f..%.1f us  B %.1f..%.1f us  C %.1f..%.1f us\n", flags, 0.0, (h[1] - h[0]) * 0.01, (h[2] - h[0]) * 0.01,
              (h[3] - h[0]) * 0.01, (h[4] - h[0]) * 0.01, (h[5] - h[0]) * 0.01);
+    }
+  }
+  // host cost of a launch call (no arguments / ~700 bytes of arguments), queue kept short
+  {
+    BigArg big{};
+    const int N = 2000;
+    for (int variant = 0; variant < 2; variant++) {
+      hipStreamSynchronize(s);
+      double tot = 0;
+      for (int i = 0; i < N; i++) {
+        if ((i & 15) == 15) hipStreamSynchronize(s);
+        const auto t0 = std::chrono::steady_clock::now();
+        if (variant == 0) hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, s, d + 6, 0ull);
+        else hipLaunchKernelGGL(spin_big, dim3(1), dim3(64), 0, s, d + 6, 0ull, big);
+        tot += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      }
+      hipStreamSynchronize(s);
+      printf("host time per launch call (%s): %.2f us\n", variant ? "704 B of arguments" : "16 B of arguments", tot / N);
     }
   }
   // two streams: A on s, B on s2, C on s behind an event recorded on s2 after B
