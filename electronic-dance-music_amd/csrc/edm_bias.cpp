@@ -97,6 +97,17 @@ struct edm_hip_bias {
                                        // uploaded list, their CVs recomputed from these positions ([nall][3])
   int debug_virtual_ranks = 0;  // tests: a one-rank communicator's packet is replicated, emulating that many ranks
   DevBuf<long long> xchg_cnt;
+  // fix edm_pair in the reference's order (edm_hip_bias_pair_step_ordered): what the step's hill batch left on the
+  // device -- count, heights, sample indices -- and the buffers of the force pass that follows it
+  struct LastBatch {
+    bool valid = false;
+    long long nh = 0, k = 0;
+    const double *heights = nullptr, *tail_h1 = nullptr, *tail_h2 = nullptr;
+    double h_const = 0;
+    const long long *sel = nullptr;
+  } last_batch;
+  DevBuf<double> ord_rec0, ord_prefix;
+  DevBuf<int> ord_dirty, ord_first;
   // multi-GPU
   Transport *comm = nullptr;   // RCCL over xGMI, or the host-staged carrier (edm_comm.h)
   int nranks = 1, rank = 0;
@@ -278,6 +289,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   b->pl_it_idx.release(); b->pl_jt_idx.release(); b->pl_it_off.release(); b->pl_jt_off.release();
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
+  b->ord_rec0.release(); b->ord_prefix.release(); b->ord_dirty.release(); b->ord_first.release();
   delete b;
   return EDM_HIP_OK;
 }
@@ -826,6 +838,14 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   if (rc) return rc;
   const LimitResult &res = oc.res;
   b->temp_hill_cum = res.cum_out;
+  b->last_batch.valid = true;
+  b->last_batch.nh = res.nh;
+  b->last_batch.k = res.k;
+  b->last_batch.heights = oc.d_base_heights;
+  b->last_batch.h_const = this_h;
+  b->last_batch.tail_h1 = oc.d_tail_h1;
+  b->last_batch.tail_h2 = oc.d_tail_h2;
+  b->last_batch.sel = d_sel;
 
   const long long k = res.k;
   const int ntail = res.n_tail;
@@ -1043,6 +1063,168 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
     last_exit_us = t_out;
   }
   return rc;
+}
+
+// fix edm_pair's hill step in the REFERENCE'S order (lammps/fix_edm_pair.cpp:173-247): the step's hills are applied as
+// in edm_hip_bias_pair_step -- selection, limiter and grid update do not depend on the forces -- and the force of pair k
+// is then interpolated on the bias as it stood when the reference's loop reached that pair: the grid after
+// pre_add_hill plus the hills of the add_hill calls before it (OrderedForcesArgs, edm_kernels.h).
+static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *d_r, double *d_force,
+                                    const int *d_first_sample, long long n_samples, const double *d_sample_r,
+                                    const double *d_runiform, double *energy) {
+  edm_hip_gauss *g = b->bias;
+  hipStream_t s = g->stream;
+  if (!ordered_forces_supported(g->g)) {
+    set_error("pair_step_ordered: needs a 1-D bias whose stencil is not wider than a periodic grid");
+    return EDM_HIP_ERR_ARG;
+  }
+  if (b->comm) {
+    set_error("pair_step_ordered: the reference-order step is single-rank (a rank's pairs would see only its own hills); "
+              "use edm_hip_bias_pair_step with a communicator");
+    return EDM_HIP_ERR_STATE;
+  }
+  // the bias the first pair sees: the grid behind the overflow flush of pre_add_hill
+  const size_t grid_doubles = (size_t)g->g.total * (size_t)g->g.rec;
+  EDM_HIP_TRY(b->ord_rec0.reserve(grid_doubles));
+  EDM_HIP_TRY(hipMemcpyAsync(b->ord_rec0.p, g->rec, sizeof(double) * grid_doubles, hipMemcpyDeviceToDevice, s));
+  b->pending = PendingForces();
+  g->wait_polled = false;
+  b->last_batch.valid = false;
+  int rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
+  if (rc) return rc;
+  int nblk = 0;
+  const unsigned long long tag = forces_poll_enabled() ? ++g->force_seq : 0;
+  bool tagged = false;
+  if (n > 0 && b->last_batch.valid && b->last_batch.nh > 0) {
+    const struct { long long nh, k; } lb{b->last_batch.nh, b->last_batch.k};
+    const size_t need = ordered_prefix_doubles(g->g, lb.nh);
+    if (need * sizeof(double) > ((size_t)1 << 30)) {
+      set_error("pair_step_ordered: more hills in one step than the reference-order force pass keeps prefix records for "
+                "(1 GiB); use edm_hip_bias_pair_step (all forces on the step-start bias) for all-samples deposition");
+      return EDM_HIP_ERR_ARG;
+    }
+    EDM_HIP_TRY(b->ord_prefix.reserve(need));
+    EDM_HIP_TRY(b->ord_dirty.reserve(1));
+    OrderedForcesArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nh = lb.nh;
+    a.k = lb.k;
+    a.heights = b->last_batch.heights;
+    a.h_const = b->last_batch.h_const;
+    a.tail_h1 = b->last_batch.tail_h1;
+    a.tail_h2 = b->last_batch.tail_h2;
+    a.hx = g->ws.hx.p;
+    a.hc = g->ws.hc.p;
+    a.ht = g->ws.ht.p;
+    a.sel = b->last_batch.sel;
+    a.rec0 = b->ord_rec0.p;
+    a.prefix = b->ord_prefix.p;
+    a.first_dirty = b->ord_dirty.p;
+    a.n = n;
+    a.r = d_r;
+    a.first_sample = d_first_sample;
+    a.force = d_force;
+    EDM_HIP_TRY(launch_ordered_prefix(g->g, g->tables(), a, s));
+    EDM_HIP_TRY(launch_pair_forces_ordered(g->g, a, g->d_partials, s, &nblk, tag));
+    tagged = tag != 0;
+  } else if (n > 0) {
+    // no new hill this step (none accepted, or edm_bias.cpp:534-535 skipped them): every pair sees the same bias
+    b->pending.active = true;
+    b->pending.n = n;
+    b->pending.d_r = d_r;
+    b->pending.d_force = d_force;
+    b->pending.tag = tag;
+    rc = pending_forces_flush(g, &b->pending);
+    if (rc) return rc;
+    nblk = b->pending.nblk;
+    tagged = tag && b->pending.tagged;
+  }
+  double e = 0;
+  if (!(tagged && poll_tagged_partials(g, nblk, tag, &e))) {
+    EDM_HIP_TRY(hipStreamSynchronize(s));
+    e = 0;
+    for (int k = 0; k < nblk; k++) e += g->h_partials[tagged ? 2 * k : k];
+  } else {
+    g->polled_forces++;
+  }
+  if (energy) *energy = e;
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_pair_step_ordered(edm_hip_bias *b, long long n, const double *d_r, double *d_force,
+                                   const int *d_first_sample, long long n_samples, const double *d_sample_r,
+                                   const double *d_runiform, long long est_hill_count, double *energy) {
+  if (energy) *energy = 0;
+  if (!b->bias && !b->b_outofbounds) {
+    set_error("pair_step before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  if (b->dim != 1) {
+    set_error("pair_step: the pair-distance CV is 1-D (fix_edm_pair.cpp:52)");
+    return EDM_HIP_ERR_ARG;
+  }
+  if (n < 0) n = 0;
+  if (n_samples < 0) n_samples = 0;
+  int rc = do_pre_add_hill(b, est_hill_count < 0 ? n_samples : est_hill_count);
+  if (rc) return rc;
+  if (b->b_outofbounds) {
+    if (n > 0) EDM_HIP_TRY(hipMemset(d_force, 0, sizeof(double) * (size_t)n));
+    return do_post_add_hill(b);
+  }
+  rc = pair_step_ordered_device(b, n, d_r, d_force, d_first_sample, n_samples, d_sample_r, d_runiform, energy);
+  if (rc) return rc;
+  return do_post_add_hill(b);
+}
+
+// ... for a caller whose arrays live in HOST memory (the host-list fix edm_pair): copies queued on the object's stream
+// around the kernels; the forces come down once the force pass -- the step's LAST kernel here -- has run
+int edm_hip_bias_pair_step_ordered_host(edm_hip_bias *b, long long n, const double *h_r, double *h_force,
+                                        const int *h_first_sample, long long n_samples, const double *h_sample_r,
+                                        const double *h_runiform, long long est_hill_count, double *energy) {
+  if (energy) *energy = 0;
+  if (!b->bias && !b->b_outofbounds) {
+    set_error("pair_step before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  if (b->dim != 1) {
+    set_error("pair_step: the pair-distance CV is 1-D (fix_edm_pair.cpp:52)");
+    return EDM_HIP_ERR_ARG;
+  }
+  if (n < 0) n = 0;
+  if (n_samples < 0) n_samples = 0;
+  int rc = do_pre_add_hill(b, est_hill_count < 0 ? n_samples : est_hill_count);
+  if (rc) return rc;
+  if (b->b_outofbounds) {
+    if (n > 0) memset(h_force, 0, sizeof(double) * (size_t)n);
+    return do_post_add_hill(b);
+  }
+  hipStream_t s = b->bias->stream;
+  EDM_HIP_TRY(b->hs_r.reserve((size_t)(n > 0 ? n : 1)));
+  EDM_HIP_TRY(b->hs_f.reserve((size_t)(n > 0 ? n : 1)));
+  EDM_HIP_TRY(b->hs_x.reserve((size_t)(n_samples > 0 ? n_samples : 1)));
+  EDM_HIP_TRY(b->hs_u.reserve((size_t)(n_samples > 0 ? n_samples : 1)));
+  EDM_HIP_TRY(b->ord_first.reserve((size_t)(n > 0 ? n : 1)));
+  // (whatever happens below, no copy may still be reading or writing the caller's arrays when the call returns)
+  struct StreamGuard {
+    hipStream_t s;
+    ~StreamGuard() { (void)hipStreamSynchronize(s); }
+  } guard{s};
+  if (n > 0) {
+    EDM_HIP_TRY(hipMemcpyAsync(b->hs_r.p, h_r, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+    if (h_first_sample)
+      EDM_HIP_TRY(hipMemcpyAsync(b->ord_first.p, h_first_sample, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+  }
+  if (n_samples > 0) {
+    EDM_HIP_TRY(hipMemcpyAsync(b->hs_x.p, h_sample_r, sizeof(double) * (size_t)n_samples, hipMemcpyHostToDevice, s));
+    if (h_runiform)
+      EDM_HIP_TRY(hipMemcpyAsync(b->hs_u.p, h_runiform, sizeof(double) * (size_t)n_samples, hipMemcpyHostToDevice, s));
+  }
+  rc = pair_step_ordered_device(b, n, b->hs_r.p, b->hs_f.p, h_first_sample ? b->ord_first.p : nullptr, n_samples,
+                                b->hs_x.p, h_runiform ? b->hs_u.p : nullptr, energy);
+  if (rc) return rc;
+  if (n > 0) EDM_HIP_TRY(hipMemcpyAsync(h_force, b->hs_f.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+  EDM_HIP_TRY(hipStreamSynchronize(s));
+  return do_post_add_hill(b);
 }
 
 // The same step for a caller whose arrays live in HOST memory (the host-list fix edm_pair): staged through HBM with

@@ -2105,6 +2105,9 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   }
   if (out) {
     out->res = res;
+    out->d_base_heights = base_heights;
+    out->d_tail_h1 = ws.tail_h1.p;
+    out->d_tail_h2 = p_h2;
     if (want_total && !spec.limited) out->total_added = g->h_scalars[1];
     if (base_heights && spec.limited && spec.fetch_heights) {
       const long long f0 = spec.fetch_all ? 0 : res.k;

@@ -243,6 +243,9 @@ struct ApplyOutcome {
   // nobody asked for positions / per-hill bias -- flags, h2, a2, pos, added above are EMPTY (they would read 1, 0, 0)
   bool plain_fast = false;
   const double *d_added = nullptr;   // where the batch's per-hill bias_added lies on the device (valid until the next batch)
+  // ... and the heights the batch was applied with (see HillHeights): per-hill base heights (NULL: the constant),
+  // the limiter's tail arrays for hills >= res.k
+  const double *d_base_heights = nullptr, *d_tail_h1 = nullptr, *d_tail_h2 = nullptr;
 };
 // prep -> integrals -> (limiter) -> ordered gather -> boundary duplication.
 // Leaves per-hill `added` in g->ws.added and the tail arrays in g->ws.tail_*.

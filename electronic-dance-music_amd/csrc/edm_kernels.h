@@ -110,6 +110,50 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
                               hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int *blocks_out = nullptr,
                               unsigned long long tag = 0, int *tagged_out = nullptr);
 
+// ---- fix edm_pair in the REFERENCE'S order (fix_edm_pair.cpp:177-238) ---------------------------------------------
+// The reference walks the neighbour list once: update_force for pair k, then its one or two add_hill calls -- so
+// pair k's force reads a bias that already holds the hills of pairs 0..k-1 of the same step.  Which samples become
+// hills does not depend on the grid (edm_bias.cpp:543), and neither do the limiter's decisions (a hill's integrated
+// bias is independent of grid contents), so the step's hill batch is applied exactly as in the batched step and the
+// forces follow from three things the batch leaves on the device: a snapshot rec0 of the node records taken before
+// the batch, the prepared hill list, and the heights the limiter settled on.
+//   launch_ordered_prefix : one thread per node walks the hills in list order and stores, for every hill j whose
+//       stencil covers the node, the node's record AFTER hill j: prefix[j][node - (centre_j - msize)] = rec0 +
+//       sum_{i <= j} (h1_i term_i, then h2_i term_i) -- the reference's sequence of += (gaussian_grid.h:343-355)
+//   launch_pair_forces_ordered : pair k counts the hills whose add_hill call precedes its update_force
+//       (m = #{j : sample(j) < first_sample[k]}), finds for each of its two corner nodes the LAST hill j < m that
+//       covers the node (walking the centre nodes backwards) and interpolates (grid.h:390-446, interp<1> :52-139) on
+//       prefix[j][.] -- or on rec0 where no earlier hill reaches.  The boundary duplication of gaussian_grid.h:571-630
+//       (value of the first / last in-boundary node copied outward after every hill with a non-zero correction) is
+//       applied on the fly: an outward copy node reads the value of its source node at the same prefix once the
+//       first such hill (first_dirty, found by the prefix pass) lies before the pair.
+// 1-D grids only (fix_edm_pair.cpp:52), stencil not wider than a periodic grid.
+struct OrderedForcesArgs {
+  long long nh;             // hills of the step's batch (true count)
+  long long k;              // hills [0, k): base height; hills >= k: the limiter's tail arrays (see HillHeights)
+  const double *heights;    // per-hill base heights or NULL (h_const)
+  double h_const;
+  const double *tail_h1, *tail_h2;
+  const double *hx;         // prepared hills: remapped position, centre node, (t1, t3)
+  const int *hc;
+  const double *ht;
+  const long long *sel;     // sample index of hill j, ascending (NULL: hill j is sample j)
+  const double *rec0;       // node records before the batch
+  double *prefix;           // [nh][2 msize + 1][2]
+  int *first_dirty;         // device int: index of the first hill with a non-zero boundary correction (INT_MAX: none)
+  long long n;              // pairs
+  const double *r;          // [n] pair distances
+  const int *first_sample;  // [n] sample index of pair k's first add_hill call, or NULL: 2 k (the virtual samples of a
+                            // device-resident neighbour list)
+  double *force;            // [n] out: -dV/dr
+};
+size_t ordered_prefix_doubles(const Geom &g, long long nh);
+bool ordered_forces_supported(const Geom &g);
+hipError_t launch_ordered_prefix(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s);
+// tagged partial energy sums like launch_pair_forces (tag != 0: scratch is host-mapped, polled by the host)
+hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
+                                      int *blocks_out, unsigned long long tag);
+
 // ---- record layout conversion ---------------------------------------------------
 hipError_t launch_pack(const Geom &g, double *rec, const double *values, const double *derivs, hipStream_t s);
 hipError_t launch_unpack(const Geom &g, const double *rec, double *values, double *derivs, hipStream_t s);

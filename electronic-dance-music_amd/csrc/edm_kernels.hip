@@ -360,9 +360,11 @@ struct Rec<4> {
 
 // Returns the flat start node (or -1 where the reference returns 0) and the
 // interpolated value / POSITIVE gradient.
-template <int DIM>
-__device__ __forceinline__ long long lookup_one(const Geom &g, const double *__restrict__ rec,
-                                                const double *xin, double &value, double *der) {
+// (SRC: where the node records come from -- src.load(Rec<R> &, node).  The grid's record array for every caller but
+//  the reference-order pair forces, which read each node as it stood after a prefix of the step's hills.)
+template <int DIM, class SRC>
+__device__ __forceinline__ long long lookup_one_src(const Geom &g, const SRC &src, const double *xin, double &value,
+                                                    double *der) {
   constexpr int R = (DIM == 1) ? 2 : 4;
   double xx[DIM];
 #pragma unroll
@@ -398,7 +400,7 @@ __device__ __forceinline__ long long lookup_one(const Geom &g, const double *__r
 
   if (!g.interp) {
     Rec<R> r;
-    r.load(rec, flat);
+    src.load(r, flat);
     value = r.v[0];
 #pragma unroll
     for (int d = 0; d < DIM; d++) der[d] = r.v[1 + d];
@@ -416,7 +418,7 @@ __device__ __forceinline__ long long lookup_one(const Geom &g, const double *__r
 #pragma unroll
     for (int d = 0; d < DIM; d++) shift += stride[d] * ((corner >> d) & 1);
     Rec<R> r;
-    r.load(rec, flat + shift);
+    src.load(r, flat + shift);
     const double tf = r.v[0];
     double C[DIM], D[DIM];
     double ff = 1.0;
@@ -449,6 +451,17 @@ __device__ __forceinline__ long long lookup_one(const Geom &g, const double *__r
   }
   value = f;
   return flat;
+}
+template <int R>
+struct RecArray {
+  const double *__restrict__ rec;
+  __device__ __forceinline__ void load(Rec<R> &r, long long node) const { r.load(rec, node); }
+};
+template <int DIM>
+__device__ __forceinline__ long long lookup_one(const Geom &g, const double *__restrict__ rec,
+                                                const double *xin, double &value, double *der) {
+  const RecArray<(DIM == 1) ? 2 : 4> src{rec};
+  return lookup_one_src<DIM>(g, src, xin, value, der);
 }
 
 template <int DIM, int MODE>
@@ -5194,6 +5207,231 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
   }
   hipLaunchKernelGGL(k_limit, dim3(1), dim3(64), 0, s, nh, added, heights, h_const, limit, cum_in, flush_mode, tail,
                      result_dev, nchunks, csum, cmax, nh_dev);
+  return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------
+// fix edm_pair in the reference's order (see OrderedForcesArgs in edm_kernels.h)
+// ---------------------------------------------------------------------------
+size_t ordered_prefix_doubles(const Geom &g, long long nh) {
+  return (size_t)(nh > 0 ? nh : 0) * (size_t)(2 * g.msize[0] + 1) * 2;
+}
+bool ordered_forces_supported(const Geom &g) {
+  return g.dim == 1 && g.rec == 2 && g.n[0] >= 2 && !(g.periodic[0] && 2 * g.msize[0] + 1 > g.n[0]);
+}
+
+// signed stencil offset of node n in the stencil of a hill centred at node c (|o| <= msize when the hill covers
+// the node), through the one periodic image a stencil narrower than the grid can reach a node by
+__device__ __forceinline__ int ordered_offset(const Geom &g, int n, int c) {
+  int o = n - c;
+  if (g.periodic[0]) {
+    if (o > g.msize[0]) o -= g.n[0];
+    else if (o < -g.msize[0]) o += g.n[0];
+  }
+  return o;
+}
+
+template <bool PERB>
+__global__ void __launch_bounds__(BLOCK) k_ordered_prefix(Geom g, Tables t, OrderedForcesArgs a) {
+  const int n = blockIdx.x * BLOCK + threadIdx.x;
+  const bool in_grid = n < g.n[0];
+  const int p[1] = {in_grid ? n : 0};
+  NodeTerms<1> nt;
+  node_terms<1, PERB>(g, t, p, nt);
+  const bool active = in_grid && nt.inside;   // (hills skip nodes outside a wall, gaussian_grid.h:273)
+  TermConst<1> tc;
+  term_const<1>(g, tc);
+  double acc0 = 0, acc1 = 0;
+  if (in_grid) {
+    const double2 r0 = reinterpret_cast<const double2 *>(a.rec0)[n];
+    acc0 = r0.x;
+    acc1 = r0.y;
+  }
+  const int msize = g.msize[0];
+  const long long W = 2 * (long long)msize + 1;
+  __shared__ int s_c[BLOCK];
+  __shared__ double s_x[BLOCK], s_t[BLOCK][2], s_a1[BLOCK], s_a2[BLOCK];
+  int my_dirty = INT_MAX;
+  double2 *P = reinterpret_cast<double2 *>(a.prefix);
+  for (long long base = 0; base < a.nh; base += BLOCK) {
+    const long long cur = base + threadIdx.x;
+    if (cur < a.nh) {
+      s_c[threadIdx.x] = a.hc[cur];
+      s_x[threadIdx.x] = a.hx[cur];
+      s_t[threadIdx.x][0] = PERB ? 0.0 : a.ht[2 * cur];
+      s_t[threadIdx.x][1] = PERB ? 0.0 : a.ht[2 * cur + 1];
+      double a1 = a.heights ? a.heights[cur] : a.h_const, a2 = 0;
+      if (cur >= a.k) {
+        a1 = a.tail_h1[cur - a.k];
+        a2 = a.tail_h2[cur - a.k];
+      }
+      s_a1[threadIdx.x] = a1;
+      s_a2[threadIdx.x] = a2;
+    }
+    __syncthreads();
+    const int cnt = (a.nh - base < BLOCK) ? (int)(a.nh - base) : BLOCK;
+    if (in_grid) {
+      for (int q = 0; q < cnt; q++) {
+        const int c = s_c[q];
+        if (c == INT_MIN) continue;   // a hill rejected at preparation (outside a wall, gaussian_grid.h:214-216)
+        if (images(g, 0, c, n, n) == 0) continue;
+        const int o = ordered_offset(g, n, c);
+        const double a1 = s_a1[q], a2 = s_a2[q];
+        if (active && !(a1 == 0 && a2 == 0)) {
+          double val, dval[1];
+          bool nz = false;
+          if (pair_term<1, PERB>(g, tc, nt, &s_x[q], s_t[q], val, dval, nz, false)) {
+            acc0 += a1 * val;
+            acc1 += a1 * dval[0];
+            if (a2 != 0) {   // the undo hill of a limit crossing: a second add_value (edm_bias.cpp:474-490)
+              acc0 += a2 * val;
+              acc1 += a2 * dval[0];
+            }
+            if (nz && my_dirty == INT_MAX) my_dirty = (int)(base + q);
+          }
+        }
+        double2 out;
+        out.x = acc0;
+        out.y = acc1;
+        P[(base + q) * W + (o + msize)] = out;
+      }
+    }
+    __syncthreads();
+  }
+  if (my_dirty != INT_MAX) atomicMin(a.first_dirty, my_dirty);
+}
+
+hipError_t launch_ordered_prefix(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s) {
+  if (!ordered_forces_supported(g)) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(a.first_dirty, 0x7F, sizeof(int), s);   // (0x7F7F7F7F: beyond any hill index)
+  if (e != hipSuccess) return e;
+  if (a.nh <= 0) return hipSuccess;
+  const unsigned nb = (unsigned)((g.n[0] + BLOCK - 1) / BLOCK);
+  if (g.bper[0])
+    hipLaunchKernelGGL(k_ordered_prefix<true>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
+  else
+    hipLaunchKernelGGL(k_ordered_prefix<false>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
+  return hipGetLastError();
+}
+
+// node records as they stood after the first m hills of the batch
+template <class LISTS>
+struct OrderedSource {
+  const Geom &g;
+  const OrderedForcesArgs &a;
+  const LISTS &l;
+  int m;
+  int first_dirty;
+  int lo_t, lo_s, hi_t, hi_s;   // outward copy nodes of the boundary duplication and their sources (-1: none)
+  __device__ __forceinline__ double2 raw(int node) const {
+    const int msize = g.msize[0];
+    const long long W = 2 * (long long)msize + 1;
+    for (int j = m - 1; j >= 0; j--) {
+      const int c = l.centre(j);
+      if (c == INT_MIN) continue;
+      if (images(g, 0, c, node, node) == 0) continue;
+      return reinterpret_cast<const double2 *>(a.prefix)[(long long)j * W + (ordered_offset(g, node, c) + msize)];
+    }
+    return reinterpret_cast<const double2 *>(a.rec0)[node];
+  }
+  __device__ __forceinline__ void load(Rec<2> &r, long long node) const {
+    double2 own = raw((int)node);
+    if (m > first_dirty && ((int)node == lo_t || (int)node == hi_t)) own.x = raw((int)node == lo_t ? lo_s : hi_s).x;
+    r.v[0] = own.x;
+    r.v[1] = own.y;
+  }
+};
+struct OrderedListsLds {
+  const int *c, *s;
+  __device__ __forceinline__ int centre(int j) const { return c[j]; }
+  __device__ __forceinline__ int sample(int j) const { return s[j]; }
+};
+struct OrderedListsGlobal {
+  const int *c;
+  const long long *s;
+  __device__ __forceinline__ int centre(int j) const { return c[j]; }
+  __device__ __forceinline__ long long sample(int j) const { return s ? s[j] : (long long)j; }
+};
+
+template <bool LDS>
+__global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedForcesArgs a, DupPlan dp,
+                                                               double *__restrict__ block_energy, unsigned long long tag) {
+  extern __shared__ int s_lists[];
+  __shared__ double red[BLOCK / 64];
+  const int H = (int)a.nh;
+  if (LDS) {
+    for (int i = threadIdx.x; i < H; i += BLOCK) {
+      s_lists[i] = a.hc[i];
+      s_lists[H + i] = a.sel ? (int)a.sel[i] : i;
+    }
+    __syncthreads();
+  }
+  const OrderedListsLds ll{s_lists, s_lists + H};
+  const OrderedListsGlobal lg{a.hc, a.sel};
+  const int first_dirty = *a.first_dirty;
+  int lo_t = -1, lo_s = -1, hi_t = -1, hi_s = -1;
+  if (!g.bper[0]) {   // duplicate_boundary_lanes' cases 0 and 3 in one dimension
+    if (dp.lo[0] > 0 && dp.lo[0] < (unsigned long long)g.n[0]) {
+      lo_t = (int)dp.lo[0] - 1;
+      lo_s = (int)dp.lo[0];
+    }
+    if (dp.hi[0] + 1 < (unsigned long long)g.n[0]) {
+      hi_t = (int)dp.hi[0] + 1;
+      hi_s = (int)dp.hi[0];
+    }
+  }
+  double e_acc = 0;
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += stride) {
+    const double x = a.r[i];
+    const long long fs = a.first_sample ? (long long)a.first_sample[i] : 2 * i;
+    int lo = 0, hi = H;   // m = number of hills whose sample index is below fs
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const long long sm = LDS ? (long long)ll.sample(mid) : lg.sample(mid);
+      if (sm < fs) lo = mid + 1; else hi = mid;
+    }
+    double v, d;
+    if (LDS) {
+      const OrderedSource<OrderedListsLds> src{g, a, ll, lo, first_dirty, lo_t, lo_s, hi_t, hi_s};
+      lookup_one_src<1>(g, src, &x, v, &d);
+    } else {
+      const OrderedSource<OrderedListsGlobal> src{g, a, lg, lo, first_dirty, lo_t, lo_s, hi_t, hi_s};
+      lookup_one_src<1>(g, src, &x, v, &d);
+    }
+    e_acc += v;
+    a.force[i] = 0.0 - d;
+  }
+  const double sum = block_sum(e_acc, red);
+  if (threadIdx.x == 0) {
+    if (tag) store_partial_tagged(block_energy, blockIdx.x, sum, tag);
+    else block_energy[blockIdx.x] = sum;
+  }
+}
+
+hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
+                                      int *blocks_out, unsigned long long tag) {
+  if (!ordered_forces_supported(g)) return hipErrorInvalidValue;
+  long long blocks = (a.n + BLOCK - 1) / BLOCK;
+  if (blocks > 4 * cu_count()) blocks = 4 * cu_count();
+  if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  const DupPlan dp = make_dup_plan(g);
+  if (a.nh <= 8192) {   // (centre nodes and sample indices of the hills as ints in LDS: 64 KB at most)
+    const size_t lds = sizeof(int) * 2 * (size_t)(a.nh > 0 ? a.nh : 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_forces_ordered<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * 2 * 8192));
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_pair_forces_ordered<true>, dim3((unsigned)blocks), dim3(BLOCK), lds, s, g, a, dp, scratch, tag);
+  } else {
+    hipLaunchKernelGGL(k_pair_forces_ordered<false>, dim3((unsigned)blocks), dim3(BLOCK), 0, s, g, a, dp, scratch, tag);
+  }
+  if (blocks_out) *blocks_out = (int)blocks;
   return hipGetLastError();
 }
 

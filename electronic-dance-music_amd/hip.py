@@ -112,6 +112,8 @@ _PROTOS = {
     "edm_hip_bias_step": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step_host": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
+    "edm_hip_bias_pair_step_ordered": (C.c_int, [vp, C.c_longlong, vp, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
+    "edm_hip_bias_pair_step_ordered_host": (C.c_int, [vp, C.c_longlong, vp, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pre_add_hill": (C.c_int, [vp, C.c_longlong]),
     "edm_hip_bias_add_hill": (C.c_int, [vp, c_dp, C.c_double]),
     "edm_hip_bias_post_add_hill": (C.c_int, [vp]),
@@ -730,6 +732,29 @@ def _bias_pair_step_host(self, r, force, sample_r, runiform, est=-1):
 
 
 Bias.pair_step_host = _bias_pair_step_host
+
+
+def _bias_pair_step_ordered_device(self, d_r, d_f, d_first_sample, n, d_sample_r, d_u, n_samples, est=-1):
+    """one hill step of fix edm_pair in the reference's own order (edm_hip_bias_pair_step_ordered); returns the energy"""
+    e = C.c_double(0)
+    check(lib().edm_hip_bias_pair_step_ordered(self.h, n, _ptr(d_r), _ptr(d_f), _ptr(d_first_sample), n_samples,
+                                               _ptr(d_sample_r), _ptr(d_u), est, C.byref(e)))
+    return e.value
+
+
+def _bias_pair_step_ordered_host(self, r, force, first_sample, sample_r, runiform, est=-1):
+    """edm_hip_bias_pair_step_ordered_host on host numpy arrays (force written in place); returns the energy"""
+    e = C.c_double(0)
+    ns = 0 if sample_r is None else len(sample_r)
+    fs = np.ascontiguousarray(first_sample, dtype=np.int32)
+    check(lib().edm_hip_bias_pair_step_ordered_host(self.h, len(r), r.ctypes.data, force.ctypes.data, fs.ctypes.data, ns,
+                                                    None if sample_r is None else sample_r.ctypes.data,
+                                                    None if runiform is None else runiform.ctypes.data, est, C.byref(e)))
+    return e.value
+
+
+Bias.pair_step_ordered_device = _bias_pair_step_ordered_device
+Bias.pair_step_ordered_host = _bias_pair_step_ordered_host
 
 
 def _bias_comm_init_shm(self, shm_name, nranks, rank):

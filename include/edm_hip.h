@@ -306,6 +306,26 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
 int edm_hip_bias_pair_step_host(edm_hip_bias *b, long long n, const double *h_r, double *h_force,
                                 long long n_samples, const double *h_sample_r, const double *h_runiform,
                                 long long est_hill_count, double *energy);
+/* One hill-depositing step of fix edm_pair in the REFERENCE'S OWN ORDER (fix_edm_pair.cpp:173-247): the reference
+ * walks the neighbour list once -- update_force for pair k (:217), then that pair's one or two add_hill calls
+ * (:230-237) -- so the force of pair k is read from a bias that already holds the hills deposited for pairs 0..k-1 of
+ * the same step.  This entry reproduces exactly that: pre_add_hill(est_hill_count); the staged samples are applied as
+ * in edm_hip_bias_pair_step (which hills are accepted, the limiter and the grid do not depend on the forces, so grid,
+ * histogram, HILLS log and limiter state are those of edm_hip_bias_pair_step bit for bit); d_force[k] and the energy
+ * are interpolated on the bias as it stood when the reference's loop reached pair k.
+ * d_first_sample[k] (int, n entries, ascending) = index into the sample arrays of pair k's first add_hill call =
+ * the number of add_hill calls issued before pair k's update_force.  Single rank only (with a communicator a rank's
+ * pairs would see only their own hills: EDM_HIP_ERR_STATE); at most 1 GiB of per-hill stencil records per step
+ * (~59 000 hills on the C1D grid; beyond: EDM_HIP_ERR_ARG -- all-samples deposition of a large system keeps
+ * edm_hip_bias_pair_step).  edm_hip_bias_pair_step evaluates every force of the step on the bias as it stands after
+ * pre_add_hill instead: faster (the forces share the selection's launch), and on a hill step its forces differ from
+ * the reference's by the bias the step itself deposits (INTEGRATION.md has the measured size). */
+int edm_hip_bias_pair_step_ordered(edm_hip_bias *b, long long n, const double *d_r, double *d_force,
+                                   const int *d_first_sample, long long n_samples, const double *d_sample_r,
+                                   const double *d_runiform, long long est_hill_count, double *energy);
+int edm_hip_bias_pair_step_ordered_host(edm_hip_bias *b, long long n, const double *h_r, double *h_force,
+                                        const int *h_first_sample, long long n_samples, const double *h_sample_r,
+                                        const double *h_runiform, long long est_hill_count, double *energy);
 /* EDMBias::pre_add_hill / add_hill / post_add_hill (edm_bias.cpp:413-442, :528-563,
  * :565-583).  add_hill stages the sample (host values); the staged batch is
  * applied on the device, in call order, at post_add_hill. */

@@ -126,6 +126,7 @@ class Lib:
         s("bias_pre_add_hill", None, [vp, C.c_int])
         s("bias_add_hill", None, [vp, c_dp, C.c_double])
         s("bias_post_add_hill", None, [vp])
+        s("bias_pair_loop", C.c_double, [vp, C.c_int, c_dp, c_ip, c_dp, C.c_int, C.c_int, c_dp, c_ip])
         s("bias_write_bias", None, [vp, C.c_char_p])
         s("bias_write_lammps_table", None, [vp, C.c_char_p])
         s("bias_write_histogram", None, [vp])
@@ -405,6 +406,18 @@ class Bias:
 
     def post_add_hill(self):
         self.lib.fn("bias_post_add_hill")(self.h)
+
+    def pair_loop(self, r, second, runiform, hill_step, est):
+        """One post_force of the reference's pair fix in its own order (fix_edm_pair.cpp:173-247):
+        returns (energy, force[n], ncalls)."""
+        r = _vec(r)
+        sec = _ivec(second)
+        ru = _vec(runiform if len(runiform) else [0.0])
+        force = np.zeros(len(r))
+        nc = np.zeros(1, dtype=np.int32)
+        e = self.lib.fn("bias_pair_loop")(self.h, len(r), _dp(r), sec.ctypes.data_as(c_ip), _dp(ru), int(hill_step),
+                                          int(est), _dp(force), nc.ctypes.data_as(c_ip))
+        return e, force, int(nc[0])
 
     def write_bias(self, filename):
         self.lib.fn("bias_write_bias")(self.h, os.fsencode(filename))

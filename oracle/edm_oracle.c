@@ -1289,6 +1289,31 @@ void ora_bias_add_hills(ora_bias *b, int n, const double *positions, int stride,
   ora_bias_post_add_hill(b);
 }
 
+/* The per-step loop of the reference's pair fix (lammps/fix_edm_pair.cpp:173-247) over flat pair records, in ITS
+ * order: on a hill step pre_add_hill(est) first (:173-174); then for every pair k in list order update_force(&r_k)
+ * (:217) -- which therefore reads a bias that already holds the hills of pairs 0..k-1 of this very step -- followed by
+ * add_hill(&r_k, u) once, and once more when j is owned (second[k] != 0; :230-237); post_add_hill last (:244-247).
+ * force[k] = edm_force[0] after update_force on a zeroed accumulator; the uniforms are consumed one per add_hill
+ * call (random->uniform()); *ncalls = number of add_hill calls (the next hill step's estimate, :245). */
+double ora_bias_pair_loop(ora_bias *b, int n, const double *r, const int *second, const double *runiform,
+                          int hill_step, int est_hill_count, double *force, int *ncalls) {
+  int k, c = 0;
+  double energy = 0;
+  if (hill_step) ora_bias_pre_add_hill(b, est_hill_count);
+  for (k = 0; k < n; k++) {
+    double f[1] = {0};
+    energy += ora_bias_update_force(b, &r[k], f);
+    force[k] = f[0];
+    if (hill_step) {
+      ora_bias_add_hill(b, &r[k], runiform[c++]);
+      if (second[k]) ora_bias_add_hill(b, &r[k], runiform[c++]);
+    }
+  }
+  if (hill_step) ora_bias_post_add_hill(b);
+  if (ncalls) *ncalls = c;
+  return energy;
+}
+
 /* edm_bias.cpp:224-262: the serial build routes all three writers to the
  * plain PLUMED writer. */
 void ora_bias_write_bias(const ora_bias *b, const char *filename) { ora_gauss_write(b->bias, filename); }

@@ -110,6 +110,10 @@ void ora_bias_add_hills(ora_bias *b, int n, const double *positions, int stride,
 void ora_bias_pre_add_hill(ora_bias *b, int est_hill_count);
 void ora_bias_add_hill(ora_bias *b, const double *position, double runiform);
 void ora_bias_post_add_hill(ora_bias *b);
+/* one post_force of the reference's pair fix (lammps/fix_edm_pair.cpp:173-247) in ITS order: per pair
+ * update_force, then one add_hill (two when second[k]); see edm_oracle.c */
+double ora_bias_pair_loop(ora_bias *b, int n, const double *r, const int *second, const double *runiform,
+                          int hill_step, int est_hill_count, double *force, int *ncalls);
 void ora_bias_write_bias(const ora_bias *b, const char *filename);
 void ora_bias_write_lammps_table(const ora_bias *b, const char *filename);
 void ora_bias_write_histogram(const ora_bias *b);

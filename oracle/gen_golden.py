@@ -24,6 +24,9 @@ sys.path.insert(0, os.path.join(ROOT, "electronic-dance-music_amd"))
 from oracle import binding as B  # noqa: E402
 import workloads as W  # noqa: E402
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pairfix_cases as PF  # noqa: E402  (seeded inputs shared with the tests)
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -274,12 +277,54 @@ def gen_kats_and_files(lib):
     shutil.rmtree(tmp)
 
 
+# --------------------------------------------------------------------------
+# scenario 4: the pair fix's post_force in the REFERENCE'S order (lammps/fix_edm_pair.cpp:173-247):
+# per pair update_force, then one or two add_hill -- pair k's force sees the hills of pairs 0..k-1
+# --------------------------------------------------------------------------
+def run_pairfix(lib, name, spec, tmp):
+    cfg = os.path.join(tmp, name + ".edm")
+    hills = os.path.join(tmp, "HILLS_pf_" + name)
+    with open(cfg, "w") as fh:
+        fh.write(spec["cfg"] + "\nhills_filename %s\nhistogram_filename %s.hist\n" % (hills, hills))
+    b = B.Bias(lib, cfg)
+    b.setup(1.0, 1.0)
+    # FixEDMPair::init (fix_edm_pair.cpp:88-106): every rank's bounds are [0, cut + skin], not periodic
+    b.subdivide([spec["lo"]], [spec["hi"]], [spec["lo"]], [spec["hi"]], [0], [spec["skin"]])
+    last_calls = spec["nmax"]
+    E, F, NC, CUM, OVF = [], [], [], [], []
+    for step, hill_step in enumerate(spec["steps"]):
+        r, second, ru = PF.pairfix_inputs(name, step)
+        e, f, nc = b.pair_loop(r, second, ru, hill_step, last_calls)
+        if hill_step:
+            last_calls = nc
+        E.append(e)
+        F.append(f)
+        NC.append(nc)
+        CUM.append(b.get("cum_bias"))
+        OVF.append([int(b.get("overflow_left")), int(b.get("overflow_right")), int(b.get("b_skip_hill_add"))])
+    gg = b.gauss.grid
+    np.savez_compressed(os.path.join(GOLDEN, "pairfix_%s.npz" % name), energy=np.array(E), force=np.array(F),
+                        ncalls=np.array(NC, dtype=np.int64), cum_bias=np.array(CUM),
+                        overflow=np.array(OVF, dtype=np.int64), grid_values=gg.values.copy(),
+                        grid_derivs=gg.derivs.copy(), hist=b.hist.values.copy())
+    del b
+    shutil.copy(hills + "_0", os.path.join(GOLDEN, "pairfix_%s.hills.txt" % name))
+
+
+def gen_pairfix(lib):
+    tmp = tempfile.mkdtemp(prefix="edm_golden_")
+    for name in sorted(PF.PAIRFIX):
+        run_pairfix(lib, name, PF.PAIRFIX[name], tmp)
+    shutil.rmtree(tmp)
+
+
 def main():
     lib = B.load("ref")
     os.makedirs(GOLDEN, exist_ok=True)
     gen_gauss(lib)
     gen_controller(lib)
     gen_kats_and_files(lib)
+    gen_pairfix(lib)
     print("golden fixtures written to", GOLDEN)
 
 

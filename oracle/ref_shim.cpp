@@ -288,6 +288,26 @@ void ref_bias_add_hills(ref_bias *h, int n, const double *positions, int stride,
 void ref_bias_pre_add_hill(ref_bias *h, int est) { h->b->pre_add_hill(est); }
 void ref_bias_add_hill(ref_bias *h, const double *position, double runiform) { h->b->add_hill(position, runiform); }
 void ref_bias_post_add_hill(ref_bias *h) { h->b->post_add_hill(); }
+/* one post_force of the reference's pair fix (lammps/fix_edm_pair.cpp:173-247) driven through the REAL library in
+ * the fix's own order: pre_add_hill, then per pair update_force followed by one or two add_hill, then post_add_hill */
+double ref_bias_pair_loop(ref_bias *h, int n, const double *r, const int *second, const double *runiform,
+                          int hill_step, int est_hill_count, double *force, int *ncalls) {
+  int c = 0;
+  double energy = 0;
+  if (hill_step) h->b->pre_add_hill(est_hill_count);
+  for (int k = 0; k < n; k++) {
+    double f[1] = {0};
+    energy += h->b->update_force(&r[k], f);
+    force[k] = f[0];
+    if (hill_step) {
+      h->b->add_hill(&r[k], runiform[c++]);
+      if (second[k]) h->b->add_hill(&r[k], runiform[c++]);
+    }
+  }
+  if (hill_step) h->b->post_add_hill();
+  if (ncalls) *ncalls = c;
+  return energy;
+}
 void ref_bias_write_bias(const ref_bias *h, const char *filename) { h->b->write_bias(std::string(filename)); }
 void ref_bias_write_lammps_table(const ref_bias *h, const char *filename) {
   h->b->write_lammps_table(std::string(filename));

@@ -292,3 +292,41 @@ def test_config_reader(oracle_lib, ref_lib, workdir):
                     + list(b.array("bias_sigma")) + list(b.array("bias_dx")))
     assert vals[0] == vals[1]
     assert vals[0][0] == 2 and vals[0][1] == 0 and vals[0][-4:] == [2.0, 1.0, 1.0, 1.0]
+
+
+# ---------------------------------------------------------------------------------
+# the pair fix's own loop order (lammps/fix_edm_pair.cpp:173-247): oracle vs the real reference, fresh seeds
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [3, 4])
+def test_pair_fix_order(oracle_lib, ref_lib, workdir, seed):
+    import edm_amd.workloads as W
+
+    text = ("tempering 0\nhill_prefactor 0.4\nhill_density 60\nbias_per_step 0.3\ndimension 1\nbox_low 0.2\n"
+            "box_high 2.6\nbias_spacing 0.004\nbias_sigma 0.05\n")
+    pair = []
+    for tag, lib in (("o", oracle_lib), ("r", ref_lib)):
+        cfg = str(workdir / ("pf_%s.edm" % tag))
+        open(cfg, "w").write(text + "hills_filename %s/H_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
+        b = B.Bias(lib, cfg)
+        b.setup(1.0, 1.0)
+        b.subdivide([0.0], [2.8], [0.0], [2.8], [0], [0.3])
+        pair.append(b)
+    o, r = pair
+    last = 3000
+    for step in range(4):
+        n = 2000
+        x = 0.1 + 2.8 * W.uniform(100 * seed + step, n)
+        second = (W.uniform(100 * seed + 50 + step, n) < 0.6).astype(np.int32)
+        ru = W.uniform(100 * seed + 70 + step, 2 * n)
+        hill = step != 2
+        eo, fo, no = o.pair_loop(x, second, ru, hill, last)
+        er, fr, nr = r.pair_loop(x, second, ru, hill, last)
+        assert eo == er and np.array_equal(fo, fr) and no == nr
+        if hill:
+            last = no
+        for key in ("cum_bias", "overflow_left", "overflow_right", "b_skip_hill_add", "hills_added", "steps"):
+            assert o.get(key) == r.get(key), key
+    assert np.array_equal(o.gauss.grid.values, r.gauss.grid.values)
+    assert np.array_equal(o.gauss.grid.derivs, r.gauss.grid.derivs)
+    del o, r
+    assert filecmp.cmp(str(workdir / "H_o_0"), str(workdir / "H_r_0"), shallow=False)
