@@ -72,7 +72,7 @@ struct edm_hip_bias {
   bool device_rng = false;
   unsigned long long rng_seed = 0, rng_cycle = 0;
   // device-resident neighbour list (edm_hip_bias_pair_list_upload / _step)
-  DevBuf<int> pl_i, pl_j, pl_type, pl_it_idx, pl_jt_idx;
+  DevBuf<int> pl_i, pl_j, pl_type, pl_it_idx, pl_jt_idx, pl_it_entry, pl_jt_entry;
   DevBuf<long long> pl_it_off, pl_jt_off;
   // which virtual samples of the uploaded list are live, and how many (static until the list, nlocal or the type
   // pair change): built on the device by the first step that needs them
@@ -108,6 +108,8 @@ struct edm_hip_bias {
   } last_batch;
   DevBuf<double> ord_rec0, ord_prefix;
   DevBuf<int> ord_dirty, ord_first;
+  int reference_order = 0;     // edm_hip_bias_set("reference_order"): edm_hip_bias_pair_list_step evaluates its forces in
+                               // the reference's order too (edm_hip_bias_pair_step_ordered is that mode's array entry)
   // multi-GPU
   Transport *comm = nullptr;   // RCCL over xGMI, or the host-staged carrier (edm_comm.h)
   int nranks = 1, rank = 0;
@@ -287,6 +289,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   if (b->h_flush) (void)hipHostFree(b->h_flush);
   b->vs_r.release(); b->vs_mask.release(); b->pl_i.release(); b->pl_j.release(); b->pl_type.release();
   b->pl_it_idx.release(); b->pl_jt_idx.release(); b->pl_it_off.release(); b->pl_jt_off.release();
+  b->pl_it_entry.release(); b->pl_jt_entry.release();
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
   b->ord_rec0.release(); b->ord_prefix.release(); b->ord_dirty.release(); b->ord_first.release();
@@ -1069,62 +1072,77 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
 // in edm_hip_bias_pair_step -- selection, limiter and grid update do not depend on the forces -- and the force of pair k
 // is then interpolated on the bias as it stood when the reference's loop reached that pair: the grid after
 // pre_add_hill plus the hills of the add_hill calls before it (OrderedForcesArgs, edm_kernels.h).
+// the bias the first pair of a reference-order step sees: the node records behind pre_add_hill's overflow flush
+static int ordered_snapshot(edm_hip_bias *b) {
+  edm_hip_gauss *g = b->bias;
+  if (!ordered_forces_supported(g->g)) {
+    set_error("reference-order pair step: needs a 1-D bias whose stencil is not wider than a periodic grid");
+    return EDM_HIP_ERR_ARG;
+  }
+  if (b->comm) {
+    set_error("reference-order pair step: single-rank only (a rank's pairs would see only its own hills); "
+              "use edm_hip_bias_pair_step / reference_order 0 with a communicator");
+    return EDM_HIP_ERR_STATE;
+  }
+  const size_t grid_doubles = (size_t)g->g.total * (size_t)g->g.rec;
+  EDM_HIP_TRY(b->ord_rec0.reserve(grid_doubles));
+  EDM_HIP_TRY(hipMemcpyAsync(b->ord_rec0.p, g->rec, sizeof(double) * grid_doubles, hipMemcpyDeviceToDevice, g->stream));
+  b->last_batch.valid = false;
+  return EDM_HIP_OK;
+}
+// ... and, once the step's hill batch has been applied (last_batch), the per-hill prefix records of the nodes it touched
+static int ordered_prefix_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
+  edm_hip_gauss *g = b->bias;
+  const size_t need = ordered_prefix_doubles(g->g, b->last_batch.nh);
+  if (need * sizeof(double) > ((size_t)1 << 30)) {
+    set_error("reference-order pair step: more hills in one step than the force pass keeps prefix records for (1 GiB); "
+              "use edm_hip_bias_pair_step (all forces on the step-start bias) for all-samples deposition");
+    return EDM_HIP_ERR_ARG;
+  }
+  EDM_HIP_TRY(b->ord_prefix.reserve(need));
+  EDM_HIP_TRY(b->ord_dirty.reserve(1));
+  OrderedForcesArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nh = b->last_batch.nh;
+  a.k = b->last_batch.k;
+  a.heights = b->last_batch.heights;
+  a.h_const = b->last_batch.h_const;
+  a.tail_h1 = b->last_batch.tail_h1;
+  a.tail_h2 = b->last_batch.tail_h2;
+  a.hx = g->ws.hx.p;
+  a.hc = g->ws.hc.p;
+  a.ht = g->ws.ht.p;
+  a.sel = b->last_batch.sel;
+  a.rec0 = b->ord_rec0.p;
+  a.prefix = b->ord_prefix.p;
+  a.first_dirty = b->ord_dirty.p;
+  EDM_HIP_TRY(launch_ordered_prefix(g->g, g->tables(), a, g->stream));
+  *out = a;
+  return EDM_HIP_OK;
+}
+
 static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *d_r, double *d_force,
                                     const int *d_first_sample, long long n_samples, const double *d_sample_r,
                                     const double *d_runiform, double *energy) {
   edm_hip_gauss *g = b->bias;
   hipStream_t s = g->stream;
-  if (!ordered_forces_supported(g->g)) {
-    set_error("pair_step_ordered: needs a 1-D bias whose stencil is not wider than a periodic grid");
-    return EDM_HIP_ERR_ARG;
-  }
-  if (b->comm) {
-    set_error("pair_step_ordered: the reference-order step is single-rank (a rank's pairs would see only its own hills); "
-              "use edm_hip_bias_pair_step with a communicator");
-    return EDM_HIP_ERR_STATE;
-  }
-  // the bias the first pair sees: the grid behind the overflow flush of pre_add_hill
-  const size_t grid_doubles = (size_t)g->g.total * (size_t)g->g.rec;
-  EDM_HIP_TRY(b->ord_rec0.reserve(grid_doubles));
-  EDM_HIP_TRY(hipMemcpyAsync(b->ord_rec0.p, g->rec, sizeof(double) * grid_doubles, hipMemcpyDeviceToDevice, s));
+  int rc = ordered_snapshot(b);
+  if (rc) return rc;
   b->pending = PendingForces();
   g->wait_polled = false;
-  b->last_batch.valid = false;
-  int rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
+  rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
   if (rc) return rc;
   int nblk = 0;
   const unsigned long long tag = forces_poll_enabled() ? ++g->force_seq : 0;
   bool tagged = false;
   if (n > 0 && b->last_batch.valid && b->last_batch.nh > 0) {
-    const struct { long long nh, k; } lb{b->last_batch.nh, b->last_batch.k};
-    const size_t need = ordered_prefix_doubles(g->g, lb.nh);
-    if (need * sizeof(double) > ((size_t)1 << 30)) {
-      set_error("pair_step_ordered: more hills in one step than the reference-order force pass keeps prefix records for "
-                "(1 GiB); use edm_hip_bias_pair_step (all forces on the step-start bias) for all-samples deposition");
-      return EDM_HIP_ERR_ARG;
-    }
-    EDM_HIP_TRY(b->ord_prefix.reserve(need));
-    EDM_HIP_TRY(b->ord_dirty.reserve(1));
     OrderedForcesArgs a;
-    memset(&a, 0, sizeof(a));
-    a.nh = lb.nh;
-    a.k = lb.k;
-    a.heights = b->last_batch.heights;
-    a.h_const = b->last_batch.h_const;
-    a.tail_h1 = b->last_batch.tail_h1;
-    a.tail_h2 = b->last_batch.tail_h2;
-    a.hx = g->ws.hx.p;
-    a.hc = g->ws.hc.p;
-    a.ht = g->ws.ht.p;
-    a.sel = b->last_batch.sel;
-    a.rec0 = b->ord_rec0.p;
-    a.prefix = b->ord_prefix.p;
-    a.first_dirty = b->ord_dirty.p;
+    rc = ordered_prefix_enqueue(b, &a);
+    if (rc) return rc;
     a.n = n;
     a.r = d_r;
     a.first_sample = d_first_sample;
     a.force = d_force;
-    EDM_HIP_TRY(launch_ordered_prefix(g->g, g->tables(), a, s));
     EDM_HIP_TRY(launch_pair_forces_ordered(g->g, a, g->d_partials, s, &nblk, tag));
     tagged = tag != 0;
   } else if (n > 0) {
@@ -1292,7 +1310,7 @@ int edm_hip_bias_pair_step_host(edm_hip_bias *b, long long n, const double *h_r,
 
 int edm_hip_bias_pair_list_upload(edm_hip_bias *b, long long npairs, const int *h_pair_i, const int *h_pair_j,
                                   long long nall, const int *h_type) {
-  if (npairs < 0 || nall < 0) return EDM_HIP_ERR_ARG;
+  if (npairs < 0 || nall < 0 || npairs > 1073741823LL) return EDM_HIP_ERR_ARG;   // (sample indices 2 e + slot are ints)
   for (long long p = 0; p < npairs; p++)
     if (h_pair_i[p] < 0 || h_pair_i[p] >= nall || h_pair_j[p] < 0 || h_pair_j[p] >= nall) {
       set_error("pair_list_upload: atom index outside [0, nall)");
@@ -1309,11 +1327,15 @@ int edm_hip_bias_pair_list_upload(edm_hip_bias *b, long long npairs, const int *
     jt_off[(size_t)a + 1] += jt_off[(size_t)a];
   }
   std::vector<int> it_idx((size_t)(npairs > 0 ? npairs : 1)), jt_idx((size_t)(npairs > 0 ? npairs : 1));
+  std::vector<int> it_ent((size_t)(npairs > 0 ? npairs : 1)), jt_ent((size_t)(npairs > 0 ? npairs : 1));
   {
     std::vector<long long> ci(it_off.begin(), it_off.end() - 1), cj(jt_off.begin(), jt_off.end() - 1);
-    // (the OTHER atom of every entry, grouped by atom: what the force pass walks -- contiguous per atom)
+    // (the OTHER atom of every entry, grouped by atom: what the force pass walks -- contiguous per atom; the entry's own
+    //  index beside it, for the reference-order pass)
     for (long long p = 0; p < npairs; p++) {
+      it_ent[(size_t)ci[(size_t)h_pair_i[p]]] = (int)p;
       it_idx[(size_t)ci[(size_t)h_pair_i[p]]++] = h_pair_j[p];
+      jt_ent[(size_t)cj[(size_t)h_pair_j[p]]] = (int)p;
       jt_idx[(size_t)cj[(size_t)h_pair_j[p]]++] = h_pair_i[p];
     }
   }
@@ -1322,6 +1344,8 @@ int edm_hip_bias_pair_list_upload(edm_hip_bias *b, long long npairs, const int *
   EDM_HIP_TRY(b->pl_j.reserve(np1));
   EDM_HIP_TRY(b->pl_it_idx.reserve(np1));
   EDM_HIP_TRY(b->pl_jt_idx.reserve(np1));
+  EDM_HIP_TRY(b->pl_it_entry.reserve(np1));
+  EDM_HIP_TRY(b->pl_jt_entry.reserve(np1));
   EDM_HIP_TRY(b->pl_type.reserve(na1));
   EDM_HIP_TRY(b->pl_it_off.reserve(na1 + 1));
   EDM_HIP_TRY(b->pl_jt_off.reserve(na1 + 1));
@@ -1330,6 +1354,8 @@ int edm_hip_bias_pair_list_upload(edm_hip_bias *b, long long npairs, const int *
     EDM_HIP_TRY(hipMemcpy(b->pl_j.p, h_pair_j, sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice));
     EDM_HIP_TRY(hipMemcpy(b->pl_it_idx.p, it_idx.data(), sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice));
     EDM_HIP_TRY(hipMemcpy(b->pl_jt_idx.p, jt_idx.data(), sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice));
+    EDM_HIP_TRY(hipMemcpy(b->pl_it_entry.p, it_ent.data(), sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice));
+    EDM_HIP_TRY(hipMemcpy(b->pl_jt_entry.p, jt_ent.data(), sizeof(int) * (size_t)npairs, hipMemcpyHostToDevice));
   }
   if (nall > 0) EDM_HIP_TRY(hipMemcpy(b->pl_type.p, h_type, sizeof(int) * (size_t)nall, hipMemcpyHostToDevice));
   EDM_HIP_TRY(hipMemcpy(b->pl_it_off.p, it_off.data(), sizeof(long long) * ((size_t)nall + 1), hipMemcpyHostToDevice));
@@ -1386,6 +1412,8 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   a.jt_off = b->pl_jt_off.p;
   a.it_partner = b->pl_it_idx.p;
   a.jt_partner = b->pl_jt_idx.p;
+  a.it_entry = b->pl_it_entry.p;
+  a.jt_entry = b->pl_jt_entry.p;
   a.fdelta = d_fdelta;
   if (hill_step && npairs > 0 && !(b->pl_mask_valid && b->pl_mask_nlocal == nlocal && b->pl_mask_itype == itype &&
                                    b->pl_mask_jtype == jtype)) {
@@ -1407,9 +1435,17 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   // where there is one, else on its own ahead of anything of the step that writes the grid
   b->bias->wait_polled = false;
   b->pending = PendingForces();
-  b->pending.active = true;
-  b->pending.list = true;
-  b->pending.pl = a;
+  // reference order (edm_hip_bias_set "reference_order"): the hills go first, the force pass reads each entry's bias as
+  // it stood when the reference's loop reached the entry (see edm_hip_bias_pair_step_ordered)
+  const bool ordered = hill_step && npairs > 0 && b->reference_order;
+  if (ordered) {
+    rc = ordered_snapshot(b);
+    if (rc) return rc;
+  } else {
+    b->pending.active = true;
+    b->pending.list = true;
+    b->pending.pl = a;
+  }
   if (hill_step && npairs > 0) {
     // add_hill(r, u) for the two virtual samples of every list entry, in list order; dead ones are masked out.
     // The CV of an accepted sample is recomputed from the positions when its hill is prepared; only the paths
@@ -1432,14 +1468,27 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   // (a step without hills: the force pass goes alone, its workgroups tag their partial energy sums and the host looks at
   //  the slots instead of waiting for the stream, see edm_hip_gauss_pair_forces)
   unsigned long long tag = 0;
-  if (b->pending.active && forces_poll_enabled()) {   // (no hills this step, or the step's new hills were skipped)
+  int nblk_ordered = 0;
+  if (ordered) {
+    if (rc) return rc;
+    if (forces_poll_enabled()) tag = ++b->bias->force_seq;
+    a.partial_tag = tag;
+    if (b->last_batch.valid && b->last_batch.nh > 0) {
+      OrderedForcesArgs oa;
+      rc = ordered_prefix_enqueue(b, &oa);
+      if (rc) return rc;
+      EDM_HIP_TRY(launch_pairlist_forces_ordered(b->bias->g, a, oa, b->bias->d_partials, s, &nblk_ordered));
+    } else {   // (no new hill: every entry sees the same bias)
+      EDM_HIP_TRY(launch_pairlist_forces(b->bias->g, b->bias->rec, a, b->bias->d_partials, s, &nblk_ordered));
+    }
+  } else if (b->pending.active && forces_poll_enabled()) {   // (no hills this step, or the step's new hills were skipped)
     tag = ++b->bias->force_seq;
     b->pending.pl.partial_tag = tag;
   }
   int rcf = pending_forces_flush(b->bias, &b->pending);   // (no hill launch carried it: nothing has touched the grid)
   if (rc) return rc;
   if (rcf) return rcf;
-  const int nblk = b->pending.nblk;
+  const int nblk = ordered ? nblk_ordered : b->pending.nblk;
   double e = 0;
   if (tag && poll_tagged_partials(b->bias, nblk, tag, &e)) {
     b->bias->polled_forces++;
@@ -1561,6 +1610,7 @@ int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
   G("polled_forces", b->bias ? b->bias->polled_forces : 0)
   G("lookup_prep_launches", b->bias ? b->bias->lookup_prep_launches : 0)
   G("bound_redos", b->bound_redos)
+  G("reference_order", b->reference_order)
 #undef G
   set_error(std::string("unknown EDMBias member ") + name);
   return EDM_HIP_ERR_ARG;
@@ -1579,6 +1629,7 @@ int edm_hip_bias_set(edm_hip_bias *b, const char *name, double value) {
   S("debug_virtual_ranks", b->debug_virtual_ranks, int)
   S("debug_force_sync", b->debug_force_sync, int)
   S("debug_pair_step_mode", b->debug_pair_step_mode, int)
+  S("reference_order", b->reference_order, int)
 #undef S
   set_error(std::string("unknown or read-only EDMBias member ") + name);
   return EDM_HIP_ERR_ARG;

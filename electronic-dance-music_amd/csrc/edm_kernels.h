@@ -87,6 +87,8 @@ struct PairListArgs {
   const long long *it_off, *jt_off;   // [nall + 1] CSR offsets of the entries with pair_i == a / pair_j == a
   const int *it_partner, *jt_partner; // [npairs] the OTHER atom of each of those entries (j of the entries with
                                       // pair_i == a, i of the entries with pair_j == a), each atom's run in list order
+  const int *it_entry, *jt_entry;     // [npairs] the list entry behind each of those slots (read by the
+                                      // reference-order pass only: launch_pairlist_forces_ordered)
   double *fdelta;               // out [nall][3]: bias force per atom (ghost atoms: zero)
   double *vs_r;                 // launch_pairlist_samples: out [2 * npairs] virtual-sample CVs
   int *vs_mask;                 // launch_pairlist_mask: out [2 * npairs] 1 = live sample
@@ -147,6 +149,10 @@ struct OrderedForcesArgs {
                             // device-resident neighbour list)
   double *force;            // [n] out: -dV/dr
 };
+// the same pass over a device-resident neighbour list (a.n / r / first_sample / force unused: list entry e is
+// "pair" e, its first sample 2 e; pl.fdelta receives the per-atom sums, pl.partial_tag as in launch_pairlist_forces)
+hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl, const OrderedForcesArgs &a, double *partials,
+                                          hipStream_t s, int *blocks_out);
 size_t ordered_prefix_doubles(const Geom &g, long long nh);
 bool ordered_forces_supported(const Geom &g);
 hipError_t launch_ordered_prefix(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s);

@@ -1094,11 +1094,15 @@ __device__ __forceinline__ bool pairlist_types_match(const PairListArgs &a, int 
 // entries per trip: their partner, type and position loads are requested together (an entry is a chain of
 // three dependent loads -- partner -> position -> grid record -- and a lane walks a handful of entries), the
 // terms are still added in list order.
-template <bool FAST>
+// ORD (default: none): the reference-order pass -- ord->lookup(r, entry, v, d) reads the bias as it stood when the
+// reference's loop reached list entry `entry` (entry_of[q]: the list entry behind slot q of the per-atom lists)
+struct NoOrder {};
+template <bool FAST, class ORD = NoOrder>
 __device__ __forceinline__ void pairlist_side(const Geom &g, const double *__restrict__ rec, const PairListArgs &a,
                                               double inv_dx, int atom, int ta, const double *xa, bool as_i,
                                               const int *__restrict__ partner, long long beg, long long end, int sub,
-                                              double &fx, double &fy, double &fz, double &e_acc) {
+                                              double &fx, double &fy, double &fz, double &e_acc,
+                                              const ORD *ord = nullptr, const int *__restrict__ entry_of = nullptr) {
   constexpr int ILP = 4;
   for (long long q0 = beg + sub; q0 < end; q0 += 16 * ILP) {
     int other[ILP];
@@ -1137,7 +1141,9 @@ __device__ __forceinline__ void pairlist_side(const Geom &g, const double *__res
         dely *= rinv;
         delz *= rinv;
         double v, d;
-        if (FAST)
+        if constexpr (!std::is_same<ORD, NoOrder>::value)
+          ord->lookup(r, entry_of[q0 + 16 * u], v, d);
+        else if (FAST)
           pair_one<false>(g, rec, nullptr, 0, 0, inv_dx, r, v, d);
         else
           lookup_one<1>(g, rec, &r, v, &d);
@@ -1167,10 +1173,10 @@ __device__ __forceinline__ void pairlist_side(const Geom &g, const double *__res
 }
 // (body of the pass for workgroup `bid` of `nblk`: shared by the plain launch and by the launch that also carries the
 //  step's selection)
-template <bool FAST>
+template <bool FAST, class ORD = NoOrder>
 __device__ __forceinline__ void pairlist_forces_body(const Geom &g, const double *__restrict__ rec, const PairListArgs &a,
                                                      double *__restrict__ partials, double inv_dx, unsigned bid,
-                                                     unsigned nblk) {
+                                                     unsigned nblk, const ORD *ord = nullptr) {
   __shared__ double lds[BLOCK / 64];
   const int sub = threadIdx.x & 15;
   double e_acc = 0;
@@ -1181,8 +1187,8 @@ __device__ __forceinline__ void pairlist_forces_body(const Geom &g, const double
       const int ta = a.type[atom];
       const double xa[3] = {a.x[3 * atom], a.x[3 * atom + 1], a.x[3 * atom + 2]};
       const long long ib = a.it_off[atom], ie = a.it_off[atom + 1], jb = a.jt_off[atom], je = a.jt_off[atom + 1];
-      pairlist_side<FAST>(g, rec, a, inv_dx, (int)atom, ta, xa, true, a.it_partner, ib, ie, sub, fx, fy, fz, e_acc);
-      pairlist_side<FAST>(g, rec, a, inv_dx, (int)atom, ta, xa, false, a.jt_partner, jb, je, sub, fx, fy, fz, e_acc);
+      pairlist_side<FAST, ORD>(g, rec, a, inv_dx, (int)atom, ta, xa, true, a.it_partner, ib, ie, sub, fx, fy, fz, e_acc, ord, a.it_entry);
+      pairlist_side<FAST, ORD>(g, rec, a, inv_dx, (int)atom, ta, xa, false, a.jt_partner, jb, je, sub, fx, fy, fz, e_acc, ord, a.jt_entry);
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {   // fixed tree within the 16-lane group
@@ -5432,6 +5438,83 @@ hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a,
     hipLaunchKernelGGL(k_pair_forces_ordered<false>, dim3((unsigned)blocks), dim3(BLOCK), 0, s, g, a, dp, scratch, tag);
   }
   if (blocks_out) *blocks_out = (int)blocks;
+  return hipGetLastError();
+}
+
+
+// ... and over a device-resident neighbour list: list entry e's two virtual add_hill samples are 2 e and 2 e + 1
+// (fix_edm_pair.cpp:230-237), so the entry's update_force sees the hills whose sample index is below 2 e
+struct OrderedListLookup {
+  const Geom &g;
+  const OrderedForcesArgs &a;
+  const OrderedListsLds &ll;
+  const OrderedListsGlobal &lg;
+  bool lds;
+  int first_dirty, lo_t, lo_s, hi_t, hi_s;
+  __device__ __forceinline__ void lookup(double r, int entry, double &v, double &d) const {
+    const long long fs = 2 * (long long)entry;
+    int lo = 0, hi = (int)a.nh;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const long long sm = lds ? (long long)ll.sample(mid) : lg.sample(mid);
+      if (sm < fs) lo = mid + 1; else hi = mid;
+    }
+    if (lds) {
+      const OrderedSource<OrderedListsLds> src{g, a, ll, lo, first_dirty, lo_t, lo_s, hi_t, hi_s};
+      lookup_one_src<1>(g, src, &r, v, &d);
+    } else {
+      const OrderedSource<OrderedListsGlobal> src{g, a, lg, lo, first_dirty, lo_t, lo_s, hi_t, hi_s};
+      lookup_one_src<1>(g, src, &r, v, &d);
+    }
+  }
+};
+__global__ void __launch_bounds__(BLOCK) k_pairlist_forces_ordered(Geom g, PairListArgs pl, OrderedForcesArgs a, DupPlan dp,
+                                                                   double *__restrict__ partials, int use_lds) {
+  extern __shared__ int s_lists[];
+  const int H = (int)a.nh;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < H; i += BLOCK) {
+      s_lists[i] = a.hc[i];
+      s_lists[H + i] = a.sel ? (int)a.sel[i] : i;
+    }
+    __syncthreads();
+  }
+  const OrderedListsLds ll{s_lists, s_lists + H};
+  const OrderedListsGlobal lg{a.hc, a.sel};
+  int lo_t = -1, lo_s = -1, hi_t = -1, hi_s = -1;
+  if (!g.bper[0]) {
+    if (dp.lo[0] > 0 && dp.lo[0] < (unsigned long long)g.n[0]) {
+      lo_t = (int)dp.lo[0] - 1;
+      lo_s = (int)dp.lo[0];
+    }
+    if (dp.hi[0] + 1 < (unsigned long long)g.n[0]) {
+      hi_t = (int)dp.hi[0] + 1;
+      hi_s = (int)dp.hi[0];
+    }
+  }
+  const OrderedListLookup ord{g, a, ll, lg, use_lds != 0, *a.first_dirty, lo_t, lo_s, hi_t, hi_s};
+  pairlist_forces_body<false, OrderedListLookup>(g, a.rec0, pl, partials, 0.0, blockIdx.x, gridDim.x, &ord);
+}
+hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl, const OrderedForcesArgs &a, double *partials,
+                                          hipStream_t s, int *blocks_out) {
+  if (!ordered_forces_supported(g) || !pl.it_entry || !pl.jt_entry) return hipErrorInvalidValue;
+  if (blocks_out) *blocks_out = 0;
+  if (pl.nall <= 0) return hipSuccess;
+  const long long threads = (long long)pl.nall * 16;
+  long long nb = (threads + BLOCK - 1) / BLOCK;
+  if (nb > MAX_BLOCKS) nb = MAX_BLOCKS;
+  const DupPlan dp = make_dup_plan(g);
+  const int use_lds = a.nh <= 8192 ? 1 : 0;
+  const size_t lds = use_lds ? sizeof(int) * 2 * (size_t)(a.nh > 0 ? a.nh : 1) : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairlist_forces_ordered),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * 2 * 8192));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_pairlist_forces_ordered, dim3((unsigned)nb), dim3(BLOCK), lds, s, g, pl, a, dp, partials, use_lds);
+  if (blocks_out) *blocks_out = (int)nb;
   return hipGetLastError();
 }
 

@@ -737,6 +737,20 @@ double EDMBias::pair_step(int npairs, const double* r, double* force_r, int n_sa
   return energy;
 }
 
+double EDMBias::pair_step_ordered(int npairs, const double* r, double* force_r, const int* first_sample, int n_samples,
+                                  const double* sample_r, const double* runiform, int est_hill_count) {
+  double energy = 0;
+  check(edm_hip_bias_pair_step_ordered_host(h_, npairs > 0 ? npairs : 0, r, force_r, first_sample,
+                                            n_samples > 0 ? n_samples : 0, sample_r, runiform, est_hill_count, &energy),
+        "edm_bias.cpp:add_hill");
+  refresh();
+  return energy;
+}
+
+void EDMBias::set_reference_order(bool enabled) {
+  check(edm_hip_bias_set(h_, "reference_order", enabled ? 1.0 : 0.0), "edm_bias.cpp:update_force");
+}
+
 double EDMBias::pair_list_step(int nlocal, int nall, const double* const* x, double** f, int inum, const int* ilist,
                                const int* numneigh, int* const* firstneigh, int neighmask, const int* type, int itype,
                                int jtype, bool list_changed, bool hill_step, int est_hill_count, int* ncalls) {

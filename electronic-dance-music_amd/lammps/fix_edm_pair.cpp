@@ -4,12 +4,12 @@
    Same command line and behaviour as the reference fix (lammps/fix_edm_pair.cpp:20-60, :139-256).
    What changed is HOW the work reaches the bias: the reference calls EDMBias::update_force and
    add_hill once per neighbour-list entry; here one pass over the list collects the pair
-   distances, ONE batched call evaluates energy and dV/dr for all of them on the GPU, a second
-   pass applies the forces in the reference's order, and the hill samples of a hill step are
-   staged and applied as one ordered batch at post_add_hill.  Consequence, documented in
-   DESIGN.md: within one hill step the reference lets a hill added for pair k already bias pair
-   k+1's force; the batch evaluates all forces of a step on the grid as it stands after
-   pre_add_hill. */
+   distances and, on hill steps, the add_hill samples in call order; ONE batched call applies the
+   step's hills and evaluates energy and dV/dr of every pair on the GPU; a second pass applies
+   the forces in the reference's order.  Within a hill step the reference lets the hills added
+   for pairs 0..k-1 bias pair k's force (fix_edm_pair.cpp:215-237): the default reproduces that
+   (EDMBias::pair_step_ordered).  Keyword batch_order evaluates every force of a hill step on
+   the bias as it stands after pre_add_hill instead (faster; INTEGRATION.md has the deviation). */
 
 #include "fix_edm_pair.h"
 
@@ -66,10 +66,22 @@ FixEDMPair::FixEDMPair(LAMMPS *lmp, int narg, char **arg) : Fix(lmp, narg, arg),
   // extensions: "... jtype device_rng" draws the acceptance uniforms on the GPU; "... jtype gpu_list" also keeps the
   // neighbour list on the GPU: per step the positions go in and the bias forces come out (24 B per atom each way)
   // instead of one distance and one force per PAIR
-  gpu_list = (narg > 11 && strcmp(arg[11], "gpu_list") == 0);
+  // "... jtype batch_order": every force of a hill step on the bias as it stands after pre_add_hill (the reference
+  // reads pair k's force behind the hills of pairs 0..k-1 -- the default here too)
+  gpu_list = device_rng = batch_order = false;
+  for (int a = 11; a < narg; a++) {
+    if (strcmp(arg[a], "gpu_list") == 0) gpu_list = true;
+    else if (strcmp(arg[a], "device_rng") == 0) device_rng = true;
+    else if (strcmp(arg[a], "batch_order") == 0) batch_order = true;
+    else error->all(FLERR, "Illegal fix edm_pair keyword (gpu_list, device_rng, batch_order)");
+  }
   last_list_size = -1;
-  device_rng = gpu_list || (narg > 11 && strcmp(arg[11], "device_rng") == 0);
+  if (gpu_list) device_rng = true;
+  // with more than one rank a rank's pairs would see only its own hills of the step: the multi-GPU exchange applies
+  // the ranks' hills as one global batch, so the batch order is the only one defined there
+  if (size > 1) batch_order = true;
   if (device_rng) bias->set_device_rng(true, (unsigned long long) seed + (unsigned long long) me);
+  bias->set_reference_order(!batch_order);
   random = new RanMars(lmp, seed + me);
   edm_energy = 0;
   last_calls = 0;
@@ -171,7 +183,7 @@ void FixEDMPair::post_force(int /*vflag*/)
   // and, on hill steps, stage the hill samples with their uniforms in the reference's call order
   // (one add_hill per list entry, a second one iff j is owned, :230-237)
   pair_r.clear(); pair_del.clear(); pair_i.clear(); pair_j.clear();
-  hill_r.clear(); hill_u.clear();
+  hill_r.clear(); hill_u.clear(); pair_first.clear();
   for (int ii = 0; ii < inum; ii++) {
     const int i = ilist[ii];
     const int itype = type[i];
@@ -197,6 +209,7 @@ void FixEDMPair::post_force(int /*vflag*/)
       pair_i.push_back(i);
       pair_j.push_back(j);
       if (hill_step) {
+        pair_first.push_back((int) hill_r.size());   // add_hill calls issued before this pair's update_force
         hill_r.push_back(r);
         if (!device_rng) hill_u.push_back(random->uniform());
         if (newton_pair || j < nlocal) {
@@ -213,8 +226,12 @@ void FixEDMPair::post_force(int /*vflag*/)
   pair_f.resize(pair_r.size());
   if (hill_step) {
     const int ncalls = (int) hill_r.size();
-    edm_energy = bias->pair_step(npairs, pair_r.data(), pair_f.data(), ncalls, hill_r.data(),
-                                 device_rng ? NULL : hill_u.data(), last_calls);
+    if (batch_order)
+      edm_energy = bias->pair_step(npairs, pair_r.data(), pair_f.data(), ncalls, hill_r.data(),
+                                   device_rng ? NULL : hill_u.data(), last_calls);
+    else
+      edm_energy = bias->pair_step_ordered(npairs, pair_r.data(), pair_f.data(), pair_first.data(), ncalls, hill_r.data(),
+                                           device_rng ? NULL : hill_u.data(), last_calls);
     last_calls = ncalls;  // next step's estimate (fix_edm_pair.cpp:245)
   } else {
     edm_energy = bias->update_pair_forces(npairs, pair_r.data(), pair_f.data());

@@ -44,6 +44,8 @@ class FixEDMPair : public Fix {
   unsigned int seed;
   bool device_rng;   // optional trailing keyword "device_rng" (see fix_edm.h)
   bool gpu_list;     // optional trailing keyword "gpu_list" (implies device_rng): neighbour list resident on the GPU
+  bool batch_order;  // optional trailing keyword "batch_order": every force of a hill step on the bias as it stands after
+                     // pre_add_hill (default: the reference's order, pair k behind the hills of pairs 0..k-1)
   int last_list_size;  // total entries of the list last uploaded (re-upload when LAMMPS rebuilt it)
   int nlevels_respa;
   int last_calls;  // an estimate of the number of add_hill calls on this processor
@@ -54,6 +56,7 @@ class FixEDMPair : public Fix {
   std::vector<double> pair_del;
   EDM::pinned_vector hill_r, hill_u;  // staged add_hill(r, uniform) calls of a hill step, in call order
   std::vector<int> pair_i, pair_j;
+  std::vector<int> pair_first;  // hill steps: number of add_hill calls issued before each pair's update_force
 };
 
 }

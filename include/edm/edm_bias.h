@@ -90,6 +90,14 @@ class EDMBias {
   // post_add_hill().  Returns the bias energy of the pairs.
   double pair_step(int npairs, const double* r, double* force_r, int n_samples, const double* sample_r,
                    const double* runiform, int est_hill_count);
+  // the same step in the REFERENCE'S OWN ORDER (lammps/fix_edm_pair.cpp:177-238): force_r[k] is read from the bias as it
+  // stood when the reference's loop reached pair k -- after the add_hill calls of pairs 0..k-1 of this step.
+  // first_sample[k] = number of add_hill calls (samples) issued before pair k.  Hills, grid, histogram and limiter
+  // state are those of pair_step; only the forces and the energy of a hill step differ.
+  double pair_step_ordered(int npairs, const double* r, double* force_r, const int* first_sample, int n_samples,
+                           const double* sample_r, const double* runiform, int est_hill_count);
+  // pair_list_step in the reference's order too (default off: every force on the bias as it stands after pre_add_hill)
+  void set_reference_order(bool enabled);
   // fix edm_pair with the neighbour list resident on the GPU (needs set_device_rng): LAMMPS' half list
   // (ilist/numneigh/firstneigh, j masked with neighmask) is flattened and uploaded when list_changed, this
   // step's positions x[nall][3] go in, the bias forces come back ADDED to f[nall][3] (i always, j iff

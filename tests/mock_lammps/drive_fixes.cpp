@@ -65,11 +65,10 @@ int main(int argc, char **argv) {
   {
     char a0[] = "1", a1[] = "all", a2[] = "edm_pair", a3[] = "1.0", a5[] = "2", a6[] = "1000000", a8[] = "7", a9[] = "1", a10[] = "1";
     std::string bf = std::string(argv[3]) + ".pairbias";
-    char kw[16];
-    std::snprintf(kw, sizeof kw, "%s", argc > 4 ? argv[4] : "");
-    const bool fast_rng = (argc > 4 && (std::string(argv[4]) == "device_rng" || std::string(argv[4]) == "gpu_list"));
-    char *args[] = {a0, a1, a2, a3, argv[1], a5, a6, &bf[0], a8, a9, a10, kw};
-    FixEDMPair fix(&lmp, fast_rng ? 12 : 11, args);
+    // argv[4..]: trailing keywords of fix edm_pair (device_rng, gpu_list, batch_order)
+    std::vector<char *> args = {a0, a1, a2, a3, argv[1], a5, a6, &bf[0], a8, a9, a10};
+    for (int a = 4; a < argc; a++) args.push_back(argv[a]);
+    FixEDMPair fix(&lmp, (int) args.size(), args.data());
     std::fprintf(out, "pair_mask %d\n", fix.setmask());
     fix.init();
     fix.init_list(0, &list);
@@ -80,16 +79,17 @@ int main(int argc, char **argv) {
       upd.ntimestep = step;
       for (size_t k = 0; k < fb.size(); k++) fb[k] = 0;
       fix.post_force(0);
-      double fsum = 0, fabs_sum = 0;
-      for (size_t k = 0; k < fb.size(); k++) { fsum += fb[k]; fabs_sum += std::fabs(fb[k]); }
-      std::fprintf(out, "pair_step %d E %.12e fsum %.6e fabs %.12e\n", step, fix.compute_scalar(), fsum, fabs_sum);
+      double fsum = 0, fabs_sum = 0, fw = 0;
+      for (size_t k = 0; k < fb.size(); k++) { fsum += fb[k]; fabs_sum += std::fabs(fb[k]); fw += fb[k] * std::cos(0.37 * (double) k); }
+      std::fprintf(out, "pair_step %d E %.12e fsum %.6e fabs %.12e fw %.12e\n", step, fix.compute_scalar(), fsum, fabs_sum, fw);
     }
   }
   {
     char a0[] = "2", a1[] = "all", a2[] = "edm", a3[] = "1.0", a5[] = "2", a6[] = "1000000", a8[] = "11";
     std::string bf = std::string(argv[3]) + ".coordbias";
     char kw[] = "device_rng";
-    const bool fast_rng = (argc > 4 && std::string(argv[4]) == "device_rng");
+    bool fast_rng = false;
+    for (int a = 4; a < argc; a++) fast_rng |= (std::string(argv[a]) == "device_rng");
     char *args[] = {a0, a1, a2, a3, argv[2], a5, a6, &bf[0], a8, kw};
     FixEDM fix(&lmp, fast_rng ? 10 : 9, args);
     std::fprintf(out, "coord_mask %d\n", fix.setmask());

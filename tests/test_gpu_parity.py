@@ -808,8 +808,11 @@ def test_device_rng_equals_explicit_uniforms(workdir):
     assert open(str(workdir / "HILLS_device_0")).read() == open(str(workdir / "HILLS_explicit_0")).read()
 
 
-def test_pair_list_step_vs_oracle(oracle_lib, workdir):
-    """fix edm_pair on a device-resident neighbour list (edm_hip_bias_pair_list_step): positions + flattened half
+@pytest.mark.parametrize("reference_order", [False, True], ids=["batch_order", "reference_order"])
+def test_pair_list_step_vs_oracle(oracle_lib, workdir, reference_order):
+    """(reference_order: edm_hip_bias_set "reference_order" 1 -- the oracle then deposits an entry's hills right behind
+    its update_force, lammps/fix_edm_pair.cpp:215-237, so later entries of the step already feel them.)
+    fix edm_pair on a device-resident neighbour list (edm_hip_bias_pair_list_step): positions + flattened half
     list in, pair distances / lookups / pair forces / hills on the GPU.  Against the oracle executing the
     reference's per-pair loop with the same uniforms (device stream, sample index 2 * entry + slot): energies,
     forces on owned and ghost atoms, add_hill call counts, limiter decisions, final grid and histogram.  Two atom
@@ -827,6 +830,7 @@ def test_pair_list_step_vs_oracle(oracle_lib, workdir):
         x.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
     seed, K, M = 4242, 0x632BE59BD9B4E019, (1 << 64) - 1
     b.set_device_rng(True, seed)
+    b.set("reference_order", 1 if reference_order else 0)
     rng = np.random.default_rng(3)
     nall, nlocal = 700, 520
     types = rng.integers(1, 3, nall).astype(np.int32)          # types 1 and 2; the fix pairs type 1 with type 2
@@ -879,6 +883,10 @@ def test_pair_list_step_vs_oracle(oracle_lib, workdir):
                 if j < nlocal:
                     staged.append((r, u[2 * p + 1]))
                     calls += 1
+                if reference_order:
+                    for rr, uu in staged:
+                        o.add_hill([rr], float(uu))
+                    staged = []
         if hill:
             for r, uu in staged:
                 o.add_hill([r], float(uu))

@@ -74,6 +74,48 @@ def _positions(n=512, box=8.0):
     return x
 
 
+def _check_pair_steps(o, pair_steps, x, pairs, r, reference_order):
+    """drives the oracle like fix edm_pair for the mock system (every j owned: two add_hill calls per pair, RanMars
+    stand-in seeded 7) and compares energy, sum |f| and a weighted force sum of every step with the fix's output"""
+    n = len(x)
+    rng = MockRanMars(7)
+    last_calls = n
+    w = np.cos(0.37 * np.arange(3 * n))
+    for step in range(6):
+        hill = step % 2 == 0
+        if reference_order:
+            ru = np.array([rng.uniform() for _ in range(2 * len(r))]) if hill else np.zeros(1)
+            E, fr, calls = o.pair_loop(r, np.ones(len(r), dtype=np.int32), ru, hill, last_calls)
+        else:
+            if hill:
+                o.pre_add_hill(last_calls)
+            E, fr = 0.0, np.zeros(len(pairs))
+            for k, rk in enumerate(r):
+                e, f = o.update_force([rk])
+                E += e
+                fr[k] = f[0]
+            calls = 0
+            if hill:
+                for rk in r:
+                    o.add_hill([rk], rng.uniform())
+                    o.add_hill([rk], rng.uniform())
+                    calls += 2
+                o.post_add_hill()
+        if hill:
+            last_calls = calls
+        fabs = np.zeros((n, 3))
+        for k, (i, j) in enumerate(pairs):
+            dvec = (x[i] - x[j]) / r[k]
+            fabs[i] += dvec * fr[k]
+            fabs[j] -= dvec * fr[k]
+        got = pair_steps[step]
+        assert abs(float(got[3]) - E) <= 1e-9 * max(abs(E), 1e-12), (step, got, E)
+        assert abs(float(got[7]) - np.abs(fabs).sum()) <= 1e-8 * max(np.abs(fabs).sum(), 1e-12)
+        assert abs(float(got[9]) - (fabs.reshape(-1) * w).sum()) <= 1e-8 * max(np.abs(fabs).sum(), 1e-12)
+        assert abs(float(got[5])) <= 1e-9 * max(float(got[7]), 1e-12)  # third law: pair forces cancel
+    assert float(pair_steps[-1][3]) > 0
+
+
 @pytest.mark.gpu
 def test_driven_fixes_agree_with_oracle(tmp_path, oracle_lib):
     from oracle import binding as B
@@ -94,7 +136,8 @@ def test_driven_fixes_agree_with_oracle(tmp_path, oracle_lib):
     mask_bits = (1 << 6) | (1 << 9) | (1 << 12) | (1 << 14)  # POST_FORCE | THERMO_ENERGY | POST_FORCE_RESPA | MIN_POST_FORCE
     assert int([ln for ln in lines if ln[0] == "pair_mask"][0][1]) == mask_bits
 
-    # ---- oracle run of the same protocol (forces of a step on the grid after pre_add_hill) ----
+    # ---- oracle run in the REFERENCE FIX'S order (lammps/fix_edm_pair.cpp:177-238: per pair update_force, then its
+    #      two add_hill calls): the default of the rewritten fix ----
     x = _positions()
     n = len(x)
     rc = 2.5 + 0.3
@@ -104,35 +147,28 @@ def test_driven_fixes_agree_with_oracle(tmp_path, oracle_lib):
     o = B.Bias(oracle_lib, cfgs["pair_o"])
     o.setup(1.0, 1.0)
     o.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
-    rng = MockRanMars(7)
-    last_calls = n
-    for step in range(6):
-        hill = step % 2 == 0
-        if hill:
-            o.pre_add_hill(last_calls)
-        E, fabs = 0.0, np.zeros((n, 3))
-        fr = np.zeros(len(pairs))
-        for k, rk in enumerate(r):
-            e, f = o.update_force([rk])
-            E += e
-            fr[k] = f[0]
-        for k, (i, j) in enumerate(pairs):
-            dvec = (x[i] - x[j]) / r[k]
-            fabs[i] += dvec * fr[k]
-            fabs[j] -= dvec * fr[k]
-        if hill:
-            calls = 0
-            for rk in r:
-                o.add_hill([rk], rng.uniform())
-                o.add_hill([rk], rng.uniform())
-                calls += 2
-            last_calls = calls
-            o.post_add_hill()
-        got = pair_steps[step]
-        assert abs(float(got[3]) - E) <= 1e-9 * max(abs(E), 1e-12), (step, got, E)
-        assert abs(float(got[7]) - np.abs(fabs).sum()) <= 1e-8 * max(np.abs(fabs).sum(), 1e-12)
-        assert abs(float(got[5])) <= 1e-9 * max(float(got[7]), 1e-12)  # third law: pair forces cancel
-    assert float(pair_steps[-1][3]) > 0
+    _check_pair_steps(o, pair_steps, x, pairs, r, reference_order=True)
+
+    # ---- keyword batch_order: every force of a hill step on the bias as it stands after pre_add_hill ----
+    for tag in ("pair", "coord"):
+        open(cfgs[tag], "w").write((PAIR_CFG if tag == "pair" else COORD_CFG)
+                                   + "hills_filename %s/HILLSB_%s\nhistogram_filename %s/HISTB_%s\n" % (tmp_path, tag, tmp_path, tag))
+    outb = str(tmp_path / "fixes_batch.out")
+    res = subprocess.run([os.path.join(MOCK, "drive_fixes"), cfgs["pair"], cfgs["coord"], outb, "batch_order"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    batch_steps = [ln.split() for ln in open(outb) if ln.startswith("pair_step")]
+    cfg_ob = str(tmp_path / "pair_ob.edm")
+    open(cfg_ob, "w").write(PAIR_CFG + "hills_filename %s/HILLS_ob\nhistogram_filename %s/HIST_ob\n" % (tmp_path, tmp_path))
+    ob = B.Bias(oracle_lib, cfg_ob)
+    ob.setup(1.0, 1.0)
+    ob.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    _check_pair_steps(ob, batch_steps, x, pairs, r, reference_order=False)
+    # the two orders differ on hill steps (that is the point of the keyword) and leave the same bias behind
+    # (step 0 deposits onto an empty bias: the batched forces are all zero, the reference's are not; the limiter then
+    #  leaves hills buffered and the later steps only flush them -- edm_bias.cpp:534-535 -- so those coincide)
+    assert float(batch_steps[0][3]) == 0.0 and float(pair_steps[0][3]) > 0.0
+    assert abs(float(batch_steps[1][3]) - float(pair_steps[1][3])) <= 1e-9 * abs(float(pair_steps[1][3]))
 
     oc = B.Bias(oracle_lib, cfgs["coord_o"])
     oc.setup(1.0, 1.0)
@@ -202,16 +238,21 @@ def test_driven_fix_edm_pair_gpu_list_matches_host_list(tmp_path):
     force atomics)."""
     subprocess.check_call(["make", "-C", os.path.join(PKG, "host")], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", MOCK, "drive_fixes"], stdout=subprocess.DEVNULL)
+    for order in ((), ("batch_order",)):   # the reference's order (default) and the batched one
+        _gpu_list_vs_host_list(tmp_path, order)
+
+
+def _gpu_list_vs_host_list(tmp_path, order):
     runs = {}
     for mode in ("device_rng", "gpu_list"):
-        d = tmp_path / mode
+        d = tmp_path / (mode + "_".join(("",) + order))
         d.mkdir()
         cfgs = {}
         for tag, text in (("pair", PAIR_CFG), ("coord", COORD_CFG)):
             cfgs[tag] = str(d / (tag + ".edm"))
             open(cfgs[tag], "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (d, tag, d, tag))
         out = str(d / "fixes.out")
-        res = subprocess.run([os.path.join(MOCK, "drive_fixes"), cfgs["pair"], cfgs["coord"], out, mode],
+        res = subprocess.run([os.path.join(MOCK, "drive_fixes"), cfgs["pair"], cfgs["coord"], out, mode] + list(order),
                              capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
         runs[mode] = [ln.split() for ln in open(out) if ln.startswith("pair_step")]
@@ -220,5 +261,6 @@ def test_driven_fix_edm_pair_gpu_list_matches_host_list(tmp_path):
         ea, eb = float(a[3]), float(b[3])
         assert abs(ea - eb) <= 1e-9 * max(abs(eb), 1e-12), (a, b)
         assert abs(float(a[7]) - float(b[7])) <= 1e-8 * max(float(b[7]), 1e-12), (a, b)
+        assert abs(float(a[9]) - float(b[9])) <= 1e-8 * max(float(b[7]), 1e-12), (a, b)
         assert abs(float(a[5])) <= 1e-9 * max(float(a[7]), 1e-12)   # pair forces cancel
     assert float(runs["gpu_list"][-1][3]) > 0
