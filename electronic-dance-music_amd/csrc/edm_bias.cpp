@@ -106,8 +106,11 @@ struct edm_hip_bias {
     double h_const = 0;
     const long long *sel = nullptr;
   } last_batch;
-  DevBuf<double> ord_rec0, ord_prefix;
-  DevBuf<int> ord_dirty, ord_first;
+  DevBuf<double> ord_slabs;          // [hills + 1] copies of the 1-D grid (OrderedForcesArgs::slabs), slab 0 taken before the batch
+  size_t ord_slab0_doubles = 0;
+  DevBuf<unsigned long long> ord_dirty;
+  unsigned ord_seq = 0;
+  DevBuf<int> ord_first;
   int reference_order = 0;     // edm_hip_bias_set("reference_order"): edm_hip_bias_pair_list_step evaluates its forces in
                                // the reference's order too (edm_hip_bias_pair_step_ordered is that mode's array entry)
   // multi-GPU
@@ -292,7 +295,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   b->pl_it_entry.release(); b->pl_jt_entry.release();
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
-  b->ord_rec0.release(); b->ord_prefix.release(); b->ord_dirty.release(); b->ord_first.release();
+  b->ord_slabs.release(); b->ord_dirty.release(); b->ord_first.release();
   delete b;
   return EDM_HIP_OK;
 }
@@ -1072,8 +1075,9 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
 // in edm_hip_bias_pair_step -- selection, limiter and grid update do not depend on the forces -- and the force of pair k
 // is then interpolated on the bias as it stood when the reference's loop reached that pair: the grid after
 // pre_add_hill plus the hills of the add_hill calls before it (OrderedForcesArgs, edm_kernels.h).
-// the bias the first pair of a reference-order step sees: the node records behind pre_add_hill's overflow flush
-static int ordered_snapshot(edm_hip_bias *b) {
+// the bias the first pair of a reference-order step sees: the node records behind pre_add_hill's overflow flush (slab 0).
+// The slab buffer is sized for the step's launch bound up front: the hill batch that follows must find it in place.
+static int ordered_snapshot(edm_hip_bias *b, long long n_samples) {
   edm_hip_gauss *g = b->bias;
   if (!ordered_forces_supported(g->g)) {
     set_error("reference-order pair step: needs a 1-D bias whose stencil is not wider than a periodic grid");
@@ -1084,26 +1088,48 @@ static int ordered_snapshot(edm_hip_bias *b) {
               "use edm_hip_bias_pair_step / reference_order 0 with a communicator");
     return EDM_HIP_ERR_STATE;
   }
+  // hills this step can deposit at most: every sample (all-samples mode), or what the stochastic selection may accept
+  // before the step is redone synchronously -- the slabs are (re)allocated for the TRUE count later if that is larger
+  long long guess = n_samples;
+  if (!(b->hill_density < 0) && b->est_hill_count > 0) {
+    const double expected = b->hill_density / (double)b->est_hill_count * (double)n_samples;
+    guess = (long long)(4.0 * expected) + 128;
+    if (guess > n_samples) guess = n_samples;
+  }
+  if (guess > 2048) guess = 2048;
+  if (guess < 1) guess = 1;
   const size_t grid_doubles = (size_t)g->g.total * (size_t)g->g.rec;
-  EDM_HIP_TRY(b->ord_rec0.reserve(grid_doubles));
-  EDM_HIP_TRY(hipMemcpyAsync(b->ord_rec0.p, g->rec, sizeof(double) * grid_doubles, hipMemcpyDeviceToDevice, g->stream));
+  EDM_HIP_TRY(b->ord_slabs.reserve(ordered_slab_doubles(g->g, guess)));
+  EDM_HIP_TRY(hipMemcpyAsync(b->ord_slabs.p, g->rec, sizeof(double) * grid_doubles, hipMemcpyDeviceToDevice, g->stream));
+  b->ord_slab0_doubles = grid_doubles;
   b->last_batch.valid = false;
   return EDM_HIP_OK;
 }
-// ... and, once the step's hill batch has been applied (last_batch), the per-hill prefix records of the nodes it touched
-static int ordered_prefix_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
+// ... and, once the step's hill batch has been applied (last_batch), one slab per hill
+static int ordered_slabs_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
   edm_hip_gauss *g = b->bias;
-  const size_t need = ordered_prefix_doubles(g->g, b->last_batch.nh);
-  if (need * sizeof(double) > ((size_t)1 << 30)) {
-    set_error("reference-order pair step: more hills in one step than the force pass keeps prefix records for (1 GiB); "
-              "use edm_hip_bias_pair_step (all forces on the step-start bias) for all-samples deposition");
+  const long long nh = b->last_batch.nh;
+  const size_t need = ordered_slab_doubles(g->g, nh);
+  if (nh > ordered_max_hills() || need * sizeof(double) > ((size_t)2 << 30)) {
+    set_error("reference-order pair step: more hills in one step than the force pass keeps grid copies for (16384 hills, "
+              "2 GiB); use edm_hip_bias_pair_step (all forces on the step-start bias) for all-samples deposition");
     return EDM_HIP_ERR_ARG;
   }
-  EDM_HIP_TRY(b->ord_prefix.reserve(need));
-  EDM_HIP_TRY(b->ord_dirty.reserve(1));
+  if (need > b->ord_slabs.cap) {
+    // (rare: more hills than the launch bound allowed for -- keep slab 0 across the reallocation)
+    DevBuf<double> keep;
+    EDM_HIP_TRY(keep.reserve(b->ord_slab0_doubles));
+    EDM_HIP_TRY(hipMemcpyAsync(keep.p, b->ord_slabs.p, sizeof(double) * b->ord_slab0_doubles, hipMemcpyDeviceToDevice, g->stream));
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    EDM_HIP_TRY(b->ord_slabs.reserve(need));
+    EDM_HIP_TRY(hipMemcpyAsync(b->ord_slabs.p, keep.p, sizeof(double) * b->ord_slab0_doubles, hipMemcpyDeviceToDevice, g->stream));
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    keep.release();
+  }
+  EDM_HIP_TRY(b->ord_dirty.reserve_zeroed(1));
   OrderedForcesArgs a;
   memset(&a, 0, sizeof(a));
-  a.nh = b->last_batch.nh;
+  a.nh = nh;
   a.k = b->last_batch.k;
   a.heights = b->last_batch.heights;
   a.h_const = b->last_batch.h_const;
@@ -1113,10 +1139,10 @@ static int ordered_prefix_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
   a.hc = g->ws.hc.p;
   a.ht = g->ws.ht.p;
   a.sel = b->last_batch.sel;
-  a.rec0 = b->ord_rec0.p;
-  a.prefix = b->ord_prefix.p;
+  a.slabs = b->ord_slabs.p;
   a.first_dirty = b->ord_dirty.p;
-  EDM_HIP_TRY(launch_ordered_prefix(g->g, g->tables(), a, g->stream));
+  a.dirty_seq = ++b->ord_seq;
+  EDM_HIP_TRY(launch_ordered_slabs(g->g, g->tables(), a, g->stream));
   *out = a;
   return EDM_HIP_OK;
 }
@@ -1126,7 +1152,7 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
                                     const double *d_runiform, double *energy) {
   edm_hip_gauss *g = b->bias;
   hipStream_t s = g->stream;
-  int rc = ordered_snapshot(b);
+  int rc = ordered_snapshot(b, n_samples);
   if (rc) return rc;
   b->pending = PendingForces();
   g->wait_polled = false;
@@ -1137,7 +1163,7 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   bool tagged = false;
   if (n > 0 && b->last_batch.valid && b->last_batch.nh > 0) {
     OrderedForcesArgs a;
-    rc = ordered_prefix_enqueue(b, &a);
+    rc = ordered_slabs_enqueue(b, &a);
     if (rc) return rc;
     a.n = n;
     a.r = d_r;
@@ -1439,7 +1465,7 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   // it stood when the reference's loop reached the entry (see edm_hip_bias_pair_step_ordered)
   const bool ordered = hill_step && npairs > 0 && b->reference_order;
   if (ordered) {
-    rc = ordered_snapshot(b);
+    rc = ordered_snapshot(b, 2 * npairs);
     if (rc) return rc;
   } else {
     b->pending.active = true;
@@ -1475,7 +1501,7 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     a.partial_tag = tag;
     if (b->last_batch.valid && b->last_batch.nh > 0) {
       OrderedForcesArgs oa;
-      rc = ordered_prefix_enqueue(b, &oa);
+      rc = ordered_slabs_enqueue(b, &oa);
       if (rc) return rc;
       EDM_HIP_TRY(launch_pairlist_forces_ordered(b->bias->g, a, oa, b->bias->d_partials, s, &nblk_ordered));
     } else {   // (no new hill: every entry sees the same bias)

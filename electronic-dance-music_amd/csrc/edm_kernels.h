@@ -117,19 +117,19 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
 // pair k's force reads a bias that already holds the hills of pairs 0..k-1 of the same step.  Which samples become
 // hills does not depend on the grid (edm_bias.cpp:543), and neither do the limiter's decisions (a hill's integrated
 // bias is independent of grid contents), so the step's hill batch is applied exactly as in the batched step and the
-// forces follow from three things the batch leaves on the device: a snapshot rec0 of the node records taken before
-// the batch, the prepared hill list, and the heights the limiter settled on.
-//   launch_ordered_prefix : one thread per node walks the hills in list order and stores, for every hill j whose
-//       stencil covers the node, the node's record AFTER hill j: prefix[j][node - (centre_j - msize)] = rec0 +
-//       sum_{i <= j} (h1_i term_i, then h2_i term_i) -- the reference's sequence of += (gaussian_grid.h:343-355)
+// forces follow from three things the batch leaves on the device: a copy of the node records taken before the batch
+// (slab 0), the prepared hill list, and the heights the limiter settled on.
+//   launch_ordered_slabs : slab m (m = 1 .. nh) = the node records after the first m hills of the batch -- slab 0 plus,
+//       hill after hill, h1 term and then h2 term: the reference's sequence of += (gaussian_grid.h:343-355).  One
+//       dense copy of the 1-D grid per hill: 179 KB each on the C1D grid, 22 MB for the ~125 hills of a W1 step.
 //   launch_pair_forces_ordered : pair k counts the hills whose add_hill call precedes its update_force
-//       (m = #{j : sample(j) < first_sample[k]}), finds for each of its two corner nodes the LAST hill j < m that
-//       covers the node (walking the centre nodes backwards) and interpolates (grid.h:390-446, interp<1> :52-139) on
-//       prefix[j][.] -- or on rec0 where no earlier hill reaches.  The boundary duplication of gaussian_grid.h:571-630
-//       (value of the first / last in-boundary node copied outward after every hill with a non-zero correction) is
-//       applied on the fly: an outward copy node reads the value of its source node at the same prefix once the
-//       first such hill (first_dirty, found by the prefix pass) lies before the pair.
-// 1-D grids only (fix_edm_pair.cpp:52), stencil not wider than a periodic grid.
+//       (m = #{j : sample(j) < first_sample[k]}, a binary search over the ascending sample indices in LDS) and
+//       interpolates (grid.h:390-446, interp<1> :52-139) on slab m -- K1 with a per-pair slab.  Consecutive pairs share
+//       their slab, so a workgroup (a contiguous run of pairs) reads one or two of them.  The boundary duplication of
+//       gaussian_grid.h:571-630 (value of the first / last in-boundary node copied outward after every hill with a
+//       non-zero correction) is applied on the fly: an outward copy node reads the value of its source node in the
+//       same slab once the first such hill (first_dirty, found by the slab pass) lies before the pair.
+// 1-D grids only (fix_edm_pair.cpp:52), stencil not wider than a periodic grid, at most ordered_max_hills() hills.
 struct OrderedForcesArgs {
   long long nh;             // hills of the step's batch (true count)
   long long k;              // hills [0, k): base height; hills >= k: the limiter's tail arrays (see HillHeights)
@@ -140,25 +140,26 @@ struct OrderedForcesArgs {
   const int *hc;
   const double *ht;
   const long long *sel;     // sample index of hill j, ascending (NULL: hill j is sample j)
-  const double *rec0;       // node records before the batch
-  double *prefix;           // [nh][2 msize + 1][2]
-  int *first_dirty;         // device int: index of the first hill with a non-zero boundary correction (INT_MAX: none)
+  double *slabs;            // [nh + 1][n][2]; slab 0 = the node records before the batch (filled by the caller)
+  unsigned long long *first_dirty;   // device word, see ordered_dirty_note in edm_kernels.hip (zero-initialised once)
+  unsigned dirty_seq;       // this step's number (grows by one per launch_ordered_slabs)
   long long n;              // pairs
   const double *r;          // [n] pair distances
   const int *first_sample;  // [n] sample index of pair k's first add_hill call, or NULL: 2 k (the virtual samples of a
                             // device-resident neighbour list)
   double *force;            // [n] out: -dV/dr
 };
+size_t ordered_slab_doubles(const Geom &g, long long nh);
+long long ordered_max_hills();
+bool ordered_forces_supported(const Geom &g);
+hipError_t launch_ordered_slabs(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s);
+// tagged partial energy sums like launch_pair_forces (tag != 0: scratch is host-mapped, polled by the host)
+hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
+                                      int *blocks_out, unsigned long long tag);
 // the same pass over a device-resident neighbour list (a.n / r / first_sample / force unused: list entry e is
 // "pair" e, its first sample 2 e; pl.fdelta receives the per-atom sums, pl.partial_tag as in launch_pairlist_forces)
 hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl, const OrderedForcesArgs &a, double *partials,
                                           hipStream_t s, int *blocks_out);
-size_t ordered_prefix_doubles(const Geom &g, long long nh);
-bool ordered_forces_supported(const Geom &g);
-hipError_t launch_ordered_prefix(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s);
-// tagged partial energy sums like launch_pair_forces (tag != 0: scratch is host-mapped, polled by the host)
-hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
-                                      int *blocks_out, unsigned long long tag);
 
 // ---- record layout conversion ---------------------------------------------------
 hipError_t launch_pack(const Geom &g, double *rec, const double *values, const double *derivs, hipStream_t s);

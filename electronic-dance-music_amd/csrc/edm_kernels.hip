@@ -5220,192 +5220,248 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
 // ---------------------------------------------------------------------------
 // fix edm_pair in the reference's order (see OrderedForcesArgs in edm_kernels.h)
 // ---------------------------------------------------------------------------
-size_t ordered_prefix_doubles(const Geom &g, long long nh) {
-  return (size_t)(nh > 0 ? nh : 0) * (size_t)(2 * g.msize[0] + 1) * 2;
+size_t ordered_slab_doubles(const Geom &g, long long nh) {
+  return (size_t)((nh > 0 ? nh : 0) + 1) * (size_t)g.n[0] * 2;
 }
 bool ordered_forces_supported(const Geom &g) {
   return g.dim == 1 && g.rec == 2 && g.n[0] >= 2 && !(g.periodic[0] && 2 * g.msize[0] + 1 > g.n[0]);
 }
 
-// signed stencil offset of node n in the stencil of a hill centred at node c (|o| <= msize when the hill covers
-// the node), through the one periodic image a stencil narrower than the grid can reach a node by
-__device__ __forceinline__ int ordered_offset(const Geom &g, int n, int c) {
-  int o = n - c;
-  if (g.periodic[0]) {
-    if (o > g.msize[0]) o -= g.n[0];
-    else if (o < -g.msize[0]) o += g.n[0];
-  }
-  return o;
+// "first hill of this step with a non-zero boundary correction", kept in one device word across launches without a
+// memset in between: seq << 32 | (0x7FFFFFFF - hill index), raised by atomic MAX -- a later launch's number always wins,
+// within a launch the smaller index does
+__device__ __forceinline__ void ordered_dirty_note(unsigned long long *w, unsigned seq, int hill) {
+  atomicMax(w, ((unsigned long long)seq << 32) | (unsigned long long)(unsigned)(0x7FFFFFFF - hill));
+}
+__device__ __forceinline__ int ordered_dirty_first(const unsigned long long *w, unsigned seq) {
+  const unsigned long long v = *w;
+  return ((unsigned)(v >> 32) == seq) ? 0x7FFFFFFF - (int)(unsigned)(v & 0xFFFFFFFFull) : INT_MAX;
 }
 
+// Slabs 1 .. nh from slab 0: a workgroup owns ORD_NODES nodes and walks the hill list ORD_CHUNK hills at a time.  Wave 0
+// tests the chunk's hills against the tile and compacts the ones that reach it IN ORDER (ballot prefix; ~15 % of a W1
+// step's hills reach a given tile); the workgroup's ORD_PARTS parts compute the unit-height stencil terms of those hills
+// side by side (value and derivative of every (listed hill, node) into LDS); part 0 then runs the heights over them in
+// hill order -- rec += h1 term, then += h2 term where the limiter added an undo hill: the reference's sequence of +=
+// (gaussian_grid.h:343-355, edm_bias.cpp:474-490) -- leaving the running record behind each listed hill in LDS; and
+// all threads store the chunk's slabs: slab q + 1 holds the record behind the last listed hill <= q.
+static constexpr int ORD_NODES = 32, ORD_PARTS = BLOCK / ORD_NODES, ORD_CHUNK = 64;
 template <bool PERB>
-__global__ void __launch_bounds__(BLOCK) k_ordered_prefix(Geom g, Tables t, OrderedForcesArgs a) {
-  const int n = blockIdx.x * BLOCK + threadIdx.x;
+__global__ void __launch_bounds__(BLOCK) k_ordered_slabs(Geom g, Tables t, OrderedForcesArgs a) {
+  static_assert(ORD_CHUNK == 64, "one wave tests and compacts a chunk");
+  const int tnode = threadIdx.x % ORD_NODES, part = threadIdx.x / ORD_NODES;
+  const int t0 = blockIdx.x * ORD_NODES;
+  const int n = t0 + tnode;
   const bool in_grid = n < g.n[0];
+  const int t1 = (t0 + ORD_NODES - 1 < g.n[0] - 1) ? t0 + ORD_NODES - 1 : g.n[0] - 1;
   const int p[1] = {in_grid ? n : 0};
   NodeTerms<1> nt;
   node_terms<1, PERB>(g, t, p, nt);
   const bool active = in_grid && nt.inside;   // (hills skip nodes outside a wall, gaussian_grid.h:273)
   TermConst<1> tc;
   term_const<1>(g, tc);
+  const long long N = g.n[0];
+  double2 *T = reinterpret_cast<double2 *>(a.slabs);
   double acc0 = 0, acc1 = 0;
-  if (in_grid) {
-    const double2 r0 = reinterpret_cast<const double2 *>(a.rec0)[n];
+  if (in_grid && part == 0) {
+    const double2 r0 = T[n];
     acc0 = r0.x;
     acc1 = r0.y;
   }
-  const int msize = g.msize[0];
-  const long long W = 2 * (long long)msize + 1;
-  __shared__ int s_c[BLOCK];
-  __shared__ double s_x[BLOCK], s_t[BLOCK][2], s_a1[BLOCK], s_a2[BLOCK];
-  int my_dirty = INT_MAX;
-  double2 *P = reinterpret_cast<double2 *>(a.prefix);
-  for (long long base = 0; base < a.nh; base += BLOCK) {
-    const long long cur = base + threadIdx.x;
-    if (cur < a.nh) {
-      s_c[threadIdx.x] = a.hc[cur];
-      s_x[threadIdx.x] = a.hx[cur];
-      s_t[threadIdx.x][0] = PERB ? 0.0 : a.ht[2 * cur];
-      s_t[threadIdx.x][1] = PERB ? 0.0 : a.ht[2 * cur + 1];
-      double a1 = a.heights ? a.heights[cur] : a.h_const, a2 = 0;
-      if (cur >= a.k) {
-        a1 = a.tail_h1[cur - a.k];
-        a2 = a.tail_h2[cur - a.k];
+  __shared__ int s_c[ORD_CHUNK], s_upto[ORD_CHUNK], s_cnt;
+  __shared__ double s_x[ORD_CHUNK], s_t[ORD_CHUNK][2], s_a1[ORD_CHUNK], s_a2[ORD_CHUNK];
+  __shared__ double s_v[ORD_CHUNK + 1][ORD_NODES], s_d[ORD_CHUNK + 1][ORD_NODES];   // (row 0: the record the chunk starts from)
+  bool noted = false;   // this thread has reported its first hill with a non-zero correction (later chunks hold later hills)
+  for (long long base = 0; base < a.nh; base += ORD_CHUNK) {
+    const int cnt = (a.nh - base < ORD_CHUNK) ? (int)(a.nh - base) : ORD_CHUNK;
+    int first_nz = -1;    // list position of this thread's first such term of the chunk
+    if (threadIdx.x < 64) {   // wave 0: one hill of the chunk per lane
+      bool take = false;
+      int c = INT_MIN;
+      double hx = 0, ht0 = 0, ht1 = 0, a1 = 0, a2 = 0;
+      if ((int)threadIdx.x < cnt) {
+        const long long cur = base + threadIdx.x;
+        c = a.hc[cur];
+        hx = a.hx[cur];
+        if (!PERB) {
+          ht0 = a.ht[2 * cur];
+          ht1 = a.ht[2 * cur + 1];
+        }
+        a1 = a.heights ? a.heights[cur] : a.h_const;
+        if (cur >= a.k) {
+          a1 = a.tail_h1[cur - a.k];
+          a2 = a.tail_h2[cur - a.k];
+        }
+        // (c == INT_MIN: a hill rejected at preparation -- outside a wall, gaussian_grid.h:214-216; both heights zero:
+        //  a hill the limiter deferred whole)
+        take = c != INT_MIN && !(a1 == 0 && a2 == 0) && images(g, 0, c, t0, t1) != 0;
       }
-      s_a1[threadIdx.x] = a1;
-      s_a2[threadIdx.x] = a2;
+      const unsigned long long bal = __ballot(take);
+      const int lane = threadIdx.x;
+      const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+      s_upto[lane] = pos + (take ? 1 : 0);   // listed hills among the chunk's hills 0 .. lane
+      if (take) {
+        s_c[pos] = c;
+        s_x[pos] = hx;
+        s_t[pos][0] = ht0;
+        s_t[pos][1] = ht1;
+        s_a1[pos] = a1;
+        s_a2[pos] = a2;
+      }
+      if (lane == 0) s_cnt = __popcll(bal);
     }
     __syncthreads();
-    const int cnt = (a.nh - base < BLOCK) ? (int)(a.nh - base) : BLOCK;
-    if (in_grid) {
-      for (int q = 0; q < cnt; q++) {
-        const int c = s_c[q];
-        if (c == INT_MIN) continue;   // a hill rejected at preparation (outside a wall, gaussian_grid.h:214-216)
-        if (images(g, 0, c, n, n) == 0) continue;
-        const int o = ordered_offset(g, n, c);
-        const double a1 = s_a1[q], a2 = s_a2[q];
-        if (active && !(a1 == 0 && a2 == 0)) {
-          double val, dval[1];
-          bool nz = false;
-          if (pair_term<1, PERB>(g, tc, nt, &s_x[q], s_t[q], val, dval, nz, false)) {
-            acc0 += a1 * val;
-            acc1 += a1 * dval[0];
-            if (a2 != 0) {   // the undo hill of a limit crossing: a second add_value (edm_bias.cpp:474-490)
-              acc0 += a2 * val;
-              acc1 += a2 * dval[0];
-            }
-            if (nz && my_dirty == INT_MAX) my_dirty = (int)(base + q);
+    const int nl = s_cnt;
+    for (int e = part; e < nl; e += ORD_PARTS) {
+      double val = 0, dval[1] = {0};
+      if (active && images(g, 0, s_c[e], n, n) != 0) {
+        bool nz = false;
+        double v1, d1[1];
+        if (pair_term<1, PERB>(g, tc, nt, &s_x[e], s_t[e], v1, d1, nz, false)) {
+          val = v1;
+          dval[0] = d1[0];
+          if (nz && first_nz < 0) first_nz = e;
+        }
+      }
+      s_v[e + 1][tnode] = val;
+      s_d[e + 1][tnode] = dval[0];
+    }
+    if (first_nz >= 0 && !noted) {
+      // list position -> chunk-local hill index: the first hill whose count of listed hills exceeds the position
+      int q = 0;
+      while (q < cnt && s_upto[q] <= first_nz) q++;
+      ordered_dirty_note(a.first_dirty, a.dirty_seq, (int)(base + q));
+      noted = true;
+    }
+    __syncthreads();
+    if (part == 0) {
+      s_v[0][tnode] = acc0;
+      s_d[0][tnode] = acc1;
+      for (int e = 0; e < nl; e++) {
+        const double v = s_v[e + 1][tnode], d = s_d[e + 1][tnode], a1 = s_a1[e], a2 = s_a2[e];
+        if (v != 0 || d != 0) {
+          acc0 += a1 * v;
+          acc1 += a1 * d;
+          if (a2 != 0) {
+            acc0 += a2 * v;
+            acc1 += a2 * d;
           }
         }
+        s_v[e + 1][tnode] = acc0;
+        s_d[e + 1][tnode] = acc1;
+      }
+    }
+    __syncthreads();
+    if (in_grid) {
+      for (int q = part; q < cnt; q += ORD_PARTS) {
+        const int u = s_upto[q];
         double2 out;
-        out.x = acc0;
-        out.y = acc1;
-        P[(base + q) * W + (o + msize)] = out;
+        out.x = s_v[u][tnode];
+        out.y = s_d[u][tnode];
+        T[(base + q + 1) * N + n] = out;
       }
     }
     __syncthreads();
   }
-  if (my_dirty != INT_MAX) atomicMin(a.first_dirty, my_dirty);
 }
 
-hipError_t launch_ordered_prefix(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s) {
+hipError_t launch_ordered_slabs(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s) {
   if (!ordered_forces_supported(g)) return hipErrorInvalidValue;
-  hipError_t e = hipMemsetAsync(a.first_dirty, 0x7F, sizeof(int), s);   // (0x7F7F7F7F: beyond any hill index)
-  if (e != hipSuccess) return e;
   if (a.nh <= 0) return hipSuccess;
-  const unsigned nb = (unsigned)((g.n[0] + BLOCK - 1) / BLOCK);
+  const unsigned nb = (unsigned)((g.n[0] + ORD_NODES - 1) / ORD_NODES);
   if (g.bper[0])
-    hipLaunchKernelGGL(k_ordered_prefix<true>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
+    hipLaunchKernelGGL(k_ordered_slabs<true>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
   else
-    hipLaunchKernelGGL(k_ordered_prefix<false>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
+    hipLaunchKernelGGL(k_ordered_slabs<false>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
   return hipGetLastError();
 }
 
-// node records as they stood after the first m hills of the batch
-template <class LISTS>
-struct OrderedSource {
-  const Geom &g;
-  const OrderedForcesArgs &a;
-  const LISTS &l;
-  int m;
-  int first_dirty;
-  int lo_t, lo_s, hi_t, hi_s;   // outward copy nodes of the boundary duplication and their sources (-1: none)
-  __device__ __forceinline__ double2 raw(int node) const {
-    const int msize = g.msize[0];
-    const long long W = 2 * (long long)msize + 1;
-    for (int j = m - 1; j >= 0; j--) {
-      const int c = l.centre(j);
-      if (c == INT_MIN) continue;
-      if (images(g, 0, c, node, node) == 0) continue;
-      return reinterpret_cast<const double2 *>(a.prefix)[(long long)j * W + (ordered_offset(g, node, c) + msize)];
-    }
-    return reinterpret_cast<const double2 *>(a.rec0)[node];
-  }
+// the node records of slab m with the boundary duplication of gaussian_grid.h:571-630 applied: after every hill with
+// a non-zero correction the value (not the derivative) of the first / last in-boundary node is copied to its outward
+// neighbour -- so from the first such hill on an outward copy node reads its source's value of the same slab
+struct OrderedSlabSource {
+  const double2 *slab;
+  bool dup;                     // some hill before this slab had a non-zero correction
+  int lo_t, lo_s, hi_t, hi_s;   // outward copy nodes and their sources (-1: none)
   __device__ __forceinline__ void load(Rec<2> &r, long long node) const {
-    double2 own = raw((int)node);
-    if (m > first_dirty && ((int)node == lo_t || (int)node == hi_t)) own.x = raw((int)node == lo_t ? lo_s : hi_s).x;
+    double2 own = slab[node];
+    if (dup && ((int)node == lo_t || (int)node == hi_t)) own.x = slab[(int)node == lo_t ? lo_s : hi_s].x;
     r.v[0] = own.x;
     r.v[1] = own.y;
   }
 };
-struct OrderedListsLds {
-  const int *c, *s;
-  __device__ __forceinline__ int centre(int j) const { return c[j]; }
-  __device__ __forceinline__ int sample(int j) const { return s[j]; }
+struct OrderedCommon {
+  int H;                        // hills
+  const int *samples;           // LDS: sample index of hill j, ascending
+  int first_dirty;
+  int lo_t, lo_s, hi_t, hi_s;
+  bool fast;                    // the specialised 1-D lookup applies (pair_fast_path)
+  double inv_dx, dup_lo_x0, dup_lo_x1, dup_hi_x0, dup_hi_x1;   // x ranges whose cells touch an outward copy node
 };
-struct OrderedListsGlobal {
-  const int *c;
-  const long long *s;
-  __device__ __forceinline__ int centre(int j) const { return c[j]; }
-  __device__ __forceinline__ long long sample(int j) const { return s ? s[j] : (long long)j; }
-};
-
-template <bool LDS>
-__global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedForcesArgs a, DupPlan dp,
-                                                               double *__restrict__ block_energy, unsigned long long tag) {
-  extern __shared__ int s_lists[];
-  __shared__ double red[BLOCK / 64];
-  const int H = (int)a.nh;
-  if (LDS) {
-    for (int i = threadIdx.x; i < H; i += BLOCK) {
-      s_lists[i] = a.hc[i];
-      s_lists[H + i] = a.sel ? (int)a.sel[i] : i;
-    }
-    __syncthreads();
-  }
-  const OrderedListsLds ll{s_lists, s_lists + H};
-  const OrderedListsGlobal lg{a.hc, a.sel};
-  const int first_dirty = *a.first_dirty;
-  int lo_t = -1, lo_s = -1, hi_t = -1, hi_s = -1;
+__device__ __forceinline__ void ordered_common_init(const Geom &g, const OrderedForcesArgs &a, const DupPlan &dp, int *s_samples,
+                                                    OrderedCommon &oc) {
+  oc.H = (int)a.nh;
+  for (int i = threadIdx.x; i < oc.H; i += blockDim.x) s_samples[i] = a.sel ? (int)a.sel[i] : i;
+  __syncthreads();
+  oc.samples = s_samples;
+  oc.first_dirty = ordered_dirty_first(a.first_dirty, a.dirty_seq);
+  oc.lo_t = oc.lo_s = oc.hi_t = oc.hi_s = -1;
   if (!g.bper[0]) {   // duplicate_boundary_lanes' cases 0 and 3 in one dimension
     if (dp.lo[0] > 0 && dp.lo[0] < (unsigned long long)g.n[0]) {
-      lo_t = (int)dp.lo[0] - 1;
-      lo_s = (int)dp.lo[0];
+      oc.lo_t = (int)dp.lo[0] - 1;
+      oc.lo_s = (int)dp.lo[0];
     }
     if (dp.hi[0] + 1 < (unsigned long long)g.n[0]) {
-      hi_t = (int)dp.hi[0] + 1;
-      hi_s = (int)dp.hi[0];
+      oc.hi_t = (int)dp.hi[0] + 1;
+      oc.hi_s = (int)dp.hi[0];
     }
   }
+  oc.fast = g.interp && !g.periodic[0] && !g.bper[0];
+  oc.inv_dx = 1.0 / g.dx[0];
+  // (generous by a cell on either side: samples in these ranges take the exact generic lookup)
+  oc.dup_lo_x0 = g.min[0] + g.dx[0] * (oc.lo_t - 2);
+  oc.dup_lo_x1 = g.min[0] + g.dx[0] * (oc.lo_t + 2);
+  oc.dup_hi_x0 = g.min[0] + g.dx[0] * (oc.hi_t - 2);
+  oc.dup_hi_x1 = g.min[0] + g.dx[0] * (oc.hi_t + 2);
+}
+// energy and dV/dr at r as the reference's loop saw them at the sample index `fs` of the pair's first add_hill call
+__device__ __forceinline__ void ordered_lookup(const Geom &g, const OrderedForcesArgs &a, const OrderedCommon &oc, double x,
+                                               long long fs, double &v, double &d) {
+  int lo = 0, hi = oc.H;   // m = number of hills whose sample index is below fs
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((long long)oc.samples[mid] < fs) lo = mid + 1; else hi = mid;
+  }
+  const int m = lo;
+  const double2 *slab = reinterpret_cast<const double2 *>(a.slabs) + (long long)m * g.n[0];
+  const bool dup = m > oc.first_dirty;
+  bool exact = !oc.fast;
+  if (dup && ((oc.lo_t >= 0 && x > oc.dup_lo_x0 && x < oc.dup_lo_x1) || (oc.hi_t >= 0 && x > oc.dup_hi_x0 && x < oc.dup_hi_x1)))
+    exact = true;
+  if (!exact) {
+    pair_one<false>(g, reinterpret_cast<const double *>(slab), nullptr, 0, 0, oc.inv_dx, x, v, d);
+  } else {
+    const OrderedSlabSource src{slab, dup, oc.lo_t, oc.lo_s, oc.hi_t, oc.hi_s};
+    lookup_one_src<1>(g, src, &x, v, &d);
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedForcesArgs a, DupPlan dp,
+                                                               double *__restrict__ block_energy, unsigned long long tag,
+                                                               long long per_block) {
+  extern __shared__ int s_samples[];
+  __shared__ double red[BLOCK / 64];
+  OrderedCommon oc;
+  ordered_common_init(g, a, dp, s_samples, oc);
   double e_acc = 0;
-  const long long stride = (long long)gridDim.x * BLOCK;
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += stride) {
+  // a workgroup owns a contiguous run of pairs: they see the same few slabs (179 KB each on the C1D grid)
+  const long long beg = (long long)blockIdx.x * per_block;
+  const long long end = (beg + per_block < a.n) ? beg + per_block : a.n;
+  for (long long i = beg + threadIdx.x; i < end; i += BLOCK) {
     const double x = a.r[i];
     const long long fs = a.first_sample ? (long long)a.first_sample[i] : 2 * i;
-    int lo = 0, hi = H;   // m = number of hills whose sample index is below fs
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      const long long sm = LDS ? (long long)ll.sample(mid) : lg.sample(mid);
-      if (sm < fs) lo = mid + 1; else hi = mid;
-    }
     double v, d;
-    if (LDS) {
-      const OrderedSource<OrderedListsLds> src{g, a, ll, lo, first_dirty, lo_t, lo_s, hi_t, hi_s};
-      lookup_one_src<1>(g, src, &x, v, &d);
-    } else {
-      const OrderedSource<OrderedListsGlobal> src{g, a, lg, lo, first_dirty, lo_t, lo_s, hi_t, hi_s};
-      lookup_one_src<1>(g, src, &x, v, &d);
-    }
+    ordered_lookup(g, a, oc, x, fs, v, d);
     e_acc += v;
     a.force[i] = 0.0 - d;
   }
@@ -5416,106 +5472,67 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
   }
 }
 
+static constexpr long long ORD_MAX_HILLS = 16384;   // (their sample indices sit in LDS: 64 KB)
 hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
                                       int *blocks_out, unsigned long long tag) {
-  if (!ordered_forces_supported(g)) return hipErrorInvalidValue;
-  long long blocks = (a.n + BLOCK - 1) / BLOCK;
-  if (blocks > 4 * cu_count()) blocks = 4 * cu_count();
+  if (!ordered_forces_supported(g) || a.nh > ORD_MAX_HILLS) return hipErrorInvalidValue;
+  long long blocks = (a.n + 4 * BLOCK - 1) / (4 * BLOCK);   // four pairs per thread
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
+  const long long per_block = (a.n + blocks - 1) / blocks;
   const DupPlan dp = make_dup_plan(g);
-  if (a.nh <= 8192) {   // (centre nodes and sample indices of the hills as ints in LDS: 64 KB at most)
-    const size_t lds = sizeof(int) * 2 * (size_t)(a.nh > 0 ? a.nh : 1);
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_forces_ordered<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * 2 * 8192));
-      if (e != hipSuccess) return e;
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(k_pair_forces_ordered<true>, dim3((unsigned)blocks), dim3(BLOCK), lds, s, g, a, dp, scratch, tag);
-  } else {
-    hipLaunchKernelGGL(k_pair_forces_ordered<false>, dim3((unsigned)blocks), dim3(BLOCK), 0, s, g, a, dp, scratch, tag);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_forces_ordered),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * ORD_MAX_HILLS));
+    if (e != hipSuccess) return e;
+    attr_set = true;
   }
+  const size_t lds = sizeof(int) * (size_t)(a.nh > 0 ? a.nh : 1);
+  hipLaunchKernelGGL(k_pair_forces_ordered, dim3((unsigned)blocks), dim3(BLOCK), lds, s, g, a, dp, scratch, tag, per_block);
   if (blocks_out) *blocks_out = (int)blocks;
   return hipGetLastError();
 }
-
 
 // ... and over a device-resident neighbour list: list entry e's two virtual add_hill samples are 2 e and 2 e + 1
 // (fix_edm_pair.cpp:230-237), so the entry's update_force sees the hills whose sample index is below 2 e
 struct OrderedListLookup {
   const Geom &g;
   const OrderedForcesArgs &a;
-  const OrderedListsLds &ll;
-  const OrderedListsGlobal &lg;
-  bool lds;
-  int first_dirty, lo_t, lo_s, hi_t, hi_s;
+  const OrderedCommon &oc;
   __device__ __forceinline__ void lookup(double r, int entry, double &v, double &d) const {
-    const long long fs = 2 * (long long)entry;
-    int lo = 0, hi = (int)a.nh;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      const long long sm = lds ? (long long)ll.sample(mid) : lg.sample(mid);
-      if (sm < fs) lo = mid + 1; else hi = mid;
-    }
-    if (lds) {
-      const OrderedSource<OrderedListsLds> src{g, a, ll, lo, first_dirty, lo_t, lo_s, hi_t, hi_s};
-      lookup_one_src<1>(g, src, &r, v, &d);
-    } else {
-      const OrderedSource<OrderedListsGlobal> src{g, a, lg, lo, first_dirty, lo_t, lo_s, hi_t, hi_s};
-      lookup_one_src<1>(g, src, &r, v, &d);
-    }
+    ordered_lookup(g, a, oc, r, 2 * (long long)entry, v, d);
   }
 };
 __global__ void __launch_bounds__(BLOCK) k_pairlist_forces_ordered(Geom g, PairListArgs pl, OrderedForcesArgs a, DupPlan dp,
-                                                                   double *__restrict__ partials, int use_lds) {
-  extern __shared__ int s_lists[];
-  const int H = (int)a.nh;
-  if (use_lds) {
-    for (int i = threadIdx.x; i < H; i += BLOCK) {
-      s_lists[i] = a.hc[i];
-      s_lists[H + i] = a.sel ? (int)a.sel[i] : i;
-    }
-    __syncthreads();
-  }
-  const OrderedListsLds ll{s_lists, s_lists + H};
-  const OrderedListsGlobal lg{a.hc, a.sel};
-  int lo_t = -1, lo_s = -1, hi_t = -1, hi_s = -1;
-  if (!g.bper[0]) {
-    if (dp.lo[0] > 0 && dp.lo[0] < (unsigned long long)g.n[0]) {
-      lo_t = (int)dp.lo[0] - 1;
-      lo_s = (int)dp.lo[0];
-    }
-    if (dp.hi[0] + 1 < (unsigned long long)g.n[0]) {
-      hi_t = (int)dp.hi[0] + 1;
-      hi_s = (int)dp.hi[0];
-    }
-  }
-  const OrderedListLookup ord{g, a, ll, lg, use_lds != 0, *a.first_dirty, lo_t, lo_s, hi_t, hi_s};
-  pairlist_forces_body<false, OrderedListLookup>(g, a.rec0, pl, partials, 0.0, blockIdx.x, gridDim.x, &ord);
+                                                                   double *__restrict__ partials) {
+  extern __shared__ int s_samples[];
+  OrderedCommon oc;
+  ordered_common_init(g, a, dp, s_samples, oc);
+  const OrderedListLookup ord{g, a, oc};
+  pairlist_forces_body<false, OrderedListLookup>(g, a.slabs, pl, partials, 0.0, blockIdx.x, gridDim.x, &ord);
 }
 hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl, const OrderedForcesArgs &a, double *partials,
                                           hipStream_t s, int *blocks_out) {
-  if (!ordered_forces_supported(g) || !pl.it_entry || !pl.jt_entry) return hipErrorInvalidValue;
+  if (!ordered_forces_supported(g) || !pl.it_entry || !pl.jt_entry || a.nh > ORD_MAX_HILLS) return hipErrorInvalidValue;
   if (blocks_out) *blocks_out = 0;
   if (pl.nall <= 0) return hipSuccess;
   const long long threads = (long long)pl.nall * 16;
   long long nb = (threads + BLOCK - 1) / BLOCK;
   if (nb > MAX_BLOCKS) nb = MAX_BLOCKS;
   const DupPlan dp = make_dup_plan(g);
-  const int use_lds = a.nh <= 8192 ? 1 : 0;
-  const size_t lds = use_lds ? sizeof(int) * 2 * (size_t)(a.nh > 0 ? a.nh : 1) : 0;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pairlist_forces_ordered),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * 2 * 8192));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * ORD_MAX_HILLS));
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_pairlist_forces_ordered, dim3((unsigned)nb), dim3(BLOCK), lds, s, g, pl, a, dp, partials, use_lds);
+  const size_t lds = sizeof(int) * (size_t)(a.nh > 0 ? a.nh : 1);
+  hipLaunchKernelGGL(k_pairlist_forces_ordered, dim3((unsigned)nb), dim3(BLOCK), lds, s, g, pl, a, dp, partials);
   if (blocks_out) *blocks_out = (int)nb;
   return hipGetLastError();
 }
+long long ordered_max_hills() { return ORD_MAX_HILLS; }
 
 }  // namespace edm

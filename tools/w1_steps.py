@@ -26,12 +26,24 @@ d_r = H.DeviceArray.from_host(W.pair_distances(npairs, 1))
 d_u = H.DeviceArray.from_host(W.uniform(3, npairs))
 d_f = H.DeviceArray.zeros((npairs,))
 est = 2 * npairs
+# W1_ORDER=1: the step in the reference's order (edm_hip_bias_pair_step_ordered; one add_hill sample per pair here)
+ordered = os.environ.get("W1_ORDER", "0") == "1"
+d_first = H.DeviceArray.from_host(np.arange(npairs, dtype=np.int32))
+
+
+def step():
+    if ordered:
+        return b.pair_step_ordered_device(d_r, d_f, d_first, npairs, d_r, d_u, npairs, est)
+    return b.pair_step_device(d_r, d_f, npairs, d_r, d_u, npairs, est)
+
+
 for _ in range(10):
-    b.pair_step_device(d_r, d_f, npairs, d_r, d_u, npairs, est)
+    step()
 H.synchronize()
 steps = int(os.environ.get("W1_STEPS", "200"))
 t = time.perf_counter()
 for _ in range(steps):
-    b.pair_step_device(d_r, d_f, npairs, d_r, d_u, npairs, est)
+    step()
 H.synchronize()
-print("ms_per_step", (time.perf_counter() - t) / steps * 1e3, "fused", b.get("fused_steps"))
+print("ordered" if ordered else "batch", "ms_per_step", (time.perf_counter() - t) / steps * 1e3, "fused", b.get("fused_steps"),
+      "hills_added", b.get("hills_added"))
