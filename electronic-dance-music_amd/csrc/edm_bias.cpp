@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <map>
 #include <string>
@@ -106,8 +107,8 @@ struct edm_hip_bias {
     double h_const = 0;
     const long long *sel = nullptr;
   } last_batch;
-  DevBuf<double> ord_slabs;          // [hills + 1] copies of the 1-D grid (OrderedForcesArgs::slabs), slab 0 taken before the batch
-  size_t ord_slab0_doubles = 0;
+  DevBuf<double> ord_rec0, ord_records;   // OrderedForcesArgs::rec0 (taken before the batch) / ::records
+  DevBuf<unsigned short> ord_counts;
   DevBuf<unsigned long long> ord_dirty;
   unsigned ord_seq = 0;
   DevBuf<int> ord_first;
@@ -295,7 +296,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   b->pl_it_entry.release(); b->pl_jt_entry.release();
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
-  b->ord_slabs.release(); b->ord_dirty.release(); b->ord_first.release();
+  b->ord_rec0.release(); b->ord_records.release(); b->ord_counts.release(); b->ord_dirty.release(); b->ord_first.release();
   delete b;
   return EDM_HIP_OK;
 }
@@ -1075,9 +1076,8 @@ int edm_hip_bias_pair_step(edm_hip_bias *b, long long n, const double *d_r, doub
 // in edm_hip_bias_pair_step -- selection, limiter and grid update do not depend on the forces -- and the force of pair k
 // is then interpolated on the bias as it stood when the reference's loop reached that pair: the grid after
 // pre_add_hill plus the hills of the add_hill calls before it (OrderedForcesArgs, edm_kernels.h).
-// the bias the first pair of a reference-order step sees: the node records behind pre_add_hill's overflow flush (slab 0).
-// The slab buffer is sized for the step's launch bound up front: the hill batch that follows must find it in place.
-static int ordered_snapshot(edm_hip_bias *b, long long n_samples) {
+// the bias the first pair of a reference-order step sees: the node records behind pre_add_hill's overflow flush
+static int ordered_snapshot(edm_hip_bias *b) {
   edm_hip_gauss *g = b->bias;
   if (!ordered_forces_supported(g->g)) {
     set_error("reference-order pair step: needs a 1-D bias whose stencil is not wider than a periodic grid");
@@ -1088,48 +1088,31 @@ static int ordered_snapshot(edm_hip_bias *b, long long n_samples) {
               "use edm_hip_bias_pair_step / reference_order 0 with a communicator");
     return EDM_HIP_ERR_STATE;
   }
-  // hills this step can deposit at most: every sample (all-samples mode), or what the stochastic selection may accept
-  // before the step is redone synchronously -- the slabs are (re)allocated for the TRUE count later if that is larger
-  long long guess = n_samples;
-  if (!(b->hill_density < 0) && b->est_hill_count > 0) {
-    const double expected = b->hill_density / (double)b->est_hill_count * (double)n_samples;
-    guess = (long long)(4.0 * expected) + 128;
-    if (guess > n_samples) guess = n_samples;
-  }
-  if (guess > 2048) guess = 2048;
-  if (guess < 1) guess = 1;
   const size_t grid_doubles = (size_t)g->g.total * (size_t)g->g.rec;
-  EDM_HIP_TRY(b->ord_slabs.reserve(ordered_slab_doubles(g->g, guess)));
-  EDM_HIP_TRY(hipMemcpyAsync(b->ord_slabs.p, g->rec, sizeof(double) * grid_doubles, hipMemcpyDeviceToDevice, g->stream));
-  b->ord_slab0_doubles = grid_doubles;
+  EDM_HIP_TRY(b->ord_rec0.reserve(grid_doubles));
+  EDM_HIP_TRY(hipMemcpyAsync(b->ord_rec0.p, g->rec, sizeof(double) * grid_doubles, hipMemcpyDeviceToDevice, g->stream));
   b->last_batch.valid = false;
   return EDM_HIP_OK;
 }
-// ... and, once the step's hill batch has been applied (last_batch), one slab per hill
-static int ordered_slabs_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
+// ... and, once the step's hill batch has been applied (last_batch), the running records of its hills
+static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
   edm_hip_gauss *g = b->bias;
   const long long nh = b->last_batch.nh;
-  const size_t need = ordered_slab_doubles(g->g, nh);
-  if (nh > ordered_max_hills() || need * sizeof(double) > ((size_t)2 << 30)) {
-    set_error("reference-order pair step: more hills in one step than the force pass keeps grid copies for (16384 hills, "
-              "2 GiB); use edm_hip_bias_pair_step (all forces on the step-start bias) for all-samples deposition");
+  if (nh > ordered_max_hills()) {
+    set_error("reference-order pair step: more than 16384 hills in one step; use edm_hip_bias_pair_step (all forces on the "
+              "step-start bias) for all-samples deposition of a large system");
     return EDM_HIP_ERR_ARG;
   }
-  if (need > b->ord_slabs.cap) {
-    // (rare: more hills than the launch bound allowed for -- keep slab 0 across the reallocation)
-    DevBuf<double> keep;
-    EDM_HIP_TRY(keep.reserve(b->ord_slab0_doubles));
-    EDM_HIP_TRY(hipMemcpyAsync(keep.p, b->ord_slabs.p, sizeof(double) * b->ord_slab0_doubles, hipMemcpyDeviceToDevice, g->stream));
-    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
-    EDM_HIP_TRY(b->ord_slabs.reserve(need));
-    EDM_HIP_TRY(hipMemcpyAsync(b->ord_slabs.p, keep.p, sizeof(double) * b->ord_slab0_doubles, hipMemcpyDeviceToDevice, g->stream));
-    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
-    keep.release();
-  }
+  long long cap = 256;   // (grown in powers of two: the buffers settle after the first steps)
+  while (cap < nh) cap *= 2;
+  if (ordered_record_doubles(g->g, cap) * sizeof(double) > ((size_t)4 << 30)) cap = nh;
+  EDM_HIP_TRY(b->ord_records.reserve(ordered_record_doubles(g->g, cap)));
+  EDM_HIP_TRY(b->ord_counts.reserve(ordered_count_shorts(g->g, cap)));
   EDM_HIP_TRY(b->ord_dirty.reserve_zeroed(1));
   OrderedForcesArgs a;
   memset(&a, 0, sizeof(a));
   a.nh = nh;
+  a.nh_cap = cap;
   a.k = b->last_batch.k;
   a.heights = b->last_batch.heights;
   a.h_const = b->last_batch.h_const;
@@ -1139,10 +1122,39 @@ static int ordered_slabs_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
   a.hc = g->ws.hc.p;
   a.ht = g->ws.ht.p;
   a.sel = b->last_batch.sel;
-  a.slabs = b->ord_slabs.p;
+  a.rec0 = b->ord_rec0.p;
+  a.records = b->ord_records.p;
+  a.counts = b->ord_counts.p;
   a.first_dirty = b->ord_dirty.p;
   a.dirty_seq = ++b->ord_seq;
-  EDM_HIP_TRY(launch_ordered_slabs(g->g, g->tables(), a, g->stream));
+  // development aid (EDM_HIP_TRACE=ordered): stamps of the 100th record pass to stderr
+  static const bool tracing = getenv("EDM_HIP_TRACE") && !strcmp(getenv("EDM_HIP_TRACE"), "ordered");
+  const size_t trace_wgs = (size_t)((g->g.n[0] + 31) / 32);
+  if (tracing && b->ord_seq == 100) {
+    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.trace), trace_wgs * 64));
+    EDM_HIP_TRY(hipMemset(a.trace, 0, trace_wgs * 64));
+  }
+  EDM_HIP_TRY(launch_ordered_records(g->g, g->tables(), a, g->stream));
+  if (a.trace) {
+    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    std::vector<unsigned long long> tr(trace_wgs * 8);
+    EDM_HIP_TRY(hipMemcpy(tr.data(), a.trace, trace_wgs * 64, hipMemcpyDeviceToHost));
+    (void)hipFree(a.trace);
+    a.trace = nullptr;
+    unsigned long long t0 = ~0ull;
+    for (size_t w = 0; w < trace_wgs; w++) if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
+    const char *names[7] = {"start", "node terms done", "chunk 0 listed", "chunk 0 terms", "chunk 0 run", "chunk 0 stored", "end"};
+    for (int k = 0; k < 7; k++) {
+      std::vector<double> v;
+      for (size_t w = 0; w < trace_wgs; w++) if (tr[w * 8 + k]) v.push_back((double)(tr[w * 8 + k] - t0) * 0.01);
+      if (v.empty()) continue;
+      std::sort(v.begin(), v.end());
+      fprintf(stderr, "[edm trace] records %-16s n=%4zu  min %6.2f  med %6.2f  max %6.2f us\n", names[k], v.size(), v.front(), v[v.size() / 2], v.back());
+    }
+    unsigned long long mx = 0, sum = 0;
+    for (size_t w = 0; w < trace_wgs; w++) { sum += tr[w * 8 + 7]; if (tr[w * 8 + 7] > mx) mx = tr[w * 8 + 7]; }
+    fprintf(stderr, "[edm trace] records: hills listed per tile in chunk 0: mean %.1f max %llu (of %lld hills)\n", (double)sum / trace_wgs, mx, nh);
+  }
   *out = a;
   return EDM_HIP_OK;
 }
@@ -1152,7 +1164,7 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
                                     const double *d_runiform, double *energy) {
   edm_hip_gauss *g = b->bias;
   hipStream_t s = g->stream;
-  int rc = ordered_snapshot(b, n_samples);
+  int rc = ordered_snapshot(b);
   if (rc) return rc;
   b->pending = PendingForces();
   g->wait_polled = false;
@@ -1163,7 +1175,7 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   bool tagged = false;
   if (n > 0 && b->last_batch.valid && b->last_batch.nh > 0) {
     OrderedForcesArgs a;
-    rc = ordered_slabs_enqueue(b, &a);
+    rc = ordered_records_enqueue(b, &a);
     if (rc) return rc;
     a.n = n;
     a.r = d_r;
@@ -1465,7 +1477,7 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   // it stood when the reference's loop reached the entry (see edm_hip_bias_pair_step_ordered)
   const bool ordered = hill_step && npairs > 0 && b->reference_order;
   if (ordered) {
-    rc = ordered_snapshot(b, 2 * npairs);
+    rc = ordered_snapshot(b);
     if (rc) return rc;
   } else {
     b->pending.active = true;
@@ -1501,7 +1513,7 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     a.partial_tag = tag;
     if (b->last_batch.valid && b->last_batch.nh > 0) {
       OrderedForcesArgs oa;
-      rc = ordered_slabs_enqueue(b, &oa);
+      rc = ordered_records_enqueue(b, &oa);
       if (rc) return rc;
       EDM_HIP_TRY(launch_pairlist_forces_ordered(b->bias->g, a, oa, b->bias->d_partials, s, &nblk_ordered));
     } else {   // (no new hill: every entry sees the same bias)

@@ -118,20 +118,23 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
 // hills does not depend on the grid (edm_bias.cpp:543), and neither do the limiter's decisions (a hill's integrated
 // bias is independent of grid contents), so the step's hill batch is applied exactly as in the batched step and the
 // forces follow from three things the batch leaves on the device: a copy of the node records taken before the batch
-// (slab 0), the prepared hill list, and the heights the limiter settled on.
-//   launch_ordered_slabs : slab m (m = 1 .. nh) = the node records after the first m hills of the batch -- slab 0 plus,
-//       hill after hill, h1 term and then h2 term: the reference's sequence of += (gaussian_grid.h:343-355).  One
-//       dense copy of the 1-D grid per hill: 179 KB each on the C1D grid, 22 MB for the ~125 hills of a W1 step.
+// (rec0), the prepared hill list, and the heights the limiter settled on.
+//   launch_ordered_records : per tile of 32 nodes, the tile's nodes' records after every hill that reaches the tile, in
+//       hill order -- rec0 plus, hill after hill, h1 term and then h2 term: the reference's sequence of +=
+//       (gaussian_grid.h:343-355) -- and, for every m, how many of the first m hills reached the tile.  A W1 step's
+//       ~125 hills leave ~3 MB of records (a hill reaches ~36 of the C1D grid's 351 tiles).
 //   launch_pair_forces_ordered : pair k counts the hills whose add_hill call precedes its update_force
-//       (m = #{j : sample(j) < first_sample[k]}, a binary search over the ascending sample indices in LDS) and
-//       interpolates (grid.h:390-446, interp<1> :52-139) on slab m -- K1 with a per-pair slab.  Consecutive pairs share
-//       their slab, so a workgroup (a contiguous run of pairs) reads one or two of them.  The boundary duplication of
-//       gaussian_grid.h:571-630 (value of the first / last in-boundary node copied outward after every hill with a
-//       non-zero correction) is applied on the fly: an outward copy node reads the value of its source node in the
-//       same slab once the first such hill (first_dirty, found by the slab pass) lies before the pair.
+//       (m = #{j : sample(j) < first_sample[k]}, a binary search over the ascending sample indices in LDS), takes for
+//       each of its two corner nodes the record behind the last of those hills that reached the node's tile (one
+//       16-bit count, one 16-byte record; rec0 where none did) and interpolates (grid.h:390-446, interp<1> :52-139).
+//       The boundary duplication of gaussian_grid.h:571-630 (value of the first / last in-boundary node copied outward
+//       after every hill with a non-zero correction) is applied on the fly: an outward copy node reads the value of
+//       its source node at the same m once the first such hill (first_dirty, found by the record pass) lies before
+//       the pair.
 // 1-D grids only (fix_edm_pair.cpp:52), stencil not wider than a periodic grid, at most ordered_max_hills() hills.
 struct OrderedForcesArgs {
   long long nh;             // hills of the step's batch (true count)
+  long long nh_cap;         // hills the record / count buffers were sized for (>= nh)
   long long k;              // hills [0, k): base height; hills >= k: the limiter's tail arrays (see HillHeights)
   const double *heights;    // per-hill base heights or NULL (h_const)
   double h_const;
@@ -140,19 +143,23 @@ struct OrderedForcesArgs {
   const int *hc;
   const double *ht;
   const long long *sel;     // sample index of hill j, ascending (NULL: hill j is sample j)
-  double *slabs;            // [nh + 1][n][2]; slab 0 = the node records before the batch (filled by the caller)
+  const double *rec0;       // the node records before the batch
+  double *records;          // [tiles][nh_cap][32][2], see launch_ordered_records
+  unsigned short *counts;   // [nh + 1][tiles]
   unsigned long long *first_dirty;   // device word, see ordered_dirty_note in edm_kernels.hip (zero-initialised once)
-  unsigned dirty_seq;       // this step's number (grows by one per launch_ordered_slabs)
+  unsigned dirty_seq;       // this step's number (grows by one per launch_ordered_records)
   long long n;              // pairs
   const double *r;          // [n] pair distances
   const int *first_sample;  // [n] sample index of pair k's first add_hill call, or NULL: 2 k (the virtual samples of a
                             // device-resident neighbour list)
   double *force;            // [n] out: -dV/dr
+  unsigned long long *trace;   // development aid (EDM_HIP_TRACE=ordered): 8 wall-clock stamps per workgroup of the record pass, or NULL
 };
-size_t ordered_slab_doubles(const Geom &g, long long nh);
+size_t ordered_record_doubles(const Geom &g, long long nh_cap);
+size_t ordered_count_shorts(const Geom &g, long long nh_cap);
 long long ordered_max_hills();
 bool ordered_forces_supported(const Geom &g);
-hipError_t launch_ordered_slabs(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s);
+hipError_t launch_ordered_records(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s);
 // tagged partial energy sums like launch_pair_forces (tag != 0: scratch is host-mapped, polled by the host)
 hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
                                       int *blocks_out, unsigned long long tag);

@@ -5220,8 +5220,15 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
 // ---------------------------------------------------------------------------
 // fix edm_pair in the reference's order (see OrderedForcesArgs in edm_kernels.h)
 // ---------------------------------------------------------------------------
-size_t ordered_slab_doubles(const Geom &g, long long nh) {
-  return (size_t)((nh > 0 ? nh : 0) + 1) * (size_t)g.n[0] * 2;
+static constexpr int ORD_NODES = 32, ORD_PARTS = BLOCK / ORD_NODES, ORD_CHUNK = 64;
+static constexpr long long ORD_MAX_HILLS = 16384;   // (sample indices in LDS: 64 KB; list counts fit 16 bits)
+long long ordered_max_hills() { return ORD_MAX_HILLS; }
+long long ordered_tiles(const Geom &g) { return (g.n[0] + ORD_NODES - 1) / ORD_NODES; }
+size_t ordered_record_doubles(const Geom &g, long long nh_cap) {
+  return (size_t)ordered_tiles(g) * (size_t)(nh_cap > 0 ? nh_cap : 1) * ORD_NODES * 2;
+}
+size_t ordered_count_shorts(const Geom &g, long long nh_cap) {
+  return (size_t)ordered_tiles(g) * (size_t)((nh_cap > 0 ? nh_cap : 0) + 1);
 }
 bool ordered_forces_supported(const Geom &g) {
   return g.dim == 1 && g.rec == 2 && g.n[0] >= 2 && !(g.periodic[0] && 2 * g.msize[0] + 1 > g.n[0]);
@@ -5238,40 +5245,51 @@ __device__ __forceinline__ int ordered_dirty_first(const unsigned long long *w, 
   return ((unsigned)(v >> 32) == seq) ? 0x7FFFFFFF - (int)(unsigned)(v & 0xFFFFFFFFull) : INT_MAX;
 }
 
-// Slabs 1 .. nh from slab 0: a workgroup owns ORD_NODES nodes and walks the hill list ORD_CHUNK hills at a time.  Wave 0
-// tests the chunk's hills against the tile and compacts the ones that reach it IN ORDER (ballot prefix; ~15 % of a W1
-// step's hills reach a given tile); the workgroup's ORD_PARTS parts compute the unit-height stencil terms of those hills
-// side by side (value and derivative of every (listed hill, node) into LDS); part 0 then runs the heights over them in
-// hill order -- rec += h1 term, then += h2 term where the limiter added an undo hill: the reference's sequence of +=
-// (gaussian_grid.h:343-355, edm_bias.cpp:474-490) -- leaving the running record behind each listed hill in LDS; and
-// all threads store the chunk's slabs: slab q + 1 holds the record behind the last listed hill <= q.
-static constexpr int ORD_NODES = 32, ORD_PARTS = BLOCK / ORD_NODES, ORD_CHUNK = 64;
+// The running records of a step's hills, tile by tile.  A workgroup owns a tile of ORD_NODES nodes and walks the hill list
+// ORD_CHUNK hills at a time.  Wave 0 tests the chunk's hills against the tile and lists the ones that reach it IN ORDER
+// (ballot prefix; ~15 % of a W1 step's hills reach a given tile); the workgroup's ORD_PARTS parts compute the
+// unit-height stencil terms of the listed hills side by side (value and derivative of every (listed hill, node) into
+// LDS); part 0 then runs the heights over them in hill order -- rec += h1 term, then += h2 term where the limiter
+// added an undo hill: the reference's sequence of += (gaussian_grid.h:343-355, edm_bias.cpp:474-490) -- and every
+// listed hill's running record of the tile's nodes goes to records[tile][list position][node]; counts[m][tile] = how
+// many of the first m hills the tile listed.  A node's record after the first m hills is then
+// records[tile][counts[m][tile] - 1][node] -- or the node's record before the batch when that count is zero.
 template <bool PERB>
-__global__ void __launch_bounds__(BLOCK) k_ordered_slabs(Geom g, Tables t, OrderedForcesArgs a) {
-  static_assert(ORD_CHUNK == 64, "one wave tests and compacts a chunk");
+__global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, OrderedForcesArgs a) {
+  static_assert(ORD_CHUNK == 64, "one wave tests and lists a chunk");
   const int tnode = threadIdx.x % ORD_NODES, part = threadIdx.x / ORD_NODES;
-  const int t0 = blockIdx.x * ORD_NODES;
+  const int tile = blockIdx.x, ntiles = gridDim.x;
+  const int t0 = tile * ORD_NODES;
   const int n = t0 + tnode;
   const bool in_grid = n < g.n[0];
   const int t1 = (t0 + ORD_NODES - 1 < g.n[0] - 1) ? t0 + ORD_NODES - 1 : g.n[0] - 1;
   const int p[1] = {in_grid ? n : 0};
+  unsigned long long *tr = a.trace ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
+  if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
   NodeTerms<1> nt;
   node_terms<1, PERB>(g, t, p, nt);
   const bool active = in_grid && nt.inside;   // (hills skip nodes outside a wall, gaussian_grid.h:273)
   TermConst<1> tc;
   term_const<1>(g, tc);
-  const long long N = g.n[0];
-  double2 *T = reinterpret_cast<double2 *>(a.slabs);
+  if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
   double acc0 = 0, acc1 = 0;
   if (in_grid && part == 0) {
-    const double2 r0 = T[n];
+    const double2 r0 = reinterpret_cast<const double2 *>(a.rec0)[n];
     acc0 = r0.x;
     acc1 = r0.y;
   }
+  double2 *R = reinterpret_cast<double2 *>(a.records) + (long long)tile * a.nh_cap * ORD_NODES;
   __shared__ int s_c[ORD_CHUNK], s_upto[ORD_CHUNK], s_cnt;
   __shared__ double s_x[ORD_CHUNK], s_t[ORD_CHUNK][2], s_a1[ORD_CHUNK], s_a2[ORD_CHUNK];
-  __shared__ double s_v[ORD_CHUNK + 1][ORD_NODES], s_d[ORD_CHUNK + 1][ORD_NODES];   // (row 0: the record the chunk starts from)
-  bool noted = false;   // this thread has reported its first hill with a non-zero correction (later chunks hold later hills)
+  __shared__ double s_v[ORD_CHUNK][ORD_NODES], s_d[ORD_CHUNK][ORD_NODES];
+  // the tile's first hill with a non-zero correction: collected in LDS, ONE device atomic per workgroup at the end (every
+  // thread of the tiles near a wall meets such a term -- thousands of atomics on one address would serialise)
+  __shared__ int s_dirty;
+  int listed = 0;       // hills of the earlier chunks the tile listed
+  if (threadIdx.x == 0) {
+    a.counts[tile] = 0;   // (row m = 0)
+    s_dirty = INT_MAX;
+  }
   for (long long base = 0; base < a.nh; base += ORD_CHUNK) {
     const int cnt = (a.nh - base < ORD_CHUNK) ? (int)(a.nh - base) : ORD_CHUNK;
     int first_nz = -1;    // list position of this thread's first such term of the chunk
@@ -5300,6 +5318,8 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_slabs(Geom g, Tables t, Order
       const int lane = threadIdx.x;
       const int pos = __popcll(bal & ((1ull << lane) - 1ull));
       s_upto[lane] = pos + (take ? 1 : 0);   // listed hills among the chunk's hills 0 .. lane
+      if ((int)threadIdx.x < cnt)            // row m = base + lane + 1: the first m hills
+        a.counts[(base + lane + 1) * ntiles + tile] = (unsigned short)(listed + pos + (take ? 1 : 0));
       if (take) {
         s_c[pos] = c;
         s_x[pos] = hx;
@@ -5311,7 +5331,9 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_slabs(Geom g, Tables t, Order
       if (lane == 0) s_cnt = __popcll(bal);
     }
     __syncthreads();
+    if (tr && threadIdx.x == 0 && base == 0) tr[2] = wall_clock64();
     const int nl = s_cnt;
+    if (tr && threadIdx.x == 0 && base == 0) tr[7] = (unsigned long long)nl;
     for (int e = part; e < nl; e += ORD_PARTS) {
       double val = 0, dval[1] = {0};
       if (active && images(g, 0, s_c[e], n, n) != 0) {
@@ -5323,22 +5345,29 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_slabs(Geom g, Tables t, Order
           if (nz && first_nz < 0) first_nz = e;
         }
       }
-      s_v[e + 1][tnode] = val;
-      s_d[e + 1][tnode] = dval[0];
+      s_v[e][tnode] = val;
+      s_d[e][tnode] = dval[0];
     }
-    if (first_nz >= 0 && !noted) {
-      // list position -> chunk-local hill index: the first hill whose count of listed hills exceeds the position
-      int q = 0;
-      while (q < cnt && s_upto[q] <= first_nz) q++;
-      ordered_dirty_note(a.first_dirty, a.dirty_seq, (int)(base + q));
-      noted = true;
+    // (wave-level minimum first: one LDS atomic per wave that met such a term)
+    {
+      int fz = first_nz < 0 ? INT_MAX : first_nz;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(fz, o, 64);
+        fz = other < fz ? other : fz;
+      }
+      if ((threadIdx.x & 63) == 0 && fz != INT_MAX) {
+        // list position -> chunk-local hill index: the first hill whose count of listed hills exceeds the position
+        int q = 0;
+        while (q < cnt && s_upto[q] <= fz) q++;
+        atomicMin(&s_dirty, (int)(base + q));
+      }
     }
     __syncthreads();
+    if (tr && threadIdx.x == 0 && base == 0) tr[3] = wall_clock64();
     if (part == 0) {
-      s_v[0][tnode] = acc0;
-      s_d[0][tnode] = acc1;
       for (int e = 0; e < nl; e++) {
-        const double v = s_v[e + 1][tnode], d = s_d[e + 1][tnode], a1 = s_a1[e], a2 = s_a2[e];
+        const double v = s_v[e][tnode], d = s_d[e][tnode], a1 = s_a1[e], a2 = s_a2[e];
         if (v != 0 || d != 0) {
           acc0 += a1 * v;
           acc1 += a1 * d;
@@ -5347,56 +5376,44 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_slabs(Geom g, Tables t, Order
             acc1 += a2 * d;
           }
         }
-        s_v[e + 1][tnode] = acc0;
-        s_d[e + 1][tnode] = acc1;
+        s_v[e][tnode] = acc0;
+        s_d[e][tnode] = acc1;
       }
     }
     __syncthreads();
-    if (in_grid) {
-      for (int q = part; q < cnt; q += ORD_PARTS) {
-        const int u = s_upto[q];
-        double2 out;
-        out.x = s_v[u][tnode];
-        out.y = s_d[u][tnode];
-        T[(base + q + 1) * N + n] = out;
-      }
+    if (tr && threadIdx.x == 0 && base == 0) tr[4] = wall_clock64();
+    for (int e = part; e < nl; e += ORD_PARTS) {
+      double2 out;
+      out.x = s_v[e][tnode];
+      out.y = s_d[e][tnode];
+      R[(long long)(listed + e) * ORD_NODES + tnode] = out;
     }
+    listed += nl;
     __syncthreads();
+    if (tr && threadIdx.x == 0 && base == 0) tr[5] = wall_clock64();
   }
+  if (threadIdx.x == 0 && s_dirty != INT_MAX) ordered_dirty_note(a.first_dirty, a.dirty_seq, s_dirty);
+  if (tr && threadIdx.x == 0) tr[6] = wall_clock64();
 }
 
-hipError_t launch_ordered_slabs(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s) {
-  if (!ordered_forces_supported(g)) return hipErrorInvalidValue;
-  if (a.nh <= 0) return hipSuccess;
-  const unsigned nb = (unsigned)((g.n[0] + ORD_NODES - 1) / ORD_NODES);
+hipError_t launch_ordered_records(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s) {
+  if (!ordered_forces_supported(g) || a.nh > a.nh_cap || a.nh > ORD_MAX_HILLS) return hipErrorInvalidValue;
+  const unsigned nb = (unsigned)ordered_tiles(g);
   if (g.bper[0])
-    hipLaunchKernelGGL(k_ordered_slabs<true>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
+    hipLaunchKernelGGL(k_ordered_records<true>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
   else
-    hipLaunchKernelGGL(k_ordered_slabs<false>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
+    hipLaunchKernelGGL(k_ordered_records<false>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
   return hipGetLastError();
 }
 
-// the node records of slab m with the boundary duplication of gaussian_grid.h:571-630 applied: after every hill with
-// a non-zero correction the value (not the derivative) of the first / last in-boundary node is copied to its outward
-// neighbour -- so from the first such hill on an outward copy node reads its source's value of the same slab
-struct OrderedSlabSource {
-  const double2 *slab;
-  bool dup;                     // some hill before this slab had a non-zero correction
-  int lo_t, lo_s, hi_t, hi_s;   // outward copy nodes and their sources (-1: none)
-  __device__ __forceinline__ void load(Rec<2> &r, long long node) const {
-    double2 own = slab[node];
-    if (dup && ((int)node == lo_t || (int)node == hi_t)) own.x = slab[(int)node == lo_t ? lo_s : hi_s].x;
-    r.v[0] = own.x;
-    r.v[1] = own.y;
-  }
-};
 struct OrderedCommon {
   int H;                        // hills
+  int ntiles;
   const int *samples;           // LDS: sample index of hill j, ascending
   int first_dirty;
-  int lo_t, lo_s, hi_t, hi_s;
+  int lo_t, lo_s, hi_t, hi_s;   // outward copy nodes of the boundary duplication and their sources (-1: none)
   bool fast;                    // the specialised 1-D lookup applies (pair_fast_path)
-  double inv_dx, dup_lo_x0, dup_lo_x1, dup_hi_x0, dup_hi_x1;   // x ranges whose cells touch an outward copy node
+  double inv_dx;
 };
 __device__ __forceinline__ void ordered_common_init(const Geom &g, const OrderedForcesArgs &a, const DupPlan &dp, int *s_samples,
                                                     OrderedCommon &oc) {
@@ -5404,6 +5421,7 @@ __device__ __forceinline__ void ordered_common_init(const Geom &g, const Ordered
   for (int i = threadIdx.x; i < oc.H; i += blockDim.x) s_samples[i] = a.sel ? (int)a.sel[i] : i;
   __syncthreads();
   oc.samples = s_samples;
+  oc.ntiles = (g.n[0] + ORD_NODES - 1) / ORD_NODES;
   oc.first_dirty = ordered_dirty_first(a.first_dirty, a.dirty_seq);
   oc.lo_t = oc.lo_s = oc.hi_t = oc.hi_s = -1;
   if (!g.bper[0]) {   // duplicate_boundary_lanes' cases 0 and 3 in one dimension
@@ -5418,11 +5436,57 @@ __device__ __forceinline__ void ordered_common_init(const Geom &g, const Ordered
   }
   oc.fast = g.interp && !g.periodic[0] && !g.bper[0];
   oc.inv_dx = 1.0 / g.dx[0];
-  // (generous by a cell on either side: samples in these ranges take the exact generic lookup)
-  oc.dup_lo_x0 = g.min[0] + g.dx[0] * (oc.lo_t - 2);
-  oc.dup_lo_x1 = g.min[0] + g.dx[0] * (oc.lo_t + 2);
-  oc.dup_hi_x0 = g.min[0] + g.dx[0] * (oc.hi_t - 2);
-  oc.dup_hi_x1 = g.min[0] + g.dx[0] * (oc.hi_t + 2);
+}
+// the node records as they stood after the first m hills of the batch, with the boundary duplication of
+// gaussian_grid.h:571-630 applied: after every hill with a non-zero correction the value (not the derivative) of the
+// first / last in-boundary node is copied to its outward neighbour -- so from the first such hill on an outward copy
+// node reads its source's value
+struct OrderedSource {
+  const OrderedForcesArgs &a;
+  const OrderedCommon &oc;
+  int m;
+  __device__ __forceinline__ double2 raw(int node) const {
+    const int tile = node / ORD_NODES;
+    const int u = a.counts[(long long)m * oc.ntiles + tile];
+    if (u == 0) return reinterpret_cast<const double2 *>(a.rec0)[node];
+    return reinterpret_cast<const double2 *>(a.records)[((long long)tile * a.nh_cap + (u - 1)) * ORD_NODES + (node % ORD_NODES)];
+  }
+  __device__ __forceinline__ double2 get(int node) const {
+    double2 own = raw(node);
+    if (m > oc.first_dirty && (node == oc.lo_t || node == oc.hi_t)) own.x = raw(node == oc.lo_t ? oc.lo_s : oc.hi_s).x;
+    return own;
+  }
+  __device__ __forceinline__ void load(Rec<2> &r, long long node) const {
+    const double2 v = get((int)node);
+    r.v[0] = v.x;
+    r.v[1] = v.y;
+  }
+};
+// pair_one<false> (the specialised 1-D lookup: same index rule, same blend) on records that come from a source
+template <class SRC>
+__device__ __forceinline__ void pair_one_src(const Geom &g, const SRC &src, double inv_dx, double x, double &v, double &d) {
+  const double lo_ok = fmax(g.bmin[0], g.min[0]);
+  const double hi_open = fmin(nextafter(g.bmax[0], 1.0e308), g.max[0] - g.dx[0]);
+  const bool in_range = (x >= lo_ok) & (x < hi_open);
+  const double q = (x - g.min[0]) * inv_dx;
+  double fq = floor(q);
+  const double eps = 1e-11 * fmax(1.0, (double)g.n[0]);
+  const double frac = q - fq;
+  const bool near = in_range & ((frac <= eps) | (frac >= 1.0 - eps));
+  if (near) fq = floor((x - g.min[0]) / g.dx[0]);
+  int idx = (int)fq;
+  idx = idx < 0 ? 0 : idx;
+  idx = idx > g.n[0] - 2 ? g.n[0] - 2 : idx;
+  const double where = x - g.min[0] - fq * g.dx[0];
+  const double X = where * inv_dx;
+  const double2 ra = src.get(idx), rb = src.get(idx + 1);
+  double vv, dd;
+  if ((X < 0.0) | (X > 1.0))   // `where` off by an ulp at a node: the reference's fabs() mirroring
+    hermite_1d_mirrored(ra.x, ra.y, rb.x, rb.y, X, g.dx[0], inv_dx, vv, dd);
+  else
+    hermite_1d_horner(ra.x, scaled_slope(ra.x, ra.y, g.dx[0]), rb.x, scaled_slope(rb.x, rb.y, g.dx[0]), X, inv_dx, vv, dd);
+  v = in_range ? vv : 0.0;
+  d = in_range ? dd : 0.0;
 }
 // energy and dV/dr at r as the reference's loop saw them at the sample index `fs` of the pair's first add_hill call
 __device__ __forceinline__ void ordered_lookup(const Geom &g, const OrderedForcesArgs &a, const OrderedCommon &oc, double x,
@@ -5432,18 +5496,11 @@ __device__ __forceinline__ void ordered_lookup(const Geom &g, const OrderedForce
     const int mid = (lo + hi) >> 1;
     if ((long long)oc.samples[mid] < fs) lo = mid + 1; else hi = mid;
   }
-  const int m = lo;
-  const double2 *slab = reinterpret_cast<const double2 *>(a.slabs) + (long long)m * g.n[0];
-  const bool dup = m > oc.first_dirty;
-  bool exact = !oc.fast;
-  if (dup && ((oc.lo_t >= 0 && x > oc.dup_lo_x0 && x < oc.dup_lo_x1) || (oc.hi_t >= 0 && x > oc.dup_hi_x0 && x < oc.dup_hi_x1)))
-    exact = true;
-  if (!exact) {
-    pair_one<false>(g, reinterpret_cast<const double *>(slab), nullptr, 0, 0, oc.inv_dx, x, v, d);
-  } else {
-    const OrderedSlabSource src{slab, dup, oc.lo_t, oc.lo_s, oc.hi_t, oc.hi_s};
+  const OrderedSource src{a, oc, lo};
+  if (oc.fast)
+    pair_one_src(g, src, oc.inv_dx, x, v, d);
+  else
     lookup_one_src<1>(g, src, &x, v, &d);
-  }
 }
 
 __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedForcesArgs a, DupPlan dp,
@@ -5454,7 +5511,7 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
   OrderedCommon oc;
   ordered_common_init(g, a, dp, s_samples, oc);
   double e_acc = 0;
-  // a workgroup owns a contiguous run of pairs: they see the same few slabs (179 KB each on the C1D grid)
+  // a workgroup owns a contiguous run of pairs: they share their hill count m, i.e. one row of the counts
   const long long beg = (long long)blockIdx.x * per_block;
   const long long end = (beg + per_block < a.n) ? beg + per_block : a.n;
   for (long long i = beg + threadIdx.x; i < end; i += BLOCK) {
@@ -5472,7 +5529,6 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
   }
 }
 
-static constexpr long long ORD_MAX_HILLS = 16384;   // (their sample indices sit in LDS: 64 KB)
 hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
                                       int *blocks_out, unsigned long long tag) {
   if (!ordered_forces_supported(g) || a.nh > ORD_MAX_HILLS) return hipErrorInvalidValue;
@@ -5510,7 +5566,7 @@ __global__ void __launch_bounds__(BLOCK) k_pairlist_forces_ordered(Geom g, PairL
   OrderedCommon oc;
   ordered_common_init(g, a, dp, s_samples, oc);
   const OrderedListLookup ord{g, a, oc};
-  pairlist_forces_body<false, OrderedListLookup>(g, a.slabs, pl, partials, 0.0, blockIdx.x, gridDim.x, &ord);
+  pairlist_forces_body<false, OrderedListLookup>(g, a.rec0, pl, partials, 0.0, blockIdx.x, gridDim.x, &ord);
 }
 hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl, const OrderedForcesArgs &a, double *partials,
                                           hipStream_t s, int *blocks_out) {
@@ -5533,6 +5589,5 @@ hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl,
   if (blocks_out) *blocks_out = (int)nb;
   return hipGetLastError();
 }
-long long ordered_max_hills() { return ORD_MAX_HILLS; }
 
 }  // namespace edm

@@ -15,6 +15,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libedm_ref.so")
+REF_MPI_SO = os.path.join(HERE, "_ref", "libedm_ref_mpi.so")   # the reference WITHOUT -DEDM_SERIAL (make ref_mpi)
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)
@@ -136,6 +137,12 @@ class Lib:
         s("bias_get", C.c_double, [vp, C.c_char_p])
         s("bias_set", None, [vp, C.c_char_p, C.c_double])
         s("bias_array", c_dp, [vp, C.c_char_p])
+        if hasattr(self.dll, self.prefix + "mpi_rank"):   # (the reference builds only)
+            s("mpi_rank", C.c_int, [])
+            s("mpi_size", C.c_int, [])
+            s("mpi_barrier", None, [])
+            s("mpi_finalize", None, [])
+            s("is_mpi_build", C.c_int, [])
 
 
 _LIBS = {}
@@ -153,6 +160,12 @@ def load(kind="oracle"):
             if not os.path.exists(REF_SO):
                 raise FileNotFoundError(REF_SO)
             _LIBS[kind] = Lib(REF_SO, "ref_")
+        elif kind == "ref_mpi":
+            if not os.path.exists(REF_MPI_SO) and os.path.isdir("/root/reference/lib"):
+                subprocess.check_call(["make", "-C", HERE, "ref_mpi"], stdout=subprocess.DEVNULL)
+            if not os.path.exists(REF_MPI_SO):
+                raise FileNotFoundError(REF_MPI_SO)
+            _LIBS[kind] = Lib(REF_MPI_SO, "ref_")
         else:
             raise ValueError(kind)
     return _LIBS[kind]

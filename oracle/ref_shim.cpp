@@ -225,7 +225,41 @@ void ref_gauss_multi_write(const ref_gauss *h, const char *filename, int b_lammp
 }
 
 /* ---- bias controller ---- */
+/* the MPI build (oracle/Makefile: ref_mpi, no -DEDM_SERIAL): the controller's constructor already asks for its
+ * rank (edm_bias.cpp:63-65), so MPI must be up before it runs; run under mpiexec every process is one rank */
+int ref_mpi_rank(void) {
+  ensure_mpi();
+  int r = 0;
+  MPI_Comm_rank(MPI_COMM_WORLD, &r);
+  return r;
+}
+int ref_mpi_size(void) {
+  ensure_mpi();
+  int n = 1;
+  MPI_Comm_size(MPI_COMM_WORLD, &n);
+  return n;
+}
+void ref_mpi_barrier(void) {
+  ensure_mpi();
+  MPI_Barrier(MPI_COMM_WORLD);
+}
+void ref_mpi_finalize(void) {
+  int flag = 0;
+  MPI_Initialized(&flag);
+  if (flag) MPI_Finalize();
+}
+int ref_is_mpi_build(void) {
+#ifdef EDM_SERIAL
+  return 0;
+#else
+  return 1;
+#endif
+}
+
 ref_bias *ref_bias_create(const char *input_filename) {
+#ifndef EDM_SERIAL
+  ensure_mpi();
+#endif
   ref_bias *h = new ref_bias;
   /* zero the storage first: the reference leaves several members
    * (hills_added_, b_skip_hill_add_, total_volume_, overflow_buffer_)
@@ -339,6 +373,10 @@ double ref_bias_get(const ref_bias *h, const char *name) {
   G("b_skip_hill_add", b->b_skip_hill_add_);
   G("hills_added", b->hills_added_);
   G("steps", b->steps_);
+  G("mpi_rank", b->mpi_rank_);
+  G("mpi_size", b->mpi_size_);
+  G("mpi_neighbor_count", b->mpi_neighbor_count_);
+  G("temp_hill_cum", b->temp_hill_cum_);
 #undef G
   return NAN;
 }

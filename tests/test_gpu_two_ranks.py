@@ -107,3 +107,93 @@ def test_two_ranks_on_one_gpu(scenario, tmp_path):
             assert np.array_equal(fr, ft), "rank %d forces" % r
             off += fr.shape[1]
         assert np.allclose(ranks[0]["energies"] + ranks[1]["energies"], twin["energies"], rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------
+# against the REFERENCE'S OWN MPI build (lib/ compiled without -DEDM_SERIAL, run under mpiexec -n 2 by
+# oracle/gen_golden_mpi.py; fixtures tests/golden/mpi2_*): edm_bias.cpp:614-706 (flush_buffers), :922-931
+# (update_height), :170-181 (density / prefactor split), :206-220 (total volume), grid.h:509-674 (multi_write)
+# ---------------------------------------------------------------------------------
+import mpi_cases as MC  # noqa: E402
+import golden_util as GU  # noqa: E402
+from test_gpu_parity import _grid_file_numbers, _parse_hills, close  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(MC.MPI_CASES))
+def test_two_ranks_vs_reference_mpi_build(name, tmp_path):
+    H.require_gpu()
+    shm = "/edm_mpi_%s" % uuid.uuid4().hex[:12]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mpi_rank_worker.py"), name, str(r), str(NR), shm,
+                               str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+             for r in range(NR)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+    got = [np.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(NR)]
+    ref = [np.load(os.path.join(GU.GOLDEN, "mpi2_%s_rank%d.npz" % (name, r)), allow_pickle=False) for r in range(NR)]
+    binding = name.endswith("_limit")
+    # what every rank holds after subdivide: density and prefactor per system (edm_bias.cpp:175-180), the volume
+    # summed over the replicas (:206-220) -- exact
+    for r in range(NR):
+        for key in ("total_volume", "hill_density", "hill_prefactor"):
+            assert float(got[r][key]) == float(ref[r][key]), (key, r)
+        # cum_bias_ = sum over ranks of every rank's step total (:925): each hill counted once per rank
+        close(got[r]["cum_bias"], ref[r]["cum_bias"], rtol=1e-12, what="cum_bias rank %d" % r)
+    # the HIP build's replicas are identical, bit for bit (the reference's agree to rounding at best, see below)
+    for key in ("values", "derivs", "hist", "overflow", "hills_added"):
+        assert np.array_equal(got[0][key], got[1][key]), key
+    vmax = np.abs(ref[0]["grid_values"]).max()
+    dmax = np.abs(ref[0]["grid_derivs"]).max()
+    if not binding:
+        # limit not binding: every rank's grid is the sum of all ranks' hills -- in a different order per rank in the
+        # reference (own hills first, then the others in rank order), hence to rounding
+        assert np.abs(ref[0]["grid_values"] - ref[1]["grid_values"]).max() <= 1e-14 * vmax
+        for r in range(NR):
+            close(got[r]["values"], ref[r]["grid_values"], rtol=1e-9, atol=1e-13 * vmax, what="grid vs the reference's rank %d" % r)
+            close(got[r]["derivs"], ref[r]["grid_derivs"], rtol=1e-9, atol=1e-11 * dmax, what="derivs vs the reference's rank %d" % r)
+            assert np.array_equal(got[r]["hist"], ref[r]["hist"])
+            assert np.array_equal(got[r]["hills_added"], ref[r]["hills_added"])
+            assert np.array_equal(got[r]["overflow"], ref[r]["overflow"])
+    else:
+        # DOCUMENTED DEVIATION.  With the limit binding the reference's ranks each limit against
+        # their OWN running sum in their OWN replay order, and their replicas drift apart -- by a quarter of the bias
+        # here.  The HIP build defines the limiter over the global rank-major hill list, which IS the order rank 0 of
+        # the reference replays in: both HIP ranks reproduce the reference's rank 0 (limiter state exact, grid to
+        # rounding) and stay identical to each other.
+        assert np.abs(ref[0]["grid_values"] - ref[1]["grid_values"]).max() > 0.05 * vmax, "the reference's replicas drift"
+        for r in range(NR):
+            close(got[r]["values"], ref[0]["grid_values"], rtol=1e-9, atol=1e-13 * vmax, what="grid vs the reference's rank 0")
+            close(got[r]["derivs"], ref[0]["grid_derivs"], rtol=1e-9, atol=1e-11 * dmax, what="derivs vs the reference's rank 0")
+            assert np.array_equal(got[r]["hist"], ref[0]["hist"])
+            assert np.array_equal(got[r]["hills_added"], ref[0]["hills_added"])
+            assert np.array_equal(got[r]["overflow"], ref[0]["overflow"])
+    # HILLS logs (per rank, <name>_<rank>): the reference's rank r lists its own hills first, then the other ranks' in
+    # rank order; the HIP ranks all list the global rank-major list -- which is rank 0's order.  Same events in the
+    # same order as the reference's rank 0, numbers to the printed precision; rank 1's log holds the same hills.
+    want0 = _parse_hills(os.path.join(GU.GOLDEN, "mpi2_%s_rank0.hills.txt" % name))
+    for r in range(NR):
+        log = _parse_hills(str(tmp_path / ("HILLS_mpi_%d" % r)))
+        assert len(log) == len(want0)
+        for a, w in zip(log, want0):
+            assert a[:3] == w[:3], (a, w)
+            close(a[3:], w[3:], rtol=0, atol=2e-8, what="HILLS line")
+    if not binding:
+        want1 = _parse_hills(os.path.join(GU.GOLDEN, "mpi2_%s_rank1.hills.txt" % name))
+        key = lambda row: (row[0], round(row[3], 7))   # (step, position)
+        assert sorted(map(key, want1)) == sorted(map(key, want0)), "both reference ranks log the same hills"
+    # write_bias of the MPI build = multi_write (grid.h:509-674), written by rank 0
+    gold = os.path.join(GU.GOLDEN, "mpi2_%s.multiwrite.grid" % name)
+    if os.path.exists(gold):
+        h1, n1 = _grid_file_numbers(str(tmp_path / "BIAS_mpi"))
+        h2, n2 = _grid_file_numbers(gold)
+        assert h1 == h2, "multi_write header must be byte-identical"
+        close(n1, n2, rtol=0, atol=1.01e-8, what="multi_write body")
