@@ -5220,7 +5220,7 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
 // ---------------------------------------------------------------------------
 // fix edm_pair in the reference's order (see OrderedForcesArgs in edm_kernels.h)
 // ---------------------------------------------------------------------------
-static constexpr int ORD_NODES = 32, ORD_PARTS = BLOCK / ORD_NODES, ORD_CHUNK = 64;
+static constexpr int ORD_NODES = 32, ORD_PARTS = BLOCK / ORD_NODES, ORD_CHUNK = 64;   // (16-node tiles, twice the workgroups: no faster)
 static constexpr long long ORD_MAX_HILLS = 16384;   // (sample indices in LDS: 64 KB; list counts fit 16 bits)
 long long ordered_max_hills() { return ORD_MAX_HILLS; }
 long long ordered_tiles(const Geom &g) { return (g.n[0] + ORD_NODES - 1) / ORD_NODES; }
@@ -5334,6 +5334,8 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
     if (tr && threadIdx.x == 0 && base == 0) tr[2] = wall_clock64();
     const int nl = s_cnt;
     if (tr && threadIdx.x == 0 && base == 0) tr[7] = (unsigned long long)nl;
+    // (one listed hill per thread and trip: four of them unrolled side by side were tried -- the terms' branches keep
+    //  the chains from interleaving, and with ~6 listed hills per chunk the parts beyond the first two sat idle: slower)
     for (int e = part; e < nl; e += ORD_PARTS) {
       double val = 0, dval[1] = {0};
       if (active && images(g, 0, s_c[e], n, n) != 0) {
@@ -5514,6 +5516,8 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
   // a workgroup owns a contiguous run of pairs: they share their hill count m, i.e. one row of the counts
   const long long beg = (long long)blockIdx.x * per_block;
   const long long end = (beg + per_block < a.n) ? beg + per_block : a.n;
+  // (one pair per thread and trip.  Four pairs per trip, stage by stage -- distances, hill counts, list counts, corner
+  //  records, so that a stage's loads travel together -- was tried and was slower: 25.9 us against 17.3 us per 1 M pairs)
   for (long long i = beg + threadIdx.x; i < end; i += BLOCK) {
     const double x = a.r[i];
     const long long fs = a.first_sample ? (long long)a.first_sample[i] : 2 * i;

@@ -146,8 +146,10 @@ def test_two_ranks_vs_reference_mpi_build(name, tmp_path):
     for r in range(NR):
         for key in ("total_volume", "hill_density", "hill_prefactor"):
             assert float(got[r][key]) == float(ref[r][key]), (key, r)
-        # cum_bias_ = sum over ranks of every rank's step total (:925): each hill counted once per rank
-        close(got[r]["cum_bias"], ref[r]["cum_bias"], rtol=1e-12, what="cum_bias rank %d" % r)
+        # cum_bias_ = sum over ranks of every rank's step total (:925): each hill counted once per rank.  (Limit binding:
+        # the reference adds up step totals that differ from rank to rank in the residue the undo hill leaves above
+        # the limit -- ~1e-7 of it -- where the HIP ranks hold NR times rank 0's.)
+        close(got[r]["cum_bias"], ref[r]["cum_bias"], rtol=1e-6 if binding else 1e-12, what="cum_bias rank %d" % r)
     # the HIP build's replicas are identical, bit for bit (the reference's agree to rounding at best, see below)
     for key in ("values", "derivs", "hist", "overflow", "hills_added"):
         assert np.array_equal(got[0][key], got[1][key]), key
