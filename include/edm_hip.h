@@ -315,9 +315,9 @@ int edm_hip_bias_pair_step_host(edm_hip_bias *b, long long n, const double *h_r,
  * are interpolated on the bias as it stood when the reference's loop reached pair k.
  * d_first_sample[k] (int, n entries, ascending) = index into the sample arrays of pair k's first add_hill call =
  * the number of add_hill calls issued before pair k's update_force.  Single rank only (with a communicator a rank's
- * pairs would see only their own hills: EDM_HIP_ERR_STATE).  The force pass keeps one copy of the 1-D grid per
- * deposited hill (179 KB each on the C1D grid): at most 16 384 hills and 2 GiB per step (beyond: EDM_HIP_ERR_ARG --
- * all-samples deposition of a large system keeps edm_hip_bias_pair_step).  edm_hip_bias_pair_step evaluates every force of the step on the bias as it stands after
+ * pairs would see only their own hills: EDM_HIP_ERR_STATE).  The force pass keeps, per 32-node tile of the grid, the
+ * tile's records behind every hill that reached it (~3 MB for the ~125 hills of a 1 M-pair step): at most 16 384 hills
+ * per step (beyond: EDM_HIP_ERR_ARG -- all-samples deposition of a large system keeps edm_hip_bias_pair_step).  edm_hip_bias_pair_step evaluates every force of the step on the bias as it stands after
  * pre_add_hill instead: faster (the forces share the selection's launch), and on a hill step its forces differ from
  * the reference's by the bias the step itself deposits (INTEGRATION.md has the measured size). */
 int edm_hip_bias_pair_step_ordered(edm_hip_bias *b, long long n, const double *d_r, double *d_force,
