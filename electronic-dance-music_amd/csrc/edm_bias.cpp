@@ -106,7 +106,11 @@ struct edm_hip_bias {
     const double *heights = nullptr, *tail_h1 = nullptr, *tail_h2 = nullptr;
     double h_const = 0;
     const long long *sel = nullptr;
+    // multi-GPU: this rank's slice of the rank-major global list (host values, or where they lie on the device)
+    long long local_off = 0, local_cnt = -1, local_cap = 0;
+    const long long *range_dev = nullptr;
   } last_batch;
+  DevBuf<long long> ord_range;
   DevBuf<double> ord_rec0, ord_records;   // OrderedForcesArgs::rec0 (taken before the batch) / ::records
   DevBuf<unsigned short> ord_counts;
   DevBuf<unsigned long long> ord_dirty;
@@ -296,7 +300,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   b->pl_it_entry.release(); b->pl_jt_entry.release();
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
-  b->ord_rec0.release(); b->ord_records.release(); b->ord_counts.release(); b->ord_dirty.release(); b->ord_first.release();
+  b->ord_range.release(); b->ord_rec0.release(); b->ord_records.release(); b->ord_counts.release(); b->ord_dirty.release(); b->ord_first.release();
   delete b;
   return EDM_HIP_OK;
 }
@@ -633,6 +637,8 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       sel_args.count_dev = b->count_dev.p;
       sel_args.ticket = b->bias->d_tickets;
       sel_args.pack = b->xchg_send.p;
+      EDM_HIP_TRY(b->sel.reserve((size_t)pack_bound));
+      sel_args.sel = b->sel.p;   // (this rank's accepted sample indices, for the reference-order force pass)
       HillList src;
       memset(&src, 0, sizeof(src));
       src.nh = pack_bound;
@@ -665,6 +671,9 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     unp_args.all = b->xchg_all.p;
     unp_args.count_dev = b->count_dev.p;
     unp_args.count_host = b->d_count;
+    EDM_HIP_TRY(b->ord_range.reserve(2));
+    unp_args.rank = (pack_ranks == b->nranks) ? b->rank : 0;
+    unp_args.local_range = b->ord_range.p;
     nh = pack_bound * pack_ranks;
     deferred_bound = nh;
     d_x = b->xchg_all.p;
@@ -725,6 +734,8 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     int rcp = pending_forces_flush(b->bias, &b->pending);
     if (rcp) return rcp;
   }
+  const long long *local_sel = d_sel;   // (before a synchronous exchange replaces the list by the global one)
+  const long long local_nh = nh;
   bool rank_heights = false;
   if (b->comm && !packed_exchange) {
     const double *d_all = nullptr;
@@ -853,6 +864,19 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   b->last_batch.tail_h1 = oc.d_tail_h1;
   b->last_batch.tail_h2 = oc.d_tail_h2;
   b->last_batch.sel = d_sel;
+  b->last_batch.local_cnt = -1;
+  b->last_batch.range_dev = nullptr;
+  if (packed_exchange) {
+    b->last_batch.sel = b->sel.p;
+    b->last_batch.range_dev = b->ord_range.p;
+    b->last_batch.local_cap = pack_bound;
+  } else if (b->comm) {
+    long long off = 0;
+    for (int r = 0; r < b->rank; r++) off += b->xchg_counts[r];
+    b->last_batch.sel = local_sel;
+    b->last_batch.local_off = off;
+    b->last_batch.local_cnt = local_nh;
+  }
 
   const long long k = res.k;
   const int ntail = res.n_tail;
@@ -1083,11 +1107,6 @@ static int ordered_snapshot(edm_hip_bias *b) {
     set_error("reference-order pair step: needs a 1-D bias whose stencil is not wider than a periodic grid");
     return EDM_HIP_ERR_ARG;
   }
-  if (b->comm) {
-    set_error("reference-order pair step: single-rank only (a rank's pairs would see only its own hills); "
-              "use edm_hip_bias_pair_step / reference_order 0 with a communicator");
-    return EDM_HIP_ERR_STATE;
-  }
   const size_t grid_doubles = (size_t)g->g.total * (size_t)g->g.rec;
   EDM_HIP_TRY(b->ord_rec0.reserve(grid_doubles));
   EDM_HIP_TRY(hipMemcpyAsync(b->ord_rec0.p, g->rec, sizeof(double) * grid_doubles, hipMemcpyDeviceToDevice, g->stream));
@@ -1097,7 +1116,9 @@ static int ordered_snapshot(edm_hip_bias *b) {
 // ... and, once the step's hill batch has been applied (last_batch), the running records of its hills
 static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
   edm_hip_gauss *g = b->bias;
-  const long long nh = b->last_batch.nh;
+  const bool sliced = b->last_batch.range_dev != nullptr || b->last_batch.local_cnt >= 0;
+  const long long nh = b->last_batch.range_dev ? b->last_batch.local_cap
+                       : (b->last_batch.local_cnt >= 0 ? b->last_batch.local_cnt : b->last_batch.nh);
   if (nh > ordered_max_hills()) {
     set_error("reference-order pair step: more than 16384 hills in one step; use edm_hip_bias_pair_step (all forces on the "
               "step-start bias) for all-samples deposition of a large system");
@@ -1113,6 +1134,8 @@ static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
   memset(&a, 0, sizeof(a));
   a.nh = nh;
   a.nh_cap = cap;
+  a.hill_off = sliced ? b->last_batch.local_off : 0;
+  a.range_dev = b->last_batch.range_dev;
   a.k = b->last_batch.k;
   a.heights = b->last_batch.heights;
   a.h_const = b->last_batch.h_const;

@@ -133,8 +133,14 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
 //       the pair.
 // 1-D grids only (fix_edm_pair.cpp:52), stencil not wider than a periodic grid, at most ordered_max_hills() hills.
 struct OrderedForcesArgs {
-  long long nh;             // hills of the step's batch (true count)
+  long long nh;             // this rank's hills of the step's batch (true count; unused with range_dev)
   long long nh_cap;         // hills the record / count buffers were sized for (>= nh)
+  // multi-GPU: the batch is the rank-major global list and this rank's hills are its slice [hill_off, hill_off + nh) --
+  // the reference's ranks see their own hills while they walk their pairs, the other ranks' only from post_add_hill
+  // on (edm_bias.cpp:565-583).  range_dev (device, {offset, count}) overrides hill_off / nh where the host does not
+  // know them (the packed exchange); nh_cap then bounds the count.
+  long long hill_off;
+  const long long *range_dev;
   long long k;              // hills [0, k): base height; hills >= k: the limiter's tail arrays (see HillHeights)
   const double *heights;    // per-hill base heights or NULL (h_const)
   double h_const;
@@ -142,7 +148,7 @@ struct OrderedForcesArgs {
   const double *hx;         // prepared hills: remapped position, centre node, (t1, t3)
   const int *hc;
   const double *ht;
-  const long long *sel;     // sample index of hill j, ascending (NULL: hill j is sample j)
+  const long long *sel;     // sample index of this rank's hill j, ascending (NULL: hill j is sample j)
   const double *rec0;       // the node records before the batch
   double *records;          // [tiles][nh_cap][32][2], see launch_ordered_records
   unsigned short *counts;   // [nh + 1][tiles]
@@ -268,6 +274,8 @@ struct UnpackArgs {
   double *all;            // out: positions of the global list, stride dim
   long long *count_dev;   // out: global count (poisoned when a rank overflowed its packet)
   long long *count_host;
+  int rank;               // this rank, and (optional) where its slice {offset, count} of the global list goes
+  long long *local_range;
 };
 hipError_t launch_unpack_prep(const UnpackArgs &a, const Geom &g, const HillList &h, hipStream_t s);
 struct RankHeights {

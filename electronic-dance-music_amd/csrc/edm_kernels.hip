@@ -1835,6 +1835,7 @@ __device__ __forceinline__ void select_emit(const SelectArgs &a, const Geom &g, 
     sample_position<DIM>(h, src, x);
 #pragma unroll
     for (int d = 0; d < DIM; d++) a.pack[1 + i * DIM + d] = x[d];
+    if (a.sel) a.sel[i] = src;   // (the reference-order force pass needs this rank's accepted sample indices)
   } else {
     a.sel[i] = src;
     hill_prep_one<DIM>(g, h, i, src);
@@ -2180,6 +2181,10 @@ __global__ void __launch_bounds__(BLOCK) k_unpack_prep(UnpackArgs a, Geom g, Hil
     }
     s_off[a.nranks] = run;
     s_bad = bad;
+    if (a.local_range) {   // this rank's slice of the rank-major list (the reference-order force pass)
+      a.local_range[0] = s_off[a.rank];
+      a.local_range[1] = s_off[a.rank + 1] - s_off[a.rank];
+    }
     const long long total = bad ? (long long)0x3fffffffffffffffLL : run;
     *a.count_dev = total;
     *a.count_host = total;
@@ -5290,15 +5295,21 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
     a.counts[tile] = 0;   // (row m = 0)
     s_dirty = INT_MAX;
   }
-  for (long long base = 0; base < a.nh; base += ORD_CHUNK) {
-    const int cnt = (a.nh - base < ORD_CHUNK) ? (int)(a.nh - base) : ORD_CHUNK;
+  // this rank's hills: the whole batch, or (multi-GPU) its slice [off, off + nloc) of the rank-major global list --
+  // the reference's ranks see their OWN hills of the step while they walk their pairs and replay the other ranks'
+  // only in post_add_hill (edm_bias.cpp:565-583)
+  const long long off = a.range_dev ? a.range_dev[0] : a.hill_off;
+  long long nloc = a.range_dev ? a.range_dev[1] : a.nh;
+  if (nloc > a.nh_cap) nloc = a.nh_cap;
+  for (long long base = 0; base < nloc; base += ORD_CHUNK) {
+    const int cnt = (nloc - base < ORD_CHUNK) ? (int)(nloc - base) : ORD_CHUNK;
     int first_nz = -1;    // list position of this thread's first such term of the chunk
     if (threadIdx.x < 64) {   // wave 0: one hill of the chunk per lane
       bool take = false;
       int c = INT_MIN;
       double hx = 0, ht0 = 0, ht1 = 0, a1 = 0, a2 = 0;
       if ((int)threadIdx.x < cnt) {
-        const long long cur = base + threadIdx.x;
+        const long long cur = off + base + threadIdx.x;   // (index in the batch's hill list)
         c = a.hc[cur];
         hx = a.hx[cur];
         if (!PERB) {
@@ -5399,7 +5410,7 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
 }
 
 hipError_t launch_ordered_records(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s) {
-  if (!ordered_forces_supported(g) || a.nh > a.nh_cap || a.nh > ORD_MAX_HILLS) return hipErrorInvalidValue;
+  if (!ordered_forces_supported(g) || (!a.range_dev && a.nh > a.nh_cap) || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
   const unsigned nb = (unsigned)ordered_tiles(g);
   if (g.bper[0])
     hipLaunchKernelGGL(k_ordered_records<true>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
@@ -5419,7 +5430,9 @@ struct OrderedCommon {
 };
 __device__ __forceinline__ void ordered_common_init(const Geom &g, const OrderedForcesArgs &a, const DupPlan &dp, int *s_samples,
                                                     OrderedCommon &oc) {
-  oc.H = (int)a.nh;
+  long long nloc = a.range_dev ? a.range_dev[1] : a.nh;
+  if (nloc > a.nh_cap) nloc = a.nh_cap;
+  oc.H = (int)nloc;
   for (int i = threadIdx.x; i < oc.H; i += blockDim.x) s_samples[i] = a.sel ? (int)a.sel[i] : i;
   __syncthreads();
   oc.samples = s_samples;
@@ -5535,7 +5548,7 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
 
 hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
                                       int *blocks_out, unsigned long long tag) {
-  if (!ordered_forces_supported(g) || a.nh > ORD_MAX_HILLS) return hipErrorInvalidValue;
+  if (!ordered_forces_supported(g) || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
   long long blocks = (a.n + 4 * BLOCK - 1) / (4 * BLOCK);   // four pairs per thread
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
@@ -5548,7 +5561,7 @@ hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a,
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const size_t lds = sizeof(int) * (size_t)(a.nh > 0 ? a.nh : 1);
+  const size_t lds = sizeof(int) * (size_t)((a.range_dev ? a.nh_cap : a.nh) > 0 ? (a.range_dev ? a.nh_cap : a.nh) : 1);
   hipLaunchKernelGGL(k_pair_forces_ordered, dim3((unsigned)blocks), dim3(BLOCK), lds, s, g, a, dp, scratch, tag, per_block);
   if (blocks_out) *blocks_out = (int)blocks;
   return hipGetLastError();
@@ -5574,7 +5587,7 @@ __global__ void __launch_bounds__(BLOCK) k_pairlist_forces_ordered(Geom g, PairL
 }
 hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl, const OrderedForcesArgs &a, double *partials,
                                           hipStream_t s, int *blocks_out) {
-  if (!ordered_forces_supported(g) || !pl.it_entry || !pl.jt_entry || a.nh > ORD_MAX_HILLS) return hipErrorInvalidValue;
+  if (!ordered_forces_supported(g) || !pl.it_entry || !pl.jt_entry || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
   if (blocks_out) *blocks_out = 0;
   if (pl.nall <= 0) return hipSuccess;
   const long long threads = (long long)pl.nall * 16;
@@ -5588,7 +5601,7 @@ hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl,
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const size_t lds = sizeof(int) * (size_t)(a.nh > 0 ? a.nh : 1);
+  const size_t lds = sizeof(int) * (size_t)((a.range_dev ? a.nh_cap : a.nh) > 0 ? (a.range_dev ? a.nh_cap : a.nh) : 1);
   hipLaunchKernelGGL(k_pairlist_forces_ordered, dim3((unsigned)nb), dim3(BLOCK), lds, s, g, pl, a, dp, partials);
   if (blocks_out) *blocks_out = (int)nb;
   return hipGetLastError();

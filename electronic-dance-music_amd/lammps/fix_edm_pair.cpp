@@ -77,9 +77,8 @@ FixEDMPair::FixEDMPair(LAMMPS *lmp, int narg, char **arg) : Fix(lmp, narg, arg),
   }
   last_list_size = -1;
   if (gpu_list) device_rng = true;
-  // with more than one rank a rank's pairs would see only its own hills of the step: the multi-GPU exchange applies
-  // the ranks' hills as one global batch, so the batch order is the only one defined there
-  if (size > 1) batch_order = true;
+  // (with more than one rank a rank's pairs see ITS OWN hills of the step, like the reference's, whose ranks replay the
+  //  other ranks' hills in post_add_hill only)
   if (device_rng) bias->set_device_rng(true, (unsigned long long) seed + (unsigned long long) me);
   bias->set_reference_order(!batch_order);
   random = new RanMars(lmp, seed + me);

@@ -314,8 +314,9 @@ int edm_hip_bias_pair_step_host(edm_hip_bias *b, long long n, const double *h_r,
  * histogram, HILLS log and limiter state are those of edm_hip_bias_pair_step bit for bit); d_force[k] and the energy
  * are interpolated on the bias as it stood when the reference's loop reached pair k.
  * d_first_sample[k] (int, n entries, ascending) = index into the sample arrays of pair k's first add_hill call =
- * the number of add_hill calls issued before pair k's update_force.  Single rank only (with a communicator a rank's
- * pairs would see only their own hills: EDM_HIP_ERR_STATE).  The force pass keeps, per 32-node tile of the grid, the
+ * the number of add_hill calls issued before pair k's update_force.  With a communicator a rank's pairs see the hills
+ * of THAT RANK'S earlier add_hill calls -- the reference's ranks replay each other's hills in post_add_hill only
+ * (edm_bias.cpp:565-583, :630-706).  The force pass keeps, per 32-node tile of the grid, the
  * tile's records behind every hill that reached it (~3 MB for the ~125 hills of a 1 M-pair step): at most 16 384 hills
  * per step (beyond: EDM_HIP_ERR_ARG -- all-samples deposition of a large system keeps edm_hip_bias_pair_step).  edm_hip_bias_pair_step evaluates every force of the step on the bias as it stands after
  * pre_add_hill instead: faster (the forces share the selection's launch), and on a hill step its forces differ from

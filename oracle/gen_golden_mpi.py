@@ -43,8 +43,17 @@ def worker(tmp):
         # the replicated decomposition of fix edm_pair (fix_edm_pair.cpp:95-104): every rank passes the whole range
         b.subdivide([spec["lo"]], [spec["hi"]], [spec["lo"]], [spec["hi"]], [0], [spec["skin"]])
         rec = dict(cum=[], temp_before_post=[], overflow=[], hills_added=[])
+        E, F, NC = [], [], []
+        last_calls = spec.get("nmax", 0)
         for step in range(spec["steps"]):
-            if spec["mode"] == "explicit":
+            if spec["mode"] == "pair_loop":
+                r, second, ru = MC.pair_loop_inputs(name, step, rank)
+                e, f, nc = b.pair_loop(r, second, ru, 1, last_calls)
+                last_calls = nc
+                E.append(e)
+                F.append(f)
+                NC.append(nc)
+            elif spec["mode"] == "explicit":
                 b.pre_add_hill(1)
                 b.add_hill(spec["hills"][rank], 1.0)
                 b.post_add_hill()
@@ -60,7 +69,8 @@ def worker(tmp):
                             cum_bias=np.array(rec["cum"]), overflow=np.array(rec["overflow"], dtype=np.int64),
                             hills_added=np.array(rec["hills_added"], dtype=np.int64),
                             total_volume=b.get("total_volume"), hill_density=b.get("hill_density"),
-                            hill_prefactor=b.get("hill_prefactor"), mpi_neighbor_count=b.get("mpi_neighbor_count"))
+                            hill_prefactor=b.get("hill_prefactor"), mpi_neighbor_count=b.get("mpi_neighbor_count"),
+                            energy=np.array(E), force=np.array(F), ncalls=np.array(NC, dtype=np.int64))
         # write_bias of the MPI build is the collective multi_write (edm_bias.cpp:224-235, grid.h:509-674): rank 0's file
         bias_file = os.path.join(tmp, "BIAS_" + name)
         b.write_bias(bias_file)

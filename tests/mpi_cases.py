@@ -28,7 +28,23 @@ MPI_CASES = {
         cfg="tempering 0\nhill_prefactor 0.5\nhill_density 40\nbias_per_step 0.3\ndimension 1\nbox_low 0\nbox_high 2.8\n"
             "bias_spacing 0.001\nbias_sigma 0.05",
         lo=0.0, hi=2.8, skin=0.3, mode="array", steps=3, n=2048),
+    # the pair fix's own loop on every rank (lammps/fix_edm_pair.cpp:173-247): per pair update_force, then its add_hill
+    # calls -- a rank's pairs see that rank's earlier hills of the step; the other ranks' arrive in post_add_hill
+    "pair_loop": dict(
+        cfg="tempering 0\nhill_prefactor 0.5\nhill_density 60\nbias_per_step 1000\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+            "bias_spacing 0.001\nbias_sigma 0.05",
+        lo=0.0, hi=2.8, skin=0.3, mode="pair_loop", steps=3, n=3000, nmax=4000),
 }
+
+
+def pair_loop_inputs(name, step, rank):
+    """(r[n], second[n], uniforms[2 n]) of `rank` at `step` (pair_loop cases)"""
+    spec = MPI_CASES[name]
+    seed = 14000 + 1000 * sorted(MPI_CASES).index(name) + 10 * step + rank
+    n = spec["n"]
+    r = np.cbrt(W.uniform(seed, n) * (2.8 ** 3 - 0.85 ** 3) + 0.85 ** 3)
+    second = (W.uniform(seed + 3, n) < 0.7).astype(np.int32)
+    return r, second, W.uniform(seed + 6, 2 * n)
 
 
 def mpi_inputs(name, step, rank):

@@ -27,8 +27,21 @@ def main():
     b.setup(1.0, 1.0)
     b.subdivide([spec["lo"]], [spec["hi"]], [spec["lo"]], [spec["hi"]], [0], [spec["skin"]])
     cum, ovf, hadd = [], [], []
+    E, F = [], []
+    last_calls = spec.get("nmax", 0)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pairfix_cases as PF
+
     for step in range(spec["steps"]):
-        if spec["mode"] == "explicit":
+        if spec["mode"] == "pair_loop":
+            # the rewritten fix's hill step in the reference's order (edm_hip_bias_pair_step_ordered_host)
+            r, second, ru = MC.pair_loop_inputs(name, step, rank)
+            xs, us = PF.staged_samples(r, second, ru)
+            f = np.zeros(len(r))
+            E.append(b.pair_step_ordered_host(r, f, PF.first_calls(second), xs, us, est=last_calls))
+            F.append(f)
+            last_calls = len(xs)
+        elif spec["mode"] == "explicit":
             b.pre_add_hill(1)
             b.add_hill(spec["hills"][rank], 1.0)
             b.post_add_hill()
@@ -42,7 +55,8 @@ def main():
     b.write_bias(os.path.join(outdir, "BIAS_mpi"), 0)    # the MPI build's write_bias = multi_write; rank 0 writes
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), values=v, derivs=dv, hist=b.hist.values, cum_bias=np.array(cum),
              overflow=np.array(ovf, dtype=np.int64), hills_added=np.array(hadd, dtype=np.int64),
-             total_volume=b.get("total_volume"), hill_density=b.get("hill_density"), hill_prefactor=b.get("hill_prefactor"))
+             total_volume=b.get("total_volume"), hill_density=b.get("hill_density"), hill_prefactor=b.get("hill_prefactor"),
+             energy=np.array(E), force=np.array(F))
     del b
     print("rank %d done" % rank)
 
