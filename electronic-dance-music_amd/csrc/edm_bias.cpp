@@ -14,6 +14,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <map>
 #include <string>
 #include <vector>
@@ -24,6 +28,94 @@
 using namespace edm;
 
 #define BIAS_CLAMP 1.0  // edm_bias.h:14
+
+// The per-rank HILLS log (edm_bias.cpp:586-599: one text line per hill event, eight decimals) written by a thread of
+// its own: the step hands over the events as numbers -- a line costs ~1 us of printf, a W1 step logs ~125 of them,
+// four times what the step's kernels take -- and the writer formats them, in order, and flushes the file after every
+// add_hill cycle like the reference's std::endl does.  drain() returns once everything handed over is in the file.
+struct HillEvent {
+  long long steps;
+  int hills_added;
+  char type;
+  double pos[3], height, added, cum_over_volume;
+};
+class HillWriter {
+ public:
+  HillWriter() : fp_(nullptr), dim_(1), stop_(false), busy_(false) {}
+  ~HillWriter() { close(); }
+  bool open(const char *path, unsigned dim) {
+    close();
+    fp_ = fopen(path, "w");
+    dim_ = dim;
+    if (!fp_) return false;
+    stop_ = false;
+    th_ = std::thread(&HillWriter::run, this);
+    return true;
+  }
+  bool is_open() const { return fp_ != nullptr; }
+  void submit(std::vector<HillEvent> &events) {   // (takes the events; leaves the vector empty)
+    if (!fp_) {
+      events.clear();
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      q_.emplace_back();
+      q_.back().swap(events);
+    }
+    cv_.notify_one();
+  }
+  void drain() {
+    if (!fp_) return;
+    std::unique_lock<std::mutex> lk(m_);
+    idle_.wait(lk, [this] { return q_.empty() && !busy_; });
+  }
+  void close() {
+    if (!fp_) return;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_one();
+    if (th_.joinable()) th_.join();
+    fclose(fp_);
+    fp_ = nullptr;
+  }
+
+ private:
+  void run() {
+    std::unique_lock<std::mutex> lk(m_);
+    for (;;) {
+      cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+      if (q_.empty()) {
+        if (stop_) return;
+        continue;
+      }
+      std::vector<HillEvent> batch;
+      batch.swap(q_.front());
+      q_.pop_front();
+      busy_ = true;
+      lk.unlock();
+      for (size_t i = 0; i < batch.size(); i++) {
+        const HillEvent &e = batch[i];
+        fprintf(fp_, "%lld %c %d ", e.steps, e.type, e.hills_added);
+        for (unsigned int d = 0; d < dim_; d++) fprintf(fp_, "%.8f ", e.pos[d]);
+        fprintf(fp_, "%.8f %.8f %.8f\n", e.height, e.added, e.cum_over_volume);
+      }
+      fflush(fp_);
+      lk.lock();
+      busy_ = false;
+      if (q_.empty()) idle_.notify_all();
+    }
+  }
+  FILE *fp_;
+  unsigned dim_;
+  std::thread th_;
+  std::mutex m_;
+  std::condition_variable cv_, idle_;
+  std::deque<std::vector<HillEvent> > q_;
+  bool stop_, busy_;
+};
 
 struct edm_hip_bias {
   // public data members of EDMBias (edm_bias.h:118-157)
@@ -47,7 +139,16 @@ struct edm_hip_bias {
   int hills_added = 0;
   long long steps = 0;
   std::string hist_output, hills_name;
-  FILE *hills_fp = nullptr;
+  // new hills whose log lines are still owed: the batch was released by its header line (every hill added in full) and
+  // its positions / per-hill bias are fetched when the next add_hill cycle begins (resolve_deferred_log)
+  struct DeferredLog {
+    bool active = false;
+    long long bound = 0, nh = 0, steps = 0;
+    int hills_added_before = 0;
+    double height = 0, cum_over_volume = 0;
+  } deferred_log;
+  HillWriter hills;                  // the HILLS log, written behind the step by a thread of its own
+  std::vector<HillEvent> hill_events;   // events of the add_hill cycle in progress
   int hill_log = 1;
   std::vector<double> overflow;  // (dim+1) doubles per record, BIAS_BUFFER_SIZE + 1 records
   size_t overflow_left = 0, overflow_right = 0;
@@ -256,16 +357,44 @@ static int read_input(edm_hip_bias *b, const char *filename) {
 }
 
 static void open_hills(edm_hip_bias *b) {
-  if (b->hills_fp) return;
-  b->hills_fp = fopen(clean_string(b->hills_name, true, b->mpi_rank).c_str(), "w");
+  if (b->hills.is_open()) return;
+  b->hills.open(clean_string(b->hills_name, true, b->mpi_rank).c_str(), b->dim);
 }
 
 // edm_bias.cpp:586-599 (text) -- the histogram part of output_hill runs on the device
 static void log_hill(edm_hip_bias *b, const double *pos, double height, double added, char type) {
-  if (!b->hill_log || !b->hills_fp) return;
-  fprintf(b->hills_fp, "%lld %c %d ", b->steps, type, b->hills_added);
-  for (unsigned int d = 0; d < b->dim; d++) fprintf(b->hills_fp, "%.8f ", pos[d]);
-  fprintf(b->hills_fp, "%.8f %.8f %.8f\n", height, added, b->cum_bias / b->total_volume);
+  if (!b->hill_log || !b->hills.is_open()) return;
+  HillEvent e;
+  e.steps = b->steps;
+  e.hills_added = b->hills_added;
+  e.type = type;
+  for (unsigned int d = 0; d < 3; d++) e.pos[d] = d < b->dim ? pos[d] : 0.0;
+  e.height = height;
+  e.added = added;
+  e.cum_over_volume = b->cum_bias / b->total_volume;
+  b->hill_events.push_back(e);
+}
+
+// the 'h' lines of a batch whose read-back was deferred (edm_bias.cpp:586-599, one per hill, in order)
+static int resolve_deferred_log(edm_hip_bias *b) {
+  if (!b->deferred_log.active) return EDM_HIP_OK;
+  b->deferred_log.active = false;
+  std::vector<double> pos, added;
+  int rc = apply_hills_fetch_deferred(b->bias, b->deferred_log.bound, b->deferred_log.nh, pos, added);
+  if (rc) return rc;
+  std::vector<HillEvent> ev((size_t)b->deferred_log.nh);
+  for (long long i = 0; i < b->deferred_log.nh; i++) {
+    HillEvent &e = ev[(size_t)i];
+    e.steps = b->deferred_log.steps;
+    e.hills_added = b->deferred_log.hills_added_before + (int)i + 1;
+    e.type = 'h';
+    for (unsigned int d = 0; d < 3; d++) e.pos[d] = d < b->dim ? pos[(size_t)i * b->dim + d] : 0.0;
+    e.height = b->deferred_log.height;
+    e.added = added[(size_t)i];
+    e.cum_over_volume = b->deferred_log.cum_over_volume;
+  }
+  b->hills.submit(ev);
+  return EDM_HIP_OK;
 }
 
 extern "C" {
@@ -289,10 +418,12 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   }
   if (b->copy_event) (void)hipEventDestroy(b->copy_event);
   b->hs_r.release(); b->hs_f.release(); b->hs_x.release(); b->hs_u.release();
+  (void)resolve_deferred_log(b);
+  b->hills.submit(b->hill_events);
+  b->hills.close();
   edm_hip_gauss_destroy(b->bias);
   edm_hip_grid_destroy(b->hist);
   edm_hip_grid_destroy(b->target);
-  if (b->hills_fp) fclose(b->hills_fp);
   b->sel.release(); b->sel_scratch.release(); b->count_dev.release(); b->sel_stage.release();
   if (b->h_flush) (void)hipHostFree(b->h_flush);
   b->vs_r.release(); b->vs_mask.release(); b->pl_i.release(); b->pl_j.release(); b->pl_type.release();
@@ -455,7 +586,7 @@ static int flush_overflow(edm_hip_bias *b, double max_bias, double *bias_added) 
   spec.cum_in = 0;
   spec.hist_g = &b->hist->g;
   spec.hist_values = b->hist->values;
-  const bool log_all = b->hill_log && b->hills_fp;
+  const bool log_all = b->hill_log && b->hills.is_open();
   spec.fetch_all = log_all;     // (per-hill bias only for the HILLS log; without one the limiter's header line is enough)
   spec.fetch_heights = false;   // (the heights came from the host's own overflow records)
   spec.forces = b->flush_forces;   // (fix edm step: its pending force kernel can share the preparation's launch)
@@ -490,6 +621,10 @@ static int do_pre_add_hill(edm_hip_bias *b, long long est) {
   if (!b->bias) {
     set_error("pre_add_hill before subdivide");
     return EDM_HIP_ERR_STATE;
+  }
+  {
+    int rcd = resolve_deferred_log(b);   // (the previous cycle's log lines, if they were deferred)
+    if (rcd) return rcd;
   }
   b->est_hill_count = est;
   b->temp_hill_prefactor = b->hill_prefactor;
@@ -813,8 +948,9 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   } else if (b->debug_virtual_ranks > 1 && !packed_exchange) {
     spec.shard_virtual = b->debug_virtual_ranks;
   }
-  const bool log_all = b->hill_log && b->hills_fp;
+  const bool log_all = b->hill_log && b->hills.is_open();
   spec.fetch_all = log_all;
+  spec.defer_fetch_ok = log_all;   // (the log lines of a batch the limiter left alone are written behind the step)
   if (local_tempering) {
     // the height of hill i depends on the grid that already holds hills < i (:547-549):
     // strictly ordered application by one workgroup
@@ -881,6 +1017,19 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   const long long k = res.k;
   const int ntail = res.n_tail;
   const unsigned int dim = b->dim;
+  if (oc.deferred_fetch) {
+    // every hill was added in full and the host was released by the limiter's header line: positions and per-hill bias
+    // are still on their way -- the 'h' lines are written when the next cycle begins (resolve_deferred_log)
+    b->deferred_log.active = true;
+    b->deferred_log.bound = oc.deferred_bound;
+    b->deferred_log.nh = res.nh;
+    b->deferred_log.steps = b->steps;
+    b->deferred_log.hills_added_before = b->hills_added;
+    b->deferred_log.height = this_h;
+    b->deferred_log.cum_over_volume = b->cum_bias / b->total_volume;
+    b->hills_added += (int)res.nh;
+    return EDM_HIP_OK;
+  }
   const long long first = oc.first;
   // base height of hill i (constant, or per hill when a target is set)
   auto height_of = [&](long long i) { return oc.heights.empty() ? this_h : oc.heights[(size_t)(i - first)]; };
@@ -931,7 +1080,7 @@ static int do_post_add_hill(edm_hip_bias *b) {
   b->temp_hill_prefactor = -1;
   b->steps++;
   b->rng_cycle++;
-  if (b->hills_fp) fflush(b->hills_fp);
+  if (!b->hill_events.empty()) b->hills.submit(b->hill_events);   // (formatted, written and flushed by the writer thread)
   return EDM_HIP_OK;
 }
 
@@ -1605,6 +1754,8 @@ int edm_hip_bias_post_add_hill(edm_hip_bias *b) {
 // reference's multi_write (rank 0 opens the file, grid.h:549) only rank 0 writes; the other ranks just let
 // their queued updates finish, so a file is never truncated under another rank's writer.
 static bool writes_files(const edm_hip_bias *b) {
+  (void)resolve_deferred_log(const_cast<edm_hip_bias *>(b));
+  const_cast<edm_hip_bias *>(b)->hills.drain();   // (a caller that writes its files expects the HILLS log on disk as well)
   if (b->nranks <= 1 || b->rank == 0) return true;
   if (b->bias) (void)hipStreamSynchronize(b->bias->stream);
   return false;
@@ -1715,6 +1866,11 @@ int edm_hip_bias_set_device_rng(edm_hip_bias *b, int enabled, unsigned long long
 }
 
 int edm_hip_bias_set_hill_log(edm_hip_bias *b, int enabled) {
+  if (!enabled) {   // (what was logged so far reaches the file now)
+    (void)resolve_deferred_log(b);
+    b->hills.submit(b->hill_events);
+    b->hills.drain();
+  }
   b->hill_log = enabled;
   return EDM_HIP_OK;
 }
@@ -1740,10 +1896,9 @@ int edm_hip_bias_comm_init(edm_hip_bias *b, const void *id_bytes, int nranks, in
     // the HILLS log is per rank (<name>_<rank>, edm_bias.cpp:1104-1107)
     // (the handle was created before its rank was known and opened <name>_0 -- which IS rank 0's log: close our
     //  descriptor, never remove the file)
-    if (b->hills_fp) {
-      fclose(b->hills_fp);
-      b->hills_fp = nullptr;
-    }
+    (void)resolve_deferred_log(b);
+    b->hills.submit(b->hill_events);
+    b->hills.close();
     b->mpi_rank = rank;
     open_hills(b);
   }

@@ -1337,7 +1337,49 @@ static long long tiles_per_hill_bound(const Geom &q) {
   return best;
 }
 
+// the read-back region of a batch released by its header line, copied out of the staging buffer (after its
+// completion word has arrived: normally long ago) so that the next batch can reuse the buffer
+static int save_pending_region(edm_hip_gauss *g) {
+  if (!g->rb_pending_seq) return EDM_HIP_OK;
+  volatile unsigned long long *w = reinterpret_cast<volatile unsigned long long *>(g->h_stage + g->h_stage_bytes - 128);
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+  bool seen = false;
+  for (unsigned spin = 0;; spin++) {
+    if (w[0] >= g->rb_pending_seq) { seen = true; break; }
+    __builtin_ia32_pause();
+    if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
+  }
+  if (!seen) EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  std::atomic_thread_fence(std::memory_order_acquire);
+  g->rb_saved.assign(g->h_stage, g->h_stage + g->rb_pending_bytes);
+  g->rb_pending_seq = 0;
+  return EDM_HIP_OK;
+}
+int apply_hills_fetch_deferred(edm_hip_gauss *g, long long nh_bound, long long nh, std::vector<double> &pos,
+                               std::vector<double> &added) {
+  int rc = save_pending_region(g);
+  if (rc) return rc;
+  const int dim = g->g.dim;
+  const size_t off_flags = 64;
+  const size_t off_h2 = off_flags + ((sizeof(int) * (size_t)nh_bound + 7) & ~(size_t)7);
+  const size_t off_added = off_h2 + 2 * sizeof(double) * (size_t)nh_bound;
+  const size_t off_pos = off_added + sizeof(double) * (size_t)nh_bound;
+  if (g->rb_saved.size() < off_pos + sizeof(double) * (size_t)nh_bound * dim || nh > nh_bound) {
+    set_error("apply_hills_fetch_deferred: no deferred read-back of that shape");
+    return EDM_HIP_ERR_STATE;
+  }
+  const double *a = reinterpret_cast<const double *>(g->rb_saved.data() + off_added);
+  const double *p = reinterpret_cast<const double *>(g->rb_saved.data() + off_pos);
+  added.assign(a, a + nh);
+  pos.assign(p, p + (size_t)nh * dim);
+  return EDM_HIP_OK;
+}
+
 int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool want_total) {
+  {
+    int rcs = save_pending_region(g);   // (a deferred read-back nobody has fetched yet: keep it before its buffer is reused)
+    if (rcs) return rcs;
+  }
   const Geom &q = g->g;
   HillWorkspace &ws = g->ws;
   const long long nh = spec.nh;
@@ -1349,6 +1391,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     out->flags.clear(); out->h2.clear(); out->a2.clear(); out->pos.clear(); out->added.clear(); out->heights.clear();
     out->first = nh;
     out->plain_fast = false;
+    out->deferred_fetch = false;
+    out->deferred_bound = 0;
   }
   if (nh <= 0) return EDM_HIP_OK;
   hipStream_t s = g->stream;
@@ -2043,7 +2087,10 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     static const bool header_env = !(getenv("EDM_HIP_FAST_HEADER") && getenv("EDM_HIP_FAST_HEADER")[0] == '0');   // (A/B and tests)
     // (A flush of the overflow buffer: the line carries the stop index and that hill's undo height -- all the host's
     // replay needs when there is no log.)
-    bool header_may_do = header_env && spec.limited && !spec.fetch_all && out != nullptr &&
+    // (With a HILLS log the caller needs positions and per-hill bias too -- but not NOW: defer_fetch_ok says it will ask
+    //  for them later, see ApplyOutcome::deferred_fetch.  New hills only; a flush's log lines carry per-hill heights.)
+    const bool defer = spec.fetch_all && spec.defer_fetch_ok && !spec.flush_mode && !spec.d_h && !spec.ordered && small;
+    bool header_may_do = header_env && spec.limited && (!spec.fetch_all || defer) && out != nullptr &&
                          rb_bytes + 256 <= g->h_stage_bytes;
     const unsigned long long want = g->done_seq;
     const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
@@ -2056,6 +2103,10 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         LimitResult hr;
         if (edm_header_line_decode(line, want, &hr)) {
           if ((hr.all_plain || spec.flush_mode) && !hr.error) {
+            if (spec.fetch_all && !hr.all_plain) {   // (only a batch the limiter left alone defers its log)
+              header_may_do = false;
+              continue;
+            }
             header_res = hr;
             plain_fast = true;
             g->header_releases++;
@@ -2123,8 +2174,14 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     const long long need = nh_act - first;
     if (plain_fast) {
       // (new hills: flags 1, undo heights 0, undo bias 0 throughout; a flush: res.stop / res.h2_stop; positions and
-      // per-hill bias not asked for)
+      // per-hill bias not asked for -- or asked for later)
       out->plain_fast = true;
+      if (spec.fetch_all) {
+        out->deferred_fetch = true;
+        out->deferred_bound = nh;
+        g->rb_pending_seq = g->done_seq;
+        g->rb_pending_bytes = rb_bytes;
+      }
     } else if (small) {
       out->flags.assign(st_flags, st_flags + ntail);
       out->h2.assign(st_h2, st_h2 + ntail);

@@ -115,6 +115,11 @@ struct edm_hip_gauss {
   char *d_stage = nullptr;               // its device-side address
   size_t h_stage_bytes = 0;
   unsigned long long done_seq = 0;       // sequence number of the last polled read-back (see PostSpec::done_flag)
+  // a batch released by its header line whose read-back region the host has not read yet (deferred_fetch): the
+  // sequence number its completion word will carry and the region's size; saved to rb_saved before the region is reused
+  unsigned long long rb_pending_seq = 0;
+  size_t rb_pending_bytes = 0;
+  std::vector<char> rb_saved;
   long long polled_batches = 0;          // hill batches whose completion was seen through the polled word ...
   long long poll_fallbacks = 0;          // ... and batches whose poll ran out (the stream wait took over)
   long long header_releases = 0;         // polled batches released by their header line alone (see LimitResult)
@@ -202,6 +207,9 @@ struct ApplySpec {
   const Geom *hist_g = nullptr;
   double *hist_values = nullptr;
   bool fetch_all = false;          // host wants position + bias_added of EVERY hill (HILLS log)
+  // ... but can take them LATER (apply_hills_fetch_deferred): a batch every hill of which was added in full is then
+  // released by its header line as if nothing had been asked for, and the log is written behind the step
+  bool defer_fetch_ok = false;
   bool fetch_heights = true;       // with d_h: copy the per-hill base heights back (a flush already has them)
   // optional: d_h is filled by the preparation kernel from this host-mapped array (nh doubles)
   const double *h_fetch_src = nullptr;
@@ -242,6 +250,8 @@ struct ApplyOutcome {
   // the batch was released by its header line alone (see LimitResult): every hill was added in full, nothing deferred,
   // nobody asked for positions / per-hill bias -- flags, h2, a2, pos, added above are EMPTY (they would read 1, 0, 0)
   bool plain_fast = false;
+  bool deferred_fetch = false;       // plain_fast with fetch_all: positions / per-hill bias wait in the read-back region
+  long long deferred_bound = 0;      // ... laid out for this launch bound (see apply_hills_fetch_deferred)
   const double *d_added = nullptr;   // where the batch's per-hill bias_added lies on the device (valid until the next batch)
   // ... and the heights the batch was applied with (see HillHeights): per-hill base heights (NULL: the constant),
   // the limiter's tail arrays for hills >= res.k
@@ -250,6 +260,10 @@ struct ApplyOutcome {
 // prep -> integrals -> (limiter) -> ordered gather -> boundary duplication.
 // Leaves per-hill `added` in g->ws.added and the tail arrays in g->ws.tail_*.
 int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool want_total);
+// original positions [nh][dim] and per-hill bias [nh] of the last batch released with deferred_fetch (waits for the
+// batch's completion word if it has not arrived yet; apply_hills itself saves the region before it reuses it)
+int apply_hills_fetch_deferred(edm_hip_gauss *g, long long nh_bound, long long nh, std::vector<double> &pos,
+                               std::vector<double> &added);
 // the lookup replica, built or rebuilt if it is wanted and not current; *faces = NULL when the grid does not use one
 int faces_prepare(edm_hip_gauss *g, const double **faces);
 inline void faces_touch(edm_hip_gauss *g) {   // the node records were written by a path that does not maintain the replica

@@ -18,7 +18,7 @@ npairs = 1 << 20
 b = H.Bias(make_bias(H, tmpdir, "gpu", 0))
 b.setup(1.0, 1.0)
 b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
-b.set_hill_log(False)
+b.set_hill_log(os.environ.get("W1_LOG", "0") == "1")   # W1_LOG=1: the reference's per-hill HILLS log (the library's default)
 hills0 = np.zeros((4096, 1))
 hills0[:, 0] = W.pair_distances(4096, 2)
 b.gauss.add_values(hills0, 1e-3)
