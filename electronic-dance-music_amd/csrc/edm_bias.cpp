@@ -193,6 +193,11 @@ struct edm_hip_bias {
   // staging of the *_host entry points: device copies of the caller's host arrays, a second stream for the copy
   // that runs against the direction of the others, and the event that orders it behind the force kernel
   DevBuf<double> hs_r, hs_f, hs_x, hs_u;
+  DevBuf<int> hs_mask;
+  double *h_delta = nullptr;       // page-locked landing zone of step_host's force delta
+  size_t h_delta_cap = 0;
+  const void *reg_ptr = nullptr, *reg_failed_ptr = nullptr;   // the caller's position block, page-locked in place (step_host)
+  size_t reg_bytes = 0;
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_event = nullptr;
   const double *pl_view_x = nullptr;   // pair_list_step: the samples of this add_hill cycle are the virtual samples of the
@@ -417,7 +422,9 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
     (void)hipStreamDestroy(b->copy_stream);
   }
   if (b->copy_event) (void)hipEventDestroy(b->copy_event);
-  b->hs_r.release(); b->hs_f.release(); b->hs_x.release(); b->hs_u.release();
+  b->hs_r.release(); b->hs_f.release(); b->hs_x.release(); b->hs_u.release(); b->hs_mask.release();
+  if (b->h_delta) (void)hipHostFree(b->h_delta);
+  if (b->reg_ptr) (void)hipHostUnregister(const_cast<void *>(b->reg_ptr));
   (void)resolve_deferred_log(b);
   b->hills.submit(b->hill_events);
   b->hills.close();
@@ -1516,6 +1523,102 @@ int edm_hip_bias_pair_step_host(edm_hip_bias *b, long long n, const double *h_r,
   const double e = pair_forces_finish(b->bias, nblk);
   if (energy) *energy = e;
   return do_post_add_hill(b);
+}
+
+// fix edm's post_force for a caller whose atom arrays live in HOST memory (lammps/fix_edm.cpp:134-162): positions up,
+// the bias force comes back as a DELTA the host adds to atom->f -- the caller's force array is never uploaded (the
+// reference's update_forces only ever subtracts dV/ds from it, edm_bias.cpp:287-293).  The position block is page-locked
+// in place (hipHostRegister, remembered until the caller's pointer or size changes: LAMMPS keeps atom->x until it
+// reallocates), so the upload is one DMA transfer; the delta lands in page-locked memory of the library's own.
+static int host_block_register(edm_hip_bias *b, const void *p, size_t bytes) {
+  if (b->reg_ptr == p && b->reg_bytes >= bytes) return EDM_HIP_OK;
+  if (b->reg_ptr) {
+    (void)hipHostUnregister(const_cast<void *>(b->reg_ptr));
+    b->reg_ptr = nullptr;
+    b->reg_bytes = 0;
+  }
+  if (b->reg_failed_ptr == p) return EDM_HIP_OK;   // (not registrable -- e.g. already page-locked by the caller: plain copies)
+  if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) {
+    b->reg_ptr = p;
+    b->reg_bytes = bytes;
+  } else {
+    (void)hipGetLastError();
+    b->reg_failed_ptr = p;
+  }
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_step_host(edm_hip_bias *b, long long n, const double *h_x, int x_stride, double *h_f, int f_stride,
+                           const int *h_mask, const double *h_runiform, int apply_mask, int hill_step,
+                           long long est_hill_count, double *energy) {
+  if (energy) *energy = 0;
+  if (!b->bias && !b->b_outofbounds) {
+    set_error("step before subdivide");
+    return EDM_HIP_ERR_STATE;
+  }
+  if (n < 0) n = 0;
+  const int dim = (int)b->dim;
+  if (n > 0 && (x_stride < dim || f_stride < dim)) {
+    set_error("step_host: row strides shorter than the dimension");
+    return EDM_HIP_ERR_ARG;
+  }
+  if (apply_mask >= 0 && n > 0 && !h_mask) {
+    set_error("step_host: apply_mask >= 0 needs a mask");
+    return EDM_HIP_ERR_ARG;
+  }
+  if (b->b_outofbounds) {
+    if (!hill_step) return EDM_HIP_OK;
+    int rc = do_pre_add_hill(b, est_hill_count < 0 ? n : est_hill_count);
+    return rc ? rc : do_post_add_hill(b);
+  }
+  hipStream_t s = b->bias->stream;
+  const size_t xcount = n > 0 ? (size_t)(n - 1) * (size_t)x_stride + (size_t)dim : 0;
+  EDM_HIP_TRY(b->hs_x.reserve(xcount > 0 ? xcount : 1));
+  EDM_HIP_TRY(b->hs_f.reserve((size_t)(n > 0 ? n : 1) * dim));
+  if (b->h_delta_cap < (size_t)n * dim) {
+    if (b->h_delta) (void)hipHostFree(b->h_delta);
+    b->h_delta = nullptr;
+    b->h_delta_cap = (size_t)n * dim + (size_t)n * dim / 4 + 64;
+    EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_delta), sizeof(double) * b->h_delta_cap, hipHostMallocDefault));
+  }
+  // (whatever happens below, no copy may still be reading the caller's arrays when the call returns)
+  struct StreamGuard {
+    hipStream_t s;
+    ~StreamGuard() { (void)hipStreamSynchronize(s); }
+  } guard{s};
+  if (n > 0) {
+    host_block_register(b, h_x, sizeof(double) * xcount);
+    EDM_HIP_TRY(hipMemcpyAsync(b->hs_x.p, h_x, sizeof(double) * xcount, hipMemcpyHostToDevice, s));
+    EDM_HIP_TRY(hipMemsetAsync(b->hs_f.p, 0, sizeof(double) * (size_t)n * dim, s));
+    if (apply_mask >= 0) {
+      EDM_HIP_TRY(b->hs_mask.reserve((size_t)n));
+      EDM_HIP_TRY(hipMemcpyAsync(b->hs_mask.p, h_mask, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+    }
+    if (hill_step && h_runiform) {
+      EDM_HIP_TRY(b->hs_u.reserve((size_t)n));
+      EDM_HIP_TRY(hipMemcpyAsync(b->hs_u.p, h_runiform, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+    }
+  }
+  const int *saved_mask = b->d_mask;
+  if (apply_mask >= 0) b->d_mask = b->hs_mask.p;
+  int rc;
+  if (hill_step)
+    rc = edm_hip_bias_step(b, n, b->hs_x.p, x_stride, b->hs_f.p, dim, h_runiform ? b->hs_u.p : nullptr, apply_mask,
+                           est_hill_count, energy);
+  else
+    rc = edm_hip_bias_update_forces(b, n, b->hs_x.p, x_stride, b->hs_f.p, dim, apply_mask, energy);
+  b->d_mask = saved_mask;
+  if (rc) return rc;
+  if (n > 0) {
+    EDM_HIP_TRY(hipMemcpyAsync(b->h_delta, b->hs_f.p, sizeof(double) * (size_t)n * dim, hipMemcpyDeviceToHost, s));
+    EDM_HIP_TRY(hipStreamSynchronize(s));
+    // f[i][d] += delta[i][d]: the delta started from zero, so it holds exactly -dV/ds_d of the masked atoms and
+    // (+0.0 or) 0 elsewhere -- the same doubles the reference's `forces[i][j] -= der[j]` subtracts
+    const double *dl = b->h_delta;
+    for (long long i = 0; i < n; i++)
+      for (int d = 0; d < dim; d++) h_f[(size_t)i * f_stride + d] += dl[(size_t)i * dim + d];
+  }
+  return EDM_HIP_OK;
 }
 
 int edm_hip_bias_pair_list_upload(edm_hip_bias *b, long long npairs, const int *h_pair_i, const int *h_pair_j,

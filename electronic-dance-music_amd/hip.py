@@ -112,6 +112,7 @@ _PROTOS = {
     "edm_hip_bias_step": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step_host": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
+    "edm_hip_bias_step_host": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step_ordered": (C.c_int, [vp, C.c_longlong, vp, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step_ordered_host": (C.c_int, [vp, C.c_longlong, vp, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pre_add_hill": (C.c_int, [vp, C.c_longlong]),
@@ -753,6 +754,19 @@ def _bias_pair_step_ordered_host(self, r, force, first_sample, sample_r, runifor
     return e.value
 
 
+def _bias_step_host(self, x, f, mask=None, runiform=None, apply_mask=-1, hill_step=True, est=-1):
+    """edm_hip_bias_step_host on host numpy arrays x [n, xs], f [n, fs] (f updated in place); returns the energy"""
+    e = C.c_double(0)
+    assert x.flags.c_contiguous and f.flags.c_contiguous and x.dtype == np.float64 and f.dtype == np.float64
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.int32)
+    check(lib().edm_hip_bias_step_host(self.h, x.shape[0], x.ctypes.data, x.shape[1], f.ctypes.data, f.shape[1],
+                                       None if m is None else m.ctypes.data,
+                                       None if runiform is None else runiform.ctypes.data, apply_mask, int(hill_step), est,
+                                       C.byref(e)))
+    return e.value
+
+
+Bias.step_host = _bias_step_host
 Bias.pair_step_ordered_device = _bias_pair_step_ordered_device
 Bias.pair_step_ordered_host = _bias_pair_step_ordered_host
 

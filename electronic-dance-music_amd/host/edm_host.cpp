@@ -553,13 +553,30 @@ double EDMBias::update_forces(int nlocal, const double* const* positions, double
 // edm_bias.cpp:276-295 with LAMMPS' host arrays staged through HBM
 double EDMBias::update_forces(int nlocal, const double* const* positions, double** forces, int apply_mask) const {
   if (b_outofbounds_ || nlocal <= 0) return 0.0;
-  if (apply_mask >= 0 && mask_ == NULL) edm_error("update_forces with a group mask needs set_mask", "edm_bias.cpp:update_forces");
+  return host_step(nlocal, positions, forces, NULL, apply_mask, 0);
+}
+
+double EDMBias::step(int nlocal, const double* const* positions, double** forces, const double* runiform, int apply_mask) {
+  if (nlocal <= 0) {  // nothing to evaluate; the hill cycle still runs (collective under a communicator)
+    add_hills(nlocal, positions, runiform, apply_mask);
+    return 0.0;
+  }
+  const double energy = host_step(nlocal, positions, forces, runiform, apply_mask, 1);
+  refresh();
+  return energy;
+}
+
+// update_forces / step on LAMMPS' own atom arrays: positions up (the block is page-locked in place by the library), the
+// bias-force delta down and added to `forces` on the host -- atom->f is never uploaded (edm_hip_bias_step_host)
+double EDMBias::host_step(int nlocal, const double* const* positions, double** forces, const double* runiform, int apply_mask,
+                          int hill_step) const {
+  if (apply_mask >= 0 && mask_ == NULL) edm_error("a group mask needs set_mask", "edm_bias.cpp:update_forces");
   Stage& st = *st_;
   const size_t n = (size_t)nlocal;
   long xs = row_stride(nlocal, positions, dim_);
   long fs = row_stride(nlocal, const_cast<const double* const*>(forces), dim_);
   const double* xsrc = positions[0];
-  double* fsrc = forces[0];
+  double* fdst = forces[0];
   if (xs == 0) {  // rows are not evenly spaced: pack
     xs = (long)dim_;
     st.pack_x.resize(n * dim_);
@@ -568,85 +585,18 @@ double EDMBias::update_forces(int nlocal, const double* const* positions, double
     xsrc = st.pack_x.data();
   }
   const bool pack_f = (fs == 0);
-  if (pack_f) {
+  if (pack_f) {   // (the delta is added to a zeroed block and scattered below)
     fs = (long)dim_;
-    st.pack_f.resize(n * dim_);
-    for (size_t i = 0; i < n; i++)
-      for (unsigned int d = 0; d < dim_; d++) st.pack_f[i * dim_ + d] = forces[i][d];
-    fsrc = st.pack_f.data();
-  }
-  const size_t xbytes = sizeof(double) * ((n - 1) * (size_t)xs + dim_);
-  const size_t fbytes = sizeof(double) * ((n - 1) * (size_t)fs + dim_);
-  st.x.reserve(xbytes);
-  st.f.reserve(fbytes);
-  check(edm_hip_memcpy_h2d(st.x.p, xsrc, xbytes), "edm_bias.cpp:update_forces");
-  check(edm_hip_memcpy_h2d(st.f.p, fsrc, fbytes), "edm_bias.cpp:update_forces");
-  if (apply_mask >= 0) {
-    st.mask.reserve(sizeof(int) * n);
-    check(edm_hip_memcpy_h2d(st.mask.p, mask_, sizeof(int) * n), "edm_bias.cpp:update_forces");
-    check(edm_hip_bias_set_mask(h_, (const int*)st.mask.p), "edm_bias.cpp:set_mask");
+    st.pack_f.assign(n * dim_, 0.0);
+    fdst = st.pack_f.data();
   }
   double energy = 0;
-  check(edm_hip_bias_update_forces(h_, nlocal, (const double*)st.x.p, (int)xs, (double*)st.f.p, (int)fs, apply_mask, &energy),
-        "edm_bias.cpp:update_forces");
-  check(edm_hip_memcpy_d2h(fsrc, st.f.p, fbytes), "edm_bias.cpp:update_forces");
+  check(edm_hip_bias_step_host(h_, nlocal, xsrc, (int)xs, fdst, (int)fs, apply_mask >= 0 ? mask_ : NULL, runiform, apply_mask,
+                               hill_step, -1, &energy),
+        hill_step ? "edm_bias.cpp:add_hills" : "edm_bias.cpp:update_forces");
   if (pack_f)
     for (size_t i = 0; i < n; i++)
-      for (unsigned int d = 0; d < dim_; d++) forces[i][d] = st.pack_f[i * dim_ + d];
-  return energy;
-}
-
-double EDMBias::step(int nlocal, const double* const* positions, double** forces, const double* runiform, int apply_mask) {
-  if (nlocal <= 0) {  // nothing to evaluate; the hill cycle still runs (collective under a communicator)
-    add_hills(nlocal, positions, runiform, apply_mask);
-    return 0.0;
-  }
-  if (apply_mask >= 0 && mask_ == NULL) edm_error("step with a group mask needs set_mask", "edm_bias.cpp:update_forces");
-  Stage& st = *st_;
-  const size_t n = (size_t)nlocal;
-  long xs = row_stride(nlocal, positions, dim_);
-  long fs = row_stride(nlocal, const_cast<const double* const*>(forces), dim_);
-  const double* xsrc = positions[0];
-  double* fsrc = forces[0];
-  if (xs == 0) {
-    xs = (long)dim_;
-    st.pack_x.resize(n * dim_);
-    for (size_t i = 0; i < n; i++)
-      for (unsigned int d = 0; d < dim_; d++) st.pack_x[i * dim_ + d] = positions[i][d];
-    xsrc = st.pack_x.data();
-  }
-  const bool pack_f = (fs == 0);
-  if (pack_f) {
-    fs = (long)dim_;
-    st.pack_f.resize(n * dim_);
-    for (size_t i = 0; i < n; i++)
-      for (unsigned int d = 0; d < dim_; d++) st.pack_f[i * dim_ + d] = forces[i][d];
-    fsrc = st.pack_f.data();
-  }
-  const size_t xbytes = sizeof(double) * ((n - 1) * (size_t)xs + dim_);
-  const size_t fbytes = sizeof(double) * ((n - 1) * (size_t)fs + dim_);
-  st.x.reserve(xbytes);
-  st.f.reserve(fbytes);
-  check(edm_hip_memcpy_h2d(st.x.p, xsrc, xbytes), "edm_bias.cpp:update_forces");
-  check(edm_hip_memcpy_h2d(st.f.p, fsrc, fbytes), "edm_bias.cpp:update_forces");
-  if (runiform) {
-    st.u.reserve(sizeof(double) * n);
-    check(edm_hip_memcpy_h2d(st.u.p, runiform, sizeof(double) * n), "edm_bias.cpp:add_hills");
-  }
-  if (apply_mask >= 0) {
-    st.mask.reserve(sizeof(int) * n);
-    check(edm_hip_memcpy_h2d(st.mask.p, mask_, sizeof(int) * n), "edm_bias.cpp:update_forces");
-    check(edm_hip_bias_set_mask(h_, (const int*)st.mask.p), "edm_bias.cpp:set_mask");
-  }
-  double energy = 0;
-  check(edm_hip_bias_step(h_, nlocal, (const double*)st.x.p, (int)xs, (double*)st.f.p, (int)fs,
-                          runiform ? (const double*)st.u.p : NULL, apply_mask, -1, &energy),
-        "edm_bias.cpp:add_hills");
-  check(edm_hip_memcpy_d2h(fsrc, st.f.p, fbytes), "edm_bias.cpp:update_forces");
-  if (pack_f)
-    for (size_t i = 0; i < n; i++)
-      for (unsigned int d = 0; d < dim_; d++) forces[i][d] = st.pack_f[i * dim_ + d];
-  refresh();
+      for (unsigned int d = 0; d < dim_; d++) forces[i][d] += st.pack_f[i * dim_ + d];
   return energy;
 }
 

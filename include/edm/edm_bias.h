@@ -150,6 +150,8 @@ class EDMBias {
  private:
   EDMBias(const EDMBias& that);  // just disable copy constructor
   void refresh() const;
+  double host_step(int nlocal, const double* const* positions, double** forces, const double* runiform, int apply_mask,
+                   int hill_step) const;
   edm_hip_bias* h_;
   Grid* cv_hist_;
   int serial_format_;

@@ -274,6 +274,16 @@ int edm_hip_bias_add_hills(edm_hip_bias *b, long long n, const double *d_x, int 
 int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_stride, double *d_f,
                       int f_stride, const double *d_runiform, int apply_mask, long long est_hill_count,
                       double *energy);
+/* fix edm's post_force for a caller whose atom arrays are in HOST memory (lammps/fix_edm.cpp:134-162): h_x rows
+ * [n][x_stride] go up (the block is page-locked in place the first time it is seen), update_forces -- and, when
+ * hill_step != 0, add_hills over the same samples -- run on the device, and the bias force comes back as a delta the
+ * library adds to h_f rows [n][f_stride] on the host: the caller's force array is never uploaded (edm_bias.cpp:287-293
+ * only ever subtracts dV/ds from it).  h_mask (int[n]) may be NULL when apply_mask < 0, h_runiform NULL without
+ * hill_density or with device uniforms.  Per atom 8 * x_stride B (+ 4 B mask, + 8 B uniform on hill steps) travel up
+ * and 8 * dim B down.  Same results as edm_hip_bias_step / edm_hip_bias_update_forces on device arrays. */
+int edm_hip_bias_step_host(edm_hip_bias *b, long long n, const double *h_x, int x_stride, double *h_f, int f_stride,
+                           const int *h_mask, const double *h_runiform, int apply_mask, int hill_step,
+                           long long est_hill_count, double *energy);
 /* fix edm_pair on a device-resident neighbour list.
  * edm_hip_bias_pair_list_upload: called when LAMMPS has rebuilt the list, with HOST arrays -- the half list
  * flattened in neighbour-list order (pair_i/pair_j, j masked with NEIGHMASK) and the atom types [nall]; the library

@@ -706,7 +706,7 @@ def test_step_equals_separate_calls(workdir):
             "box_high 8 8\nbias_spacing 0.05 0.05\nbias_sigma 0.2 0.2\n")
     n = 5000
     state = []
-    for tag in ("fused", "separate"):
+    for tag in ("fused", "separate", "host_arrays"):
         cfg = str(workdir / (tag + ".edm"))
         open(cfg, "w").write(text + "hills_filename %s/HILLS_%s\nhistogram_filename %s/HIST_%s\n" % (workdir, tag, workdir, tag))
         b = H.Bias(cfg)
@@ -721,6 +721,22 @@ def test_step_equals_separate_calls(workdir):
             d_u = H.DeviceArray.from_host(u)
             d_f = H.DeviceArray.zeros((n, 3))
             b.set_mask(mask)
+            if tag == "host_arrays":
+                # edm_hip_bias_step_host: positions up, the bias-force DELTA down and added to the host force array,
+                # which is never uploaded -- started from zero it ends with the same doubles as the device array
+                fh = np.zeros((n, 3))
+                e = b.step_host(np.ascontiguousarray(x), fh, mask=mask, runiform=u, apply_mask=1, hill_step=True)
+                f0 = W.uniform(990 + step, 3 * n).reshape(n, 3) - 0.5
+                f1 = f0.copy()
+                e2 = b.step_host(np.ascontiguousarray(x), f1, mask=mask, apply_mask=1, hill_step=False)   # forces only
+                d_chk = H.DeviceArray.zeros((n, 3))
+                ec = H.C.c_double(0)
+                b.set_mask(mask)
+                H.check(H.lib().edm_hip_bias_update_forces(b.h, n, d_x.ptr, 3, d_chk.ptr, 3, 1, H.C.byref(ec)))
+                assert e2 == ec.value and np.array_equal(f1, f0 + d_chk.to_host()), "delta added to a non-zero force array"
+                energies.append(e)
+                forces.append(fh)
+                continue
             if tag == "fused":
                 e = b.step_device(d_x, 3, d_f, 3, n, d_u, apply_mask=1)
             else:
@@ -734,8 +750,9 @@ def test_step_equals_separate_calls(workdir):
         state.append((v, dv, b.hist.values, np.array(energies), np.array(forces), b.get("cum_bias"),
                       b.get("overflow_right"), b.get("hills_added")))
         del b
-    for a, c in zip(state[0], state[1]):
-        assert np.array_equal(np.asarray(a), np.asarray(c))
+    for other in (1, 2):
+        for a, c in zip(state[0], state[other]):
+            assert np.array_equal(np.asarray(a), np.asarray(c))
     assert state[0][0].max() > 0 and state[0][7] > 10 and np.abs(state[0][4]).max() > 0
 
 
