@@ -7,7 +7,11 @@ One "step" = one pass of the hot path over one batch of synthetic input on every
   (1) bias-force evaluation for W1 = 1,048,576 pair distances of a 1-D r-CV
       (fix edm_pair, BASELINE.json configs[1]): EDMBias::update_force batched, and
   (2) one hill step: EDMBias::add_hills semantics, hill_density 250, 2 add_hill calls
-      per pair worth of estimate, bias limiting active (bias_per_step = hill_prefactor).
+      per pair worth of estimate, bias limiting active (bias_per_step = hill_prefactor),
+  in the REFERENCE FIX'S ORDER (lammps/fix_edm_pair.cpp:177-238: pair k's force is read behind the hills of the
+  add_hill calls before it -- edm_hip_bias_pair_step_ordered, the default of the rewritten fix edm_pair) and with the
+  reference's per-hill HILLS log ON (the library's default).  The batched order (every force on the bias as it
+  stands after pre_add_hill: keyword batch_order) and the log-off step are timed beside it.
 Inputs are resident in HBM before the timed region.  N > 1 is weak scaling: every rank
 (one process per GPU) owns its own W1-sized pair set of the same system, hill_density is
 a per-system quantity (divided by the rank count exactly like EDMBias::subdivide does
@@ -16,11 +20,13 @@ With --gpus N > 1 and no WORLD_SIZE in the environment the script starts the N r
 (python -m torch.distributed.run, one process per GPU) before anything touches a GPU.
 
 Rank 0 prints ONE JSON line (see the driver contract) with these extra objects:
-  roofline      -- dominant kernel of the W1 step: algorithmic 16 B/eval over its HIP-event duration
-                   measured on the kernel's own stream inside the timed region
-  hill_adds_strong_scaling -- the metric's second quantity: 1,048,576 hills per step split over the GPUs
+  roofline      -- the bias-force kernel of the W1 step: algorithmic 16 B/eval over its HIP-event duration
+                   measured on the kernel's own stream inside the timed region; roofline.other holds the same figure
+                   for W2 (38.8 M pairs, the HBM-bound capture), for K2 on the 2048^2 and 512^3 coordinate-CV grids,
+                   and the metric's second quantity, hill adds/s (1,048,576 hills per step split over the GPUs)
   coordinate_cv -- BASELINE configs[3] / [4] (2048^2 and 512^3 coordinate-CV grids, 262 144 atoms): lookup kernel
-                   time, algorithmic bytes per atom, roofline fraction, full fix-edm step
+                   time, algorithmic bytes per atom, roofline fraction, full fix-edm step (per-step min / median / max,
+                   polled / fallback batches, replica rebuilds), the step from HOST arrays (PCIe-inclusive)
   pcie_inclusive -- the same W1 step with pair arrays starting and ending in HOST memory
   cpu_baseline  -- the real reference build (or the CPU oracle) timed on a bounded sample on the host cores
 """
@@ -204,6 +210,8 @@ def all_samples_measure(rank, world, dist, H, W, tmpdir, steps, warmup):
         b.comm_init(ident[0], world, rank)
     b.setup(1.0, 1.0)
     b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    # (the one place the per-hill HILLS log is switched off: a million hills per step are 80 MB of text per step --
+    #  the reference writes them, at ~1 us of printf per line; every other section runs with the log on, the default)
     b.set_hill_log(False)
     r = W.pair_distances(total, 1)[rank * n:(rank + 1) * n]
     d_r = H.DeviceArray.from_host(np.ascontiguousarray(r))
@@ -262,13 +270,13 @@ def headline_dict(args, world, npairs, elapsed, k_ms, k_launches, timed_every, t
     samples.sort()
     k_s = (samples[len(samples) // 2] if samples else timed_us) * 1e-6
     # 16 B per evaluation (8 B distance in + 8 B force out) x the pairs one launch processes.  The
-    # launch also carries the step's selection, which reads one 8-B acceptance uniform per staged sample -- real
+    # reference-order launch also reads one 4-B sample index per pair (where the pair's add_hill calls begin) -- real
     # traffic of the same launch, reported beside the 8(d) figure, not inside it
     alg_bytes = BYTES_PER_EVAL * npairs
     achieved = alg_bytes / k_s / 1e9
-    with_u = (alg_bytes + 8 * npairs) / k_s / 1e9
+    with_u = (alg_bytes + 4 * npairs) / k_s / 1e9
     return {
-        "metric": "million bias-force evals/sec (1M-pair 1D CV, force eval + hill step per step)",
+        "metric": "million bias-force evals/sec (1M-pair 1D CV, force eval + hill step per step, reference fix's order, HILLS log on)",
         "value": total_pairs / (elapsed / args.steps) / 1e6,
         "unit": "million evals/s",
         "n_gpus": world,
@@ -286,29 +294,32 @@ def headline_dict(args, world, npairs, elapsed, k_ms, k_launches, timed_every, t
                         "bias_per_step = hill_prefactor, bias pre-populated with 4096 hills" % npairs,
             "pairs_per_gpu": npairs,
             "hill_step_every": 1,
+            "order": "reference (lammps/fix_edm_pair.cpp:177-238: pair k's force behind the hills of pairs 0..k-1; the fix's default)",
+            "hills_log": "on (edm_bias.cpp:586-599, the library's default)",
             "parallelism": "replicated bias grid, samples sharded, dp%d" % world,
         },
         "roofline": {
-            "kernel": "k_pair_forces_select (K1 = k_pair_forces_fast<false,256> body + the step's selection/preparation, one launch)",
+            "kernel": "k_pair_forces_ordered (K1 in the reference fix's order: each pair's two corner records as they stood behind "
+                      "the hills of the add_hill calls before it)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("edm::k_pair_forces_select"),
+            "traffic": pmc_traffic("edm::k_pair_forces_ordered"),
             "kernel_us": k_s * 1e6,
             "kernel_us_timed_region": timed_us,
             "kernel_us_samples": [round(v, 2) for v in samples],
             "kernel_us_note": "median over the stamped launches: the timed region's (mean of `launches`) and a tail of stamped "
                               "steps of the same loop right behind it",
-            "kernel_us_rocprof": rocprof_avg_us("edm::k_pair_forces_select"),
+            "kernel_us_rocprof": rocprof_avg_us("edm::k_pair_forces_ordered"),
             "launches": k_launches,
             "timed_every": timed_every,
             "bytes_per_launch": alg_bytes,
             "bytes_per_launch_note": "16 B per pair (SURVEY 8d: distance in + force out)",
-            "achieved_incl_selection_uniforms": with_u,
-            "frac_incl_selection_uniforms": with_u / HBM_PEAK_GBS,
-            "bytes_per_launch_incl_selection_uniforms": alg_bytes + 8 * npairs,
+            "achieved_incl_sample_indices": with_u,
+            "frac_incl_sample_indices": with_u / HBM_PEAK_GBS,
+            "bytes_per_launch_incl_sample_indices": alg_bytes + 4 * npairs,
         },
     }
 
@@ -438,17 +449,58 @@ def coordinate_cv_measure(H, W, tmpdir):
         bb = H.Bias(cfgp)
         bb.setup(1.0, 1.0)
         bb.subdivide([0.0] * dim, [64.0] * dim, [0.0] * dim, [64.0] * dim, [1] * dim, [0.0] * dim)
-        bb.set_hill_log(False)
         d_fs = H.DeviceArray.zeros((natoms, 3))
         for _ in range(3):
             bb.step_device(d_x, 3, d_fs, 3, natoms, d_uu, -1, natoms)
         H.synchronize()
+        pf0, pb0 = bb.get("poll_fallbacks"), bb.get("polled_batches")
+        rb0 = bb.gauss.lookup_replica_info()[2]
+        per_step = []
         t4 = time.perf_counter()
         for _ in range(40):
+            t5 = time.perf_counter()
             bb.step_device(d_x, 3, d_fs, 3, natoms, d_uu, -1, natoms)
+            per_step.append(time.perf_counter() - t5)
         H.synchronize()
         t_step = (time.perf_counter() - t4) / 40
+        per_step.sort()
+        step_stats = dict(min_ms=per_step[0] * 1e3, median_ms=per_step[len(per_step) // 2] * 1e3, max_ms=per_step[-1] * 1e3,
+                          poll_fallbacks=bb.get("poll_fallbacks") - pf0, polled_batches=bb.get("polled_batches") - pb0,
+                          replica_rebuilds=bb.gauss.lookup_replica_info()[2] - rb0,
+                          note="host clock around each of the 40 calls (a call returns when its results are on the host; the "
+                               "grid update may still run); a poll fallback = a batch whose completion word did not arrive "
+                               "within 2 ms and was waited for on the stream")
         hills_step = bb.get("hills_added") / 43.0
+        # the same step as the fix pays for it: atom->x / atom->f in HOST memory (edm_hip_bias_step_host: positions up,
+        # the bias-force delta down and added on the host; the force array is never uploaded)
+        xh = np.ascontiguousarray(x)
+        fh = np.zeros((natoms, 3))
+        uh = W.uniform(77, natoms)
+        for _ in range(3):
+            bb.step_host(xh, fh, runiform=uh, apply_mask=-1, hill_step=True, est=natoms)
+        H.synchronize()
+        t6 = time.perf_counter()
+        for _ in range(20):
+            bb.step_host(xh, fh, runiform=uh, apply_mask=-1, hill_step=True, est=natoms)
+        H.synchronize()
+        t_host = (time.perf_counter() - t6) / 20
+        # ... against plain copies of the same bytes (24 B per atom up, 8 * dim down)
+        hip = C.CDLL("libamdhip64.so")
+        d_tmp = H.DeviceArray((natoms, 3))
+        t7 = time.perf_counter()
+        rc_copy = 0
+        for _ in range(20):
+            # (hipMemcpyDefault: the position block is page-locked in place by now, and an explicit host-to-device kind
+            #  on registered memory is refused as an invalid value)
+            rc_copy |= hip.hipMemcpy(C.c_void_p(d_tmp.ptr), C.c_void_p(xh.ctypes.data), C.c_size_t(xh.nbytes), 4)
+            rc_copy |= hip.hipMemcpy(C.c_void_p(fh.ctypes.data), C.c_void_p(d_tmp.ptr), C.c_size_t(8 * dim * natoms), 4)
+        t_copy = (time.perf_counter() - t7) / 20
+        if rc_copy:
+            raise RuntimeError("plain hipMemcpy probe failed: %d" % rc_copy)
+        pcie = dict(ms_per_step=t_host * 1e3, bytes_up_per_atom=24 + 8, bytes_down_per_atom=8 * dim,
+                    plain_copies_of_the_same_bytes_ms=t_copy * 1e3, ratio_to_plain_copies=t_host / t_copy,
+                    note="edm_hip_bias_step_host on pageable numpy arrays (the position block is page-locked in place by the "
+                         "library): positions + uniforms up, bias-force delta down, added to the force array on the host")
         del bb
         kname = "edm::k_lookup_quad<%d" % dim
         nd[tag] = dict(workload="BASELINE configs[%d]: fix edm coordinate CV, %s periodic bias grid, %d atoms at random positions"
@@ -466,6 +518,7 @@ def coordinate_cv_measure(H, W, tmpdir):
                        lookup_kernel_us_bin_sorted_atoms=ms_s / ln_s * 1e3,
                        frac_of_hbm_peak_bin_sorted_atoms=per_atom * natoms / (ms_s / ln_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        step_ms=t_step * 1e3, step_million_atom_evals_per_s=natoms / t_step / 1e6,
+                       step_stats=step_stats, pcie_inclusive_step=pcie,
                        step_hills_added_avg=hills_step,
                        hill_batch_250_ms=t_h * 1e3, hill_adds_per_s=250 / t_h)
     return nd
@@ -503,17 +556,20 @@ def pcie_inclusive_measure(H, b, r, u, npairs, est, steps=20):
         H.synchronize()
         return (time.perf_counter() - t0) / steps
 
+    first = np.arange(npairs, dtype=np.int32)
     dt_sync = timed(sync_copies)
     dt_pageable = timed(lambda: b.pair_step_host(r, f_host, r, u, est))
-    dt_pinned = timed(lambda: b.pair_step_host(p_r, p_f, p_r, p_u, est))
+    dt_pinned_batch = timed(lambda: b.pair_step_host(p_r, p_f, p_r, p_u, est))
+    dt_pinned = timed(lambda: b.pair_step_ordered_host(p_r, p_f, first, p_r, p_u, est))
     return dict(ms_per_step=dt_pinned * 1e3, million_evals_per_s=npairs / dt_pinned / 1e6,
-                bytes_over_pcie_per_step=3 * 8 * npairs,
-                effective_GBs=3 * 8 * npairs / dt_pinned / 1e9,
-                ms_per_step_pageable_arrays=dt_pageable * 1e3,
-                ms_per_step_synchronous_copies=dt_sync * 1e3,
-                note="8 B distance + 8 B uniform in, 8 B force out per pair, per step; ms_per_step = "
-                     "edm_hip_bias_pair_step_host on page-locked host arrays (copies queued around the kernels, forces "
-                     "down while uniforms go up)")
+                bytes_over_pcie_per_step=(3 * 8 + 4) * npairs,
+                effective_GBs=(3 * 8 + 4) * npairs / dt_pinned / 1e9,
+                ms_per_step_batch_order=dt_pinned_batch * 1e3,
+                ms_per_step_batch_order_pageable_arrays=dt_pageable * 1e3,
+                ms_per_step_batch_order_synchronous_copies=dt_sync * 1e3,
+                note="8 B distance + 8 B uniform + 4 B sample index in, 8 B force out per pair, per step; ms_per_step = "
+                     "edm_hip_bias_pair_step_ordered_host (the fix's default order) on page-locked host arrays; batch order: "
+                     "edm_hip_bias_pair_step_host (copies queued around the kernels, forces down while uniforms go up)")
 
 
 def main():
@@ -580,7 +636,7 @@ def main():
         b.comm_init(ident[0], world, rank)
     b.setup(1.0, 1.0)
     b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
-    b.set_hill_log(False)   # the HILLS text log is host I/O outside the hot path
+    # (the reference's per-hill HILLS log stays ON, the library's default: written by a thread of its own)
     g = b.gauss
     # bias pre-populated with 4096 hills (seed 2), identical on every rank
     hills0 = np.zeros((4096, 1))
@@ -595,9 +651,17 @@ def main():
     d_f = H.DeviceArray.zeros((npairs,))
     est = 2 * npairs  # fix_edm_pair makes up to two add_hill calls per pair (fix_edm_pair.cpp:230-237)
 
+    # one add_hill sample per pair here: pair k's first (only) sample is sample k
+    d_first = H.DeviceArray.from_host(np.arange(npairs, dtype=np.int32))
+
     def step():
-        # one hill-depositing fix edm_pair step: pre_add_hill(est), forces of all pairs, add_hill(r, u) for the
-        # staged samples, post_add_hill -- a single C-ABI call (edm_hip_bias_pair_step)
+        # one hill-depositing fix edm_pair step IN THE REFERENCE FIX'S ORDER (lammps/fix_edm_pair.cpp:173-247):
+        # pre_add_hill(est); per pair update_force, then its add_hill(r, u); post_add_hill -- a single C-ABI call
+        # (edm_hip_bias_pair_step_ordered, what the rewritten fix edm_pair calls by default)
+        return b.pair_step_ordered_device(d_r, d_f, d_first, npairs, d_r, d_u, npairs, est)
+
+    def step_batch():
+        # the same step with every force evaluated on the bias as it stands after pre_add_hill (keyword batch_order)
         return b.pair_step_device(d_r, d_f, npairs, d_r, d_u, npairs, est)
 
     def barrier():
@@ -649,11 +713,6 @@ def main():
     # the CPU baseline).  The headline numbers are complete at this point: if an extra ever failed to finish -- the
     # multi-rank ones run collectives -- rank 0 still prints the line, marked, instead of losing the measurement.
     headline = headline_dict(args, world, npairs, elapsed, k_ms, k_launches, TIMED_EVERY, tail_us)
-    if b.get("fused_steps") > 0:   # (EDM_HIP_PAIR_STEP_MODE=1 in the environment: the stamped launch was the whole step)
-        headline["roofline"]["kernel"] = ("k_pair_step (the WHOLE step in one launch: selection + per-hill integrals | K1 | "
-                                          "bookkeeper | gather tiles; only K1's 16 B per pair are counted)")
-        headline["roofline"]["traffic"] = pmc_traffic("edm::k_pair_step")
-        headline["roofline"]["kernel_us_rocprof"] = rocprof_avg_us("edm::k_pair_step")
     # second quantity of the metric (BASELINE.json: "... + hill-adds/sec", target: strong scaling at 8 GPUs): the
     # all-samples hill mode, 1,048,576 hills per step in total split over the GPUs (a collective: every rank runs it);
     # part of the measured line, not of the guarded extras
@@ -679,36 +738,32 @@ def main():
     ms_step_device_rng = (time.perf_counter() - t_r) / args.steps * 1e3
     b.set_device_rng(False, 0)
 
-    # the same step queued as ONE launch (k_pair_step, opt-in: selection with per-hill integrals | pair forces |
-    # bookkeeper | gather tiles in one grid); informational: the default keeps the two launches
-    one_launch = None
+    # the other ways to run the step, each timed like the headline (warm-up, steps between barriers), unstamped:
+    # batch order (keyword batch_order), and both orders without the HILLS log
     guard.stage("step_modes")
-    if dist is None:
-        # both ways of queueing the step, WITHOUT the dispatch stamps of the timed region above (a stamped launch costs
-        # the stream ~6 us), alternating so that drift hits both alike
-        modes = {0: [], 1: []}
-        fused = 0
-        for rep in range(4):
-            for m in (0, 1):
-                b.set("debug_pair_step_mode", m)
-                f0 = b.get("fused_steps")
-                for _ in range(3):
-                    step()
-                barrier()
-                t_o = time.perf_counter()
-                for _ in range(args.steps):
-                    step()
-                barrier()
-                modes[m].append((time.perf_counter() - t_o) / args.steps * 1e3)
-                if m == 1:
-                    fused += int(b.get("fused_steps") - f0)
-        b.set("debug_pair_step_mode", -1)
-        one_launch = dict(ms_per_step=min(modes[1]), ms_per_step_runs=modes[1],
-                          two_launches_ms_per_step=min(modes[0]), two_launches_ms_per_step_runs=modes[0],
-                          steps_run_as_one_launch=fused, steps_per_run=args.steps,
-                          note="edm_hip_bias_pair_step unstamped, alternating EDM_HIP_PAIR_STEP_MODE 0 (k_pair_forces_select, "
-                               "k_integrals_gather) and 1 (the whole step in one k_pair_step launch); bit-identical results "
-                               "(tests/test_gpu_one_launch.py)")
+
+    def timed_steps(fn, steps):
+        for _ in range(3):
+            fn()
+        barrier()
+        t_o = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        return (time.perf_counter() - t_o) / steps * 1e3
+
+    ms_ordered_unstamped = timed_steps(step, args.steps)
+    ms_batch = timed_steps(step_batch, args.steps)
+    b.set_hill_log(False)
+    ms_ordered_nolog = timed_steps(step, args.steps)
+    ms_batch_nolog = timed_steps(step_batch, args.steps)
+    b.set_hill_log(True)
+    step_modes = dict(
+        ms_per_step_reference_order=ms_ordered_unstamped, ms_per_step_batch_order=ms_batch,
+        ms_per_step_reference_order_hills_log_off=ms_ordered_nolog, ms_per_step_batch_order_hills_log_off=ms_batch_nolog,
+        note="reference order = edm_hip_bias_pair_step_ordered (the headline's step, here without dispatch stamps); batch order = "
+             "edm_hip_bias_pair_step (every force on the bias as it stands after pre_add_hill: fix keyword batch_order; its "
+             "hill-step forces differ from the reference's, INTEGRATION.md); HILLS log on unless stated")
 
     # BASELINE configs[1] end to end from POSITIONS: 32k atoms at the LJ-melt density, half neighbour list within
     # r_c + skin = 2.8 resident on the GPU (fix edm_pair ... gpu_list), every step deposits hills; informational
@@ -726,8 +781,8 @@ def main():
             bl = H.Bias(make_bias(H, tmpdir, "lj", rank))
             bl.setup(1.0, 1.0)
             bl.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
-            bl.set_hill_log(False)
             bl.set_device_rng(True, 777)
+            bl.set("reference_order", 1)   # (the fix's default order; gpu_list keeps the neighbour list on the GPU)
             bl.pair_list_upload(pr[:, 0], pr[:, 1], np.ones(na, dtype=np.int32))
             d_xa = H.DeviceArray.from_host(xa)
             d_fa = H.DeviceArray.zeros((na, 3))
@@ -803,11 +858,24 @@ def main():
         out = dict(headline)
         out["roofline"] = dict(headline["roofline"])
         out["roofline"]["device_copy_same_traffic_us"] = copy_us
+        # the other kernels' rooflines and the metric's second quantity ride INSIDE the roofline object (the record keeps
+        # nested objects whole); the top-level copies below stay for readers of earlier rounds' lines
+        other = {}
+        if roof_w2:
+            other["w2_38.8M_pairs_k_pair_forces_fast"] = roof_w2
+        if nd:
+            for tag in nd:
+                other["k2_" + tag] = nd[tag]["roofline"]
+        other["hill_adds_strong_scaling"] = headline.get("hill_adds_strong_scaling")
+        out["roofline"]["other"] = other
         out.update({
             "evals_only_million_per_s": npairs / t_eval / 1e6,
             "ms_per_step_device_rng": ms_step_device_rng,
             "lj_melt_32k_from_positions": lj,
-            "one_launch_step": one_launch,
+            "step_modes": step_modes,
+            "ms_per_step_hills_log_on": headline["ms_per_step"],
+            "ms_per_step_batch_order": step_modes["ms_per_step_batch_order"],
+            "forces_only_ms_per_call": t_eval * 1e3,
             "energy_last_step": energy,
             # (batches released by the polled completion word / by the stream-wait fallback, whole run of this object)
             "polled_batches": b.get("polled_batches"),

@@ -195,6 +195,7 @@ struct edm_hip_bias {
   DevBuf<double> hs_r, hs_f, hs_x, hs_u;
   DevBuf<int> hs_mask;
   double *h_delta = nullptr;       // page-locked landing zone of step_host's force delta
+  hipEvent_t delta_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t h_delta_cap = 0;
   const void *reg_ptr = nullptr, *reg_failed_ptr = nullptr;   // the caller's position block, page-locked in place (step_host)
   size_t reg_bytes = 0;
@@ -424,6 +425,8 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   if (b->copy_event) (void)hipEventDestroy(b->copy_event);
   b->hs_r.release(); b->hs_f.release(); b->hs_x.release(); b->hs_u.release(); b->hs_mask.release();
   if (b->h_delta) (void)hipHostFree(b->h_delta);
+  for (int c = 0; c < 4; c++)
+    if (b->delta_ev[c]) (void)hipEventDestroy(b->delta_ev[c]);
   if (b->reg_ptr) (void)hipHostUnregister(const_cast<void *>(b->reg_ptr));
   (void)resolve_deferred_log(b);
   b->hills.submit(b->hill_events);
@@ -1360,7 +1363,9 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
     a.r = d_r;
     a.first_sample = d_first_sample;
     a.force = d_force;
-    EDM_HIP_TRY(launch_pair_forces_ordered(g->g, a, g->d_partials, s, &nblk, tag));
+    hipEvent_t e0, e1;
+    profile_slot(g, &e0, &e1);
+    EDM_HIP_TRY(launch_pair_forces_ordered(g->g, a, g->d_partials, s, &nblk, tag, e0, e1));
     tagged = tag != 0;
   } else if (n > 0) {
     // no new hill this step (none accepted, or edm_bias.cpp:534-535 skipped them): every pair sees the same bias
@@ -1587,7 +1592,8 @@ int edm_hip_bias_step_host(edm_hip_bias *b, long long n, const double *h_x, int 
     ~StreamGuard() { (void)hipStreamSynchronize(s); }
   } guard{s};
   if (n > 0) {
-    host_block_register(b, h_x, sizeof(double) * xcount);
+    // (whole rows: a copy of the caller's own that spans the block must not straddle locked and unlocked memory)
+    host_block_register(b, h_x, sizeof(double) * (size_t)n * (size_t)x_stride);
     EDM_HIP_TRY(hipMemcpyAsync(b->hs_x.p, h_x, sizeof(double) * xcount, hipMemcpyHostToDevice, s));
     EDM_HIP_TRY(hipMemsetAsync(b->hs_f.p, 0, sizeof(double) * (size_t)n * dim, s));
     if (apply_mask >= 0) {
@@ -1610,13 +1616,34 @@ int edm_hip_bias_step_host(edm_hip_bias *b, long long n, const double *h_x, int 
   b->d_mask = saved_mask;
   if (rc) return rc;
   if (n > 0) {
-    EDM_HIP_TRY(hipMemcpyAsync(b->h_delta, b->hs_f.p, sizeof(double) * (size_t)n * dim, hipMemcpyDeviceToHost, s));
-    EDM_HIP_TRY(hipStreamSynchronize(s));
+    // the delta comes down in a few pieces and the host adds piece k while piece k + 1 is on the link.
     // f[i][d] += delta[i][d]: the delta started from zero, so it holds exactly -dV/ds_d of the masked atoms and
     // (+0.0 or) 0 elsewhere -- the same doubles the reference's `forces[i][j] -= der[j]` subtracts
+    constexpr int PIECES = 4;
+    if (!b->delta_ev[0])
+      for (int c = 0; c < PIECES; c++) EDM_HIP_TRY(hipEventCreateWithFlags(&b->delta_ev[c], hipEventDisableTiming));
+    const long long per = (n + PIECES - 1) / PIECES;
+    for (int c = 0; c < PIECES; c++) {
+      const long long i0 = c * per, i1 = (i0 + per < n) ? i0 + per : n;
+      if (i0 < i1)
+        EDM_HIP_TRY(hipMemcpyAsync(b->h_delta + (size_t)i0 * dim, b->hs_f.p + (size_t)i0 * dim,
+                                   sizeof(double) * (size_t)(i1 - i0) * dim, hipMemcpyDeviceToHost, s));
+      EDM_HIP_TRY(hipEventRecord(b->delta_ev[c], s));
+    }
     const double *dl = b->h_delta;
-    for (long long i = 0; i < n; i++)
-      for (int d = 0; d < dim; d++) h_f[(size_t)i * f_stride + d] += dl[(size_t)i * dim + d];
+    for (int c = 0; c < PIECES; c++) {
+      const long long i0 = c * per, i1 = (i0 + per < n) ? i0 + per : n;
+      EDM_HIP_TRY(hipEventSynchronize(b->delta_ev[c]));
+      if (dim == 3 && f_stride == 3) {
+        double *fp = h_f + (size_t)i0 * 3;
+        const double *dp = dl + (size_t)i0 * 3;
+        const size_t m = (size_t)(i1 > i0 ? i1 - i0 : 0) * 3;
+        for (size_t q = 0; q < m; q++) fp[q] += dp[q];
+      } else {
+        for (long long i = i0; i < i1; i++)
+          for (int d = 0; d < dim; d++) h_f[(size_t)i * f_stride + d] += dl[(size_t)i * dim + d];
+      }
+    }
   }
   return EDM_HIP_OK;
 }

@@ -900,7 +900,8 @@ int edm_hip_gauss_device_buffer(edm_hip_gauss *g, double **d_records, int *doubl
 }
 
 // event pair for the next timed launch (nullptrs when profiling is off or the ring is full)
-static void profile_slot(const edm_hip_gauss *gc, hipEvent_t *e0, hipEvent_t *e1) {
+}  // extern "C"
+void edm::profile_slot(const edm_hip_gauss *gc, hipEvent_t *e0, hipEvent_t *e1) {
   edm_hip_gauss *g = const_cast<edm_hip_gauss *>(gc);
   *e0 = *e1 = nullptr;
   if (!g->profiling || !g->prof_ev) return;
@@ -909,6 +910,7 @@ static void profile_slot(const edm_hip_gauss *gc, hipEvent_t *e0, hipEvent_t *e1
   *e1 = g->prof_ev[2 * g->prof_pending + 1];
   g->prof_pending++;
 }
+extern "C" {
 // sums the stamped launches (their kernels must have completed: call after a stream synchronisation)
 static void profile_drain(edm_hip_gauss *g) {
   for (int i = 0; i < g->prof_pending; i++) {

@@ -189,6 +189,8 @@ struct PendingForces {
   LookupArgs la;
 };
 void ht_mark(edm_hip_gauss *g, int slot);   // development aid, edm_gauss.cpp
+// event pair for the next stamped launch of the handle's dominant lookup kernel (nullptrs when profiling is off)
+void profile_slot(const edm_hip_gauss *g, hipEvent_t *e0, hipEvent_t *e1);
 
 struct ApplySpec {
   long long nh = 0;

@@ -168,7 +168,8 @@ bool ordered_forces_supported(const Geom &g);
 hipError_t launch_ordered_records(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s);
 // tagged partial energy sums like launch_pair_forces (tag != 0: scratch is host-mapped, polled by the host)
 hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
-                                      int *blocks_out, unsigned long long tag);
+                                      int *blocks_out, unsigned long long tag, hipEvent_t ev0 = nullptr,
+                                      hipEvent_t ev1 = nullptr);
 // the same pass over a device-resident neighbour list (a.n / r / first_sample / force unused: list entry e is
 // "pair" e, its first sample 2 e; pl.fdelta receives the per-atom sums, pl.partial_tag as in launch_pairlist_forces)
 hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl, const OrderedForcesArgs &a, double *partials,

@@ -5547,7 +5547,7 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
 }
 
 hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
-                                      int *blocks_out, unsigned long long tag) {
+                                      int *blocks_out, unsigned long long tag, hipEvent_t ev0, hipEvent_t ev1) {
   if (!ordered_forces_supported(g) || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
   long long blocks = (a.n + 4 * BLOCK - 1) / (4 * BLOCK);   // four pairs per thread
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
@@ -5562,7 +5562,7 @@ hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a,
     attr_set = true;
   }
   const size_t lds = sizeof(int) * (size_t)((a.range_dev ? a.nh_cap : a.nh) > 0 ? (a.range_dev ? a.nh_cap : a.nh) : 1);
-  hipLaunchKernelGGL(k_pair_forces_ordered, dim3((unsigned)blocks), dim3(BLOCK), lds, s, g, a, dp, scratch, tag, per_block);
+  EDM_LAUNCH_TIMED(k_pair_forces_ordered, dim3((unsigned)blocks), dim3(BLOCK), lds, s, ev0, ev1, g, a, dp, scratch, tag, per_block);
   if (blocks_out) *blocks_out = (int)blocks;
   return hipGetLastError();
 }

@@ -38,7 +38,19 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["hill_adds_strong_scaling"]["value"] > 0 and d["hill_adds_strong_scaling"]["scaling"] == "strong"
     # both conventions for the fused launch's bytes: SURVEY 8(d)'s 16 B per evaluation is `frac`
     assert r["bytes_per_launch"] == 16 * d["config"]["pairs_per_gpu"]
-    assert r["frac_incl_selection_uniforms"] > r["frac"]
+    assert r["frac_incl_sample_indices"] > r["frac"]
+    # the driver's record keeps nested objects whole: the other kernels' rooflines live inside `roofline`
+    assert r["other"]["hill_adds_strong_scaling"]["value"] > 0
+    for key in ("k2_c2d_2048sq", "k2_c3d_512cube"):
+        assert 0 < r["other"][key]["frac"] < 1
+    # the default configuration is what is timed: reference fix's order, HILLS log on; the other modes beside it
+    assert "reference" in d["config"]["order"] and d["config"]["hills_log"].startswith("on")
+    assert d["ms_per_step_hills_log_on"] == d["ms_per_step"]
+    sm = d["step_modes"]
+    for key in ("ms_per_step_reference_order", "ms_per_step_batch_order", "ms_per_step_reference_order_hills_log_off",
+                "ms_per_step_batch_order_hills_log_off"):
+        assert sm[key] > 0
+    assert d["forces_only_ms_per_call"] > 0
     # BASELINE configs[3] / [4] in the default line: coordinate-CV lookups with their own roofline objects
     for tag, per_atom in (("c2d_2048sq", 156), ("c3d_512cube", 332)):
         c = d["coordinate_cv"][tag]
@@ -46,6 +58,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert rr["bytes_per_launch"] == per_atom * c["atoms"] and rr["bound"] == "hbm"
         assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) <= 1e-9 and 0 < rr["frac"] < 1
         assert c["step_ms"] > 0 and c["lookup_replica"]["in_use"] is True
+        st = c["step_stats"]
+        assert st["min_ms"] <= st["median_ms"] <= st["max_ms"] and st["poll_fallbacks"] >= 0 and st["replica_rebuilds"] >= 0
+        assert c["pcie_inclusive_step"]["ms_per_step"] > c["step_ms"]
     assert d["pcie_inclusive"]["ms_per_step"] > d["ms_per_step"]
 
 
