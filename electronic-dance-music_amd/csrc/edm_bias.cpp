@@ -636,6 +636,7 @@ static int do_pre_add_hill(edm_hip_bias *b, long long est) {
     int rcd = resolve_deferred_log(b);   // (the previous cycle's log lines, if they were deferred)
     if (rcd) return rcd;
   }
+  b->bias->shared_device = b->comm != nullptr && strcmp(b->comm->name(), "rccl") != 0;
   b->est_hill_count = est;
   b->temp_hill_prefactor = b->hill_prefactor;
   if (b->global_tempering > 0)
@@ -978,6 +979,8 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     spec.op.divisor = (b->hill_density < 0) ? (double)b->est_hill_count : b->hill_density;
     spec.op.clamp = BIAS_CLAMP * b->bias_per_step;
   }
+  // (ranks that share a GPU -- the host-staged carrier exists for exactly that -- never let waiting gather tiles go first)
+  b->bias->shared_device = b->comm != nullptr && strcmp(b->comm->name(), "rccl") != 0;
   ApplyOutcome oc;
   if (deferred_bound) {
     spec.d_nh = b->count_dev.p;
@@ -1972,6 +1975,7 @@ int edm_hip_bias_set(edm_hip_bias *b, const char *name, double value) {
   S("debug_force_sync", b->debug_force_sync, int)
   S("debug_pair_step_mode", b->debug_pair_step_mode, int)
   S("reference_order", b->reference_order, int)
+  if (strcmp(name, "debug_tiles_first") == 0 && b->bias) { b->bias->debug_tiles_first = (int)value; return EDM_HIP_OK; }
 #undef S
   set_error(std::string("unknown or read-only EDMBias member ") + name);
   return EDM_HIP_ERR_ARG;

@@ -1727,6 +1727,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       la.tag_seq = ++ws.tag_seq;
     }
     la.expected_hills = (spec.d_nh && spec.expected_nh >= 0) ? (long long)(spec.expected_nh + 0.5) : nh;
+    la.shared_device = g->shared_device ? 1 : 0;
+    la.tiles_first_mode = g->debug_tiles_first;
     if (small && rb_bytes + 128 <= g->h_stage_bytes) {
       // ... and so does the read-back: everything the host reads is final once the limiter has run, so the
       // same workgroup copies the packed region into host-mapped memory and flags it; the host polls the flag

@@ -127,6 +127,8 @@ struct edm_hip_gauss {
   long long polled_forces = 0;           // forces-only calls that returned on their workgroups' tagged sums (telemetry)
   bool wait_polled = false;              // the last apply_hills saw its results through the polled words: the
                                          // stream was NOT synchronised (its last kernel may still be retiring)
+  bool shared_device = false;            // another rank of the job runs on this GPU (host-staged carrier): see LimitArgs::shared_device
+  int debug_tiles_first = -1;            // tests: LimitArgs::tiles_first_mode
   int *d_dirty = nullptr;
   long long tiles_per_hill = 0;          // cached tiles_per_hill_bound() of the current geometry / boundary
   int *d_tickets = nullptr;              // three last-workgroup tickets (EDM_TICKET_INTS ints each), kept zero

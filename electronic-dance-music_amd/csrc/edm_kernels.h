@@ -507,6 +507,11 @@ struct LimitArgs {
   unsigned long long tag_seq;
   // host-side hint: the hill count the batch is expected to have (<= the launch bound h.nh); 0: unknown
   long long expected_hills;
+  // host-side, k_integrals_gather: another process runs kernels on this device (ranks sharing a GPU): the waiting
+  // gather tiles are never dispatched ahead of the integrals; tiles_first_mode: -1 = the launcher's choice (memset
+  // leaves 0 = integrals first, so callers set it), 0 / 1 = forced (tests)
+  int shared_device;
+  int tiles_first_mode;
   // development aid (EDM_HIP_TRACE=1): 8 wall-clock stamps (10 ns units) per workgroup of k_integrals_gather, or NULL
   unsigned long long *trace;
 };

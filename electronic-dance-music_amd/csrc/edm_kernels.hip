@@ -4229,9 +4229,27 @@ hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, 
   // hills against 512 slots -- tiles first, 86 hills waited for a slot until the first ones had finished: integrals
   // done at 11 us instead of 6; a launch bound without a hint counts as its own expectation)
   const long long live = (chain.expected_hills > 0 && chain.expected_hills < h.nh) ? chain.expected_hills : h.nh;
-  constexpr int PER_CU = 3;   // (47 KB of LDS, 139 registers)
-  const unsigned tiles_first = ((size_t)nb_tiles + 64 <= (size_t)PER_CU * cu_count() &&
-                                (long long)nb_tiles + live + live / 4 <= (long long)PER_CU * cu_count()) ? 1u : 0u;
+  // how many workgroups of THIS kernel a CU keeps resident: asked of the runtime for the instantiation that is launched
+  // (registers and LDS as this compiler allotted them -- 139 registers and 47 KB gave three when this was written),
+  // never more than the three the reasoning above was measured with.  The waiting tiles go first only on a device this
+  // process has to itself: a second rank on the same GPU (the host-staged carrier of the tests) brings waiting tiles of
+  // its own, and the slots the integrals count on may be theirs.
+  static int per_cu_cached[2] = {0, 0};
+  int &per_cu = per_cu_cached[g.bper[0] ? 1 : 0];
+  if (per_cu == 0) {
+    int nblk = 0;
+    hipError_t eo = g.bper[0] ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_integrals_gather<true>, BLOCK, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, k_integrals_gather<false>, BLOCK, 0);
+    if (eo != hipSuccess) {
+      (void)hipGetLastError();
+      nblk = 1;
+    }
+    per_cu = nblk < 1 ? 1 : (nblk > 3 ? 3 : nblk);
+  }
+  const long long slots = (long long)per_cu * cu_count();
+  unsigned tiles_first = ((long long)nb_tiles + 64 <= slots && (long long)nb_tiles + live + live / 4 <= slots) ? 1u : 0u;
+  if (chain.shared_device) tiles_first = 0;             // integrals first: deadlock-free by construction
+  if (chain.tiles_first_mode >= 0) tiles_first = chain.tiles_first_mode ? 1u : 0u;   // (tests)
   if (post.enabled) dup_ticket_tiles_1d(g, post, nb_tiles, BLOCK / 8);
   if (!g.bper[0])
     hipLaunchKernelGGL((k_integrals_gather<false>), dim3(nb_int + nb_tiles), dim3(BLOCK), 0, s, g, t, rec, h, heights, h_const,

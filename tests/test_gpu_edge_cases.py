@@ -214,3 +214,58 @@ def test_deferred_bound_exceeded_redo(entry, tmp_path, oracle_lib):
     assert np.allclose(runs["deferred"][1], ov, rtol=1e-9, atol=1e-13 * np.abs(ov).max())
     assert np.array_equal(runs["deferred"][3], o.hist.values)
     assert runs["deferred"][0][1][2][1] > 0, "the all-accepted step must have pushed hills into the overflow buffer"
+
+
+# ---------------------------------------------------------------------------------
+# k_integrals_gather: which half of the launch is dispatched first (gather tiles that WAIT for the limiter's word, or the
+# per-hill integrals the limiter needs).  The tiles go first only where they and the expected hills fit the kernel's
+# measured residency (hipOccupancyMaxActiveBlocksPerMultiprocessor of the launched instantiation) with room to spare,
+# and never on a device another rank uses; either order must give the same bits.
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("tiles", [690, 705, 740, 1500], ids=lambda t: "%d_tiles" % t)
+def test_integrals_gather_dispatch_order_near_the_residency_limit(tiles, workdir, oracle_lib):
+    import edm_amd.workloads as W
+
+    nodes = 32 * tiles - 5                      # 32-node gather tiles; 3 workgroups per CU x 256 CUs = 768 slots
+    hi = 2.8
+    spacing = hi / (nodes - 1)
+    text = ("tempering 0\nhill_prefactor 0.5\nhill_density 200\ndimension 1\nbox_low 0\nbox_high %.17g\n"
+            "bias_spacing %.17g\nbias_sigma 0.02\n" % (hi, spacing))
+    n = 100_000
+    results = {}
+    for mode in (-1, 0, 1):                     # the launcher's choice / integrals first / tiles first (forced)
+        if mode == 1 and tiles > 700:
+            continue                            # (forcing the waiting tiles ahead where they fill the machine is the deadlock the rule avoids)
+        cfg = str(workdir / ("order_%d_%d.edm" % (tiles, mode + 1)))
+        open(cfg, "w").write(text + "hills_filename %s/H_%d_%d\nhistogram_filename %s/HI_%d_%d\n"
+                             % (workdir, tiles, mode + 1, workdir, tiles, mode + 1))
+        b = H.Bias(cfg)
+        b.setup(1.0, 1.0)
+        b.subdivide([0], [hi], [0], [hi], [0], [0.3])
+        b.set("debug_tiles_first", mode)
+        for step in range(3):
+            r = W.pair_distances(n, 700 + step).reshape(-1, 1)
+            b.add_hills(r, W.uniform(750 + step, n), -1, est=2 * n)
+        v, dv = b.gauss.download()
+        results[mode] = (v, dv, b.hist.values, b.get("cum_bias"), b.get("overflow_right"), b.get("hills_added"))
+        assert b.get("polled_batches") > 0 and b.get("poll_fallbacks") == 0, "the chained launch completed through its polled word"
+        del b
+    for mode in results:
+        for a, c in zip(results[-1], results[mode]):
+            assert np.array_equal(np.asarray(a), np.asarray(c)), "dispatch order %d changed the results" % mode
+    # and the hills are the reference's
+    cfg = str(workdir / ("order_%d_o.edm" % tiles))
+    open(cfg, "w").write(text + "hills_filename %s/H_o%d\nhistogram_filename %s/HI_o%d\n" % (workdir, tiles, workdir, tiles))
+    o = B.Bias(oracle_lib, cfg)
+    o.setup(1.0, 1.0)
+    o.subdivide([0], [hi], [0], [hi], [0], [0.3])
+    for step in range(3):
+        r = W.pair_distances(n, 700 + step).reshape(-1, 1)
+        u = W.uniform(750 + step, n)
+        o.pre_add_hill(2 * n)
+        for i in np.nonzero(u < 200.0 / (2 * n))[0]:
+            o.add_hill(r[i], float(u[i]))
+        o.post_add_hill()
+    v = results[-1][0]
+    assert np.allclose(v, o.gauss.grid.values, rtol=1e-9, atol=1e-13 * np.abs(v).max())
+    assert results[-1][4] == o.get("overflow_right") and results[-1][5] == o.get("hills_added")
