@@ -1506,6 +1506,15 @@ int edm_hip_bias_pair_step_host(edm_hip_bias *b, long long n, const double *h_r,
   EDM_HIP_TRY(b->hs_u.reserve((size_t)(n_samples > 0 ? n_samples : 1)));
   int nblk = 0;
   b->bias->wait_polled = false;
+  // (whatever happens below -- a full overflow buffer, a communicator error -- no copy may still be reading or writing
+  //  the caller's arrays when the call returns)
+  struct CopyGuard {
+    hipStream_t a, c;
+    ~CopyGuard() {
+      (void)hipStreamSynchronize(a);
+      (void)hipStreamSynchronize(c);
+    }
+  } copy_guard{s, b->copy_stream};
   if (n > 0) {
     EDM_HIP_TRY(hipMemcpyAsync(b->hs_r.p, h_r, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
     rc = pair_forces_enqueue(b->bias, n, b->hs_r.p, b->hs_f.p, &nblk);   // (behind the overflow flush, ahead of the new hills)
@@ -1989,6 +1998,12 @@ int edm_hip_bias_get_array(const edm_hip_bias *b, const char *name, double *out)
   if (strcmp(name, "max") == 0) v = &b->max;
   if (!v) return EDM_HIP_ERR_ARG;
   for (size_t i = 0; i < v->size(); i++) out[i] = (*v)[i];
+  return EDM_HIP_OK;
+}
+
+int edm_hip_bias_wait(edm_hip_bias *b) {
+  if (b && b->bias) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
+  if (b && b->copy_stream) EDM_HIP_TRY(hipStreamSynchronize(b->copy_stream));
   return EDM_HIP_OK;
 }
 

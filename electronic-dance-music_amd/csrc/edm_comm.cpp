@@ -57,7 +57,8 @@ struct ShmHeader {
   std::atomic<int> generation;
   std::atomic<int> attached;
   int nranks;
-  char pad[128 - 3 * sizeof(std::atomic<int>) - sizeof(int)];
+  std::atomic<int> magic;   // written last by the creator: the object is ready
+  char pad[128 - 4 * sizeof(std::atomic<int>) - sizeof(int)];
 };
 static const size_t SHM_SLOT = (size_t)4 << 20;
 static const double SHM_TIMEOUT_S = 120.0;
@@ -165,12 +166,40 @@ int make_shm_transport(const char *shm_name, int nranks, int rank, Transport **o
   t->n = nranks;
   t->r = rank;
   t->map_bytes = sizeof(ShmHeader) + (size_t)nranks * SHM_SLOT;
-  const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
-  if (fd < 0 || ftruncate(fd, (off_t)t->map_bytes) != 0) {
-    if (fd >= 0) close(fd);
-    delete t;
-    set_error(std::string("host transport: cannot create the shared-memory object ") + shm_name);
-    return EDM_HIP_ERR_COMM;
+  // Rank 0 creates the object -- removing whatever a crashed job left behind under the same name first, O_EXCL so that
+  // nobody else's object is adopted -- sizes it (a fresh object is zero-filled: the barrier counters start at 0) and
+  // writes its magic word LAST; the other ranks open without O_CREAT, retrying until the object exists, has its full
+  // size and shows the magic word, and check the rank count the creator recorded.
+  static const int SHM_MAGIC = 0x45444d31;   // "EDM1"
+  const auto t0 = std::chrono::steady_clock::now();
+  auto timed_out = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > SHM_TIMEOUT_S; };
+  int fd = -1;
+  if (rank == 0) {
+    (void)shm_unlink(shm_name);
+    fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)t->map_bytes) != 0) {
+      if (fd >= 0) close(fd);
+      delete t;
+      set_error(std::string("host transport: cannot create the shared-memory object ") + shm_name);
+      return EDM_HIP_ERR_COMM;
+    }
+  } else {
+    for (;;) {
+      fd = shm_open(shm_name, O_RDWR, 0600);
+      if (fd >= 0) {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && (size_t)st.st_size >= t->map_bytes) break;
+        close(fd);
+        fd = -1;
+      }
+      if (timed_out()) {
+        t->shm.clear();
+        delete t;
+        set_error(std::string("host transport: rank 0 did not create the shared-memory object ") + shm_name + " within the time limit");
+        return EDM_HIP_ERR_COMM;
+      }
+      usleep(200);
+    }
   }
   void *p = mmap(nullptr, t->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
   close(fd);
@@ -179,14 +208,30 @@ int make_shm_transport(const char *shm_name, int nranks, int rank, Transport **o
     set_error("host transport: mmap failed");
     return EDM_HIP_ERR_COMM;
   }
-  t->base = static_cast<char *>(p);   // (a fresh object is zero-filled: barrier counters start at 0)
-  t->hdr()->nranks = nranks;
+  t->base = static_cast<char *>(p);
+  if (rank == 0) {
+    t->hdr()->nranks = nranks;
+    t->hdr()->magic.store(SHM_MAGIC, std::memory_order_release);
+  } else {
+    while (t->hdr()->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
+      sched_yield();
+      if (timed_out()) {
+        delete t;
+        set_error("host transport: the shared-memory object never became ready");
+        return EDM_HIP_ERR_COMM;
+      }
+    }
+    if (t->hdr()->nranks != nranks) {
+      delete t;
+      set_error("host transport: the ranks disagree about the rank count");
+      return EDM_HIP_ERR_ARG;
+    }
+  }
   // wait until every rank has attached, so that rank 0's unlink at the end cannot precede an attach
   t->hdr()->attached.fetch_add(1, std::memory_order_acq_rel);
-  const auto t0 = std::chrono::steady_clock::now();
   while (t->hdr()->attached.load(std::memory_order_acquire) < nranks) {
     sched_yield();
-    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > SHM_TIMEOUT_S) {
+    if (timed_out()) {
       delete t;
       set_error("host transport: not every rank attached within the time limit");
       return EDM_HIP_ERR_COMM;

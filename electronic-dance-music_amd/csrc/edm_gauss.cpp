@@ -1032,6 +1032,11 @@ int edm_hip_gauss_pair_forces(const edm_hip_gauss *g, long long n, const double 
   return EDM_HIP_OK;
 }
 
+int edm_hip_gauss_wait(edm_hip_gauss *g) {
+  if (g) EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  return EDM_HIP_OK;
+}
+
 int edm_hip_gauss_profile_enable(edm_hip_gauss *g, int enabled) {
   if (enabled && !g->prof_ev) {
     g->prof_ev = new hipEvent_t[2 * edm_hip_gauss::PROF_RING];

@@ -112,6 +112,8 @@ _PROTOS = {
     "edm_hip_bias_step": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step_host": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
+    "edm_hip_gauss_wait": (C.c_int, [vp]),
+    "edm_hip_bias_wait": (C.c_int, [vp]),
     "edm_hip_bias_step_host": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step_ordered": (C.c_int, [vp, C.c_longlong, vp, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step_ordered_host": (C.c_int, [vp, C.c_longlong, vp, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
@@ -767,6 +769,8 @@ def _bias_step_host(self, x, f, mask=None, runiform=None, apply_mask=-1, hill_st
 
 
 Bias.step_host = _bias_step_host
+Bias.wait = lambda self: check(lib().edm_hip_bias_wait(self.h))
+Gauss.wait = lambda self: check(lib().edm_hip_gauss_wait(self.h))
 Bias.pair_step_ordered_device = _bias_pair_step_ordered_device
 Bias.pair_step_ordered_host = _bias_pair_step_ordered_host
 

@@ -53,7 +53,18 @@ typedef struct edm_hip_bias edm_hip_bias;   /* EDMBias controller */
  * from host-mapped memory flagged by the device instead of waiting for the stream (EDM_HIP_POLL=0 in the
  * environment: always wait).  Every later call on the same object is ordered behind that work; the streams are
  * blocking streams, so edm_hip_memcpy_* / edm_hip_memset (null stream) and the writers wait for it as well;
- * edm_hip_device_synchronize() waits for everything.  The caller's input arrays are not read after the call. */
+ * edm_hip_device_synchronize() waits for everything.  The caller's input arrays are not read after the call.
+ *
+ * DEVICE output arrays (d_force, d_f, d_fdelta of the *_device / d_* entry points): a forces-only call returns as soon
+ * as every workgroup's energy sum has reached the host -- the force kernel itself may not have retired, and its
+ * stores are made visible by its end-of-kernel release.  The arrays are therefore ordered for work queued LATER on
+ * the handle's own stream and on the null stream (blocking streams: hipMemcpy, edm_hip_memcpy_*, kernels launched on
+ * stream 0), which is what every consumer in this repository is.  A consumer on a stream of its own created with
+ * hipStreamNonBlocking (Kokkos-style), a peer GPU, or the host reading through a mapping must call
+ * edm_hip_bias_wait() / edm_hip_gauss_wait() first: they wait for everything the object has queued. */
+
+int edm_hip_gauss_wait(edm_hip_gauss *g);
+int edm_hip_bias_wait(edm_hip_bias *b);
 
 /* ---- runtime ---------------------------------------------------------- */
 const char *edm_hip_last_error(void);

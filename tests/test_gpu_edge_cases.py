@@ -269,3 +269,38 @@ def test_integrals_gather_dispatch_order_near_the_residency_limit(tiles, workdir
     v = results[-1][0]
     assert np.allclose(v, o.gauss.grid.values, rtol=1e-9, atol=1e-13 * np.abs(v).max())
     assert results[-1][4] == o.get("overflow_right") and results[-1][5] == o.get("hills_added")
+
+
+def test_device_forces_read_from_a_non_blocking_stream_after_wait(oracle_lib, workdir):
+    """A forces-only call returns when the energy sums are on the host; the force kernel may not have retired.  A
+    consumer on a hipStreamNonBlocking stream of its own (which the handle's blocking stream does not order) calls
+    edm_hip_bias_wait() first (include/edm_hip.h, 'Completion'): the array it then copies holds the call's forces."""
+    import ctypes as C
+
+    cfg = str(workdir / "wait.edm")
+    open(cfg, "w").write("tempering 0\nhill_prefactor 0.5\nhill_density 250\ndimension 1\nbox_low 0\nbox_high 2.8\n"
+                         "bias_spacing 0.00025\nbias_sigma 0.025\nhills_filename %s/H\nhistogram_filename %s/HI\n" % (workdir, workdir))
+    b = H.Bias(cfg)
+    b.setup(1.0, 1.0)
+    b.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
+    hx = np.zeros((300, 3))
+    hx[:, 0] = W.pair_distances(300, 5)
+    b.gauss.add_values(hx, 0.01)
+    hip = C.CDLL("libamdhip64.so")
+    stream = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(stream), 1) == 0   # hipStreamNonBlocking
+    n = 1 << 20
+    d_f = H.DeviceArray.zeros((n,))
+    out = np.empty(n)
+    polled0 = b.get("polled_forces")
+    for rep in range(5):
+        r = W.pair_distances(n, 40 + rep)
+        d_r = H.DeviceArray.from_host(r)
+        e = b.pair_forces_device(d_r, d_f, n)
+        b.wait()
+        assert hip.hipMemcpyAsync(C.c_void_p(out.ctypes.data), C.c_void_p(d_f.ptr), C.c_size_t(out.nbytes), 2, stream) == 0
+        assert hip.hipStreamSynchronize(stream) == 0
+        assert np.array_equal(out, d_f.to_host())
+        assert np.isfinite(e) and np.abs(out).max() > 0
+    assert b.get("polled_forces") > polled0, "the calls did return on their polled energy sums"
+    hip.hipStreamDestroy(stream)
