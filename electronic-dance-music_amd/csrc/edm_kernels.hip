@@ -526,29 +526,41 @@ __device__ __forceinline__ int quad_bcast_i(int v) {
   constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
   return __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true);
 }
-// one corner of interp<DIM> (grid.h:85-131): tf * prod C and tf * D_d * prod_{e != d} C_e
+// quad_perm:[1,0,3,2] / [2,3,0,1]: the value of the lane whose index within the quad differs in bit 0 / bit 1
+template <int XOR>
+__device__ __forceinline__ double quad_xor(double v) {
+  constexpr int ctrl = (XOR == 1) ? (1 | (0 << 2) | (3 << 4) | (2 << 6)) : (2 | (3 << 2) | (0 << 4) | (1 << 6));
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {   // every lane of the quad: the quad's sum, (0+1) + (2+3)
+  v += quad_xor<1>(v);
+  v += quad_xor<2>(v);
+  return v;
+}
+// one corner of interp<DIM> (grid.h:85-131): tf * prod C and tf * D_d * prod_{e != d} C_e.  The reference's
+// qq = -d / f per dimension (grid.h:117) is formed from ONE reciprocal of the corner's value, and D's scaling by
+// sgn / dx (grid.h:123) from the launch's 1 / dx: a double division is ~30 instructions, a 3-D sample had fifteen of them
+// per lane and the kernel is bound by fp64 issue, not by HBM.  Values move by ~1e-16 relative (as in K1's fast path).
 template <int DIM>
-__device__ __forceinline__ void corner_terms(const Geom &g, const double4 &r, const double *wod, int b0, int b1, int b2,
-                                             double &tF, double *tD) {
+__device__ __forceinline__ void corner_terms(const Geom &g, const double *inv_dx, const double4 &r, const double *wod,
+                                             int b0, int b1, int b2, double &tF, double *tD) {
   const double tf = r.x;
   const double dv[3] = {r.y, r.z, r.w};
+  const double rf = (fabs(tf) < 0.0000001) ? 0.0 : 1.0 / tf;   // grid.h:113-116: derivative term dropped near zero
   double C[DIM], D[DIM];
   double ff = 1.0;
 #pragma unroll
   for (int d = 0; d < DIM; d++) {
     const int bit = (d == 0) ? b0 : (d == 1) ? b1 : b2;
-    const int sgn = bit ? -1 : 1;
+    const double sgn = bit ? -1.0 : 1.0;
     const double X = fabs(wod[d] - bit);
     const double X2 = X * X;
     const double X3 = X2 * X;
-    double qq;
-    if (fabs(tf) < 0.0000001)  // grid.h:113-116: derivative term dropped near zero
-      qq = 0.0;
-    else
-      qq = -dv[d] / tf;
-    C[d] = (1 - 3 * X2 + 2 * X3) - sgn * qq * (X - 2 * X2 + X3) * g.dx[d];
-    D[d] = (-6 * X + 6 * X2) - sgn * qq * (1 - 4 * X + 3 * X2) * g.dx[d];
-    D[d] *= sgn / g.dx[d];
+    const double sq = sgn * (-dv[d] * rf) * g.dx[d];
+    C[d] = (1 - 3 * X2 + 2 * X3) - sq * (X - 2 * X2 + X3);
+    D[d] = ((-6 * X + 6 * X2) - sq * (1 - 4 * X + 3 * X2)) * (sgn * inv_dx[d]);
     ff *= C[d];
   }
   tF = tf * ff;
@@ -565,6 +577,11 @@ __device__ __forceinline__ void corner_terms(const Geom &g, const double4 &r, co
 // enough to sit in L2): lane q loads corner q (and q + 4) at its node's address -- a quad covers the 64-byte corner
 // pairs of two grid rows per instruction, 32 lines per wave-instruction instead of 64, a quarter of the load
 // instructions per sample.
+// Lane d < DIM owns dimension d: it loads coordinate d of the sample (one 8-byte load per lane instead of DIM), runs
+// the bounds / remap / in-grid tests of that dimension (gaussian_grid.h:490-541, grid.h:865-874: all per dimension) and
+// derives its node index and cell coordinate; DPP quad moves hand the pieces round.  The corner terms are added up
+// over the quad as (0 + 1) + (2 + 3), in 3-D after each lane has added its two faces -- not the reference's corner
+// order, a difference of association (~1e-16).
 // (body for workgroup `bid` of `nb`: shared by the plain launch and by the launch that also prepares a hill list)
 template <int DIM, int MODE, bool REPLICA>
 __device__ __forceinline__ void lookup_quad_body(const Geom &g, const double *__restrict__ faces, const LookupArgs &a,
@@ -573,40 +590,56 @@ __device__ __forceinline__ void lookup_quad_body(const Geom &g, const double *__
   __shared__ double lds[BLOCK / 64];
   const int q = threadIdx.x & 3;
   const int b0 = q & 1, b1 = q >> 1;
+  // this lane's dimension (lane 3, and lane 2 in 2-D, shadow another lane's: their results are not read)
+  const int myd = (q < DIM) ? q : DIM - 1;
+  const double mn = (myd == 0) ? g.min[0] : (myd == 1) ? g.min[1] : g.min[2];
+  const double mx = (myd == 0) ? g.max[0] : (myd == 1) ? g.max[1] : g.max[2];
+  const double dxd = (myd == 0) ? g.dx[0] : (myd == 1) ? g.dx[1] : g.dx[2];
+  const double bmn = (myd == 0) ? g.bmin[0] : (myd == 1) ? g.bmin[1] : g.bmin[2];
+  const double bmx = (myd == 0) ? g.bmax[0] : (myd == 1) ? g.bmax[1] : g.bmax[2];
+  const int nd = (myd == 0) ? g.n[0] : (myd == 1) ? g.n[1] : g.n[2];
+  const int perd = (myd == 0) ? g.periodic[0] : (myd == 1) ? g.periodic[1] : g.periodic[2];
+  const int bperd = (myd == 0) ? g.bper[0] : (myd == 1) ? g.bper[1] : g.bper[2];
+  const double inv_dxd = 1.0 / dxd;
+  double inv_dx[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; d++) inv_dx[d] = 1.0 / g.dx[d];
   double e_acc = 0;
   const long long stride = (long long)nb * (BLOCK / 4);
   for (long long i = (long long)bid * (BLOCK / 4) + (threadIdx.x >> 2); i < a.n; i += stride) {
     if (MODE == LOOKUP_FORCES && !(a.apply_mask < 0 || (a.mask[i] & a.apply_mask))) continue;   // (uniform over the quad)
-    double xx[DIM];
-#pragma unroll
-    for (int d = 0; d < DIM; d++) xx[d] = a.x[i * a.x_stride + d];
+    double xi = a.x[i * a.x_stride + myd];
     // the force component this lane will update: requested now, needed last
     double f_old = 0;
     if (MODE == LOOKUP_FORCES && q < DIM) f_old = a.f[i * a.f_stride + q];
-    bool ok = true;
-    if (!in_bounds<DIM>(g, xx)) {
-      remap<DIM>(g, xx);
-      if (!in_bounds<DIM>(g, xx)) ok = false;
+    // in_bounds (closed interval on the boundary), remap if ANY dimension is outside, in_bounds again, in_grid
+    int out_d = (xi < bmn || xi > bmx) ? 1 : 0;
+    int any_out = quad_bcast_i<0>(out_d) | quad_bcast_i<1>(out_d);
+    if (DIM == 3) any_out |= quad_bcast_i<2>(out_d);
+    if (any_out) {   // gaussian_grid.h:504-541, one dimension
+      if (xi < mn || xi > mx) {
+        if (perd) {
+          xi -= (mx - mn) * ifloor((xi - mn) / (mx - mn));
+        } else if (bperd) {
+          const double period = bmx - bmn;
+          const double s0 = round_half((mn - xi) / (bmx - bmn)) * period;
+          const double s1 = round_half((mx - xi) / (bmx - bmn)) * period;
+          if (fabs(mn - xi - s0) < fabs(mx - xi - s1)) xi += s0; else xi += s1;
+        }
+      }
+      out_d = (xi < bmn || xi > bmx) ? 1 : 0;
     }
-    if (ok && !in_grid<DIM>(g, xx)) ok = false;
-    double value = 0, der[DIM];
-#pragma unroll
-    for (int d = 0; d < DIM; d++) der[d] = 0;
-    if (ok) {   // (uniform over the quad: every lane holds the same xx)
-      // lane d: node index, offset inside the cell and scaled coordinate of dimension d (grid.h:264-273, :426-430, :99)
-      const int myd = (q < DIM) ? q : 0;
-      const double mn = (myd == 0) ? g.min[0] : (myd == 1) ? g.min[1] : g.min[2];
-      const double mx = (myd == 0) ? g.max[0] : (myd == 1) ? g.max[1] : g.max[2];
-      const double dxd = (myd == 0) ? g.dx[0] : (myd == 1) ? g.dx[1] : g.dx[2];
-      const int nd = (myd == 0) ? g.n[0] : (myd == 1) ? g.n[1] : g.n[2];
-      const int perd = (myd == 0) ? g.periodic[0] : (myd == 1) ? g.periodic[1] : g.periodic[2];
-      double xi = (myd == 0) ? xx[0] : (myd == 1) ? xx[1] : xx[DIM - 1];
+    if (!perd && (xi < mn || xi >= mx - dxd)) out_d = 1;   // grid.h:865-874
+    int bad = quad_bcast_i<0>(out_d) | quad_bcast_i<1>(out_d);
+    if (DIM == 3) bad |= quad_bcast_i<2>(out_d);
+    double value = 0, my_der = 0;
+    if (!bad) {   // (uniform over the quad)
+      // node index, offset inside the cell and scaled coordinate of this lane's dimension (grid.h:264-273, :426-430, :99)
       if (perd) xi -= (mx - mn) * ifloor((xi - mn) / (mx - mn));
       long long id = (long long)floor((xi - mn) / dxd);
       if (id > nd - 1) id = nd - 1;   // (the reference reads past the array when the wrap rounds up to max: stay inside)
       if (id < 0) id = 0;
-      const double wh = xi - mn - id * dxd;
-      const double wd = wh / dxd;
+      const double wd = (xi - mn - id * dxd) * inv_dxd;
       const int my_idx = (int)id;
       int idx[DIM];
       double wod[DIM];
@@ -634,43 +667,27 @@ __device__ __forceinline__ void lookup_quad_body(const Geom &g, const double *__
         at = blk + (b0 ? s0 : 0) + (b1 ? s1 : 0);
       }
       const double4 rA = f4[at];
-      double tFA, tDA[DIM], tFB = 0, tDB[DIM];
+      double tF, tD[DIM];
       if (DIM == 3) {
         // the face above: node i2 + 1, or node 0 across a periodic seam (grid.h:432-433)
         long long up = (long long)g.n[0] * g.n[1];
         if (g.periodic[DIM - 1] && idx[DIM - 1] == g.n[DIM - 1] - 1) up *= (1 - g.n[DIM - 1]);
         const double4 rB = f4[REPLICA ? (blk + up) * 4 + q : at + up];
-        corner_terms<DIM>(g, rA, wod, b0, b1, 0, tFA, tDA);
-        corner_terms<DIM>(g, rB, wod, b0, b1, 1, tFB, tDB);
-      } else {
-        corner_terms<DIM>(g, rA, wod, b0, b1, 0, tFA, tDA);
-      }
-      // sums in the reference's corner order: corner c = b0 + 2 b1 + 4 b2 sits in lane c & 3
-      value += quad_bcast<0>(tFA);
-      value += quad_bcast<1>(tFA);
-      value += quad_bcast<2>(tFA);
-      value += quad_bcast<3>(tFA);
-      if (DIM == 3) {
-        value += quad_bcast<0>(tFB);
-        value += quad_bcast<1>(tFB);
-        value += quad_bcast<2>(tFB);
-        value += quad_bcast<3>(tFB);
-      }
+        double tFB, tDB[DIM];
+        corner_terms<DIM>(g, inv_dx, rA, wod, b0, b1, 0, tF, tD);
+        corner_terms<DIM>(g, inv_dx, rB, wod, b0, b1, 1, tFB, tDB);
+        tF += tFB;
 #pragma unroll
-      for (int d = 0; d < DIM; d++) {
-        der[d] += quad_bcast<0>(tDA[d]);
-        der[d] += quad_bcast<1>(tDA[d]);
-        der[d] += quad_bcast<2>(tDA[d]);
-        der[d] += quad_bcast<3>(tDA[d]);
-        if (DIM == 3) {
-          der[d] += quad_bcast<0>(tDB[d]);
-          der[d] += quad_bcast<1>(tDB[d]);
-          der[d] += quad_bcast<2>(tDB[d]);
-          der[d] += quad_bcast<3>(tDB[d]);
-        }
+        for (int d = 0; d < DIM; d++) tD[d] += tDB[d];
+      } else {
+        corner_terms<DIM>(g, inv_dx, rA, wod, b0, b1, 0, tF, tD);
       }
+      value = quad_sum(tF);
+      double der[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; d++) der[d] = quad_sum(tD[d]);
+      my_der = (q == 0) ? der[0] : (q == 1) ? der[1] : der[DIM - 1];
     }
-    const double my_der = (q == 0) ? der[0] : (q == 1) ? der[1] : der[DIM - 1];
     if (MODE == LOOKUP_FORCES) {
       if (q < DIM) a.f[i * a.f_stride + q] = f_old - my_der;
       if (q == 3) e_acc += value;
@@ -693,6 +710,7 @@ __global__ void __launch_bounds__(BLOCK) k_lookup_quad(Geom g, const double *__r
   lookup_quad_body<DIM, MODE, REPLICA>(g, faces, a, block_energy, blockIdx.x, gridDim.x);
 }
 
+static int cu_count();
 template <int DIM>
 static hipError_t lookup_dim(const Geom &g, const double *rec, LookupMode mode, const LookupArgs &a,
                              double *scratch, double *energy_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
@@ -705,6 +723,30 @@ static hipError_t lookup_dim(const Geom &g, const double *rec, LookupMode mode, 
     constexpr int QD = (DIM > 1) ? DIM : 2;
     long long qb = (a.n * 4 + BLOCK - 1) / BLOCK;
     if (qb > MAX_BLOCKS) qb = MAX_BLOCKS;
+    {
+      // as many workgroups as the device keeps resident of this kernel (the workgroups stride over the samples, so any
+      // count is correct): a launch of 2048 on a device that keeps 1280 resident runs a full round and a 60 % one
+      static int resident[2][2] = {{0, 0}, {0, 0}};
+      int &res = resident[faces ? 1 : 0][mode == LOOKUP_FORCES ? 1 : 0];
+      if (res == 0) {
+        int per_cu = 0;
+        hipError_t eo;
+        if (faces)
+          eo = mode == LOOKUP_FORCES ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lookup_quad<QD, LOOKUP_FORCES, true>, BLOCK, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lookup_quad<QD, LOOKUP_VALUES, true>, BLOCK, 0);
+        else
+          eo = mode == LOOKUP_FORCES ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lookup_quad<QD, LOOKUP_FORCES, false>, BLOCK, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lookup_quad<QD, LOOKUP_VALUES, false>, BLOCK, 0);
+        if (eo != hipSuccess) {
+          (void)hipGetLastError();
+          per_cu = 0;
+        }
+        res = per_cu > 0 ? per_cu * cu_count() : -1;
+      }
+      // (one round -- as many workgroups as stay resident, striding -- measured 12.1 / 17.5 us against 12.7 / 18.4 us for
+      //  2048 workgroups on the 2048^2 / 512^3 grids at 262 144 atoms; two or three rounds: no different from 2048)
+      if (res > 0 && qb > (long long)res) qb = (long long)res;
+    }
     blocks = (int)(qb < 1 ? 1 : qb);
     if (faces) {
       if (mode == LOOKUP_FORCES)
