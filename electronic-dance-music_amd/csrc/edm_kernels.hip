@@ -5520,9 +5520,14 @@ struct OrderedSource {
   const OrderedForcesArgs &a;
   const OrderedCommon &oc;
   int m;
+  // optional: rows [row0, row0 + nrows) of the counts staged in LDS by the workgroup (its pairs are contiguous, so
+  // their hill counts m span a handful of rows): the count then costs no global round trip
+  const unsigned short *rows = nullptr;
+  int row0 = 0, nrows = 0;
   __device__ __forceinline__ double2 raw(int node) const {
     const int tile = node / ORD_NODES;
-    const int u = a.counts[(long long)m * oc.ntiles + tile];
+    const int u = (m >= row0 && m < row0 + nrows) ? rows[(m - row0) * oc.ntiles + tile]
+                                                  : a.counts[(long long)m * oc.ntiles + tile];
     if (u == 0) return reinterpret_cast<const double2 *>(a.rec0)[node];
     return reinterpret_cast<const double2 *>(a.records)[((long long)tile * a.nh_cap + (u - 1)) * ORD_NODES + (node % ORD_NODES)];
   }
@@ -5564,14 +5569,18 @@ __device__ __forceinline__ void pair_one_src(const Geom &g, const SRC &src, doub
   d = in_range ? dd : 0.0;
 }
 // energy and dV/dr at r as the reference's loop saw them at the sample index `fs` of the pair's first add_hill call
-__device__ __forceinline__ void ordered_lookup(const Geom &g, const OrderedForcesArgs &a, const OrderedCommon &oc, double x,
-                                               long long fs, double &v, double &d) {
-  int lo = 0, hi = oc.H;   // m = number of hills whose sample index is below fs
+__device__ __forceinline__ int ordered_hills_before(const OrderedCommon &oc, long long fs) {
+  int lo = 0, hi = oc.H;   // number of hills whose sample index is below fs
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     if ((long long)oc.samples[mid] < fs) lo = mid + 1; else hi = mid;
   }
-  const OrderedSource src{a, oc, lo};
+  return lo;
+}
+__device__ __forceinline__ void ordered_lookup(const Geom &g, const OrderedForcesArgs &a, const OrderedCommon &oc, double x,
+                                               long long fs, double &v, double &d, const unsigned short *rows = nullptr,
+                                               int row0 = 0, int nrows = 0) {
+  const OrderedSource src{a, oc, ordered_hills_before(oc, fs), rows, row0, nrows};
   if (oc.fast)
     pair_one_src(g, src, oc.inv_dx, x, v, d);
   else
@@ -5583,19 +5592,33 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
                                                                long long per_block) {
   extern __shared__ int s_samples[];
   __shared__ double red[BLOCK / 64];
+  constexpr int ROWS_LDS = 4096;   // 16-bit counts staged per workgroup: 8 KB, eleven rows of the C1D grid's 351 tiles
+  __shared__ unsigned short s_rows[ROWS_LDS];
   OrderedCommon oc;
   ordered_common_init(g, a, dp, s_samples, oc);
   double e_acc = 0;
-  // a workgroup owns a contiguous run of pairs: they share their hill count m, i.e. one row of the counts
+  // a workgroup owns a contiguous run of pairs: their hill counts m span a handful of consecutive rows of the counts
+  // (a W1 step has ~8 000 pairs between two hills), staged in LDS so that a pair's chain is distance -> record, two
+  // round trips, not distance -> count -> record
   const long long beg = (long long)blockIdx.x * per_block;
   const long long end = (beg + per_block < a.n) ? beg + per_block : a.n;
+  int row0 = 0, nrows = 0;
+  if (beg < end) {
+    const long long fs0 = a.first_sample ? (long long)a.first_sample[beg] : 2 * beg;
+    const long long fs1 = a.first_sample ? (long long)a.first_sample[end - 1] : 2 * (end - 1);
+    row0 = ordered_hills_before(oc, fs0);
+    nrows = ordered_hills_before(oc, fs1) - row0 + 1;
+    if (nrows * oc.ntiles > ROWS_LDS) nrows = ROWS_LDS / oc.ntiles;
+    for (int e = threadIdx.x; e < nrows * oc.ntiles; e += BLOCK) s_rows[e] = a.counts[(long long)row0 * oc.ntiles + e];
+  }
+  __syncthreads();
   // (one pair per thread and trip.  Four pairs per trip, stage by stage -- distances, hill counts, list counts, corner
   //  records, so that a stage's loads travel together -- was tried and was slower: 25.9 us against 17.3 us per 1 M pairs)
   for (long long i = beg + threadIdx.x; i < end; i += BLOCK) {
     const double x = a.r[i];
     const long long fs = a.first_sample ? (long long)a.first_sample[i] : 2 * i;
     double v, d;
-    ordered_lookup(g, a, oc, x, fs, v, d);
+    ordered_lookup(g, a, oc, x, fs, v, d, s_rows, row0, nrows);
     e_acc += v;
     a.force[i] = 0.0 - d;
   }
@@ -5609,7 +5632,9 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
 hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
                                       int *blocks_out, unsigned long long tag, hipEvent_t ev0, hipEvent_t ev1) {
   if (!ordered_forces_supported(g) || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
-  long long blocks = (a.n + 4 * BLOCK - 1) / (4 * BLOCK);   // four pairs per thread
+  // four pairs per thread: 17.8 us per 1 M pairs; two or one (more workgroups, each paying the prologue that stages the
+  // hills' sample indices and its rows of the counts) 20.7 us; fewer, fatter workgroups (2 / 1 per CU) 22 / 33 us
+  long long blocks = (a.n + 4 * BLOCK - 1) / (4 * BLOCK);
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
   const long long per_block = (a.n + blocks - 1) / blocks;
