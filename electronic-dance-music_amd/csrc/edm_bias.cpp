@@ -186,7 +186,6 @@ struct edm_hip_bias {
   DevBuf<int> vs_mask;
   bool force_sync = false;      // redo of a deferred step whose launch bound proved too small
   int debug_force_sync = 0;     // tests: never defer the count (every step takes the synchronous path)
-  int debug_pair_step_mode = -1;  // tests: how a short fix edm_pair hill step is queued (see apply_hills); -1 = the library's choice
   long long bound_redos = 0;    // steps redone because the accepted count exceeded the deferred launch bound
   PendingForces pending;        // pair forces of a fused step waiting for the launch of the step's selection
   PendingForces *flush_forces = nullptr;   // fix edm step: the pending force kernel an overflow flush may carry (else NULL)
@@ -989,7 +988,6 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     else {
       spec.sel_chain = &sel_args;
       spec.forces = &b->pending;
-      spec.pair_step_mode = b->debug_pair_step_mode;
     }
   }
   int rc = apply_hills(b->bias, spec, &oc, false);
@@ -1958,7 +1956,6 @@ int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
   G("mpi_size", b->mpi_size)
   // telemetry of the polled completion: batches released by the polled word / by the stream wait
   G("polled_batches", b->bias ? b->bias->polled_batches : 0)
-  G("fused_steps", b->bias ? b->bias->fused_steps : 0)
   G("poll_fallbacks", b->bias ? b->bias->poll_fallbacks : 0)
   G("header_releases", b->bias ? b->bias->header_releases : 0)
   G("polled_forces", b->bias ? b->bias->polled_forces : 0)
@@ -1982,7 +1979,6 @@ int edm_hip_bias_set(edm_hip_bias *b, const char *name, double value) {
   S("total_volume", b->total_volume, double)
   S("debug_virtual_ranks", b->debug_virtual_ranks, int)
   S("debug_force_sync", b->debug_force_sync, int)
-  S("debug_pair_step_mode", b->debug_pair_step_mode, int)
   S("reference_order", b->reference_order, int)
   if (strcmp(name, "debug_tiles_first") == 0 && b->bias) { b->bias->debug_tiles_first = (int)value; return EDM_HIP_OK; }
 #undef S

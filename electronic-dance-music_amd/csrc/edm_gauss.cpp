@@ -25,6 +25,23 @@ namespace edm {
 static constexpr long long EDM_TAG_CAP_HOST = 1024;   // = EDM_TAG_CAP of edm_kernels.hip
 
 // development aid (EDM_HIP_TRACE): host clock, microseconds after the traced step's entry, at marked place `slot`
+// EDM_HIP_TEST_FORCE=<token>[,<token>...] in the environment (tests only): sends work down the paths production
+// reaches only under other conditions -- long lists, grids without a ball list, batches that cannot be fused -- so
+// that they stay covered.  Tokens: no_ball_list, no_lookup_prep, no_tagged_integrals, no_fast_header,
+// no_add_values_chain, dup_ticket_all, gather_wgs=<n>.
+static std::string test_force_env() {
+  const char *e = getenv("EDM_HIP_TEST_FORCE");
+  return e ? std::string(",") + e + "," : std::string();
+}
+bool test_force(const char *token) {
+  static const std::string env = test_force_env();
+  return !env.empty() && env.find(std::string(",") + token + ",") != std::string::npos;
+}
+long long test_force_value(const char *key) {
+  static const std::string env = test_force_env();
+  const size_t at = env.find(std::string(",") + key + "=");
+  return at == std::string::npos ? 0 : atoll(env.c_str() + at + strlen(key) + 2);
+}
 void ht_mark(edm_hip_gauss *g, int slot) {
   static const bool on = getenv("EDM_HIP_TRACE") != nullptr;
   if (!on || !g || slot < 0 || slot >= 12) return;
@@ -732,11 +749,8 @@ int edm_hip_gauss_destroy(edm_hip_gauss *g) {
   if (g->d_dirty) (void)hipFree(g->d_dirty);
   if (g->d_tickets) (void)hipFree(g->d_tickets);
   if (g->d_ready) (void)hipFree(g->d_ready);
-  if (g->fs_rec) (void)hipFree(g->fs_rec);
-  if (g->rec_alt) (void)hipFree(g->rec_alt);
   if (g->node_tab) (void)hipFree(g->node_tab);
   if (g->ball) (void)hipFree(g->ball);
-  if (g->fs_counters) (void)hipFree(g->fs_counters);
   if (g->prof_ev) {
     for (int i = 0; i < 2 * edm_hip_gauss::PROF_RING; i++) (void)hipEventDestroy(g->prof_ev[i]);
     delete[] g->prof_ev;
@@ -765,7 +779,7 @@ static int ball_list_ensure(edm_hip_gauss *g) {
   }
   g->ball = nullptr;
   g->nball = 0;
-  static const bool off = getenv("EDM_HIP_BALL_LIST") && getenv("EDM_HIP_BALL_LIST")[0] == '0';   // (A/B, tests)
+  static const bool off = test_force("no_ball_list");   // (tests: the stencil box walked point by point)
   if (off || q.dim < 2) return EDM_HIP_OK;
   long long box = 1;
   for (int d = 0; d < q.dim; d++) {
@@ -892,7 +906,6 @@ int edm_hip_gauss_device_buffer(edm_hip_gauss *g, double **d_records, int *doubl
   EDM_HIP_TRY(hipStreamSynchronize(g->stream));
   g->faces_mode = 0;
   faces_touch(g);
-  g->rec_handed_out = true;   // (the pointer must stay the grid: no one-launch steps, whose output is the second buffer)
   if (d_records) *d_records = g->rec;
   if (doubles_per_node) *doubles_per_node = g->g.rec;
   if (nodes) *nodes = g->g.total;
@@ -1210,7 +1223,7 @@ int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a_in, const Hi
     EDM_HIP_TRY(launch_pairlist_forces_select(a, g->g, h, g->rec, pf->pl, g->d_partials, g->stream, &pf->nblk));
     return EDM_HIP_OK;
   }
-  static const bool lookup_fuse_env = !(getenv("EDM_HIP_LOOKUP_PREP") && getenv("EDM_HIP_LOOKUP_PREP")[0] == '0');   // (A/B, tests)
+  static const bool lookup_fuse_env = !test_force("no_lookup_prep");
   if (pf && pf->active && pf->lookup && lookup_fuse_env && !a.pack && g->g.dim > 1 && g->g.interp && g->g.rec == 4 &&
       pf->la.n > 0 && a.n > 0) {
     // fix edm step without an overflow flush: the pending force kernel (K2) and the step's selection share a launch
@@ -1485,7 +1498,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     } else {
       PendingForces *pf = spec.forces;
       double *fetch_dst = spec.h_fetch_src ? const_cast<double *>(spec.d_h) : nullptr;
-      static const bool fuse_env = !(getenv("EDM_HIP_LOOKUP_PREP") && getenv("EDM_HIP_LOOKUP_PREP")[0] == '0');   // (A/B, tests)
+      static const bool fuse_env = !test_force("no_lookup_prep");
       if (pf && pf->active && pf->lookup && fuse_env && pf->la.n > 0 && lookup_prep_fusable(q, hl)) {
         // fix edm step: the pending force kernel (K2) and this list's preparation share a launch
         pf->active = false;
@@ -1563,8 +1576,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   plan.tile_parity = 0;
   plan.tile_bound = 0;
   plan.tiles_marked = 0;
-  static const int compact_env = getenv("EDM_HIP_COMPACT_WAVES") ? atoi(getenv("EDM_HIP_COMPACT_WAVES")) : 1;   // (A/B)
-  plan.compact_waves = compact_env;
+  plan.compact_waves = 1;
   const long long ntiles = gather_tiles(q);
   if (fused) {
     // planned above
@@ -1631,17 +1643,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   const bool fused_post = spec.limited && spec.hist_g && spec.hist_values;
   bool chain_post = false;
   bool gather_done = false;   // the gather rode in the integrals' launch (launch_integrals_gather)
-  // how a short fix edm_pair hill step is queued: 0 = k_pair_forces_select, then k_integrals_gather -- the default: on
-  // the MI355X the two ways take the same time, and this one keeps the pair forces in a launch
-  // of their own size; 1 = everything in ONE k_pair_step launch.  EDM_HIP_PAIR_STEP_MODE in the environment overrides
-  // the built-in choice, spec.pair_step_mode (tests) both.
-  static const int mode_env = getenv("EDM_HIP_PAIR_STEP_MODE") ? atoi(getenv("EDM_HIP_PAIR_STEP_MODE")) : 0;
-  const int pair_step_mode = spec.pair_step_mode >= 0 ? spec.pair_step_mode : mode_env;
-  const bool one_launch = pair_step_mode == 1 && chain_limit && spec.sel_chain && spec.forces && spec.forces->active &&
-                          !spec.forces->list && small &&
-                          rb_bytes + 128 <= g->h_stage_bytes && fused_post && !sharded && !g->rec_handed_out &&
-                          pair_step_fusable(q, spec.forces->n, *spec.sel_chain, hl, spec.d_h, plan);
-  if (!one_launch) {
+  {
     int rcp = enqueue_preparation();
     if (rcp) return rcp;
   }
@@ -1725,7 +1727,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     la.tail = LimitTail{ws.tail_h1.p, p_h2, p_a2, ws.tail_cum.p, p_flags};
     la.res = dres;
     // the hills' workgroups hand their integrals to the limiter's workgroup as tagged 16-byte stores (LimitArgs::tagged)
-    static const bool tagged_env = !(getenv("EDM_HIP_TAGGED_INTEGRALS") && getenv("EDM_HIP_TAGGED_INTEGRALS")[0] == '0');   // (A/B, tests)
+    static const bool tagged_env = !test_force("no_tagged_integrals");   // (tests: the last-arrival ticket, which batches of more than 1024 hills take anyway)
     if (tagged_env && nh <= EDM_TAG_CAP_HOST) {
       EDM_HIP_TRY(ws.tagged.reserve_zeroed(2 * (size_t)EDM_TAG_CAP_HOST));
       la.tagged = ws.tagged.p;
@@ -1759,8 +1761,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       }
       la.ready_flag = g->d_ready;
       la.ready_seq = ++g->ready_seq;
-      static const bool early = !(getenv("EDM_HIP_EARLY_WORD") && getenv("EDM_HIP_EARLY_WORD")[0] == '0');
-      la.early_word = early ? 1 : 0;
+      la.early_word = 1;
       static const bool tracing = getenv("EDM_HIP_TRACE") != nullptr;   // development aid: stamps of one launch to stderr
       const size_t trace_wgs = (size_t)nh + (size_t)((q.n[0] + 31) / 32);
       unsigned long long *d_trace = nullptr;
@@ -1785,102 +1786,11 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         ps.rb_bytes = (long long)rb_bytes;
         rb_pushed = true;
       }
-      size_t trace_wgs_fused = 0;
-      if (one_launch) {
-        // the whole step in one launch: selection (+ per-hill integrals), pair forces, bookkeeper, gather tiles
-        const SelectArgs &sa = *spec.sel_chain;
-        const size_t nsel = (size_t)pair_step_sel_blocks(sa.n);
-        if (!g->fs_counters) {
-          EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->fs_counters), sizeof(unsigned) * 32 * 3 * EDM_FS_SUB));
-          EDM_HIP_TRY(hipMemset(g->fs_counters, 0, sizeof(unsigned) * 32 * 3 * EDM_FS_SUB));
-          g->fs_sel_total = g->fs_k1_total = g->fs_int_total = 0;
-        }
-        if (g->fs_rec_wgs < nsel) {
-          if (g->fs_rec) (void)hipFree(g->fs_rec);
-          g->fs_rec = nullptr;
-          g->fs_rec_wgs = 0;
-          EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->fs_rec), sizeof(double) * EDM_FS_CAP * EDM_FS_REC * (nsel + 64)));
-          g->fs_rec_wgs = nsel + 64;
-        }
-        if (!g->rec_alt) EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->rec_alt), sizeof(double) * grid_doubles));
-        PendingForces *pf = spec.forces;
-        hipEvent_t e0, e1;
-        profile_slot(g, &e0, &e1);
-        FusedStep fsd;
-        memset(&fsd, 0, sizeof(fsd));
-        fsd.wgrec = g->fs_rec;
-        fsd.sel_done = g->fs_counters;
-        fsd.k1_done = g->fs_counters + 32 * EDM_FS_SUB;
-        fsd.int_done = g->fs_counters + 2 * 32 * EDM_FS_SUB;
-        fsd.int_target = g->fs_int_total;
-        int nk1 = 0;
-        // (the targets are known only once the launcher has sized the grid: it fills nsel / nk1; the sums are advanced here)
-        fsd.sel_target = g->fs_sel_total;   // (sums so far: the launcher adds this launch's workgroup counts)
-        fsd.k1_target = g->fs_k1_total;
-        int nsel_launched = 0;
-        if (d_trace) {
-          (void)hipFree(d_trace);
-          d_trace = nullptr;
-          la.trace = nullptr;
-        }
-        if (tracing && g->ready_seq == 150) {
-          trace_wgs_fused = nsel + 4 * 256 + 8 + (size_t)((q.n[0] + 31) / 32);
-          EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_trace), trace_wgs_fused * 64));
-          EDM_HIP_TRY(hipMemset(d_trace, 0, trace_wgs_fused * 64));
-          la.trace = d_trace;
-        }
-        pf->active = false;
-        EDM_HIP_TRY(launch_pair_step(sa, q, tabs, g->rec, hl, spec.h_const, p_added, la, hh, plan, g->d_dirty, &ps, pf->d_r, pf->n,
-                                     pf->d_force, g->d_partials, fsd, s, e0, e1, &nk1, &nsel_launched, g->rec_alt));
-        g->fs_int_total += (unsigned)nsel_launched;
-        pf->nblk = nk1;
-        g->fs_sel_total += (unsigned)nsel_launched;
-        g->fs_k1_total += (unsigned)nk1;
-        g->fused_steps++;
-      } else {
-        ht_mark(g, 3);
-        EDM_HIP_TRY(launch_integrals_gather(q, tabs, g->rec, hl, spec.d_h, spec.h_const, p_added, la, hh, plan, g->d_dirty, s,
-                                            chain_post ? &ps : nullptr));
-        ht_mark(g, 4);
-      }
+      ht_mark(g, 3);
+      EDM_HIP_TRY(launch_integrals_gather(q, tabs, g->rec, hl, spec.d_h, spec.h_const, p_added, la, hh, plan, g->d_dirty, s,
+                                          chain_post ? &ps : nullptr));
+      ht_mark(g, 4);
       gather_done = true;
-      if (d_trace && one_launch) {
-        EDM_HIP_TRY(hipStreamSynchronize(s));
-        std::vector<unsigned long long> tr(trace_wgs_fused * 8);
-        EDM_HIP_TRY(hipMemcpy(tr.data(), d_trace, trace_wgs_fused * 64, hipMemcpyDeviceToHost));
-        (void)hipFree(d_trace);
-        d_trace = nullptr;
-        unsigned long long t0 = ~0ull;
-        for (size_t w = 0; w < trace_wgs_fused; w++)
-          if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
-        const size_t nsel = (size_t)pair_step_sel_blocks(spec.sel_chain->n), nk1 = (size_t)spec.forces->nblk;
-        const size_t lo[4] = {0, nsel, nsel + nk1, nsel + nk1 + 1}, hi[4] = {nsel, nsel + nk1, nsel + nk1 + 1, trace_wgs_fused};
-        const char *role[4] = {"select   ", "forces   ", "bookkeep ", "tiles    "};
-        const char *names[4][8] = {{"start", "flags done", "published", "hills walked", "", "", "", "end"},
-                                   {"start", "", "", "", "", "", "", "end"},
-                                   {"start", "selection seen", "list written", "word published", "host released", "", "", "end"},
-                                   {"start", "selection seen", "terms parked", "heights known", "forces seen", "", "body end", "end"}};
-        for (int kk = 1; kk <= 8; kk++) {   // selection workgroups by the number of samples they accepted
-          std::vector<double> v;
-          for (size_t w = 0; w < nsel; w++)
-            if (tr[w * 8 + 5] == (unsigned long long)kk && tr[w * 8 + 3]) v.push_back((double)(tr[w * 8 + 3] - tr[w * 8 + 1]) * 0.01);
-          if (v.empty()) continue;
-          std::sort(v.begin(), v.end());
-          fprintf(stderr, "[edm trace] select: %d hill(s) in the workgroup: n=%3zu  stencil walks took min %5.2f med %5.2f max %5.2f us\n", kk,
-                  v.size(), v.front(), v[v.size() / 2], v.back());
-        }
-        for (size_t w = 0; w < nsel; w++) tr[w * 8 + 5] = 0;
-        for (int r = 0; r < 4; r++)
-          for (int k = 0; k < 8; k++) {
-            std::vector<double> v;
-            for (size_t w = lo[r]; w < hi[r] && w < trace_wgs_fused; w++)
-              if (tr[w * 8 + k]) v.push_back((double)(tr[w * 8 + k] - t0) * 0.01);
-            if (v.empty()) continue;
-            std::sort(v.begin(), v.end());
-            fprintf(stderr, "[edm trace] %s %-16s n=%4zu  min %6.2f  med %6.2f  max %6.2f us\n", role[r], names[r][k], v.size(),
-                    v.front(), v[v.size() / 2], v.back());
-          }
-      }
       if (d_trace) {
         EDM_HIP_TRY(hipStreamSynchronize(s));
         std::vector<unsigned long long> tr(trace_wgs * 8);
@@ -2093,7 +2003,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     // caller wants neither positions nor per-hill bias, nothing else of the region is needed and the call returns
     // ~3 us before the acknowledgements of the region's other stores would let the completion word out.
     volatile unsigned long long *hd = reinterpret_cast<volatile unsigned long long *>(g->h_stage + g->h_stage_bytes - 256);
-    static const bool header_env = !(getenv("EDM_HIP_FAST_HEADER") && getenv("EDM_HIP_FAST_HEADER")[0] == '0');   // (A/B and tests)
+    static const bool header_env = !test_force("no_fast_header");   // (tests: every polled batch waits for its completion word)
     // (A flush of the overflow buffer: the line carries the stop index and that hill's undo height -- all the host's
     // replay needs when there is no log.)
     // (With a HILLS log the caller needs positions and per-hill bias too -- but not NOW: defer_fetch_ok says it will ask
@@ -2159,9 +2069,6 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
       return EDM_HIP_ERR_OVERFLOW;
     }
     nh_act = res.nh;
-    // a one-launch step wrote the updated grid into the second buffer: it is the grid from here on (an error above
-    // means nothing was applied -- the tiles stood down -- and the buffers stay as they are)
-    if (one_launch) std::swap(g->rec, g->rec_alt);
   }
   if (out) {
     out->res = res;
@@ -2237,7 +2144,7 @@ int edm_hip_gauss_add_values(edm_hip_gauss *g, long long n, const double *d_x, i
   // A short batch whose total is wanted goes through the chained limiter with a limit nothing reaches: integrals +
   // "limiter" + tile list in one launch and the total on the limiter's header line, polled -- instead of integrals,
   // a sum launch, a tile-list launch, and a copy behind a stream wait.  (The total is then the limiter's ordered sum.)
-  static const bool chain_env = !(getenv("EDM_HIP_ADD_VALUES_CHAIN") && getenv("EDM_HIP_ADD_VALUES_CHAIN")[0] == '0');   // (A/B, tests)
+  static const bool chain_env = !test_force("no_add_values_chain");   // (tests: the launches long lists take)
   const bool chained = want && chain_env && hill_integrals_can_chain_limit(n);
   if (chained) {
     spec.limited = true;
@@ -2449,10 +2356,6 @@ int edm_hip_gauss_reread(edm_hip_gauss *g, const char *filename) {
     EDM_HIP_TRY(hipFree(g->rec));
     g->rec = nullptr;
     EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->rec), sizeof(double) * (size_t)q.total * q.rec));
-  }
-  if (g->rec_alt && q.total != g->g.total) {   // (the second buffer of the one-launch steps has the old size)
-    (void)hipFree(g->rec_alt);
-    g->rec_alt = nullptr;
   }
   g->g = q;
   g->tiles_per_hill = 0;

@@ -134,16 +134,6 @@ struct edm_hip_gauss {
   int *d_tickets = nullptr;              // three last-workgroup tickets (EDM_TICKET_INTS ints each), kept zero
   unsigned long long *d_ready = nullptr; // word the gather half of k_integrals_gather polls for ...
   unsigned long long ready_seq = 0;      // ... the sequence number of its launch
-  // k_pair_step (a whole fix edm_pair hill step as one launch, see FusedStep): per-workgroup hill records, the two
-  // sets of cumulative completion counters and the sums their launches have been told to wait for
-  double *fs_rec = nullptr;
-  double *rec_alt = nullptr;             // the grid's second buffer: a one-launch step reads `rec` and writes this one, and the two
-                                         // change places once the step is known to have been applied (never after an error)
-  bool rec_handed_out = false;           // edm_hip_gauss_device_buffer gave `rec` to the caller: the buffers must not change places
-  size_t fs_rec_wgs = 0;
-  unsigned *fs_counters = nullptr;       // 2 * EDM_FS_SUB sub-counters, 32 ints apart
-  unsigned fs_sel_total = 0, fs_k1_total = 0, fs_int_total = 0;
-  long long fused_steps = 0;             // steps that ran as one launch (telemetry / tests)
   double ht_ref_us = 0;                  // development aid (EDM_HIP_TRACE): host clock at the entry of the step being traced
   double ht_marks[12] = {0};             // ... and at marked places of that step (ht_mark), printed by the step's entry point
   // lookup replica of a 2-D / 3-D grid with a periodic boundary (see lookup_one / launch_build_faces): g.total
@@ -191,6 +181,9 @@ struct PendingForces {
   LookupArgs la;
 };
 void ht_mark(edm_hip_gauss *g, int slot);   // development aid, edm_gauss.cpp
+// EDM_HIP_TEST_FORCE tokens (tests only; edm_gauss.cpp)
+bool test_force(const char *token);
+long long test_force_value(const char *key);
 // event pair for the next stamped launch of the handle's dominant lookup kernel (nullptrs when profiling is off)
 void profile_slot(const edm_hip_gauss *g, hipEvent_t *e0, hipEvent_t *e1);
 
@@ -224,8 +217,6 @@ struct ApplySpec {
   // with a deferred count: selection chained in front of the hill preparation (one launch for both)
   const SelectArgs *sel_chain = nullptr;
   PendingForces *forces = nullptr;   // launched together with sel_chain where possible
-  int pair_step_mode = -1;           // ... and, for a short 1-D step, with everything else of the step (k_pair_step): see apply_hills;
-                                     // -1 = the library's choice
   // multi-GPU packed exchange: the hill list is unpacked from the gathered packets (replaces preparation)
   const UnpackArgs *unpack_chain = nullptr;
   // sharded application of a dense batch on a replicated grid (multi-GPU): this rank gathers only its own

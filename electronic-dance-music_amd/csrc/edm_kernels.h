@@ -370,43 +370,6 @@ bool integrals_gather_fusable(const Geom &g, long long nh_bound, const GatherPla
 hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, const HillList &h, const double *heights,
                                    double h_const, double *added, const LimitArgs &chain, const HillHeights &hh,
                                    const GatherPlan &plan, int *dirty_flag, hipStream_t s, const PostSpec *post_chain);
-// A whole hill-depositing fix edm_pair step as ONE launch (k_pair_step; short pair arrays, 1-D, stochastic selection
-// against a launch bound, constant base height).  Roles by workgroup index:
-//   [0, nsel)            selection: flags of SEL_CHUNK samples; every ACCEPTED sample is prepared and its integrated
-//                        bias computed on the spot by the workgroup that found it (the integral of a hill does not
-//                        depend on its place in the ordered list), the record goes to the workgroup's own slots
-//   [nsel, nsel + nk1)   K1, the pair forces (they read the grid as it stands before this step's hills)
-//   nsel + nk1           the bookkeeper: ordered list -> canonical arrays, limiter, read-back, CV histogram
-//   the rest             the 32-node gather tiles: each builds the ordered list ITSELF from the per-workgroup counts
-//                        and records (no serial compaction stage in front of it), decides from the integrals whether the
-//                        limiter can bind (if it cannot, nobody waits for it), and writes ALL its nodes to the grid's
-//                        second buffer (rec_next), which the host makes the grid once the step is known to have been
-//                        applied: K1 reads a buffer nobody writes, the tiles wait for no force workgroup
-// Hand-over between the roles: records and counts travel at agent scope; two sets of sub-counters (one 128-byte line
-// each) count finished selection / K1 workgroups, cumulatively over launches -- nothing is ever reset -- and the
-// waiting workgroups poll for this launch's target.  Waiting workgroups carry the higher indices: they are
-// dispatched after the ones they wait for.
-#define EDM_FS_CAP 16        // accepted samples ONE selection workgroup can hand on; more: the step is redone synchronously
-#define EDM_FS_REC 8         // doubles per record: hx, t1, t3, x0, integral, centre node, chunk-local sample index, -
-#define EDM_FS_MAX_SEL 1024  // selection workgroups of 4096 samples (LDS scan of their counts)
-#define EDM_FS_SUB 16        // sub-counters per set, 32 ints apart
-struct FusedStep {
-  double *wgrec;             // [nsel][EDM_FS_CAP][EDM_FS_REC]
-  unsigned *sel_done, *int_done, *k1_done;   // selection: accepted samples out | their integrals out; pair forces done
-  unsigned sel_target, int_target, k1_target;   // sums the counters reach when this launch's workgroups are done (the launcher adds
-                                    // its workgroup counts to the sums the caller passes)
-  unsigned nsel, nk1;
-  double limit, cum_in;      // (the limiter's, for the tiles' own "cannot bind" test)
-};
-long long pair_step_sel_blocks(long long n_samples);   // selection workgroups of a k_pair_step launch
-bool pair_step_fusable(const Geom &g, long long n_pairs, const SelectArgs &a, const HillList &h, const double *heights,
-                       const GatherPlan &plan);
-// h.nh is the launch bound; chain.ready_flag / ready_seq as for launch_integrals_gather; post_chain must be given
-hipError_t launch_pair_step(const SelectArgs &a, const Geom &g, const Tables &t, double *rec, const HillList &h,
-                            double h_const, double *added, const LimitArgs &chain, const HillHeights &hh,
-                            const GatherPlan &plan, int *dirty_flag, const PostSpec *post_chain, const double *pair_r,
-                            long long n_pairs, double *pair_force, double *pair_scratch, FusedStep fs, hipStream_t s,
-                            hipEvent_t ev0, hipEvent_t ev1, int *k1_blocks_out, int *sel_blocks_out, double *rec_next);
 
 // pieces of launch_hill_gather_correct_and_apply for the sharded multi-GPU application: the correction pass
 // alone (writes partial buffer [plan.groups], zeroed first) and dst[i] += sum of `groups` partial buffers

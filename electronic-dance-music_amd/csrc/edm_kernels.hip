@@ -18,8 +18,8 @@
 // tail run by the last workgroup to finish (last_block_done); in a fix edm_pair step K1 rides in the first launch
 // (k_pair_forces_select; the force pass over a device-resident neighbour list likewise, k_pairlist_forces_select).  The
 // host is released by a word K3's last workgroup stores behind the read-back region in host-mapped memory: it polls
-// that word, not the stream.  k_pair_step (opt-in, EDM_HIP_PAIR_STEP_MODE=1) is the same step as ONE launch with the
-// roles side by side -- bit-identical and, on the MI355X, no faster: DESIGN.md section 5 has the stamps.
+// that word, not the stream.  fix edm_pair's default order (pair k's force behind the hills of pairs 0..k-1) adds
+// k_ordered_records and k_pair_forces_ordered behind the hill batch (OrderedForcesArgs, edm_kernels.h).
 #include "edm_kernels.h"
 
 #include <hip/hip_ext.h>
@@ -40,6 +40,9 @@
   } while (0)
 
 namespace edm {
+
+bool test_force(const char *token);        // EDM_HIP_TEST_FORCE tokens (tests only; edm_gauss.cpp)
+long long test_force_value(const char *key);
 
 static constexpr int BLOCK = 256;
 static constexpr int HIST_LDS_BINS = 2048;  // histograms up to this many bins are accumulated per workgroup in LDS
@@ -1096,9 +1099,7 @@ __device__ __forceinline__ void pair_forces_fast_body(const Geom &g, const doubl
   }
   double s = block_sum(e_acc, red);
   if (threadIdx.x == 0) {
-    // (untagged: a system-scope store -- written through to the host-mapped array now.  Inside k_pair_step the host is
-    //  released by a workgroup of the SAME launch once this workgroup has arrived on k1_done: a plain store could still
-    //  sit in this XCD's L2 then, and the host would add up last step's sum)
+    // (untagged: a system-scope store too -- written through to the host-mapped array the host adds the sums up from)
     if (tag) store_partial_tagged(block_energy, bid, s, tag);
     else __hip_atomic_store(&block_energy[bid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -1841,29 +1842,6 @@ __device__ __forceinline__ unsigned long long wait_for_word(const unsigned long 
   }
 }
 
-// Cumulative completion counters of k_pair_step (FusedStep::sel_done / k1_done): EDM_FS_SUB sub-counters, one per
-// 128-byte line.  A finished workgroup adds one to sub-counter (id mod EDM_FS_SUB) -- no return value, nothing waits
-// for the add -- after its published stores have been acknowledged; a waiting workgroup's thread reads all the
-// sub-counters in one round trip and compares their sum with the launch's target (the sums only ever grow, 32-bit
-// wrap-around included, so nothing is reset between launches).
-__device__ __forceinline__ void counter_arrive(unsigned *sub, unsigned id) {
-  (void)__hip_atomic_fetch_add(sub + 32 * (id % EDM_FS_SUB), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wait_counter(const unsigned *sub, unsigned target) {
-  const unsigned long long t0 = wall_clock64();
-  for (;;) {
-    unsigned v[EDM_FS_SUB];
-#pragma unroll
-    for (int i = 0; i < EDM_FS_SUB; i++) v[i] = acquire(sub + 32 * i);
-    unsigned sum = 0;
-#pragma unroll
-    for (int i = 0; i < EDM_FS_SUB; i++) sum += v[i];
-    if (sum == target) return;
-    __builtin_amdgcn_s_sleep(4);
-    if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();   // 10 s: never, short of a lost launch
-  }
-}
-
 // Selection + hill preparation in one launch (stochastic steps with a deferred count): every
 // workgroup compacts its SEL_CHUNK samples IN ORDER into its own stretch of `stage`, the last one
 // scans the per-workgroup counts, moves at most `h.nh` (the launch bound of the step) entries to the
@@ -2158,9 +2136,8 @@ hipError_t launch_pair_forces_select(const SelectArgs &a, const Geom &g, const H
   f.nk1 = (unsigned)pair_short_blocks(n);
   // (selection workgroups dispatched AHEAD of K1's: their serial tail -- ticket, scan, preparation -- is the longest chain
   // of the launch and ends 0.9 us earlier when it starts first: list prepared at 8.6 instead of 9.5 us, launch 12.0-12.3
-  // instead of 12.5-13.3 us; EDM_HIP_SEL_FIRST=0 for the old order)
-  static const int sel_first_env = getenv("EDM_HIP_SEL_FIRST") ? atoi(getenv("EDM_HIP_SEL_FIRST")) : 1;
-  f.sel_first = sel_first_env;
+  // instead of 12.5-13.3 us)
+  f.sel_first = 1;
   EDM_LAUNCH_TIMED(k_pair_forces_select, dim3(f.nsel + f.nk1), dim3(BLOCK), 256, s, ev0, ev1, a, g, h, f);
   if (blocks_out) *blocks_out = (int)f.nk1;
   return hipGetLastError();
@@ -2515,13 +2492,12 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            const double *chunk_sum, const double *chunk_max,
                                            const long long *nh_dev, long long mirror = 0, long long *k_out = nullptr,
                                            int *err_out = nullptr, long long nh_known = -1,
-                                           const FusedStep *fsrc = nullptr, const unsigned short *fs_off = nullptr,
                                            LimitResult *out_local = nullptr, const double *s_added = nullptr);
 
 // The stencil walk of one hill by TPH cooperating threads (lt = this thread's index among them): the thread's share of
 // height * (expo + corr) * vol over the reference's stencil (gaussian_grid.h:227-281), summed in stencil order.  The
 // caller adds the shares up (wave_sum, then the waves in order): k_hill_integrals and the selection workgroups of
-// k_pair_step call this same walk, so the two paths yield the same bits.
+// every caller of this walk yields the same bits.
 template <int DIM, int TPH, bool PERB>
 __device__ __forceinline__ double hill_stencil_partial(const Geom &g, const Tables &t, const TermConst<DIM> &tc,
                                                        const int *c_r, const double *hx_r, const double *ht_r,
@@ -2757,13 +2733,11 @@ __device__ __forceinline__ void header_line_to_host(unsigned long long *host_lin
 
 // The serial stage behind the per-hill integrals, run by ONE workgroup once all of them are published: ordered
 // limiter (wave 0), read-back region to host-mapped memory, release of the host.  n_true_known >= 0: the caller
-// knows the batch's true hill count (else it is read from h.nh_dev); k1_done: see below.
-__device__ __forceinline__ void wait_counter(const unsigned *sub, unsigned target);
+// knows the batch's true hill count (else it is read from h.nh_dev).
 template <int DIM, int NT>
 __device__ __forceinline__ void limiter_stage(const HillList &h, const double *__restrict__ heights, double h_const,
                                               double *__restrict__ added, const LimitArgs &la, unsigned bid,
-                                              long long n_true_known, const unsigned *k1_done, unsigned k1_target,
-                                              const double *s_added = nullptr) {
+                                              long long n_true_known, const double *s_added = nullptr) {
   // wave 0 walks the limiter; with a read-back region (la.rb_dst) it stores its outputs to the device region and
   // to its host-mapped copy alike, while the other waves copy what does not depend on the limiter -- per-hill
   // bias and positions, by the true hill count -- so nothing is left to read back once the limiter is done.
@@ -2781,7 +2755,7 @@ __device__ __forceinline__ void limiter_stage(const HillList &h, const double *_
     int err = 0;
     LimitResult rl;
     limit_wave<true>(h.nh, added, heights, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr,
-               nullptr, h.nh_dev, mirror, &k_first, &err, h.nh_dev ? n_true : -1, nullptr, nullptr, &rl, s_added);
+               nullptr, h.nh_dev, mirror, &k_first, &err, h.nh_dev ? n_true : -1, &rl, s_added);
     if (la.fast_line) header_line_to_host(la.fast_line, rl, la.done_seq);
     if (concurrent) {
       // the word carries what every gather workgroup needs first -- the error code and k, the first hill of the
@@ -2820,12 +2794,6 @@ __device__ __forceinline__ void limiter_stage(const HillList &h, const double *_
     // is checked against byte-identical results of the stream-wait path (EDM_HIP_POLL=0) in
     // test_polled_completion_equals_stream_wait, and a poll that does not see its word within 2 ms falls back
     // to hipStreamSynchronize.
-    // (k_pair_step: the pair forces ride in this launch -- their partial energy sums must be in host memory before
-    //  the host is released)
-    if (k1_done) {
-      if (threadIdx.x == 0) wait_counter(k1_done, k1_target);
-      __syncthreads();
-    }
     if (threadIdx.x == 0 && la.done_flag)
       __hip_atomic_store(la.done_flag, la.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -2908,7 +2876,7 @@ __device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables 
         if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();   // 10 s at 100 MHz: never, short of a lost workgroup
       }
       if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 2] = wall_clock64();
-      limiter_stage<DIM, NT>(h, heights, h_const, added, la, bid, -1, nullptr, 0u, s_val);
+      limiter_stage<DIM, NT>(h, heights, h_const, added, la, bid, -1, s_val);
       if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 4] = wall_clock64();
       __syncthreads();
       return true;
@@ -2942,7 +2910,7 @@ __device__ __forceinline__ bool hill_integrals_body(const Geom &g, const Tables 
       if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 1] = wall_clock64();
       if (!last_block_done(la.ticket, ticket_blocks, bid, ticket_blocks <= 512)) return false;
       if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 2] = wall_clock64();
-      limiter_stage<DIM, NT>(h, heights, h_const, added, la, bid, -1, nullptr, 0u);
+      limiter_stage<DIM, NT>(h, heights, h_const, added, la, bid, -1);
       if (la.trace && threadIdx.x == 0) la.trace[(size_t)bid * 8 + 4] = wall_clock64();
       __syncthreads();
       return true;
@@ -3178,57 +3146,6 @@ __device__ __forceinline__ void gather_post(const Geom &g, double *__restrict__ 
   }
 }
 
-// exclusive scan of the selection workgroups' counts into LDS (s_off[0 .. nsel], s_off[nsel] = total), by the whole
-// workgroup; returns the total.  Every thread takes PERC consecutive counts, requested together.
-// (offsets are kept as 16-bit values, saturated: a total beyond any launch bound -- 2048 -- makes the caller give up
-//  before it looks at them)
-__device__ __forceinline__ int fused_scan_counts(const int *counts, int nsel, unsigned short *s_off, int *s_ws) {
-  constexpr int PERC_MAX = EDM_FS_MAX_SEL / BLOCK;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int PERC = (nsel + BLOCK - 1) / BLOCK;
-  const int blk0 = threadIdx.x * PERC;
-  int cj[PERC_MAX];
-  int c = 0;
-#pragma unroll
-  for (int j = 0; j < PERC_MAX; j++) {
-    cj[j] = (j < PERC && blk0 + j < nsel) ? acquire(&counts[blk0 + j]) : 0;
-    c += cj[j];
-  }
-  int inc = c;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int up = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += up;
-  }
-  if (lane == 63) s_ws[wave] = inc;
-  __syncthreads();
-  int off = inc - c, total = 0;
-#pragma unroll
-  for (int w = 0; w < BLOCK / 64; w++) {
-    if (w < wave) off += s_ws[w];
-    total += s_ws[w];
-  }
-#pragma unroll
-  for (int j = 0; j < PERC_MAX; j++) {
-    if (j < PERC && blk0 + j < nsel) s_off[blk0 + j] = (unsigned short)(off < 65535 ? off : 65535);
-    off += cj[j];
-  }
-  if (threadIdx.x == 0) s_off[nsel] = (unsigned short)(total < 65535 ? total : 65535);
-  __syncthreads();
-  return total;
-}
-// record of hill e of the ordered list: last k with s_off[k] <= e (empty workgroups share their successor's offset
-// and are skipped); *blk_out = that selection workgroup
-__device__ __forceinline__ const double *fused_record(const FusedStep &fs, const unsigned short *s_off, int e, int *blk_out = nullptr) {
-  int lo = 0, hi = (int)fs.nsel;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if ((int)s_off[mid] <= e) lo = mid; else hi = mid;
-  }
-  if (blk_out) *blk_out = lo;
-  return fs.wgrec + ((size_t)lo * EDM_FS_CAP + (size_t)(e - (int)s_off[lo])) * EDM_FS_REC;
-}
-
 // PARTS (1 or 8; 8 on the 1-D grid only): the tile is BLOCK / PARTS nodes wide and thread (part, node)
 // accumulates every PARTS-th batch of the tile's hill list for its node; the parts are combined in LDS in a
 // fixed order.  A node's serial chain is its number of overlapping hills, and a tile's work lands on ONE CU:
@@ -3245,24 +3162,15 @@ __device__ __forceinline__ constexpr int tile_extent(int d) {
 // depend on the limiter -- are computed and parked in LDS, and only then does the workgroup wait for the limiter's
 // word (ready_flag == ready_seq), fetch k and the tail heights and accumulate.  Hills the limiter deferred (height 0)
 // are skipped at that point instead of at staging.
-// FUSED (k_pair_step; implies DEFER): there is no prepared hill list yet when the tile starts -- it waits for the
-// selection workgroups (fs->sel_done), scans their counts and reads the hills' records from their slots, in list order;
-// it decides from the integrals in those records whether the limiter can bind at all (if not, nobody waits for the
-// limiter: base heights throughout); and it writes EVERY node of its tile -- rewritten or not -- to the grid's second
-// buffer rec_out, which becomes the grid once the step is known to have been applied: the K1 workgroups of the same
-// launch read `rec`, which nobody writes, so the tiles wait for none of them.  Boundary corrections are noted in the
-// workgroup's *s_dirty (LDS) instead of the device flag.
-template <int DIM, int MODE, int PARTS, bool PERB, bool DEFER = false, bool FUSED = false>
+// (s_dirty, optional: boundary corrections are noted in that LDS word of the workgroup instead of the device flag.)
+template <int DIM, int MODE, int PARTS, bool PERB, bool DEFER = false>
 __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t, double *__restrict__ rec,
                                                  const HillList &h, const HillHeights &hh, const GatherPlan &plan,
                                                  int use_list, int *__restrict__ dirty_flag, int coherent,
                                                  long long tile, const unsigned long long *ready_flag = nullptr,
                                                  unsigned long long ready_seq = 0, unsigned long long *trace = nullptr,
-                                                 const FusedStep *fs = nullptr, const int *sel_counts = nullptr,
-                                                 unsigned short *s_foff = nullptr, int *s_fws = nullptr,
-                                                 double *__restrict__ rec_out = nullptr, int *s_dirty = nullptr) {
+                                                 int *s_dirty = nullptr) {
   static_assert(!DEFER || (DIM == 1 && MODE == 0), "deferred heights: the 1-D in-place gather only");
-  static_assert(!FUSED || DEFER, "the fused step defers its heights");
   constexpr int R = (DIM == 1) ? 2 : 4;
   constexpr int NODES = BLOCK / PARTS;
   const int tnode = threadIdx.x % NODES;   // this thread's node within the tile
@@ -3327,16 +3235,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   // (limiter result and hill count in one round trip: the kernel is a chain of dependent loads)
   long long k_first_tail = hh.k;
   long long nh_eff = h.nh;
-  __shared__ double s_fred[BLOCK / 64];
-  if (FUSED) {
-    if (threadIdx.x == 0) wait_counter(fs->sel_done, fs->sel_target);
-    __syncthreads();
-    if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
-    const long long n_true = fused_scan_counts(sel_counts, (int)fs->nsel, s_foff, s_fws);
-    if (n_true > h.nh) return;   // bound exceeded (or a selection workgroup out of slots): the bookkeeper reports it, nothing is applied
-    nh_eff = n_true;
-    k_first_tail = nh_eff;
-  } else if (DEFER) {
+  if (DEFER) {
     nh_eff = hill_count(h);   // (the selection's count; the limiter's result is read after the wait below)
     k_first_tail = nh_eff;
   } else if (hh.res_dev) {
@@ -3365,9 +3264,9 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   for (int d = 0; d < DIM; d++) vol *= g.dx[d];
 
   double acc[1 + DIM];
-  if (in_place && (active || (FUSED && in_grid0)) && part == 0) {
+  if (in_place && active && part == 0) {
     // in-place: start from the stored record so the adds follow the reference's
-    // sequence V0 + h0*t0 + h1*t1 + ... exactly  (FUSED: also the nodes outside the boundary, which are only copied)
+    // sequence V0 + h0*t0 + h1*t1 + ... exactly
 #pragma unroll
     for (int j = 0; j <= DIM; j++) acc[j] = rec[flat * R + j];
   } else {
@@ -3387,15 +3286,15 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
   __shared__ double s_t[PERB ? 1 : BLOCK][2 * DIM];  // (hill-side wall exponentials: none without walls)
   __shared__ double s_h1[BLOCK], s_h2[BLOCK];
   __shared__ int s_wcnt[BLOCK / 64];
-  using id_t = typename std::conditional<FUSED, int, long long>::type;   // (FUSED: LDS is what limits the workgroups per CU)
+  using id_t = long long;
   __shared__ id_t s_id[(MODE == 1 || DEFER) ? BLOCK : 1];
   // DEFER: parked stencil terms of the first chunk, NTS per thread (value, derivative, multiplicity | nz << 30)
   constexpr int DEFER_ILP = 4;
   // (a tile meets ~13 of the ~125 hills of a W1 step, 40 where the pairs are dense: 4 per part cover 32.  Eight cost
   //  20 KB more LDS and 30 registers -- two workgroups per CU instead of three -- and bought the W1 step nothing)
   constexpr int NTS = 4;
-  using tm_t = typename std::conditional<FUSED, short, int>::type;
-  constexpr int TM_NZ = FUSED ? 14 : 30;
+  using tm_t = int;
+  constexpr int TM_NZ = 30;
   __shared__ double s_tv[DEFER ? NTS : 1][DEFER ? BLOCK : 1], s_td[DEFER ? NTS : 1][DEFER ? BLOCK : 1];
   __shared__ tm_t s_tm[DEFER ? NTS : 1][DEFER ? BLOCK : 1];
   bool waited = !DEFER;   // (block-uniform) the limiter's result is known
@@ -3418,21 +3317,12 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
     int c[DIM];
     double h1 = 0, h2 = 0;
     double hx_r[DIM], ht_r[2 * DIM];
-    double integ_abs = 0;   // FUSED: |integrated bias| of the hills this thread looked at (first chunk: of all its hills)
-    if (FUSED && cur < hend) {
-      // (the selection workgroup that accepted the sample published its position and went on to integrate the hill:
-      //  the prepared fields are recomputed here from the position -- hill_prep_compute, the same bits)
-      double xq[1] = {acquire(fused_record(*fs, s_foff, (int)cur) + 3)};
-      hill_prep_compute<1>(g, xq, c, ht_r);
-      hx_r[0] = xq[0];
-    }
     if (cur < hend) {
       // 1-D: all of this hill's fields are requested together (one memory round trip; a tile overlaps a
       // good part of the hills).  2-D/3-D: a tile meets a few hills out of hundreds, so only the centre
       // node is fetched for the test and the rest follows for the hills that pass.
 #pragma unroll
       for (int d = 0; d < DIM; d++) {
-        if (FUSED) continue;
         c[d] = h.hc[cur * DIM + d];
         if (DIM == 1) {
           hx_r[d] = h.hx[cur * DIM + d];
@@ -3537,29 +3427,11 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
         }
       }
       // 2. the limiter's word (its workgroups were dispatched ahead of this one and wait for nobody)
-      if (trace && threadIdx.x == 0) trace[FUSED ? 2 : 1] = wall_clock64();
+      if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
       __shared__ unsigned long long s_word;
-      if (FUSED) {
-        // ... unless the batch provably stays below the limit whatever the limiter does: the sum of the |integrals|
-        // -- published by the selection workgroups while this tile computed its terms -- against the limit, with the
-        // margin of the early word
-        if (threadIdx.x == 0) wait_counter(fs->int_done, fs->int_target);
-        __syncthreads();
-        for (long long e = threadIdx.x; e < nh_eff; e += BLOCK) integ_abs += fabs(acquire(fused_record(*fs, s_foff, (int)e) + 4));
-        const double part = wave_sum(integ_abs);
-        if (lane == 0) s_fred[wave] = part;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          double sum = 0;
-          for (int w = 0; w < BLOCK / 64; w++) sum += s_fred[w];
-          const bool below = fs->cum_in >= 0 && (fs->cum_in + sum) * (1.0 + 1e-9) < fs->limit;
-          s_word = below ? ready_word(ready_seq, EDM_READY_BELOW, nh_eff) : wait_for_word(ready_flag, ready_seq, true);
-        }
-      } else if (threadIdx.x == 0) {
-        s_word = wait_for_word(ready_flag, ready_seq, false);
-      }
+      if (threadIdx.x == 0) s_word = wait_for_word(ready_flag, ready_seq, false);
       __syncthreads();
-      if (trace && threadIdx.x == 0) trace[FUSED ? 3 : 2] = wall_clock64();
+      if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
       waited = true;
       const unsigned long long word = s_word;
       const int state = ready_state_of(word);
@@ -3707,15 +3579,7 @@ __device__ __forceinline__ void hill_gather_body(const Geom &g, const Tables &t,
       touched |= (s_ptouch[q][tnode] != 0);
     }
   }
-  if (FUSED) {
-    if (in_grid0) {
-      double *dst = rec_out + flat * R;
-      publish(&dst[0], acc[0]);   // (the boundary duplication of the last tile reads node values)
-#pragma unroll
-      for (int j = 1; j <= DIM; j++) dst[j] = acc[j];
-      if (any_corr && active) *s_dirty = 1;
-    }
-  } else if (active && (touched || !in_place)) {
+  if (active && (touched || !in_place)) {
     double *dst = in_place ? rec + flat * R : plan.partial + ((long long)grp * g.total + flat) * R;
     if (coherent) {
       // the chained boundary duplication (another workgroup) reads node values and the flag
@@ -3769,217 +3633,6 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MOD
 }
 
 // ---------------------------------------------------------------------------
-// k_pair_step: a whole hill-depositing fix edm_pair step as one launch (roles and hand-over: FusedStep, edm_kernels.h)
-// ---------------------------------------------------------------------------
-// selection workgroup: the flags of its SEL_CHUNK samples (the samples' CVs are requested with the uniforms -- one
-// memory round trip for both), then every accepted sample is prepared and integrated right here
-static constexpr int FS_SPT = 4;                   // samples per thread of a k_pair_step selection workgroup
-static constexpr int FS_CHUNK = BLOCK * FS_SPT;   // samples per selection workgroup
-template <bool PERB>
-__device__ __forceinline__ void select_integral_body(const SelectArgs &a, const Geom &g, const Tables &t, const HillList &h,
-                                                     double h_const, const FusedStep &fs, unsigned bid,
-                                                     unsigned long long *trace) {
-  __shared__ int s_w[FS_SPT][BLOCK / 64];
-  __shared__ int s_loc[EDM_FS_CAP];
-  __shared__ double s_px[EDM_FS_CAP];
-  __shared__ double s_part[EDM_FS_CAP][BLOCK / 64];
-  __shared__ double s_prep[EDM_FS_CAP][3];
-  __shared__ int s_pc[EDM_FS_CAP];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long base = (long long)bid * FS_CHUNK + threadIdx.x;
-  // every load of the workgroup's rows is requested before the first one is looked at (uniforms, masks); the CVs of
-  // the few accepted samples follow afterwards -- one more round trip for the workgroups that found one, against 8 MB
-  // more for all of them to pull through HBM beside the pair forces' 16 MB
-  bool fl[FS_SPT];
-  double uu[FS_SPT];
-  int mk[FS_SPT];
-  unsigned long long bal[FS_SPT];
-  const bool has_mask = a.apply_mask >= 0;
-#pragma unroll
-  for (int j = 0; j < FS_SPT; j++) {
-    const long long i = base + (long long)j * BLOCK;
-    const long long ic = i < a.n ? i : a.n - 1;
-    mk[j] = has_mask ? a.mask[ic] : 0;
-  }
-  if (a.ru) {
-#pragma unroll
-    for (int j = 0; j < FS_SPT; j++) {
-      const long long i = base + (long long)j * BLOCK;
-      uu[j] = __builtin_nontemporal_load(&a.ru[i < a.n ? i : a.n - 1]);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < FS_SPT; j++) uu[j] = device_uniform(a.rng, base + (long long)j * BLOCK);
-  }
-#pragma unroll
-  for (int j = 0; j < FS_SPT; j++) {
-    const long long i = base + (long long)j * BLOCK;
-    fl[j] = (i < a.n) && (!has_mask || (a.apply_mask & mk[j])) && (!a.use_thr || uu[j] < a.thr);   // sel_flag()
-  }
-#pragma unroll
-  for (int j = 0; j < FS_SPT; j++) {
-    bal[j] = __ballot(fl[j]);
-    if (lane == 0) s_w[j][wave] = __popcll(bal[j]);
-  }
-  __syncthreads();
-  int run = 0;   // accepted samples of the rows walked so far (the same in every thread)
-#pragma unroll
-  for (int j = 0; j < FS_SPT; j++) {
-    int before = 0, row = 0;
-#pragma unroll
-    for (int w = 0; w < BLOCK / 64; w++) {
-      if (w < wave) before += s_w[j][w];
-      row += s_w[j][w];
-    }
-    if (fl[j]) {
-      const int pos = run + before + __popcll(bal[j] & ((1ull << lane) - 1ull));
-      if (pos < EDM_FS_CAP) {
-        s_loc[pos] = j * BLOCK + (int)threadIdx.x;
-        s_px[pos] = h.x[(base + (long long)j * BLOCK) * h.x_stride];
-      }
-    }
-    run += row;
-  }
-  if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
-  if (run > 0) {
-    __syncthreads();
-    const int ndo = run < EDM_FS_CAP ? run : EDM_FS_CAP;
-    // stage A: WHICH samples were accepted and where they sit -- all the gather tiles need to start on their stencil
-    // terms -- goes out at once; the tiles are under way while this workgroup integrates its hills (stage B)
-    if ((int)threadIdx.x < ndo) {
-      double *rp = fs.wgrec + ((size_t)bid * EDM_FS_CAP + (size_t)threadIdx.x) * EDM_FS_REC;
-      publish(rp + 3, s_px[threadIdx.x]);
-      publish(reinterpret_cast<long long *>(rp + 6), (long long)s_loc[threadIdx.x]);
-    }
-    // (more accepted samples than slots: an impossible count makes the whole step fall back, like a bound exceeded)
-    if (threadIdx.x == 0) publish(&a.counts[bid], run > EDM_FS_CAP ? (1 << 20) : run);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) counter_arrive(fs.sel_done, bid);
-    // stage B: the workgroup's hills one after the other (the stencil walk of each is shared by all 256 threads exactly
-    // as in k_hill_integrals), their sums and the publication of the records side by side afterwards: thread j owns hill j
-    TermConst<1> tc;
-    term_const<1>(g, tc);
-    for (int j = 0; j < ndo; j++) {
-      double x[1] = {s_px[j]};
-      int c[1];
-      double ht[2];
-      hill_prep_compute<1>(g, x, c, ht);
-      double acc = hill_stencil_partial<1, BLOCK, PERB>(g, t, tc, c, x, ht, h_const, true, (int)threadIdx.x);
-      acc = wave_sum(acc);
-      if (lane == 0) s_part[j][wave] = acc;
-      if (threadIdx.x == 0) {
-        s_prep[j][0] = x[0];
-        s_prep[j][1] = ht[0];
-        s_prep[j][2] = ht[1];
-        s_pc[j] = c[0];
-      }
-    }
-    if (trace && threadIdx.x == 0) {
-      trace[3] = wall_clock64();
-      trace[5] = (unsigned long long)run;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < ndo) {
-      const int j = threadIdx.x;
-      double r = 0;
-      for (int w = 0; w < BLOCK / 64; w++) r += s_part[j][w];
-      double *rp = fs.wgrec + ((size_t)bid * EDM_FS_CAP + (size_t)j) * EDM_FS_REC;
-      publish(rp + 0, s_prep[j][0]);
-      publish(rp + 1, s_prep[j][1]);
-      publish(rp + 2, s_prep[j][2]);
-      publish(rp + 4, r);
-      publish(reinterpret_cast<long long *>(rp + 5), (long long)s_pc[j]);
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) counter_arrive(fs.int_done, bid);
-  } else if (threadIdx.x == 0) {
-    publish(&a.counts[bid], 0);
-    __builtin_amdgcn_s_waitcnt(0);
-    counter_arrive(fs.sel_done, bid);
-    counter_arrive(fs.int_done, bid);
-  }
-  if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
-}
-
-// the bookkeeper: as soon as the selection is complete, wave 0 walks the ordered limiter straight off the selection
-// workgroups' records -- its outputs go to the device region and to its host-mapped copy alike -- while the other
-// waves write the ordered list out: canonical per-hill arrays (what every other path of the library leaves behind),
-// and the per-hill bias and positions of the read-back region, device and host copy.  Then the host is released
-// (once the pair forces' energy sums are in host memory) and the CV histogram updated.
-template <bool PERB>
-__device__ __forceinline__ void fused_bookkeeper(const SelectArgs &a, const HillList &h, double h_const,
-                                                 double *__restrict__ added, const LimitArgs &la, const PostArgs &post,
-                                                 const FusedStep &fs, unsigned bid, unsigned long long *trace,
-                                                 unsigned short *s_off, int *s_ws) {
-  if (threadIdx.x == 0) wait_counter(fs.sel_done, fs.sel_target);
-  __syncthreads();
-  if (trace && threadIdx.x == 0) trace[1] = wall_clock64();
-  const long long n_true = fused_scan_counts(a.counts, (int)fs.nsel, s_off, s_ws);
-  const long long nb = h.nh;
-  const long long na = n_true <= nb ? n_true : 0;
-  const long long mirror = la.rb_dst ? (long long)(la.rb_dst - la.rb_src) : 0;
-  if (threadIdx.x == 0) wait_counter(fs.int_done, fs.int_target);   // (the hills' integrals and prepared fields)
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    long long k_first = 0;
-    int err = 0;
-    LimitResult rl;
-    limit_wave<true>(nb, added, nullptr, h_const, la.limit, la.cum_in, la.flush_mode, la.tail, la.res, 0, nullptr, nullptr,
-                     h.nh_dev, mirror, &k_first, &err, n_true, &fs, s_off, &rl);
-    __builtin_amdgcn_s_waitcnt(0);
-    // (only a tile that could not rule the limiter out waits for this word)
-    if (threadIdx.x == 0) ready_publish(la.ready_flag, ready_word(la.ready_seq, EDM_READY_FINAL | err, k_first));
-    if (trace && threadIdx.x == 0) trace[3] = wall_clock64();
-    if (la.fast_line) {
-      // the result as one line for a host that needs nothing else (see header_line_to_host) -- once the pair forces of
-      // this launch are complete too: the host reads their energy sums the moment it is released
-      if (threadIdx.x == 0) wait_counter(fs.k1_done, fs.k1_target);
-      __builtin_amdgcn_wave_barrier();
-      header_line_to_host(la.fast_line, rl, la.done_seq);
-    }
-  } else {
-    auto put = [mirror](double *p, double v) {
-      publish(p, v);
-      if (mirror)
-        __hip_atomic_store(reinterpret_cast<double *>(reinterpret_cast<char *>(p) + mirror), v, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    };
-    for (long long e = threadIdx.x - 64; e < na; e += BLOCK - 64) {
-      int blk;
-      const double *rp = fused_record(fs, s_off, (int)e, &blk);
-      const double hx = acquire(rp + 0), t1 = acquire(rp + 1), t3 = acquire(rp + 2), x0 = acquire(rp + 3), ai = acquire(rp + 4);
-      const long long c = acquire(reinterpret_cast<const long long *>(rp + 5));
-      const long long loc = acquire(reinterpret_cast<const long long *>(rp + 6));
-      publish(&h.hx[e], hx);
-      publish(&h.ht[2 * e], t1);
-      publish(&h.ht[2 * e + 1], t3);
-      publish(&h.hc[e], (int)c);
-      put(&h.hx0[e], x0);      // (both live in the read-back region: apply_hills' layout)
-      put(&added[e], ai);
-      a.sel[e] = (long long)blk * FS_CHUNK + loc;
-    }
-    if (threadIdx.x == 64) {
-      *a.count_host = n_true;
-      publish(a.count_dev, n_true);
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-  }
-  __syncthreads();
-  if (trace && threadIdx.x == 0) trace[2] = wall_clock64();
-  if (la.rb_dst) {
-    // release of the host: see limiter_stage (relaxed system-scope flag behind acknowledged system-scope stores)
-    if (threadIdx.x == 0) wait_counter(fs.k1_done, fs.k1_target);
-    __syncthreads();
-    if (threadIdx.x == 0 && la.done_flag)
-      __hip_atomic_store(la.done_flag, la.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (trace && threadIdx.x == 0) trace[4] = wall_clock64();
-  if (post.enabled && !la.res->error)
-    hist_batch<1>(post.hg, post.hist, h.nh, h.hx0, la.res, post.flags, post.flush_mode, threadIdx.x, BLOCK);
-}
-
 // One launch for the two halves of a short 1-D hill step that do not depend on each other: workgroups
 // [0, nb_int) compute the per-hill integrals and -- the last of them -- run the ordered limiter and the read-back
 // (k_hill_integrals' body); the rest are the tile-owned gather, which computes its stencil terms while the limiter
@@ -4020,8 +3673,7 @@ __global__ void __launch_bounds__(BLOCK) k_integrals_gather(Geom g, Tables t, do
   const bool ticket_dirty = post.enabled && post.skip_hist && !post.rb_dst && ntile < 0xFFFFu;
   if (threadIdx.x == 0) s_dirty = 0;
   hill_gather_body<1, 0, 8, PERB, true>(g, t, rec, h, hh, plan, 0, dirty_flag, post.enabled, tile, la.ready_flag, la.ready_seq,
-                                        la.trace ? la.trace + (size_t)wg * 8 : nullptr, nullptr, nullptr, nullptr, nullptr,
-                                        nullptr, ticket_dirty ? &s_dirty : nullptr);
+                                        la.trace ? la.trace + (size_t)wg * 8 : nullptr, ticket_dirty ? &s_dirty : nullptr);
   EDM_STAMP(6);
   if (!post.enabled) return;
   if (ticket_dirty) {
@@ -4191,7 +3843,7 @@ static hipError_t gather_dim(const Geom &g, const Tables &t, double *rec, const 
     // workgroup that finds nothing to do is not free -- the bound is several times the list's length (it is taken on
     // the launch bound of the hill count), 18 000 workgroups for a list of 9 000 tiles on W4, and the launch's
     // duration followed the launched count, not the list (PMC: busy cycles 1.0 M at 410 workgroups, 5.4 M at 18 000)
-    static const long long cap_env = getenv("EDM_HIP_GATHER_WGS") ? atoll(getenv("EDM_HIP_GATHER_WGS")) : 0;   // (A/B)
+    static const long long cap_env = test_force_value("gather_wgs");   // (tests: a launch narrower than its tile list)
     // (four per CU = what is resident at once at the kernel's 120-128 registers: every workgroup starts at once and
     //  strides; measured on W4: 512 -> 0.127, 768 -> 0.115, 1024 -> 0.110, 1536 -> 0.115, 2048 -> 0.113, unbounded
     //  0.124 ms per step; the 2-D gather, whose bound is closer to its list, does not care)
@@ -4332,119 +3984,6 @@ __device__ __forceinline__ void tile_ticket_duplicate(const Geom &g, double *__r
   }
   __syncthreads();
   if (!PERB && *s_last == 2 && threadIdx.x < 64) duplicate_boundary_wave(g, rec, post.dp, threadIdx.x);
-}
-
-// the whole step (see FusedStep): selection + integrals | pair forces | bookkeeper | gather tiles
-template <bool PERB>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) k_pair_step(SelectArgs a, Geom g, Tables t, double *__restrict__ rec, HillList h,
-                                                     double h_const, double *__restrict__ added, LimitArgs la,
-                                                     HillHeights hh, GatherPlan plan, int *__restrict__ dirty_flag,
-                                                     PostArgs post, PairForcesArgs f, FusedStep fs,
-                                                     double *__restrict__ rec_next) {
-  extern __shared__ double2 lds_all[];
-  __shared__ unsigned short s_foff[EDM_FS_MAX_SEL + 1];
-  __shared__ int s_fws[BLOCK / 64];
-  // roles, in DISPATCH order: selection | bookkeeper | tiles | pair forces.  The bookkeeper and the tiles wait for
-  // selection workgroups only, which are dispatched ahead of them; K1 waits for nobody and nobody but the bookkeeper's
-  // release of the host waits for K1 -- so it goes last: behind it in the queue the tiles would get their slots only as
-  // K1's workgroups retire (stamps: tiles starting at 15 us, the kernel ending with them at 32 us).
-  // (below, `b` is the workgroup's index in the order selection | pair forces | bookkeeper | tiles the roles are written in)
-  const unsigned n_sel = fs.nsel, n_k1 = fs.nk1;
-  const unsigned n_rest = gridDim.x - n_sel - n_k1;   // bookkeeper + tiles
-  const unsigned b = blockIdx.x < n_sel ? blockIdx.x
-                                        : (blockIdx.x < n_sel + n_rest ? blockIdx.x + n_k1 : blockIdx.x - n_rest);
-  unsigned long long *trace = la.trace ? la.trace + (size_t)b * 8 : nullptr;
-  if (trace && threadIdx.x == 0) trace[0] = wall_clock64();
-  // the hill chain is what the step waits for; the pair forces only have to be done by the time the host is released:
-  // every role but K1 issues ahead of K1's waves where they share a SIMD
-  if (b < n_sel || b >= n_sel + n_k1) __builtin_amdgcn_s_setprio(3);
-  if (b < n_sel) {
-    select_integral_body<PERB>(a, g, t, h, h_const, fs, b, trace);
-  } else if (b < n_sel + n_k1) {
-    const unsigned kb = b - n_sel;
-    pair_forces_fast_body<false, BLOCK>(g, f.rec, f.n, f.r, f.force, f.block_energy, 0LL, 0, f.inv_dx, lds_all, kb, fs.nk1);
-    // (block_sum's barriers: every thread of the workgroup has read its grid records; thread 0's partial energy sum
-    //  must have reached host memory before the bookkeeper releases the host)
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_s_waitcnt(0);
-      counter_arrive(fs.k1_done, kb);
-    }
-  } else if (b == n_sel + n_k1) {
-    fused_bookkeeper<PERB>(a, h, h_const, added, la, post, fs, b, trace, s_foff, s_fws);
-  } else {
-    const unsigned tile = b - (n_sel + n_k1 + 1), ntile = gridDim.x - (n_sel + n_k1 + 1);
-    __shared__ int s_dirty, s_last;
-    if (threadIdx.x == 0) s_dirty = 0;   // (barriers inside the body lie between this and any thread's write)
-    hill_gather_body<1, 0, 8, PERB, true, true>(g, t, rec, h, hh, plan, 0, dirty_flag, post.enabled, tile, la.ready_flag,
-                                                la.ready_seq, trace, &fs, a.counts, s_foff, s_fws, rec_next, &s_dirty);
-    if (trace && threadIdx.x == 0) trace[6] = wall_clock64();
-    tile_ticket_duplicate<PERB>(g, rec_next, post, ntile, tile, &s_dirty, &s_last);
-  }
-  if (trace && threadIdx.x == 0) trace[7] = wall_clock64();
-}
-
-long long pair_step_sel_blocks(long long n_samples) { return (n_samples + FS_CHUNK - 1) / FS_CHUNK; }
-bool pair_step_fusable(const Geom &g, long long n_pairs, const SelectArgs &a, const HillList &h, const double *heights,
-                       const GatherPlan &plan) {
-  if (!pair_forces_select_fusable(g, n_pairs, a.n) || !integrals_gather_fusable(g, h.nh, plan)) return false;
-  if (a.pack || heights || !h.x || h.pl_x || h.sel != a.sel || !h.hx0 || !h.nh_dev) return false;
-  // a selection workgroup hands on at most EDM_FS_CAP accepted samples (and works its hills off one after the other):
-  // only steps that expect a few per workgroup -- the stochastic regime, ~0.5 for W1 -- run as one launch
-  if (!a.use_thr || !(a.thr * (double)(a.n < FS_CHUNK ? a.n : FS_CHUNK) <= 4.0)) return false;
-  const long long nsel = (a.n + FS_CHUNK - 1) / FS_CHUNK;
-  return nsel <= EDM_FS_MAX_SEL;
-}
-hipError_t launch_pair_step(const SelectArgs &a, const Geom &g, const Tables &t, double *rec, const HillList &h,
-                            double h_const, double *added, const LimitArgs &chain, const HillHeights &hh,
-                            const GatherPlan &plan, int *dirty_flag, const PostSpec *post_chain, const double *pair_r,
-                            long long n_pairs, double *pair_force, double *pair_scratch, FusedStep fs, hipStream_t s,
-                            hipEvent_t ev0, hipEvent_t ev1, int *k1_blocks_out, int *sel_blocks_out, double *rec_next) {
-  if (!pair_step_fusable(g, n_pairs, a, h, nullptr, plan) || !chain.ready_flag || !hh.res_dev || !post_chain || !rec_next ||
-      rec_next == rec)
-    return hipErrorInvalidValue;
-  LimitArgs la = chain;
-  la.enabled = 1;
-  la.early_word = 0;   // (the tiles make that test themselves)
-  PostArgs post;
-  memset(&post, 0, sizeof(post));
-  post.enabled = 1;
-  post.ticket = post_chain->ticket;
-  post.dp = make_dup_plan(g);
-  post.hg = *post_chain->hist_geom;
-  post.hist = post_chain->hist;
-  post.flags = post_chain->flags;
-  post.flush_mode = post_chain->flush_mode;
-  post.skip_hist = 1;   // (the bookkeeper updates the histogram)
-  PairForcesArgs f;
-  f.rec = rec;
-  f.n = n_pairs;
-  f.r = pair_r;
-  f.force = pair_force;
-  f.block_energy = pair_scratch;
-  f.inv_dx = 1.0 / g.dx[0];
-  f.nsel = (unsigned)((a.n + FS_CHUNK - 1) / FS_CHUNK);
-  f.nk1 = (unsigned)pair_short_blocks(n_pairs);
-  fs.nsel = f.nsel;
-  fs.nk1 = f.nk1;
-  // the caller passes the sums the counters stand at before this launch; the launch is told the sums that mean
-  // "complete": every selection workgroup arrives once on sel_done and once on int_done, every K1 workgroup on k1_done
-  fs.sel_target += f.nsel;
-  fs.int_target += f.nsel;
-  fs.k1_target += f.nk1;
-  fs.limit = chain.limit;
-  fs.cum_in = chain.cum_in;
-  const unsigned nb_tiles = (unsigned)((g.n[0] + BLOCK / 8 - 1) / (BLOCK / 8));
-  const dim3 grid(fs.nsel + fs.nk1 + 1 + nb_tiles);
-  dup_ticket_tiles_1d(g, post, nb_tiles, BLOCK / 8);
-  if (!g.bper[0])
-    EDM_LAUNCH_TIMED((k_pair_step<false>), grid, dim3(BLOCK), 256, s, ev0, ev1, a, g, t, rec, h, h_const, added, la, hh, plan,
-                     dirty_flag, post, f, fs, rec_next);
-  else
-    EDM_LAUNCH_TIMED((k_pair_step<true>), grid, dim3(BLOCK), 256, s, ev0, ev1, a, g, t, rec, h, h_const, added, la, hh, plan,
-                     dirty_flag, post, f, fs, rec_next);
-  if (k1_blocks_out) *k1_blocks_out = (int)f.nk1;
-  if (sel_blocks_out) *sel_blocks_out = (int)f.nsel;
-  return hipGetLastError();
 }
 
 int gather_slots_per_hill(const Geom &g) {
@@ -4842,10 +4381,10 @@ static DupPlan make_dup_plan(const Geom &g) {
 // meet a non-zero boundary correction only where a wall blend is non-zero (pair_term: corr = (..) t2 + (..) t4, and
 // node_terms: t2 != 0 only for bmin <= x < bmin + EDM_BC_MAR sigma, t4 != 0 only for bmax - EDM_BC_MAR sigma < x <= bmax);
 // the duplication copies node lo -> lo - 1 and hi -> hi + 1 where those exist (duplicate_boundary_lanes).  Ranges are
-// widened by two nodes against rounding in the node positions.  EDM_HIP_DUP_TICKET_ALL=1: every tile (A/B, tests).
+// widened by two nodes against rounding in the node positions.  EDM_HIP_TEST_FORCE=dup_ticket_all: every tile (tests).
 static void dup_ticket_tiles_1d(const Geom &g, PostArgs &post, unsigned ntile, unsigned tile_nodes) {
   post.tk_lo_end = post.tk_hi_begin = 0;   // every tile
-  static const bool all_env = getenv("EDM_HIP_DUP_TICKET_ALL") && getenv("EDM_HIP_DUP_TICKET_ALL")[0] == '1';
+  static const bool all_env = test_force("dup_ticket_all");
   if (all_env || g.dim != 1 || ntile == 0 || ntile >= 0xFFFFu) return;
   if (g.bper[0]) {   // no walls: no corrections, nothing to duplicate
     post.tk_hi_begin = ntile;
@@ -5048,12 +4587,9 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
                                            const LimitTail &tail, LimitResult *res, long long nchunks,
                                            const double *chunk_sum, const double *chunk_max,
                                            const long long *nh_dev, long long mirror, long long *k_out, int *err_out,
-                                           long long nh_known, const FusedStep *fsrc, const unsigned short *fs_off,
-                                           LimitResult *out_local, const double *s_added) {
+                                           long long nh_known, LimitResult *out_local, const double *s_added) {
   // (out_local: the result as every lane of the wave holds it -- the walk is uniform -- for a caller that writes the
   //  header line to the host in one instruction)
-  // (fsrc, k_pair_step: the per-hill bias is read from the selection workgroups' records, hill i found through the
-  //  scanned counts in LDS -- no ordered array has been written yet)
   // (k_out / err_out: the first tail hill and the error code, for a caller that hands them on in registers;
   //  nh_known >= 0: the caller has already read *nh_dev)
   // `mirror` != 0: the result and the tail's flags / h2 / added2 live in the packed read-back region, whose copy in
@@ -5159,7 +4695,6 @@ __device__ __forceinline__ void limit_wave(long long nh_bound, const double *add
   // (the next slab's hills are requested before the current slab is walked: one memory round trip per slab hidden)
   auto load_a = [&](long long i) {
     if (!(i < nh)) return 0.0;
-    if (fsrc) return acquire(fused_record(*fsrc, fs_off, (int)i) + 4);
     if (s_added) return s_added[i];   // (LDS: the polling limiter workgroup has the integrals already)
     return COHERENT ? acquire(&added[i]) : added[i];
   };
@@ -5600,7 +5135,13 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
   // a workgroup owns a contiguous run of pairs: their hill counts m span a handful of consecutive rows of the counts
   // (a W1 step has ~8 000 pairs between two hills), staged in LDS so that a pair's chain is distance -> record, two
   // round trips, not distance -> count -> record
-  const long long beg = (long long)blockIdx.x * per_block;
+  // XCD-aware: workgroup i runs on XCD i mod 8, each with an L2 of its own.  Handing XCD x the x-th EIGHTH of the pairs
+  // (workgroups x, x + 8, x + 16, ... take consecutive runs of it) keeps each L2 to the records behind an eighth of
+  // the step's hills: with runs dealt out round robin every XCD pulled the whole table through the fabric -- counted
+  // traffic 38 MB per launch against 20 MB of distances, sample indices and forces.
+  unsigned run = blockIdx.x;
+  if ((gridDim.x & 7u) == 0) run = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const long long beg = (long long)run * per_block;
   const long long end = (beg + per_block < a.n) ? beg + per_block : a.n;
   int row0 = 0, nrows = 0;
   if (beg < end) {

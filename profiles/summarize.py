@@ -37,13 +37,14 @@ def main():
         per[key].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     per = {k: [d for _, d in sorted(v)] for k, v in per.items()}   # launch order
     summary = {"kernels": [], "pmc": {}}
-    # the trace command runs `--warmup 5 --steps 50`: launches 6..55 of the step's first kernel are bench.py's timed
-    # region (acceptance uniforms read from memory); the later ones belong to the device-RNG extra, which reads none
-    warmup, steps = 5, 50
+    # the trace command runs `--warmup 5 --steps 50`: bench.py runs 5 warm-up steps, 2 more that switch the queue's
+    # profiling on, then the 50 steps of the timed region: launches 8..57 of each kernel of the reference-order step
+    warmup, steps = 7, 50
     for (name, grid, wg), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
         e = dict(kernel=name, grid=grid, workgroup=wg, calls=len(v), avg_us=sum(v) / len(v),
                  min_us=min(v), max_us=max(v), total_us=sum(v))
-        if ("k_pair_forces_select" in name or "k_integrals_gather" in name) and len(v) >= warmup + steps:
+        if any(k in name for k in ("k_pair_forces_ordered", "k_ordered_records", "k_select_prep", "k_integrals_gather")) \
+                and len(v) >= warmup + steps:
             e["avg_us_timed_region"] = sum(v[warmup:warmup + steps]) / steps
         summary["kernels"].append(e)
     for which, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
@@ -81,7 +82,8 @@ def main():
             agg[(r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
         out = {}
         for (name, grid), cs in agg.items():
-            if not any(k in name for k in ("k_lookup_quad", "k_pair_forces", "k_integrals_gather", "k_hill_gather", "k_pairlist")):
+            if not any(k in name for k in ("k_lookup_quad", "k_pair_forces", "k_integrals_gather", "k_hill_gather", "k_pairlist",
+                                           "k_ordered", "k_select_prep")):
                 continue
             out["%s grid=%d" % (name, grid)] = {c: sum(v) / len(v) for c, v in cs.items()}
         with open(os.path.join(here, "%s_pmc_instr.json" % tag), "w") as fh:

@@ -1,6 +1,6 @@
 """Child process of test_ball_list_equals_box_walk: per-hill integrals (the value add_value returns, gaussian_grid.h:227-281)
 of seeded hills on 2-D / 3-D grids, periodic and walled, printed as hex floats.  The parent runs it with the list of
-support offsets (default) and with EDM_HIP_BALL_LIST=0 (the reference's stencil box walked point by point) and compares."""
+support offsets (default) and with EDM_HIP_TEST_FORCE=no_ball_list (the reference's stencil box walked point by point) and compares."""
 import hashlib
 import json
 import os
@@ -43,7 +43,7 @@ def main():
         al = g.hill_integrals(xl, 0.75)
         out[name + "_long"] = [float(v).hex() for v in al]
         # batched add_value of a short list with its total (edm_hip_gauss_add_values): chained limiter launch, or
-        # (EDM_HIP_ADD_VALUES_CHAIN=0) integrals, sum, tile list and copy as launches of their own
+        # (EDM_HIP_TEST_FORCE=no_add_values_chain) integrals, sum, tile list and copy as launches of their own
         dx, dh, da = H.DeviceArray.from_host(x), H.DeviceArray.from_host(h), H.DeviceArray((nh,))
         tot = H.C.c_double(0)
         H.check(H.lib().edm_hip_gauss_add_values(g.h, nh, dx.ptr, dim, dh.ptr, 0.0, da.ptr, H.C.byref(tot)))

@@ -71,7 +71,7 @@ def main(workdir):
     gv, gd = b.gauss.download()
     feed(gv, gd, b.hist.values, [b.get("cum_bias"), b.get("overflow_right"), b.get("hills_added")])
     # (steps with an overflow flush: the force kernel rides in the launch that prepares the flush's hill list,
-    #  EDM_HIP_LOOKUP_PREP=0: a launch of its own, ahead of it)
+    #  EDM_HIP_TEST_FORCE=no_lookup_prep: a launch of its own, ahead of it)
     nshared = int(b.get("lookup_prep_launches"))
     del b
     # ... a 3-D grid with a group mask, device-drawn acceptance numbers, and the limiter far away (no flush: the force
@@ -100,7 +100,7 @@ def main(workdir):
     print("LOOKUP_PREP", nshared)
     print("SECTION", 2, dig.hexdigest()[:16])
     # 1-D pair CV, no HILLS log, limiter far away: the steps whose host call returns on the limiter's HEADER LINE alone
-    # (EDM_HIP_FAST_HEADER=0 makes them wait for the completion word like every other polled batch)
+    # (EDM_HIP_TEST_FORCE=no_fast_header makes them wait for the completion word like every other polled batch)
     cfg = os.path.join(workdir, "p3.edm")
     open(cfg, "w").write("tempering 0\nhill_prefactor 0.5\nhill_density 120\nbias_per_step 50\ndimension 1\nbox_low 0\n"
                          "box_high 2.8\nbias_spacing 0.00025\nbias_sigma 0.025\nhills_filename %s/HILLS_p3\n"
@@ -135,7 +135,7 @@ def main(workdir):
     print("SECTION", 3, dig.hexdigest()[:16])
     # 1-D pair CV whose walls lie INSIDE the rank's grid (a sub-domain with skin): hills at both walls meet boundary
     # corrections, and the duplication behind the gather copies the wall nodes outwards (gaussian_grid.h:571-630).  Only
-    # the tiles near the walls take the ticket that decides it (EDM_HIP_DUP_TICKET_ALL=1: every tile, the old way).
+    # the tiles near the walls take the ticket that decides it (EDM_HIP_TEST_FORCE=dup_ticket_all: every tile, the old way).
     for tag, limit in (("p4", 50.0), ("p5", 0.2)):
         cfg = os.path.join(workdir, tag + ".edm")
         open(cfg, "w").write("tempering 0\nhill_prefactor 0.5\nhill_density 150\nbias_per_step %g\ndimension 1\nbox_low 0.9\n"

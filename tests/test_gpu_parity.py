@@ -948,20 +948,20 @@ def test_polled_completion_equals_stream_wait(workdir):
         d.mkdir()
         env = dict(os.environ)
         env.pop("EDM_HIP_POLL", None)
-        env.pop("EDM_HIP_FAST_HEADER", None)
-        env.pop("EDM_HIP_DUP_TICKET_ALL", None)
-        env.pop("EDM_HIP_LOOKUP_PREP", None)
-        env.pop("EDM_HIP_TAGGED_INTEGRALS", None)
+        env.pop("EDM_HIP_TEST_FORCE", None)
+        force = []   # EDM_HIP_TEST_FORCE tokens (csrc/edm_gauss.cpp:test_force): the paths production takes under other conditions
         if tag == "lookup_alone":
-            env["EDM_HIP_LOOKUP_PREP"] = "0"
+            force.append("no_lookup_prep")
         if tag == "integrals_ticket":   # (the per-hill integrals behind a last-arrival ticket, not as tagged stores)
-            env["EDM_HIP_TAGGED_INTEGRALS"] = "0"
+            force.append("no_tagged_integrals")
         if poll is not None:
             env["EDM_HIP_POLL"] = poll
         if header is not None:
-            env["EDM_HIP_FAST_HEADER"] = header
+            force.append("no_fast_header")
         if dup_all is not None:
-            env["EDM_HIP_DUP_TICKET_ALL"] = dup_all
+            force.append("dup_ticket_all")
+        if force:
+            env["EDM_HIP_TEST_FORCE"] = ",".join(force)
         res = subprocess.run([sys.executable, worker, str(d)], env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
         lines = [ln for ln in res.stdout.splitlines() if ln.startswith("DIGEST ")]
@@ -1065,12 +1065,11 @@ def test_ball_list_equals_box_walk():
 
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ball_worker.py")
     res = {}
-    for tag, var, val in (("list", None, None), ("box", "EDM_HIP_BALL_LIST", "0"), ("unchained", "EDM_HIP_ADD_VALUES_CHAIN", "0")):
+    for tag, token in (("list", None), ("box", "no_ball_list"), ("unchained", "no_add_values_chain")):
         env = dict(os.environ)
-        env.pop("EDM_HIP_BALL_LIST", None)
-        env.pop("EDM_HIP_ADD_VALUES_CHAIN", None)
-        if var is not None:
-            env[var] = val
+        env.pop("EDM_HIP_TEST_FORCE", None)
+        if token is not None:
+            env["EDM_HIP_TEST_FORCE"] = token
         r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("INTEGRALS ")][-1]

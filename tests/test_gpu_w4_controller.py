@@ -95,7 +95,7 @@ def test_w4_limited_steps_vs_equivalent_oracle(oracle_lib, workdir):
 
 def test_w4_controller_with_a_narrow_gather_launch():
     """The culled gather's launch is capped at a few workgroups per CU and its workgroups stride over the tile list: the
-    same controller test with the launch only SEVEN workgroups wide (EDM_HIP_GATHER_WGS, read once per process), i.e.
+    same controller test with the launch only SEVEN workgroups wide (EDM_HIP_TEST_FORCE=gather_wgs=7, read once per process), i.e.
     every workgroup walking hundreds of tiles, must pass unchanged."""
     import os
     import subprocess
@@ -104,7 +104,7 @@ def test_w4_controller_with_a_narrow_gather_launch():
     if os.environ.get("EDM_TEST_CHILD"):
         pytest.skip("child run")
     env = dict(os.environ)
-    env["EDM_HIP_GATHER_WGS"] = "7"
+    env["EDM_HIP_TEST_FORCE"] = "gather_wgs=7"
     env["EDM_TEST_CHILD"] = "1"
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q"], env=env,
                          capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

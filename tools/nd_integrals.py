@@ -1,5 +1,5 @@
 """Development aid: per-hill integrals of a long list on the 512^3 / 2048^2 grids (the wave-per-hill launch), timed.
-   EDM_HIP_BALL_LIST=0 python tools/nd_integrals.py 3   # the stencil box walked point by point"""
+   EDM_HIP_TEST_FORCE=no_ball_list python tools/nd_integrals.py 3   # the stencil box walked point by point"""
 import os
 import sys
 import time

@@ -1,5 +1,5 @@
 """Development aid: only the W1 step loop of bench.py (fix edm_pair, BASELINE configs[1]), for a kernel trace:
-   EDM_HIP_PAIR_STEP_MODE=2 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/w1 -o w1 -- python3 tools/w1_steps.py"""
+   W1_ORDER=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/w1 -o w1 -- python3 tools/w1_steps.py"""
 import os
 import sys
 import tempfile
@@ -45,5 +45,5 @@ t = time.perf_counter()
 for _ in range(steps):
     step()
 H.synchronize()
-print("ordered" if ordered else "batch", "ms_per_step", (time.perf_counter() - t) / steps * 1e3, "fused", b.get("fused_steps"),
+print("ordered" if ordered else "batch", "ms_per_step", (time.perf_counter() - t) / steps * 1e3,
       "hills_added", b.get("hills_added"))
