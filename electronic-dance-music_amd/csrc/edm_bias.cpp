@@ -215,11 +215,15 @@ struct edm_hip_bias {
     // multi-GPU: this rank's slice of the rank-major global list (host values, or where they lie on the device)
     long long local_off = 0, local_cnt = -1, local_cap = 0;
     const long long *range_dev = nullptr;
+    bool terms_emitted = false;   // the batch's launch stored the hills' stencil terms in ord_terms (rows: ord_terms_rows)
   } last_batch;
+  bool ord_step_active = false;   // between ordered_snapshot and the step's force pass: hill batches may emit their terms
+  DevBuf<double> ord_terms;
+  long long ord_terms_rows = 0;
   DevBuf<long long> ord_range;
   DevBuf<double> ord_rec0, ord_records;   // OrderedForcesArgs::rec0 (taken before the batch) / ::records
   DevBuf<unsigned short> ord_counts;
-  DevBuf<unsigned long long> ord_dirty;
+  DevBuf<unsigned> ord_dirty;   // OrderedForcesArgs::dirty_hill (kept zero-initialised: step numbers start at 1)
   unsigned ord_seq = 0;
   DevBuf<int> ord_first;
   int reference_order = 0;     // edm_hip_bias_set("reference_order"): edm_hip_bias_pair_list_step evaluates its forces in
@@ -440,7 +444,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   b->pl_it_entry.release(); b->pl_jt_entry.release();
   if (b->h_count) (void)hipHostFree(b->h_count);
   b->stage_x.release(); b->stage_u.release(); b->stage_h.release(); b->tail_w.release(); b->hx0.release();
-  b->ord_range.release(); b->ord_rec0.release(); b->ord_records.release(); b->ord_counts.release(); b->ord_dirty.release(); b->ord_first.release();
+  b->ord_terms.release(); b->ord_range.release(); b->ord_rec0.release(); b->ord_records.release(); b->ord_counts.release(); b->ord_dirty.release(); b->ord_first.release();
   delete b;
   return EDM_HIP_OK;
 }
@@ -980,6 +984,16 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   }
   // (ranks that share a GPU -- the host-staged carrier exists for exactly that -- never let waiting gather tiles go first)
   b->bias->shared_device = b->comm != nullptr && strcmp(b->comm->name(), "rccl") != 0;
+  if (b->ord_step_active && nh <= 2048 && b->dim == 1) {
+    // a reference-order step: the batch's launch may store the hills' unit-height stencil terms for the force pass
+    const size_t row = (size_t)(2 * b->bias->g.msize[0] + 1) * 2;
+    EDM_HIP_TRY(b->ord_terms.reserve((size_t)nh * row));
+    EDM_HIP_TRY(b->ord_dirty.reserve_zeroed((size_t)(nh > 4096 ? nh : 4096)));
+    b->ord_terms_rows = nh;
+    spec.ord_terms = b->ord_terms.p;
+    spec.ord_dirty = b->ord_dirty.p;
+    spec.ord_seq = ++b->ord_seq;   // (a fresh number per attempt: a step redone with exact counts starts clean)
+  }
   ApplyOutcome oc;
   if (deferred_bound) {
     spec.d_nh = b->count_dev.p;
@@ -1013,6 +1027,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   b->last_batch.sel = d_sel;
   b->last_batch.local_cnt = -1;
   b->last_batch.range_dev = nullptr;
+  b->last_batch.terms_emitted = oc.terms_emitted;
   if (packed_exchange) {
     b->last_batch.sel = b->sel.p;
     b->last_batch.range_dev = b->ord_range.p;
@@ -1271,6 +1286,7 @@ static int ordered_snapshot(edm_hip_bias *b) {
   EDM_HIP_TRY(b->ord_rec0.reserve(grid_doubles));
   EDM_HIP_TRY(hipMemcpyAsync(b->ord_rec0.p, g->rec, sizeof(double) * grid_doubles, hipMemcpyDeviceToDevice, g->stream));
   b->last_batch.valid = false;
+  b->ord_step_active = true;
   return EDM_HIP_OK;
 }
 // ... and, once the step's hill batch has been applied (last_batch), the running records of its hills
@@ -1289,7 +1305,7 @@ static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
   if (ordered_record_doubles(g->g, cap) * sizeof(double) > ((size_t)4 << 30)) cap = nh;
   EDM_HIP_TRY(b->ord_records.reserve(ordered_record_doubles(g->g, cap)));
   EDM_HIP_TRY(b->ord_counts.reserve(ordered_count_shorts(g->g, cap)));
-  EDM_HIP_TRY(b->ord_dirty.reserve_zeroed(1));
+  EDM_HIP_TRY(b->ord_dirty.reserve_zeroed((size_t)(b->last_batch.nh > 4096 ? b->last_batch.nh : 4096)));
   OrderedForcesArgs a;
   memset(&a, 0, sizeof(a));
   a.nh = nh;
@@ -1308,8 +1324,14 @@ static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
   a.rec0 = b->ord_rec0.p;
   a.records = b->ord_records.p;
   a.counts = b->ord_counts.p;
-  a.first_dirty = b->ord_dirty.p;
-  a.dirty_seq = ++b->ord_seq;
+  a.dirty_hill = b->ord_dirty.p;
+  if (b->last_batch.terms_emitted) {   // (the emitters of the batch's launch noted the first dirty hill under this number)
+    a.terms = b->ord_terms.p;
+    a.terms_rows = b->ord_terms_rows;
+    a.dirty_seq = b->ord_seq;
+  } else {
+    a.dirty_seq = ++b->ord_seq;
+  }
   // development aid (EDM_HIP_TRACE=ordered): stamps of the 100th record pass to stderr
   static const bool tracing = getenv("EDM_HIP_TRACE") && !strcmp(getenv("EDM_HIP_TRACE"), "ordered");
   const size_t trace_wgs = (size_t)((g->g.n[0] + 31) / 32);
@@ -1352,6 +1374,7 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   b->pending = PendingForces();
   g->wait_polled = false;
   rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
+  b->ord_step_active = false;
   if (rc) return rc;
   int nblk = 0;
   const unsigned long long tag = forces_poll_enabled() ? ++g->force_seq : 0;
@@ -1812,6 +1835,7 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     const int *saved_mask = b->d_mask;
     b->d_mask = b->vs_mask.p;
     rc = process_new_hills(b, 2 * npairs, sample_r, 1, nullptr, 1);
+    b->ord_step_active = false;
     b->d_mask = saved_mask;
     b->pl_view_x = nullptr;
   }

@@ -1413,6 +1413,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     out->plain_fast = false;
     out->deferred_fetch = false;
     out->deferred_bound = 0;
+    out->terms_emitted = false;
   }
   if (nh <= 0) return EDM_HIP_OK;
   hipStream_t s = g->stream;
@@ -1787,6 +1788,12 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         rb_pushed = true;
       }
       ht_mark(g, 3);
+      if (spec.ord_terms && !spec.flush_mode) {   // (a reference-order step: the launch also stores the hills' stencil terms)
+        la.ord_terms = spec.ord_terms;
+        la.ord_dirty = spec.ord_dirty;
+        la.ord_seq = spec.ord_seq;
+        if (out) out->terms_emitted = true;
+      }
       EDM_HIP_TRY(launch_integrals_gather(q, tabs, g->rec, hl, spec.d_h, spec.h_const, p_added, la, hh, plan, g->d_dirty, s,
                                           chain_post ? &ps : nullptr));
       ht_mark(g, 4);

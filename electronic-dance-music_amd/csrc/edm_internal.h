@@ -207,6 +207,11 @@ struct ApplySpec {
   // ... but can take them LATER (apply_hills_fetch_deferred): a batch every hill of which was added in full is then
   // released by its header line as if nothing had been asked for, and the log is written behind the step
   bool defer_fetch_ok = false;
+  // a reference-order fix edm_pair step: where the hill batch's launch may store the hills' unit-height stencil terms
+  // (LimitArgs::ord_terms; room for `nh` rows) -- only the launch that fuses integrals and gather does
+  double *ord_terms = nullptr;
+  unsigned *ord_dirty = nullptr;
+  unsigned ord_seq = 0;
   bool fetch_heights = true;       // with d_h: copy the per-hill base heights back (a flush already has them)
   // optional: d_h is filled by the preparation kernel from this host-mapped array (nh doubles)
   const double *h_fetch_src = nullptr;
@@ -245,6 +250,7 @@ struct ApplyOutcome {
   // the batch was released by its header line alone (see LimitResult): every hill was added in full, nothing deferred,
   // nobody asked for positions / per-hill bias -- flags, h2, a2, pos, added above are EMPTY (they would read 1, 0, 0)
   bool plain_fast = false;
+  bool terms_emitted = false;        // spec.ord_terms was filled by the batch's launch
   bool deferred_fetch = false;       // plain_fast with fetch_all: positions / per-hill bias wait in the read-back region
   long long deferred_bound = 0;      // ... laid out for this launch bound (see apply_hills_fetch_deferred)
   const double *d_added = nullptr;   // where the batch's per-hill bias_added lies on the device (valid until the next batch)

@@ -150,10 +150,14 @@ struct OrderedForcesArgs {
   const double *ht;
   const long long *sel;     // sample index of this rank's hill j, ascending (NULL: hill j is sample j)
   const double *rec0;       // the node records before the batch
+  const double *terms;      // optional: [nh_cap rows][2 msize + 1][2] unit-height terms of the batch's hills (LimitArgs::ord_terms;
+                            // row = index in the batch's hill list); NULL: the record pass computes them
+  long long terms_rows;     // rows `terms` has room for
   double *records;          // [tiles][nh_cap][32][2], see launch_ordered_records
   unsigned short *counts;   // [nh + 1][tiles]
-  unsigned long long *first_dirty;   // device word, see ordered_dirty_note in edm_kernels.hip (zero-initialised once)
-  unsigned dirty_seq;       // this step's number (grows by one per launch_ordered_records)
+  unsigned *dirty_hill;     // [rows of the batch's hill list] == dirty_seq where the hill met a non-zero boundary correction
+                            // (ordered_dirty_note in edm_kernels.hip; zero-initialised once, never reset)
+  unsigned dirty_seq;       // this step's number (> 0, grows from step to step)
   long long n;              // pairs
   const double *r;          // [n] pair distances
   const int *first_sample;  // [n] sample index of pair k's first add_hill call, or NULL: 2 k (the virtual samples of a
@@ -470,6 +474,14 @@ struct LimitArgs {
   unsigned long long tag_seq;
   // host-side hint: the hill count the batch is expected to have (<= the launch bound h.nh); 0: unknown
   long long expected_hills;
+  // optional, k_integrals_gather (a reference-order fix edm_pair step): extra workgroups at the END of the launch store the
+  // unit-height stencil terms (value, derivative) of every hill -- ord_parts workgroups per hill, ord_terms[hill][2 msize + 1][2],
+  // zeros where the hill does not reach -- and note the hills with a non-zero boundary correction in ord_dirty
+  // (ordered_dirty_note).  They wait for nobody; the record pass that follows (launch_ordered_records) reads the terms
+  // instead of computing them tile by tile, where a dense tile's hills queue on one CU.
+  double *ord_terms;
+  unsigned *ord_dirty;      // OrderedForcesArgs::dirty_hill
+  unsigned ord_seq;
   // host-side, k_integrals_gather: another process runs kernels on this device (ranks sharing a GPU): the waiting
   // gather tiles are never dispatched ahead of the integrals; tiles_first_mode: -1 = the launcher's choice (memset
   // leaves 0 = integrals first, so callers set it), 0 / 1 = forced (tests)

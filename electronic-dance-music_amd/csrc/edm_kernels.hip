@@ -3641,19 +3641,86 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MOD
 // workgroups can never keep them off the machine.  Arithmetic per node and per hill is that of the two separate
 // launches; what changes is that the gather's ~10 us of exp-bound work no longer starts after the limiter's ~10 us
 // chain of dependent round trips but beside it (W1 step: 37.9 -> see DESIGN.md section 5).
+// "hill j of this step's batch met a non-zero boundary correction" (gaussian_grid.h:357-358: the boundary duplication
+// follows such a hill): one word per hill holding the STEP'S NUMBER where it did -- no memset between steps, stale
+// numbers do not match.  Per hill, not one minimum: with several ranks a rank's pairs see its own slice of the list only.
+__device__ __forceinline__ void ordered_dirty_note(unsigned *dirty_hill, unsigned seq, long long hill) {
+  dirty_hill[hill] = seq;   // (every writer stores the same value)
+}
+// unit-height stencil terms of hill `hill` (LimitArgs::ord_terms): this workgroup's share `part` of `parts` of the
+// 2 msize + 1 stencil offsets, one (value, derivative) pair per offset -- zeros where the node lies outside the grid, a
+// wall or the hill's support.  The same node_terms / pair_term the gather and the record pass evaluate.
+static constexpr int ORD_EMIT_PARTS = 2;
+template <bool PERB>
+__device__ __forceinline__ void ordered_emit_terms(const Geom &g, const Tables &t, const HillList &h, const LimitArgs &la,
+                                                   long long hill, int part) {
+  if (hill >= hill_count(h)) return;
+  const int c = h.hc[hill];
+  const double hx[1] = {h.hx[hill]};
+  const double ht[2] = {PERB ? 0.0 : h.ht[2 * hill], PERB ? 0.0 : h.ht[2 * hill + 1]};
+  const int m = g.msize[0], W = 2 * m + 1;
+  double2 *row = reinterpret_cast<double2 *>(la.ord_terms) + hill * (long long)W;
+  TermConst<1> tc;
+  term_const<1>(g, tc);
+  __shared__ int s_nz;
+  if (threadIdx.x == 0) s_nz = 0;
+  __syncthreads();
+  bool any_nz = false;
+  const int per = (W + ORD_EMIT_PARTS - 1) / ORD_EMIT_PARTS;
+  const int o_end = ((part + 1) * per < W) ? (part + 1) * per : W;
+  for (int o = part * per + threadIdx.x; o < o_end; o += BLOCK) {
+    double2 out;
+    out.x = out.y = 0.0;
+    if (c != INT_MIN) {
+      int idx = c + o - m;   // the reference's wrap rules (gaussian_grid.h:251-266): >= n wraps by %, < 0 by a single + n
+      bool ok = true;
+      if (idx >= g.n[0]) {
+        if (g.periodic[0]) idx %= g.n[0]; else ok = false;
+      }
+      if (idx < 0) {
+        if (g.periodic[0]) idx += g.n[0]; else ok = false;
+        if (idx < 0) ok = false;
+      }
+      if (ok) {
+        const int p[1] = {idx};
+        NodeTerms<1> nt;
+        node_terms<1, PERB>(g, t, p, nt);
+        double val, dval[1];
+        bool nz = false;
+        if (nt.inside && pair_term<1, PERB>(g, tc, nt, hx, ht, val, dval, nz, false)) {
+          out.x = val;
+          out.y = dval[0];
+          any_nz |= nz;
+        }
+      }
+    }
+    row[o] = out;
+  }
+  if (any_nz) s_nz = 1;
+  __syncthreads();
+  if (threadIdx.x == 0 && s_nz) ordered_dirty_note(la.ord_dirty, la.ord_seq, hill);
+}
+
 template <bool PERB>
 __global__ void __launch_bounds__(BLOCK) k_integrals_gather(Geom g, Tables t, double *__restrict__ rec, HillList h,
                                                             const double *__restrict__ heights, double h_const,
                                                             double *__restrict__ added, LimitArgs la, HillHeights hh,
                                                             GatherPlan plan, int *__restrict__ dirty_flag, PostArgs post,
-                                                            unsigned nb_int, unsigned tiles_first) {
+                                                            unsigned nb_int, unsigned tiles_first, unsigned nb_emit) {
+  // (the term emitters of a reference-order step: the last nb_emit workgroups of the launch, dispatched behind everybody
+  //  else, waiting for nobody)
+  if (blockIdx.x >= gridDim.x - nb_emit) {
+    const unsigned e = blockIdx.x - (gridDim.x - nb_emit);
+    ordered_emit_terms<PERB>(g, t, h, la, (long long)(e / ORD_EMIT_PARTS), (int)(e % ORD_EMIT_PARTS));
+    return;
+  }
   // Dispatch order.  The tiles wait for the limiter's word, so they must never keep the integrals' workgroups off the
   // machine: with the integrals first that holds by construction, but the launch is sized by a BOUND on the hill count
   // (628 integrals workgroups for ~125 hills) and the tiles -- whose terms are the longest stretch of the launch --
   // then start 2-4 us late, behind hundreds of workgroups that exit at once.  When the tiles cannot fill the machine
   // (host-checked against two resident workgroups per CU) they go first.
   // (`wg`: this workgroup's index in the order integrals | tiles, which the stamps and the rest of the code use)
-  const unsigned ntile_all = gridDim.x - nb_int;
+  const unsigned ntile_all = gridDim.x - nb_emit - nb_int;
   const unsigned wg = tiles_first ? (blockIdx.x < ntile_all ? nb_int + blockIdx.x : blockIdx.x - ntile_all) : blockIdx.x;
 #define EDM_STAMP(k) do { if (la.trace && threadIdx.x == 0) la.trace[(size_t)wg * 8 + (k)] = wall_clock64(); } while (0)
   EDM_STAMP(0);
@@ -3945,12 +4012,14 @@ hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, 
   if (chain.shared_device) tiles_first = 0;             // integrals first: deadlock-free by construction
   if (chain.tiles_first_mode >= 0) tiles_first = chain.tiles_first_mode ? 1u : 0u;   // (tests)
   if (post.enabled) dup_ticket_tiles_1d(g, post, nb_tiles, BLOCK / 8);
+  // (term emitters of a reference-order step, sized by the expected hill count like the rest of the launch)
+  const unsigned nb_emit = la.ord_terms ? (unsigned)h.nh * ORD_EMIT_PARTS : 0u;
   if (!g.bper[0])
-    hipLaunchKernelGGL((k_integrals_gather<false>), dim3(nb_int + nb_tiles), dim3(BLOCK), 0, s, g, t, rec, h, heights, h_const,
-                       added, la, hh, plan, dirty_flag, post, nb_int, tiles_first);
+    hipLaunchKernelGGL((k_integrals_gather<false>), dim3(nb_int + nb_tiles + nb_emit), dim3(BLOCK), 0, s, g, t, rec, h, heights,
+                       h_const, added, la, hh, plan, dirty_flag, post, nb_int, tiles_first, nb_emit);
   else
-    hipLaunchKernelGGL((k_integrals_gather<true>), dim3(nb_int + nb_tiles), dim3(BLOCK), 0, s, g, t, rec, h, heights, h_const,
-                       added, la, hh, plan, dirty_flag, post, nb_int, tiles_first);
+    hipLaunchKernelGGL((k_integrals_gather<true>), dim3(nb_int + nb_tiles + nb_emit), dim3(BLOCK), 0, s, g, t, rec, h, heights,
+                       h_const, added, la, hh, plan, dirty_flag, post, nb_int, tiles_first, nb_emit);
   return hipGetLastError();
 }
 
@@ -4834,15 +4903,15 @@ bool ordered_forces_supported(const Geom &g) {
   return g.dim == 1 && g.rec == 2 && g.n[0] >= 2 && !(g.periodic[0] && 2 * g.msize[0] + 1 > g.n[0]);
 }
 
-// "first hill of this step with a non-zero boundary correction", kept in one device word across launches without a
-// memset in between: seq << 32 | (0x7FFFFFFF - hill index), raised by atomic MAX -- a later launch's number always wins,
-// within a launch the smaller index does
-__device__ __forceinline__ void ordered_dirty_note(unsigned long long *w, unsigned seq, int hill) {
-  atomicMax(w, ((unsigned long long)seq << 32) | (unsigned long long)(unsigned)(0x7FFFFFFF - hill));
-}
-__device__ __forceinline__ int ordered_dirty_first(const unsigned long long *w, unsigned seq) {
-  const unsigned long long v = *w;
-  return ((unsigned)(v >> 32) == seq) ? 0x7FFFFFFF - (int)(unsigned)(v & 0xFFFFFFFFull) : INT_MAX;
+// signed stencil offset of node n in the stencil of a hill centred at node c (|o| <= msize when the hill covers
+// the node), through the one periodic image a stencil narrower than the grid can reach a node by
+__device__ __forceinline__ int ordered_offset(const Geom &g, int n, int c) {
+  int o = n - c;
+  if (g.periodic[0]) {
+    if (o > g.msize[0]) o -= g.n[0];
+    else if (o < -g.msize[0]) o += g.n[0];
+  }
+  return o;
 }
 
 // The running records of a step's hills, tile by tile.  A workgroup owns a tile of ORD_NODES nodes and walks the hill list
@@ -4867,7 +4936,8 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
   unsigned long long *tr = a.trace ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
   if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
   NodeTerms<1> nt;
-  node_terms<1, PERB>(g, t, p, nt);
+  nt.inside = true;
+  if (!a.terms) node_terms<1, PERB>(g, t, p, nt);   // (with the terms stored by the batch's launch the node side is not needed)
   const bool active = in_grid && nt.inside;   // (hills skip nodes outside a wall, gaussian_grid.h:273)
   TermConst<1> tc;
   term_const<1>(g, tc);
@@ -4879,17 +4949,11 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
     acc1 = r0.y;
   }
   double2 *R = reinterpret_cast<double2 *>(a.records) + (long long)tile * a.nh_cap * ORD_NODES;
-  __shared__ int s_c[ORD_CHUNK], s_upto[ORD_CHUNK], s_cnt;
+  __shared__ int s_c[ORD_CHUNK], s_upto[ORD_CHUNK], s_cnt, s_row[ORD_CHUNK];
   __shared__ double s_x[ORD_CHUNK], s_t[ORD_CHUNK][2], s_a1[ORD_CHUNK], s_a2[ORD_CHUNK];
   __shared__ double s_v[ORD_CHUNK][ORD_NODES], s_d[ORD_CHUNK][ORD_NODES];
-  // the tile's first hill with a non-zero correction: collected in LDS, ONE device atomic per workgroup at the end (every
-  // thread of the tiles near a wall meets such a term -- thousands of atomics on one address would serialise)
-  __shared__ int s_dirty;
   int listed = 0;       // hills of the earlier chunks the tile listed
-  if (threadIdx.x == 0) {
-    a.counts[tile] = 0;   // (row m = 0)
-    s_dirty = INT_MAX;
-  }
+  if (threadIdx.x == 0) a.counts[tile] = 0;   // (row m = 0)
   // this rank's hills: the whole batch, or (multi-GPU) its slice [off, off + nloc) of the rank-major global list --
   // the reference's ranks see their OWN hills of the step while they walk their pairs and replay the other ranks'
   // only in post_add_hill (edm_bias.cpp:565-583)
@@ -4898,7 +4962,6 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
   if (nloc > a.nh_cap) nloc = a.nh_cap;
   for (long long base = 0; base < nloc; base += ORD_CHUNK) {
     const int cnt = (nloc - base < ORD_CHUNK) ? (int)(nloc - base) : ORD_CHUNK;
-    int first_nz = -1;    // list position of this thread's first such term of the chunk
     if (threadIdx.x < 64) {   // wave 0: one hill of the chunk per lane
       bool take = false;
       int c = INT_MIN;
@@ -4928,6 +4991,7 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
         a.counts[(base + lane + 1) * ntiles + tile] = (unsigned short)(listed + pos + (take ? 1 : 0));
       if (take) {
         s_c[pos] = c;
+        s_row[pos] = (int)(off + base + threadIdx.x);
         s_x[pos] = hx;
         s_t[pos][0] = ht0;
         s_t[pos][1] = ht1;
@@ -4942,50 +5006,64 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
     if (tr && threadIdx.x == 0 && base == 0) tr[7] = (unsigned long long)nl;
     // (one listed hill per thread and trip: four of them unrolled side by side were tried -- the terms' branches keep
     //  the chains from interleaving, and with ~6 listed hills per chunk the parts beyond the first two sat idle: slower)
-    for (int e = part; e < nl; e += ORD_PARTS) {
-      double val = 0, dval[1] = {0};
-      if (active && images(g, 0, s_c[e], n, n) != 0) {
-        bool nz = false;
-        double v1, d1[1];
-        if (pair_term<1, PERB>(g, tc, nt, &s_x[e], s_t[e], v1, d1, nz, false)) {
-          val = v1;
-          dval[0] = d1[0];
-          if (nz && first_nz < 0) first_nz = e;
+    if (a.terms) {
+      // the terms were stored by the emitters of the hill batch's launch (LimitArgs::ord_terms): one 16-byte load per
+      // (listed hill, node) -- all of a thread's loads requested before the first is used
+      for (int e = part; e < nl; e += ORD_PARTS) {
+        double2 tv;
+        tv.x = tv.y = 0.0;
+        const int c = s_c[e];
+        if (in_grid && images(g, 0, c, n, n) != 0)
+          tv = reinterpret_cast<const double2 *>(a.terms)[(long long)s_row[e] * (2 * g.msize[0] + 1) + (ordered_offset(g, n, c) + g.msize[0])];
+        s_v[e][tnode] = tv.x;
+        s_d[e][tnode] = tv.y;
+      }
+    } else {
+      for (int e = part; e < nl; e += ORD_PARTS) {
+        double val = 0, dval[1] = {0};
+        if (active && images(g, 0, s_c[e], n, n) != 0) {
+          bool nz = false;
+          double v1, d1[1];
+          if (pair_term<1, PERB>(g, tc, nt, &s_x[e], s_t[e], v1, d1, nz, false)) {
+            val = v1;
+            dval[0] = d1[0];
+            if (nz) ordered_dirty_note(a.dirty_hill, a.dirty_seq, s_row[e]);
+          }
         }
-      }
-      s_v[e][tnode] = val;
-      s_d[e][tnode] = dval[0];
-    }
-    // (wave-level minimum first: one LDS atomic per wave that met such a term)
-    {
-      int fz = first_nz < 0 ? INT_MAX : first_nz;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int other = __shfl_xor(fz, o, 64);
-        fz = other < fz ? other : fz;
-      }
-      if ((threadIdx.x & 63) == 0 && fz != INT_MAX) {
-        // list position -> chunk-local hill index: the first hill whose count of listed hills exceeds the position
-        int q = 0;
-        while (q < cnt && s_upto[q] <= fz) q++;
-        atomicMin(&s_dirty, (int)(base + q));
+        s_v[e][tnode] = val;
+        s_d[e][tnode] = dval[0];
       }
     }
     __syncthreads();
     if (tr && threadIdx.x == 0 && base == 0) tr[3] = wall_clock64();
     if (part == 0) {
-      for (int e = 0; e < nl; e++) {
-        const double v = s_v[e][tnode], d = s_d[e][tnode], a1 = s_a1[e], a2 = s_a2[e];
-        if (v != 0 || d != 0) {
-          acc0 += a1 * v;
-          acc1 += a1 * d;
-          if (a2 != 0) {
-            acc0 += a2 * v;
-            acc1 += a2 * d;
+      // (four listed hills per trip: their LDS reads are requested together, the adds -- rec += h1 term, then += h2 term,
+      //  hill after hill -- stay one dependent chain; adding a zero term leaves the record as it is)
+      for (int e0 = 0; e0 < nl; e0 += 4) {
+        double v[4], d[4], a1[4], a2[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int e = (e0 + q < nl) ? e0 + q : e0;
+          v[q] = s_v[e][tnode];
+          d[q] = s_d[e][tnode];
+          a1[q] = s_a1[e];
+          a2[q] = s_a2[e];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (e0 + q < nl) {
+            if (v[q] != 0 || d[q] != 0) {
+              acc0 += a1[q] * v[q];
+              acc1 += a1[q] * d[q];
+              if (a2[q] != 0) {
+                acc0 += a2[q] * v[q];
+                acc1 += a2[q] * d[q];
+              }
+            }
+            s_v[e0 + q][tnode] = acc0;
+            s_d[e0 + q][tnode] = acc1;
           }
         }
-        s_v[e][tnode] = acc0;
-        s_d[e][tnode] = acc1;
       }
     }
     __syncthreads();
@@ -5000,7 +5078,6 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
     __syncthreads();
     if (tr && threadIdx.x == 0 && base == 0) tr[5] = wall_clock64();
   }
-  if (threadIdx.x == 0 && s_dirty != INT_MAX) ordered_dirty_note(a.first_dirty, a.dirty_seq, s_dirty);
   if (tr && threadIdx.x == 0) tr[6] = wall_clock64();
 }
 
@@ -5032,7 +5109,17 @@ __device__ __forceinline__ void ordered_common_init(const Geom &g, const Ordered
   __syncthreads();
   oc.samples = s_samples;
   oc.ntiles = (g.n[0] + ORD_NODES - 1) / ORD_NODES;
-  oc.first_dirty = ordered_dirty_first(a.first_dirty, a.dirty_seq);
+  {
+    // the first of THIS RANK'S hills with a non-zero boundary correction (list position within its slice)
+    __shared__ int s_fd;
+    if (threadIdx.x == 0) s_fd = INT_MAX;
+    __syncthreads();
+    const long long off = a.range_dev ? a.range_dev[0] : a.hill_off;
+    for (int i = threadIdx.x; i < oc.H; i += blockDim.x)
+      if (a.dirty_hill[off + i] == a.dirty_seq) atomicMin(&s_fd, i);
+    __syncthreads();
+    oc.first_dirty = s_fd;
+  }
   oc.lo_t = oc.lo_s = oc.hi_t = oc.hi_s = -1;
   if (!g.bper[0]) {   // duplicate_boundary_lanes' cases 0 and 3 in one dimension
     if (dp.lo[0] > 0 && dp.lo[0] < (unsigned long long)g.n[0]) {
