@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -117,6 +118,118 @@ class HillWriter {
   bool stop_, busy_;
 };
 
+// step_host's host side: the bias-force delta arrives in pieces (one event each) and is added into the caller's force
+// array.  One core adds ~1 MB of delta in ~35 us -- as long as the link needs to deliver it -- so a few helper threads
+// share every piece.
+struct DeltaAddJob {
+  double *h_f = nullptr;
+  const double *dl = nullptr;
+  long long n = 0, per = 0;
+  int dim = 1, f_stride = 1, pieces = 1;
+  hipEvent_t *ev = nullptr;
+};
+static double g_add_trace[64][4];   // development aid (EDM_HIP_TRACE=step_host): per thread, woken / first piece seen / waited / done
+static double trace_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static int delta_add_pieces(const DeltaAddJob &j, int me, int threads) {
+  g_add_trace[me][0] = trace_now_us();
+  g_add_trace[me][2] = 0;
+  // every thread takes its share of EVERY piece: the copies stay few and large (the link's rate), the add of a piece is
+  // spread over the threads
+  for (int c = 0; c < j.pieces; c++) {
+    const long long p0 = c * j.per, p1 = (p0 + j.per < j.n) ? p0 + j.per : j.n;
+    const double tw = trace_now_us();
+    hipError_t e = hipEventSynchronize(j.ev[c]);
+    g_add_trace[me][2] += trace_now_us() - tw;
+    if (c == 0) g_add_trace[me][1] = trace_now_us();
+    g_add_trace[me][3] = 0;
+    if (e != hipSuccess) return (int)e;
+    if (p0 >= p1) continue;
+    const long long share = (p1 - p0 + threads - 1) / threads;
+    const long long i0 = p0 + me * share, i1 = (i0 + share < p1) ? i0 + share : p1;
+    if (i0 >= i1) continue;
+    // f[i][d] += delta[i][d]: the delta started from zero, so it holds exactly -dV/ds_d of the masked atoms and
+    // (+0.0 or) 0 elsewhere -- the same doubles the reference's `forces[i][j] -= der[j]` subtracts
+    if (j.dim == j.f_stride) {
+      double *fp = j.h_f + (size_t)i0 * j.dim;
+      const double *dp = j.dl + (size_t)i0 * j.dim;
+      const size_t m = (size_t)(i1 - i0) * j.dim;
+      for (size_t q = 0; q < m; q++) fp[q] += dp[q];
+    } else {
+      for (long long i = i0; i < i1; i++)
+        for (int d = 0; d < j.dim; d++) j.h_f[(size_t)i * j.f_stride + d] += j.dl[(size_t)i * j.dim + d];
+    }
+  }
+  g_add_trace[me][3] = trace_now_us();
+  return 0;
+}
+class DeltaAddPool {
+ public:
+  DeltaAddPool() : gen_(0), stop_(false), left_(0), err_(0) {}
+  ~DeltaAddPool() { close(); }
+  int threads() const { return (int)th_.size() + 1; }
+  void resize(int total, int device) {
+    if (total < 1) total = 1;
+    if (total == threads()) return;
+    close();
+    stop_ = false;
+    for (int t = 1; t < total; t++) th_.emplace_back(&DeltaAddPool::run, this, t, total, device);
+  }
+  int run_job(const DeltaAddJob &j) {   // returns a hipError_t (0 = fine)
+    const int total = threads();
+    if (total > 1) {
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        job_ = j;
+        left_.store(total - 1, std::memory_order_relaxed);
+        err_.store(0, std::memory_order_relaxed);
+        gen_++;
+      }
+      cv_.notify_all();
+    }
+    int rc = delta_add_pieces(j, 0, total);
+    if (total > 1) {
+      while (left_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+      if (!rc) rc = err_.load(std::memory_order_relaxed);
+    }
+    return rc;
+  }
+  void close() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : th_)
+      if (t.joinable()) t.join();
+    th_.clear();
+  }
+
+ private:
+  void run(int me, int total, int device) {
+    (void)hipSetDevice(device);
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(m_);
+    for (;;) {
+      cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+      if (stop_) return;
+      seen = gen_;
+      const DeltaAddJob j = job_;
+      lk.unlock();
+      const int rc = delta_add_pieces(j, me, total);
+      if (rc) err_.store(rc, std::memory_order_relaxed);
+      left_.fetch_sub(1, std::memory_order_release);
+      lk.lock();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  unsigned long long gen_;
+  bool stop_;
+  DeltaAddJob job_;
+  std::atomic<int> left_, err_;
+};
+
 struct edm_hip_bias {
   // public data members of EDMBias (edm_bias.h:118-157)
   int b_tempering = 0, b_targeting = 0;
@@ -194,10 +307,17 @@ struct edm_hip_bias {
   DevBuf<double> hs_r, hs_f, hs_x, hs_u;
   DevBuf<int> hs_mask;
   double *h_delta = nullptr;       // page-locked landing zone of step_host's force delta
-  hipEvent_t delta_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t delta_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t h_delta_cap = 0;
-  const void *reg_ptr = nullptr, *reg_failed_ptr = nullptr;   // the caller's position block, page-locked in place (step_host)
-  size_t reg_bytes = 0;
+  // the caller's position / uniform / mask blocks, page-locked in place (step_host)
+  enum { REG_X = 0, REG_U = 1, REG_MASK = 2, REG_SLOTS = 3 };
+  const void *reg_ptr[REG_SLOTS] = {nullptr, nullptr, nullptr}, *reg_failed_ptr[REG_SLOTS] = {nullptr, nullptr, nullptr};
+  size_t reg_bytes[REG_SLOTS] = {0, 0, 0};
+  DeltaAddPool add_pool;        // step_host: helper threads of the host-side add
+  int host_add_threads = 4;     // edm_hip_bias_set("host_add_threads"): threads adding the delta (the caller's included)
+  // fix edm step: called right behind the launch that carries the step's force kernel (PendingForces::on_launched)
+  void (*step_hook)(void *) = nullptr;
+  void *step_hook_ctx = nullptr;
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_event = nullptr;
   const double *pl_view_x = nullptr;   // pair_list_step: the samples of this add_hill cycle are the virtual samples of the
@@ -428,9 +548,10 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   if (b->copy_event) (void)hipEventDestroy(b->copy_event);
   b->hs_r.release(); b->hs_f.release(); b->hs_x.release(); b->hs_u.release(); b->hs_mask.release();
   if (b->h_delta) (void)hipHostFree(b->h_delta);
-  for (int c = 0; c < 4; c++)
+  for (int c = 0; c < 8; c++)
     if (b->delta_ev[c]) (void)hipEventDestroy(b->delta_ev[c]);
-  if (b->reg_ptr) (void)hipHostUnregister(const_cast<void *>(b->reg_ptr));
+  for (int k = 0; k < edm_hip_bias::REG_SLOTS; k++)
+    if (b->reg_ptr[k]) (void)hipHostUnregister(const_cast<void *>(b->reg_ptr[k]));
   (void)resolve_deferred_log(b);
   b->hills.submit(b->hill_events);
   b->hills.close();
@@ -1156,10 +1277,13 @@ int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_str
       b->pending.la.mask = b->d_mask;
       b->pending.la.apply_mask = apply_mask;
       b->pending.la.partial_tag = ftag;
+      b->pending.on_launched = b->step_hook;
+      b->pending.on_launched_ctx = b->step_hook_ctx;
       lookup_pending = true;
     } else {
       int rc = update_forces_enqueue(b->bias, n, d_x, x_stride, d_f, f_stride, b->d_mask, apply_mask, &nblk, ftag);
       if (rc) return rc;
+      if (n > 0 && b->step_hook) b->step_hook(b->step_hook_ctx);
     }
   }
   // add_hills behind it on the same stream (:401-411): pre_add_hill, the samples, post_add_hill
@@ -1568,22 +1692,53 @@ int edm_hip_bias_pair_step_host(edm_hip_bias *b, long long n, const double *h_r,
 // reference's update_forces only ever subtracts dV/ds from it, edm_bias.cpp:287-293).  The position block is page-locked
 // in place (hipHostRegister, remembered until the caller's pointer or size changes: LAMMPS keeps atom->x until it
 // reallocates), so the upload is one DMA transfer; the delta lands in page-locked memory of the library's own.
-static int host_block_register(edm_hip_bias *b, const void *p, size_t bytes) {
-  if (b->reg_ptr == p && b->reg_bytes >= bytes) return EDM_HIP_OK;
-  if (b->reg_ptr) {
-    (void)hipHostUnregister(const_cast<void *>(b->reg_ptr));
-    b->reg_ptr = nullptr;
-    b->reg_bytes = 0;
+static int host_block_register(edm_hip_bias *b, int slot, const void *p, size_t bytes) {
+  if (b->reg_ptr[slot] == p && b->reg_bytes[slot] >= bytes) return EDM_HIP_OK;
+  if (b->reg_ptr[slot]) {
+    (void)hipHostUnregister(const_cast<void *>(b->reg_ptr[slot]));
+    b->reg_ptr[slot] = nullptr;
+    b->reg_bytes[slot] = 0;
   }
-  if (b->reg_failed_ptr == p) return EDM_HIP_OK;   // (not registrable -- e.g. already page-locked by the caller: plain copies)
+  if (b->reg_failed_ptr[slot] == p) return EDM_HIP_OK;   // (not registrable -- e.g. already page-locked by the caller: plain copies)
   if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) {
-    b->reg_ptr = p;
-    b->reg_bytes = bytes;
+    b->reg_ptr[slot] = p;
+    b->reg_bytes[slot] = bytes;
   } else {
     (void)hipGetLastError();
-    b->reg_failed_ptr = p;
+    b->reg_failed_ptr[slot] = p;
   }
   return EDM_HIP_OK;
+}
+
+// the force delta's way down: pieces on the copy stream behind the launch that carries the force kernel, an event
+// behind each -- the host adds piece k while piece k + 1 is on the link and the step's hills run on the main stream
+struct DeltaCopy {
+  edm_hip_bias *b;
+  long long n;
+  int dim, pieces;
+  int rc;
+  bool queued;
+  long long per() const { return (((n + pieces - 1) / pieces) + 1) & ~1LL; }   // (even: pieces start 16-byte aligned)
+};
+static void delta_copy_queue(void *ctx) {
+  DeltaCopy *d = static_cast<DeltaCopy *>(ctx);
+  edm_hip_bias *b = d->b;
+  if (d->queued || d->n <= 0) return;
+  d->queued = true;
+  auto ok = [&](hipError_t e) {
+    if (e != hipSuccess && !d->rc) d->rc = (int)e;
+    return e == hipSuccess;
+  };
+  if (!ok(hipEventRecord(b->copy_event, b->bias->stream))) return;
+  if (!ok(hipStreamWaitEvent(b->copy_stream, b->copy_event, 0))) return;
+  const long long per = d->per();
+  for (int c = 0; c < d->pieces; c++) {
+    const long long i0 = c * per, i1 = (i0 + per < d->n) ? i0 + per : d->n;
+    if (i0 < i1)
+      ok(launch_copy_to_host(b->hs_f.p + (size_t)i0 * d->dim, b->h_delta + (size_t)i0 * d->dim, (i1 - i0) * d->dim,
+                             b->copy_stream));
+    ok(hipEventRecord(b->delta_ev[c], b->copy_stream));
+  }
 }
 
 int edm_hip_bias_step_host(edm_hip_bias *b, long long n, const double *h_x, int x_stride, double *h_f, int f_stride,
@@ -1610,6 +1765,7 @@ int edm_hip_bias_step_host(edm_hip_bias *b, long long n, const double *h_x, int 
     return rc ? rc : do_post_add_hill(b);
   }
   hipStream_t s = b->bias->stream;
+  const double t_entry = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
   const size_t xcount = n > 0 ? (size_t)(n - 1) * (size_t)x_stride + (size_t)dim : 0;
   EDM_HIP_TRY(b->hs_x.reserve(xcount > 0 ? xcount : 1));
   EDM_HIP_TRY(b->hs_f.reserve((size_t)(n > 0 ? n : 1) * dim));
@@ -1619,64 +1775,100 @@ int edm_hip_bias_step_host(edm_hip_bias *b, long long n, const double *h_x, int 
     b->h_delta_cap = (size_t)n * dim + (size_t)n * dim / 4 + 64;
     EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_delta), sizeof(double) * b->h_delta_cap, hipHostMallocDefault));
   }
-  // (whatever happens below, no copy may still be reading the caller's arrays when the call returns)
+  if (!b->copy_stream) {
+    EDM_HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+    EDM_HIP_TRY(hipEventCreateWithFlags(&b->copy_event, hipEventDisableTiming));
+  }
+  // few, large pieces: each costs a launch and an event, and the add starts with the first
+  constexpr int MAX_PIECES = 4;
+  int PIECES = (int)(((size_t)n * dim * sizeof(double)) >> 21);
+  PIECES = PIECES < 1 ? 1 : (PIECES > MAX_PIECES ? MAX_PIECES : PIECES);
+  if (!b->delta_ev[0])
+    for (int c = 0; c < MAX_PIECES; c++) EDM_HIP_TRY(hipEventCreateWithFlags(&b->delta_ev[c], hipEventDisableTiming));
+  // (whatever happens below, no copy may still be reading or writing the caller's arrays when the call returns)
   struct StreamGuard {
-    hipStream_t s;
-    ~StreamGuard() { (void)hipStreamSynchronize(s); }
-  } guard{s};
+    hipStream_t a, c;
+    bool armed;
+    ~StreamGuard() {
+      if (!armed) return;
+      (void)hipStreamSynchronize(a);
+      (void)hipStreamSynchronize(c);
+    }
+  } guard{s, b->copy_stream, true};
   if (n > 0) {
     // (whole rows: a copy of the caller's own that spans the block must not straddle locked and unlocked memory)
-    host_block_register(b, h_x, sizeof(double) * (size_t)n * (size_t)x_stride);
+    host_block_register(b, edm_hip_bias::REG_X, h_x, sizeof(double) * (size_t)n * (size_t)x_stride);
     EDM_HIP_TRY(hipMemcpyAsync(b->hs_x.p, h_x, sizeof(double) * xcount, hipMemcpyHostToDevice, s));
     EDM_HIP_TRY(hipMemsetAsync(b->hs_f.p, 0, sizeof(double) * (size_t)n * dim, s));
     if (apply_mask >= 0) {
       EDM_HIP_TRY(b->hs_mask.reserve((size_t)n));
+      host_block_register(b, edm_hip_bias::REG_MASK, h_mask, sizeof(int) * (size_t)n);
       EDM_HIP_TRY(hipMemcpyAsync(b->hs_mask.p, h_mask, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
     }
     if (hill_step && h_runiform) {
       EDM_HIP_TRY(b->hs_u.reserve((size_t)n));
+      host_block_register(b, edm_hip_bias::REG_U, h_runiform, sizeof(double) * (size_t)n);
       EDM_HIP_TRY(hipMemcpyAsync(b->hs_u.p, h_runiform, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
     }
   }
+  static const bool host_trace = getenv("EDM_HIP_TRACE") && strcmp(getenv("EDM_HIP_TRACE"), "step_host") == 0;
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tr[4 + MAX_PIECES] = {0};
+  if (host_trace) tr[1] = now_us();
   const int *saved_mask = b->d_mask;
   if (apply_mask >= 0) b->d_mask = b->hs_mask.p;
+  DeltaCopy dc{b, n, dim, PIECES, 0, false};
   int rc;
-  if (hill_step)
+  if (hill_step) {
+    b->step_hook = delta_copy_queue;
+    b->step_hook_ctx = &dc;
     rc = edm_hip_bias_step(b, n, b->hs_x.p, x_stride, b->hs_f.p, dim, h_runiform ? b->hs_u.p : nullptr, apply_mask,
                            est_hill_count, energy);
-  else
+    b->step_hook = nullptr;
+    b->step_hook_ctx = nullptr;
+  } else {
     rc = edm_hip_bias_update_forces(b, n, b->hs_x.p, x_stride, b->hs_f.p, dim, apply_mask, energy);
+  }
   b->d_mask = saved_mask;
   if (rc) return rc;
+  if (host_trace) tr[2] = now_us();
   if (n > 0) {
-    // the delta comes down in a few pieces and the host adds piece k while piece k + 1 is on the link.
-    // f[i][d] += delta[i][d]: the delta started from zero, so it holds exactly -dV/ds_d of the masked atoms and
-    // (+0.0 or) 0 elsewhere -- the same doubles the reference's `forces[i][j] -= der[j]` subtracts
-    constexpr int PIECES = 4;
-    if (!b->delta_ev[0])
-      for (int c = 0; c < PIECES; c++) EDM_HIP_TRY(hipEventCreateWithFlags(&b->delta_ev[c], hipEventDisableTiming));
-    const long long per = (n + PIECES - 1) / PIECES;
-    for (int c = 0; c < PIECES; c++) {
-      const long long i0 = c * per, i1 = (i0 + per < n) ? i0 + per : n;
-      if (i0 < i1)
-        EDM_HIP_TRY(hipMemcpyAsync(b->h_delta + (size_t)i0 * dim, b->hs_f.p + (size_t)i0 * dim,
-                                   sizeof(double) * (size_t)(i1 - i0) * dim, hipMemcpyDeviceToHost, s));
-      EDM_HIP_TRY(hipEventRecord(b->delta_ev[c], s));
+    delta_copy_queue(&dc);   // (forces only, or a step that never launched them through the hook: now)
+    if (dc.rc) {
+      set_error(std::string("step_host: queueing the force delta's copies failed: ") + hipGetErrorString((hipError_t)dc.rc));
+      return EDM_HIP_ERR_HIP;
     }
-    const double *dl = b->h_delta;
-    for (int c = 0; c < PIECES; c++) {
-      const long long i0 = c * per, i1 = (i0 + per < n) ? i0 + per : n;
-      EDM_HIP_TRY(hipEventSynchronize(b->delta_ev[c]));
-      if (dim == 3 && f_stride == 3) {
-        double *fp = h_f + (size_t)i0 * 3;
-        const double *dp = dl + (size_t)i0 * 3;
-        const size_t m = (size_t)(i1 > i0 ? i1 - i0 : 0) * 3;
-        for (size_t q = 0; q < m; q++) fp[q] += dp[q];
-      } else {
-        for (long long i = i0; i < i1; i++)
-          for (int d = 0; d < dim; d++) h_f[(size_t)i * f_stride + d] += dl[(size_t)i * dim + d];
-      }
+    DeltaAddJob job;
+    job.h_f = h_f;
+    job.dl = b->h_delta;
+    job.n = n;
+    job.per = dc.per();
+    job.dim = dim;
+    job.f_stride = f_stride;
+    job.pieces = PIECES;
+    job.ev = b->delta_ev;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    b->add_pool.resize(n * dim >= 65536 ? b->host_add_threads : 1, dev);
+    const int rca = b->add_pool.run_job(job);
+    if (rca) {
+      set_error(std::string("step_host: waiting for the force delta failed: ") + hipGetErrorString((hipError_t)rca));
+      return EDM_HIP_ERR_HIP;
     }
+  }
+  // (success: the step's completion record is behind the uploads on the main stream, every piece's event has been
+  //  waited for on the copy stream -- nothing of the caller's is in flight, no stream wait needed: ~17 us each)
+  guard.armed = false;
+  if (host_trace) {   // development aid: the call's host marks, us since entry
+    const double t_added = now_us();
+    (void)hipStreamSynchronize(b->copy_stream);
+    const double t_copy = now_us();
+    (void)hipStreamSynchronize(s);
+    fprintf(stderr, "[edm trace] step_host: uploads queued %.1f  step returned %.1f  delta added %.1f (%d pieces, %d threads)  copy stream idle %.1f  main stream idle %.1f\n",
+            tr[1] - t_entry, tr[2] - t_entry, t_added - t_entry, PIECES, b->add_pool.threads(), t_copy - t_entry, now_us() - t_entry);
+    for (int t = 0; t < b->add_pool.threads(); t++)
+      fprintf(stderr, "[edm trace]   add thread %d: started %.1f  first piece seen %.1f  waited %.1f in all  done %.1f\n", t,
+              g_add_trace[t][0] - t_entry, g_add_trace[t][1] - t_entry, g_add_trace[t][2], g_add_trace[t][3] - t_entry);
   }
   return EDM_HIP_OK;
 }
@@ -1986,6 +2178,7 @@ int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
   G("lookup_prep_launches", b->bias ? b->bias->lookup_prep_launches : 0)
   G("bound_redos", b->bound_redos)
   G("reference_order", b->reference_order)
+  G("host_add_threads", b->host_add_threads)
 #undef G
   set_error(std::string("unknown EDMBias member ") + name);
   return EDM_HIP_ERR_ARG;
@@ -2004,6 +2197,11 @@ int edm_hip_bias_set(edm_hip_bias *b, const char *name, double value) {
   S("debug_virtual_ranks", b->debug_virtual_ranks, int)
   S("debug_force_sync", b->debug_force_sync, int)
   S("reference_order", b->reference_order, int)
+  if (strcmp(name, "host_add_threads") == 0) {
+    if (value < 1 || value > 64) return EDM_HIP_ERR_ARG;
+    b->host_add_threads = (int)value;
+    return EDM_HIP_OK;
+  }
   if (strcmp(name, "debug_tiles_first") == 0 && b->bias) { b->bias->debug_tiles_first = (int)value; return EDM_HIP_OK; }
 #undef S
   set_error(std::string("unknown or read-only EDMBias member ") + name);

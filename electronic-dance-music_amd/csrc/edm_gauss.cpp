@@ -1160,10 +1160,12 @@ int pending_forces_flush(const edm_hip_gauss *g, PendingForces *pf) {
     int rcf = faces_prepare(const_cast<edm_hip_gauss *>(g), &faces);
     if (rcf) return rcf;
     EDM_HIP_TRY(launch_lookup(g->g, g->rec, LOOKUP_FORCES, pf->la, g->d_partials, nullptr, g->stream, e0, e1, &pf->nblk, faces));
+    pf->launched();
     return EDM_HIP_OK;
   }
   if (pf->list) {
     EDM_HIP_TRY(launch_pairlist_forces(g->g, g->rec, pf->pl, g->d_partials, g->stream, &pf->nblk));
+    pf->launched();
     return EDM_HIP_OK;
   }
   if (pf->tag) {
@@ -1177,9 +1179,12 @@ int pending_forces_flush(const edm_hip_gauss *g, PendingForces *pf) {
     EDM_HIP_TRY(launch_pair_forces(g->g, g->rec, pf->n, pf->d_r, pf->d_force, g->d_partials, nullptr, g->stream, e0, e1,
                                    &pf->nblk, pf->tag, &tagged));
     pf->tagged = tagged != 0;
+    pf->launched();
     return EDM_HIP_OK;
   }
-  return pair_forces_enqueue(g, pf->n, pf->d_r, pf->d_force, &pf->nblk);
+  int rc = pair_forces_enqueue(g, pf->n, pf->d_r, pf->d_force, &pf->nblk);
+  if (!rc) pf->launched();
+  return rc;
 }
 int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a_in, const HillList &h, PendingForces *pf) {
   SelectArgs a = a_in;
@@ -1221,6 +1226,7 @@ int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a_in, const Hi
   if (pf && pf->active && pf->list && g->g.dim == 1 && a.n > 0 && pf->pl.nall > 0) {
     pf->active = false;
     EDM_HIP_TRY(launch_pairlist_forces_select(a, g->g, h, g->rec, pf->pl, g->d_partials, g->stream, &pf->nblk));
+    pf->launched();
     return EDM_HIP_OK;
   }
   static const bool lookup_fuse_env = !test_force("no_lookup_prep");
@@ -1234,6 +1240,7 @@ int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a_in, const Hi
     int rcf = faces_prepare(const_cast<edm_hip_gauss *>(g), &faces);
     if (rcf) return rcf;
     EDM_HIP_TRY(launch_lookup_select(g->g, g->rec, pf->la, g->d_partials, g->stream, e0, e1, &pf->nblk, faces, a, h));
+    pf->launched();
     const_cast<edm_hip_gauss *>(g)->lookup_prep_launches++;
     return EDM_HIP_OK;
   }
@@ -1244,6 +1251,7 @@ int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a_in, const Hi
     ht_mark(const_cast<edm_hip_gauss *>(g), 1);
     EDM_HIP_TRY(launch_pair_forces_select(a, g->g, h, g->rec, pf->n, pf->d_r, pf->d_force, g->d_partials, g->stream, e0, e1,
                                           &pf->nblk));
+    pf->launched();
     ht_mark(const_cast<edm_hip_gauss *>(g), 2);
     return EDM_HIP_OK;
   }
@@ -1509,6 +1517,7 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         int rcf = faces_prepare(g, &faces);
         if (rcf) return rcf;
         EDM_HIP_TRY(launch_lookup_prep(q, g->rec, pf->la, g->d_partials, s, e0, e1, &pf->nblk, faces, hl, spec.h_fetch_src, fetch_dst));
+        pf->launched();
         g->lookup_prep_launches++;
         return EDM_HIP_OK;
       }

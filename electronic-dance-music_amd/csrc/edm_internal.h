@@ -179,6 +179,14 @@ struct PendingForces {
   // preparation of the overflow flush's hill list (launch_lookup_prep); `la.partial_tag` as for `tag` above
   bool lookup = false;
   LookupArgs la;
+  // called once, right behind the launch that carries the forces (whichever launch that turns out to be): a caller that
+  // wants the forces elsewhere while the rest of the step runs hangs its copies on it (edm_hip_bias_step_host)
+  void (*on_launched)(void *) = nullptr;
+  void *on_launched_ctx = nullptr;
+  void launched() {
+    if (on_launched) on_launched(on_launched_ctx);
+    on_launched = nullptr;
+  }
 };
 void ht_mark(edm_hip_gauss *g, int slot);   // development aid, edm_gauss.cpp
 // EDM_HIP_TEST_FORCE tokens (tests only; edm_gauss.cpp)

@@ -545,4 +545,7 @@ hipError_t launch_gather_positions(long long n, const double *x, int x_stride, c
 
 hipError_t launch_sum(long long n, const double *v, double *out, double *scratch, hipStream_t s);
 
+// device array -> page-locked host memory by zero-copy stores (both 16-byte aligned), see edm_kernels.hip
+hipError_t launch_copy_to_host(const double *d_src, double *h_dst_mapped, long long n, hipStream_t s);
+
 }  // namespace edm

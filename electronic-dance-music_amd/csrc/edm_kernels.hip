@@ -5320,4 +5320,30 @@ hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl,
   return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------------------------------------------------
+// Device array -> page-locked host memory through the shader (zero-copy stores over PCIe), for results that go down
+// BESIDE a running step (edm_hip_bias_step_host): which SDMA engine a stream's copies get is the runtime's choice, and
+// the engines differ (measured on one box, same 2 MB device-to-host copy: 42 GB/s on one stream, 11 GB/s on the stream
+// of the process's third object -- tools/nd_steps.py ND_PRE=2); a kernel's stores take the same path every time.
+// 16 bytes per lane, a wave writes 1 KB contiguous; few workgroups -- the link, not the CUs, is the limit.
+__global__ void __launch_bounds__(256) k_copy_to_host(const double *__restrict__ src, double *__restrict__ dst, long long n) {
+  const long long pairs = n >> 1;
+  typedef double vec2 __attribute__((ext_vector_type(2)));
+  const vec2 *__restrict__ s2 = reinterpret_cast<const vec2 *>(src);
+  vec2 *__restrict__ d2 = reinterpret_cast<vec2 *>(dst);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride)
+    __builtin_nontemporal_store(s2[i], &d2[i]);
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+}
+hipError_t launch_copy_to_host(const double *d_src, double *h_dst_mapped, long long n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(h_dst_mapped)) & 15) return hipErrorInvalidValue;
+  long long nb = ((n >> 1) + 255) / 256;
+  if (nb > 8) nb = 8;   // (8 ... 256 workgroups measured alike; the fewest leave the step's kernels alone)
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_copy_to_host, dim3((unsigned)nb), dim3(256), 0, s, d_src, h_dst_mapped, n);
+  return hipGetLastError();
+}
+
 }  // namespace edm

@@ -291,7 +291,11 @@ int edm_hip_bias_step(edm_hip_bias *b, long long n, const double *d_x, int x_str
  * library adds to h_f rows [n][f_stride] on the host: the caller's force array is never uploaded (edm_bias.cpp:287-293
  * only ever subtracts dV/ds from it).  h_mask (int[n]) may be NULL when apply_mask < 0, h_runiform NULL without
  * hill_density or with device uniforms.  Per atom 8 * x_stride B (+ 4 B mask, + 8 B uniform on hill steps) travel up
- * and 8 * dim B down.  Same results as edm_hip_bias_step / edm_hip_bias_update_forces on device arrays. */
+ * and 8 * dim B down.  Same results as edm_hip_bias_step / edm_hip_bias_update_forces on device arrays.
+ * The position, uniform and mask blocks are page-locked in place the first time they are seen (and again when a
+ * pointer or size changes); the delta starts its way down behind the launch that carries the force kernel, beside the
+ * step's hills, and is added into h_f by edm_hip_bias_set("host_add_threads", k) threads (default 4, the caller's
+ * included; 1 = no helper threads). */
 int edm_hip_bias_step_host(edm_hip_bias *b, long long n, const double *h_x, int x_stride, double *h_f, int f_stride,
                            const int *h_mask, const double *h_runiform, int apply_mask, int hill_step,
                            long long est_hill_count, double *energy);

@@ -43,3 +43,32 @@ for _ in range(steps):
 H.synchronize()
 print("dim", dim, "ms_per_step", (time.perf_counter() - t) / steps * 1e3, "overflow_right", bb.get("overflow_right"), "hills", bb.get("hills_added"),
       "shared launches", bb.get("lookup_prep_launches"))
+if os.environ.get("ND_HOST"):
+    for k in range(int(os.environ.get("ND_PRE", "0"))):   # throwaway objects first: later streams get other copy engines
+        pre = H.Bias(cfgp)
+        pre.setup(1.0, 1.0)
+        pre.subdivide([0.0] * dim, [64.0] * dim, [0.0] * dim, [64.0] * dim, [1] * dim, [0.0] * dim)
+        pre.set_hill_log(False)
+        xp = np.ascontiguousarray(x[:4096])
+        pre.step_host(xp, np.zeros((4096, 3)), runiform=W.uniform(5, 4096), apply_mask=-1, hill_step=True, est=4096)
+        del pre
+    if os.environ.get("ND_PRE"):
+        bb = H.Bias(cfgp)
+        bb.setup(1.0, 1.0)
+        bb.subdivide([0.0] * dim, [64.0] * dim, [0.0] * dim, [64.0] * dim, [1] * dim, [0.0] * dim)
+    # the same loop from HOST arrays (edm_hip_bias_step_host), per-call times and the fallbacks of the polled completion
+    xh = np.ascontiguousarray(x)
+    fh = np.zeros((natoms, 3))
+    uh = W.uniform(77, natoms)
+    bb.set_hill_log(os.environ.get("ND_LOG", "1") == "1")
+    for _ in range(3):
+        bb.step_host(xh, fh, runiform=uh, apply_mask=-1, hill_step=True, est=natoms)
+    pf0 = bb.get("poll_fallbacks")
+    per = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        bb.step_host(xh, fh, runiform=uh, apply_mask=-1, hill_step=True, est=natoms)
+        per.append((time.perf_counter() - t0) * 1e3)
+    print("host step: mean %.3f ms  min %.3f  median %.3f  max %.3f  poll_fallbacks %d" % (
+        sum(per) / len(per), min(per), sorted(per)[len(per) // 2], max(per), bb.get("poll_fallbacks") - pf0))
+    print(" ".join("%.2f" % v for v in per))
