@@ -756,6 +756,52 @@ def test_step_equals_separate_calls(workdir):
     assert state[0][0].max() > 0 and state[0][7] > 10 and np.abs(state[0][4]).max() > 0
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+def test_step_host_helper_threads_and_pieces(dim, workdir):
+    """edm_hip_bias_step_host on enough atoms that the delta comes down in several pieces and helper threads share the
+    add (odd atom count: the copy kernel's last double, the pieces' rounding): bit-identical to the device-array step,
+    with one adding thread and with five, on a force array that starts non-zero."""
+    n = 300001
+    span = 16.0
+    text = ("tempering 0\nhill_prefactor 0.4\nhill_density 40\nbias_per_step 0.3\ndimension %d\nbox_low %s\n"
+            "box_high %s\nbias_spacing %s\nbias_sigma %s\n" % (
+                dim, " ".join(["0"] * dim), " ".join(["16"] * dim), " ".join(["0.125"] * dim), " ".join(["0.4"] * dim)))
+    results = []
+    for tag, threads in (("device", 0), ("host1", 1), ("host5", 5)):
+        cfg = str(workdir / ("sh_%s_%d.edm" % (tag, dim)))
+        open(cfg, "w").write(text + "hills_filename %s/HILLS_sh_%s%d\nhistogram_filename %s/HIST_sh_%s%d\n" % (
+            workdir, tag, dim, workdir, tag, dim))
+        b = H.Bias(cfg)
+        b.setup(1.0, 1.0)
+        b.subdivide([0] * dim, [span] * dim, [0] * dim, [span] * dim, [1] * dim, [0.0] * dim)
+        if threads:
+            b.set("host_add_threads", threads)
+            assert b.get("host_add_threads") == threads
+        out = []
+        for step in range(3):
+            x = np.ascontiguousarray(W.uniform(4100 + step, 3 * n).reshape(n, 3) * span)
+            u = W.uniform(4200 + step, n)
+            f0 = W.uniform(4300 + step, 3 * n).reshape(n, 3) - 0.5
+            if threads:
+                f = f0.copy()
+                e = b.step_host(x, f, runiform=u, apply_mask=-1, hill_step=True, est=n)
+                out.append((e, f))
+            else:
+                d_x, d_u = H.DeviceArray.from_host(x), H.DeviceArray.from_host(u)
+                d_f = H.DeviceArray.zeros((n, 3))
+                e = b.step_device(d_x, 3, d_f, 3, n, d_u, -1, n)
+                out.append((e, f0 + d_f.to_host()))
+        results.append((out, b.gauss.download(), b.get("hills_added"), b.get("cum_bias")))
+        del b
+    for other in results[1:]:
+        for (e0, f0), (e1, f1) in zip(results[0][0], other[0]):
+            assert e0 == e1 and np.array_equal(f0, f1)
+        assert np.array_equal(results[0][1][0], other[1][0]) and results[0][2:] == other[2:]
+    assert results[0][2] > 20
+    if dim < 3:   # columns beyond the dimension are the caller's own, untouched
+        assert np.array_equal(results[1][0][-1][1][:, dim:], (W.uniform(4302, 3 * n).reshape(n, 3) - 0.5)[:, dim:])
+
+
 def test_large_selection_vs_oracle(oracle_lib, workdir):
     """Stochastic selection over 8 M samples (3907 selection workgroups: the multi-pass branch of the chained
     scan) against the oracle: same accepted hills in the same order -> same grid, histogram, counters."""
