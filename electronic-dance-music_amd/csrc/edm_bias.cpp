@@ -1513,7 +1513,45 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
     a.force = d_force;
     hipEvent_t e0, e1;
     profile_slot(g, &e0, &e1);
+    // development aid (EDM_HIP_TRACE=k1o): stamps of the 100th force pass to stderr
+    static const bool tracing = getenv("EDM_HIP_TRACE") && !strcmp(getenv("EDM_HIP_TRACE"), "k1o");
+    const size_t trace_wgs = 65536;
+    if (tracing && b->ord_seq == 100) {
+      EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.trace), trace_wgs * 64));
+      EDM_HIP_TRY(hipMemset(a.trace, 0, trace_wgs * 64));
+    }
     EDM_HIP_TRY(launch_pair_forces_ordered(g->g, a, g->d_partials, s, &nblk, tag, e0, e1));
+    if (a.trace) {
+      EDM_HIP_TRY(hipStreamSynchronize(s));
+      std::vector<unsigned long long> tr(trace_wgs * 8);
+      EDM_HIP_TRY(hipMemcpy(tr.data(), a.trace, trace_wgs * 64, hipMemcpyDeviceToHost));
+      (void)hipFree(a.trace);
+      a.trace = nullptr;
+      unsigned long long t0 = ~0ull;
+      for (size_t w = 0; w < trace_wgs; w++) if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
+      const char *names[5] = {"start", "hills staged", "rows staged", "first trip done", "last trip done"};
+      for (int k = 0; k < 5; k++) {
+        std::vector<double> v;
+        for (size_t w = 0; w < trace_wgs; w++) if (tr[w * 8 + k]) v.push_back((double)(tr[w * 8 + k] - t0) * 0.01);
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        fprintf(stderr, "[edm trace] k1o %-16s n=%4zu  min %6.2f  p25 %6.2f  med %6.2f  p75 %6.2f  max %6.2f us\n", names[k], v.size(),
+                v.front(), v[v.size() / 4], v[v.size() / 2], v[3 * v.size() / 4], v.back());
+      }
+      std::vector<double> life, pro, trip;
+      for (size_t w = 0; w < trace_wgs; w++)
+        if (tr[w * 8]) {
+          life.push_back((double)(tr[w * 8 + 4] - tr[w * 8]) * 0.01);
+          pro.push_back((double)(tr[w * 8 + 2] - tr[w * 8]) * 0.01);
+          trip.push_back((double)(tr[w * 8 + 3] - tr[w * 8 + 2]) * 0.01);
+        }
+      std::sort(life.begin(), life.end());
+      std::sort(pro.begin(), pro.end());
+      std::sort(trip.begin(), trip.end());
+      if (!life.empty())
+        fprintf(stderr, "[edm trace] k1o per workgroup: life med %.2f max %.2f  prologue med %.2f max %.2f  first trip med %.2f max %.2f us\n",
+                life[life.size() / 2], life.back(), pro[pro.size() / 2], pro.back(), trip[trip.size() / 2], trip.back());
+    }
     tagged = tag != 0;
   } else if (n > 0) {
     // no new hill this step (none accepted, or edm_bias.cpp:534-535 skipped them): every pair sees the same bias

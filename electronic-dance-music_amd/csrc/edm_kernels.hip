@@ -5191,22 +5191,84 @@ __device__ __forceinline__ void pair_one_src(const Geom &g, const SRC &src, doub
   d = in_range ? dd : 0.0;
 }
 // energy and dV/dr at r as the reference's loop saw them at the sample index `fs` of the pair's first add_hill call
-__device__ __forceinline__ int ordered_hills_before(const OrderedCommon &oc, long long fs) {
-  int lo = 0, hi = oc.H;   // number of hills whose sample index is below fs
+__device__ __forceinline__ int ordered_hills_before(const OrderedCommon &oc, long long fs, int lo = 0, int hi = -1) {
+  if (hi < 0) hi = oc.H;   // number of hills whose sample index is below fs, known to lie in [lo, hi]
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     if ((long long)oc.samples[mid] < fs) lo = mid + 1; else hi = mid;
   }
   return lo;
 }
-__device__ __forceinline__ void ordered_lookup(const Geom &g, const OrderedForcesArgs &a, const OrderedCommon &oc, double x,
-                                               long long fs, double &v, double &d, const unsigned short *rows = nullptr,
-                                               int row0 = 0, int nrows = 0) {
-  const OrderedSource src{a, oc, ordered_hills_before(oc, fs), rows, row0, nrows};
+__device__ __forceinline__ void ordered_lookup_m(const Geom &g, const OrderedForcesArgs &a, const OrderedCommon &oc, double x,
+                                                 int m, double &v, double &d, const unsigned short *rows = nullptr,
+                                                 int row0 = 0, int nrows = 0) {
+  const OrderedSource src{a, oc, m, rows, row0, nrows};
   if (oc.fast)
     pair_one_src(g, src, oc.inv_dx, x, v, d);
   else
     lookup_one_src<1>(g, src, &x, v, &d);
+}
+__device__ __forceinline__ void ordered_lookup(const Geom &g, const OrderedForcesArgs &a, const OrderedCommon &oc, double x,
+                                               long long fs, double &v, double &d) {
+  ordered_lookup_m(g, a, oc, x, ordered_hills_before(oc, fs), v, d);
+}
+
+// One pair of the force pass, lean form: the specialised 1-D lookup (pair_one_src's index rule and blend, word for word)
+// for a workgroup whose rows of the counts are all in LDS.  No flat loads -- a load that might be LDS or global waits for both counters, and with
+// them for the next pair's prefetched distance -- no divergent branches but the two rare ones, 32-bit index
+// arithmetic.  ~230 VALU instructions per pair in the general form, which the pass is bound by (16 waves per CU busy
+// through all four trips, in-kernel stamps), against ~63 in K1.
+struct OrderedLean {
+  const double2 *__restrict__ rec0;
+  const double2 *__restrict__ records;
+  const unsigned short *rows;   // LDS
+  int row0, ntiles, nh_cap;
+  int lo_t, hi_t, first_dirty;   // outward copy nodes of the boundary duplication (-1: none), first hill that duplicates
+  double lo_ok, hi_open, eps, inv_dx;
+};
+__device__ __forceinline__ double2 ordered_lean_record(const OrderedLean &L, int m, int node) {
+  const int tile = node >> 5;   // ORD_NODES == 32
+  const int u = L.rows[(m - L.row0) * L.ntiles + tile];
+  const unsigned off = (unsigned)((tile * L.nh_cap + (u - 1)) * ORD_NODES + (node & (ORD_NODES - 1)));
+  const double2 *p = u ? L.records + off : L.rec0 + node;
+  return *p;
+}
+// in two halves, so that a thread can have two pairs' records in flight: the loads ...
+struct OrderedLeanLoaded {
+  double2 ra, rb;
+  double X;
+  bool in_range, ok;   // ok == false: the pair touches an outward copy node after a hill that duplicates -- one grid cell
+                       // per wall; the caller takes the general form for it
+};
+__device__ __forceinline__ OrderedLeanLoaded ordered_lean_load(const Geom &g, const OrderedLean &L, int m, double x) {
+  OrderedLeanLoaded o;
+  o.in_range = (x >= L.lo_ok) & (x < L.hi_open);
+  const double q = (x - g.min[0]) * L.inv_dx;
+  double fq = floor(q);
+  const double frac = q - fq;
+  const bool near = o.in_range & ((frac <= L.eps) | (frac >= 1.0 - L.eps));
+  if (near) fq = floor((x - g.min[0]) / g.dx[0]);
+  int idx = (int)fq;
+  idx = idx < 0 ? 0 : idx;
+  idx = idx > g.n[0] - 2 ? g.n[0] - 2 : idx;
+  const double where = x - g.min[0] - fq * g.dx[0];
+  o.X = where * L.inv_dx;
+  o.ok = !((m > L.first_dirty) & ((idx == L.lo_t) | (idx + 1 == L.lo_t) | (idx == L.hi_t) | (idx + 1 == L.hi_t)));
+  o.ra = ordered_lean_record(L, m, idx);
+  o.rb = ordered_lean_record(L, m, idx + 1);
+  return o;
+}
+// ... and the blend
+__device__ __forceinline__ void ordered_lean_blend(const Geom &g, const OrderedLean &L, const OrderedLeanLoaded &o, double &v,
+                                                   double &d) {
+  double vv, dd;
+  if ((o.X < 0.0) | (o.X > 1.0))   // `where` off by an ulp at a node: the reference's fabs() mirroring
+    hermite_1d_mirrored(o.ra.x, o.ra.y, o.rb.x, o.rb.y, o.X, g.dx[0], L.inv_dx, vv, dd);
+  else
+    hermite_1d_horner(o.ra.x, scaled_slope(o.ra.x, o.ra.y, g.dx[0]), o.rb.x, scaled_slope(o.rb.x, o.rb.y, g.dx[0]), o.X, L.inv_dx,
+                      vv, dd);
+  v = o.in_range ? vv : 0.0;
+  d = o.in_range ? dd : 0.0;
 }
 
 __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedForcesArgs a, DupPlan dp,
@@ -5214,11 +5276,9 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
                                                                long long per_block) {
   extern __shared__ int s_samples[];
   __shared__ double red[BLOCK / 64];
+  __shared__ int s_fd;
   constexpr int ROWS_LDS = 4096;   // 16-bit counts staged per workgroup: 8 KB, eleven rows of the C1D grid's 351 tiles
   __shared__ unsigned short s_rows[ROWS_LDS];
-  OrderedCommon oc;
-  ordered_common_init(g, a, dp, s_samples, oc);
-  double e_acc = 0;
   // a workgroup owns a contiguous run of pairs: their hill counts m span a handful of consecutive rows of the counts
   // (a W1 step has ~8 000 pairs between two hills), staged in LDS so that a pair's chain is distance -> record, two
   // round trips, not distance -> count -> record
@@ -5230,26 +5290,144 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
   if ((gridDim.x & 7u) == 0) run = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const long long beg = (long long)run * per_block;
   const long long end = (beg + per_block < a.n) ? beg + per_block : a.n;
-  int row0 = 0, nrows = 0;
+  unsigned long long *tr = a.trace ? a.trace + (size_t)blockIdx.x * 8 : nullptr;   // (development aid: EDM_HIP_TRACE=k1o)
+  if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
+  // ---- prologue: everything it reads from memory leaves at once (the hills' sample indices and correction flags, the
+  //      run's first and last sample index, the first pair), two barriers ----
+  long long i = beg + threadIdx.x;
+  double x_next = 0.0;
+  int fs_next = 0;   // (kept as loaded: a conversion here would wait for the load)
+  if (i < end) {
+    x_next = a.r[i];
+    if (a.first_sample) fs_next = a.first_sample[i];
+  }
+  long long fs0 = 0, fs1 = -1;
   if (beg < end) {
-    const long long fs0 = a.first_sample ? (long long)a.first_sample[beg] : 2 * beg;
-    const long long fs1 = a.first_sample ? (long long)a.first_sample[end - 1] : 2 * (end - 1);
+    fs0 = a.first_sample ? (long long)a.first_sample[beg] : 2 * beg;
+    fs1 = a.first_sample ? (long long)a.first_sample[end - 1] : 2 * (end - 1);
+  }
+  OrderedCommon oc;
+  {
+    long long nloc = a.range_dev ? a.range_dev[1] : a.nh;
+    if (nloc > a.nh_cap) nloc = a.nh_cap;
+    oc.H = (int)nloc;
+    const long long off = a.range_dev ? a.range_dev[0] : a.hill_off;
+    int my_first = INT_MAX;   // the first of THIS RANK'S hills with a non-zero boundary correction (position in its slice)
+    for (int k = threadIdx.x; k < oc.H; k += blockDim.x) {
+      s_samples[k] = a.sel ? (int)a.sel[k] : k;
+      if (a.dirty_hill[off + k] == a.dirty_seq && k < my_first) my_first = k;
+    }
+    if (threadIdx.x == 0) s_fd = INT_MAX;
+    __syncthreads();
+    if (my_first != INT_MAX) atomicMin(&s_fd, my_first);
+    oc.samples = s_samples;
+    oc.ntiles = (g.n[0] + ORD_NODES - 1) / ORD_NODES;
+    oc.lo_t = oc.lo_s = oc.hi_t = oc.hi_s = -1;
+    if (!g.bper[0]) {   // duplicate_boundary_lanes' cases 0 and 3 in one dimension
+      if (dp.lo[0] > 0 && dp.lo[0] < (unsigned long long)g.n[0]) {
+        oc.lo_t = (int)dp.lo[0] - 1;
+        oc.lo_s = (int)dp.lo[0];
+      }
+      if (dp.hi[0] + 1 < (unsigned long long)g.n[0]) {
+        oc.hi_t = (int)dp.hi[0] + 1;
+        oc.hi_s = (int)dp.hi[0];
+      }
+    }
+    oc.fast = g.interp && !g.periodic[0] && !g.bper[0];
+    oc.inv_dx = 1.0 / g.dx[0];
+  }
+  if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
+  double e_acc = 0;
+  int row0 = 0, row1 = 0, nrows = 0;
+  if (beg < end) {
     row0 = ordered_hills_before(oc, fs0);
-    nrows = ordered_hills_before(oc, fs1) - row0 + 1;
+    row1 = ordered_hills_before(oc, fs1, row0);
+    nrows = row1 - row0 + 1;
     if (nrows * oc.ntiles > ROWS_LDS) nrows = ROWS_LDS / oc.ntiles;
     for (int e = threadIdx.x; e < nrows * oc.ntiles; e += BLOCK) s_rows[e] = a.counts[(long long)row0 * oc.ntiles + e];
   }
   __syncthreads();
-  // (one pair per thread and trip.  Four pairs per trip, stage by stage -- distances, hill counts, list counts, corner
-  //  records, so that a stage's loads travel together -- was tried and was slower: 25.9 us against 17.3 us per 1 M pairs)
-  for (long long i = beg + threadIdx.x; i < end; i += BLOCK) {
-    const double x = a.r[i];
-    const long long fs = a.first_sample ? (long long)a.first_sample[i] : 2 * i;
-    double v, d;
-    ordered_lookup(g, a, oc, x, fs, v, d, s_rows, row0, nrows);
-    e_acc += v;
-    a.force[i] = 0.0 - d;
+  oc.first_dirty = s_fd;
+  if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
+  const bool lean = oc.fast && nrows == row1 - row0 + 1 &&
+                    (long long)oc.ntiles * a.nh_cap * ORD_NODES < (1ll << 31);   // (32-bit record offsets)
+  OrderedLean L;
+  L.rec0 = reinterpret_cast<const double2 *>(a.rec0);
+  L.records = reinterpret_cast<const double2 *>(a.records);
+  L.rows = s_rows;
+  L.row0 = row0;
+  L.ntiles = oc.ntiles;
+  L.nh_cap = (int)a.nh_cap;
+  L.lo_t = oc.lo_t;
+  L.hi_t = oc.hi_t;
+  L.first_dirty = oc.first_dirty;
+  L.lo_ok = fmax(g.bmin[0], g.min[0]);
+  L.hi_open = fmin(nextafter(g.bmax[0], 1.0e308), g.max[0] - g.dx[0]);
+  L.eps = 1e-11 * fmax(1.0, (double)g.n[0]);
+  L.inv_dx = oc.inv_dx;
+  if (lean) {
+    // two pairs per trip: both pairs' records are requested before either is blended (a record comes from the L2 of
+    // the XCD that wrote it or from memory: ~1.2 us under load, the trip's length); the next two pairs' distances and
+    // sample indices travel meanwhile (the loads do not move above the force stores by themselves)
+    double x_next1 = 0.0;
+    int fs_next1 = 0;
+    if (i + BLOCK < end) {
+      x_next1 = a.r[i + BLOCK];
+      if (a.first_sample) fs_next1 = a.first_sample[i + BLOCK];
+    }
+    for (; i < end; i += 2 * BLOCK) {
+      const long long i1 = i + BLOCK;
+      const bool two = i1 < end;
+      const double x0 = x_next, x1 = x_next1;
+      const long long f0 = a.first_sample ? (long long)fs_next : 2 * i;
+      const long long f1 = a.first_sample ? (long long)fs_next1 : 2 * i1;
+      if (i + 2 * BLOCK < end) {
+        x_next = a.r[i + 2 * BLOCK];
+        if (a.first_sample) fs_next = a.first_sample[i + 2 * BLOCK];
+      }
+      if (i + 3 * BLOCK < end) {
+        x_next1 = a.r[i + 3 * BLOCK];
+        if (a.first_sample) fs_next1 = a.first_sample[i + 3 * BLOCK];
+      }
+      // (sample indices ascend with the pair index in the fix's list, so the count lies between the run's ends: a step
+      //  or none of the search instead of log2(hills); any other order: the whole list, and the general form -- the
+      //  pair's row of the counts is not staged)
+      const bool in0 = (f0 >= fs0) & (f0 <= fs1), in1 = two & (f1 >= fs0) & (f1 <= fs1);
+      const int m0 = ordered_hills_before(oc, f0, in0 ? row0 : 0, in0 ? row1 : oc.H);
+      const int m1 = two ? ordered_hills_before(oc, f1, in1 ? row0 : 0, in1 ? row1 : oc.H) : row0;
+      const OrderedLeanLoaded o0 = ordered_lean_load(g, L, in0 ? m0 : row0, x0);
+      const OrderedLeanLoaded o1 = ordered_lean_load(g, L, in1 ? m1 : row0, x1);
+      double v0, d0, v1 = 0.0, d1 = 0.0;
+      ordered_lean_blend(g, L, o0, v0, d0);
+      ordered_lean_blend(g, L, o1, v1, d1);
+      if (!in0 || !o0.ok) ordered_lookup_m(g, a, oc, x0, m0, v0, d0, s_rows, row0, nrows);
+      if (two && (!in1 || !o1.ok)) ordered_lookup_m(g, a, oc, x1, m1, v1, d1, s_rows, row0, nrows);
+      e_acc += v0;
+      a.force[i] = 0.0 - d0;
+      if (two) {
+        e_acc += v1;
+        a.force[i1] = 0.0 - d1;
+      }
+      if (tr && threadIdx.x == 0 && i < beg + BLOCK) tr[3] = wall_clock64();   // (first trip done)
+    }
+  } else {
+    for (; i < end; i += BLOCK) {
+      const double x = x_next;
+      const long long fs = a.first_sample ? (long long)fs_next : 2 * i;
+      const long long j = i + BLOCK;
+      if (j < end) {
+        x_next = a.r[j];
+        if (a.first_sample) fs_next = a.first_sample[j];
+      }
+      const bool inside = (fs >= fs0) & (fs <= fs1);
+      const int m = ordered_hills_before(oc, fs, inside ? row0 : 0, inside ? row1 : oc.H);
+      double v, d;
+      ordered_lookup_m(g, a, oc, x, m, v, d, s_rows, row0, nrows);
+      e_acc += v;
+      a.force[i] = 0.0 - d;
+    }
   }
+  if (tr && threadIdx.x == 0) tr[4] = wall_clock64();
   const double sum = block_sum(e_acc, red);
   if (threadIdx.x == 0) {
     if (tag) store_partial_tagged(block_energy, blockIdx.x, sum, tag);
