@@ -337,6 +337,7 @@ struct edm_hip_bias {
     const long long *range_dev = nullptr;
     bool terms_emitted = false;   // the batch's launch stored the hills' stencil terms in ord_terms (rows: ord_terms_rows)
   } last_batch;
+  bool ord_snap_pending = false;  // ordered_snapshot has been asked for, no launch has made the copy yet
   bool ord_step_active = false;   // between ordered_snapshot and the step's force pass: hill batches may emit their terms
   DevBuf<double> ord_terms;
   long long ord_terms_rows = 0;
@@ -833,6 +834,8 @@ static int exchange_hills(edm_hip_bias *b, long long nh_local, const double *d_x
 }
 
 // the add_hill loop of one cycle (edm_bias.cpp:528-563 and :444-526) over device arrays
+static void ordered_snapshot_ride(edm_hip_bias *b, SelectArgs *a);
+static int ordered_snapshot_now(edm_hip_bias *b);
 static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, int x_stride, const double *d_ru,
                              int apply_mask) {
   if (n <= 0 && !b->comm) return EDM_HIP_OK;  // with a communicator every rank must reach the exchange
@@ -907,6 +910,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       sel_args.count_dev = b->count_dev.p;
       sel_args.ticket = b->bias->d_tickets;
       sel_args.pack = b->xchg_send.p;
+      ordered_snapshot_ride(b, &sel_args);
       EDM_HIP_TRY(b->sel.reserve((size_t)pack_bound));
       sel_args.sel = b->sel.p;   // (this rank's accepted sample indices, for the reference-order force pass)
       HillList src;
@@ -996,6 +1000,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       sel_args.count_host = b->d_count;
       sel_args.count_dev = b->count_dev.p;
       sel_args.ticket = b->bias->d_tickets;
+      ordered_snapshot_ride(b, &sel_args);
       nh = bound;
     }
     d_sel = b->sel.p;
@@ -1124,6 +1129,10 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       spec.sel_chain = &sel_args;
       spec.forces = &b->pending;
     }
+  }
+  {   // (reference-order step whose selection launch did not carry the grid's step-start copy: now, ahead of the hills)
+    int rs = ordered_snapshot_now(b);
+    if (rs) return rs;
   }
   int rc = apply_hills(b->bias, spec, &oc, false);
   if (rc == EDM_APPLY_BOUND_EXCEEDED) {
@@ -1408,9 +1417,26 @@ static int ordered_snapshot(edm_hip_bias *b) {
   }
   const size_t grid_doubles = (size_t)g->g.total * (size_t)g->g.rec;
   EDM_HIP_TRY(b->ord_rec0.reserve(grid_doubles));
-  EDM_HIP_TRY(hipMemcpyAsync(b->ord_rec0.p, g->rec, sizeof(double) * grid_doubles, hipMemcpyDeviceToDevice, g->stream));
+  b->ord_snap_pending = true;
   b->last_batch.valid = false;
   b->ord_step_active = true;
+  return EDM_HIP_OK;
+}
+// ... deferred: the step's selection launch carries the copy (SelectArgs::snap_*); whoever is about to touch the grid
+// without having launched a selection makes it here
+static void ordered_snapshot_ride(edm_hip_bias *b, SelectArgs *a) {
+  if (!b->ord_snap_pending || b->bias->g.rec != 2) return;
+  a->snap_src = b->bias->rec;
+  a->snap_dst = b->ord_rec0.p;
+  a->snap_n = (long long)b->bias->g.total;   // (1-D interpolating grid: records of two doubles)
+  b->ord_snap_pending = false;
+}
+static int ordered_snapshot_now(edm_hip_bias *b) {
+  if (!b->ord_snap_pending) return EDM_HIP_OK;
+  b->ord_snap_pending = false;
+  edm_hip_gauss *g = b->bias;
+  EDM_HIP_TRY(hipMemcpyAsync(b->ord_rec0.p, g->rec, sizeof(double) * (size_t)g->g.total * (size_t)g->g.rec, hipMemcpyDeviceToDevice,
+                             g->stream));
   return EDM_HIP_OK;
 }
 // ... and, once the step's hill batch has been applied (last_batch), the running records of its hills
@@ -1499,6 +1525,7 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   g->wait_polled = false;
   rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
   b->ord_step_active = false;
+  b->ord_snap_pending = false;   // (no hill batch was applied: nobody needs the copy)
   if (rc) return rc;
   int nblk = 0;
   const unsigned long long tag = forces_poll_enabled() ? ++g->force_seq : 0;
@@ -2066,6 +2093,7 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     b->d_mask = b->vs_mask.p;
     rc = process_new_hills(b, 2 * npairs, sample_r, 1, nullptr, 1);
     b->ord_step_active = false;
+    b->ord_snap_pending = false;
     b->d_mask = saved_mask;
     b->pl_view_x = nullptr;
   }

@@ -268,6 +268,11 @@ struct SelectArgs {
   double *pack;           // multi-GPU: instead of sel/prep, write this rank's exchange packet
                           // [count, x_0 .. x_{bound-1}] (bound = h.nh, dim doubles per position)
   unsigned long long *trace;   // development aid (EDM_HIP_TRACE): 8 wall-clock stamps per workgroup of k_pair_forces_select, or NULL
+  // reference-order pair step: the step-start copy of the 1-D grid's records rides in this launch (nothing has touched
+  // the grid yet: the hills are applied by a later launch); snap_n 16-byte records, or snap_dst == NULL
+  const double *snap_src;
+  double *snap_dst;
+  long long snap_n;
 };
 // receive side of the packed exchange (see k_unpack_prep)
 #define EDM_MAX_RANKS 16

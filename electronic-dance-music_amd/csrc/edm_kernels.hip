@@ -1868,6 +1868,12 @@ __device__ __forceinline__ void select_prep_body(const SelectArgs &a, const Geom
   __shared__ int s_w[SEL_PER_THREAD][BLOCK / 64];
   __shared__ long long s_carry;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (a.snap_dst) {   // (the step-start copy of the grid for the reference-order force pass: 179 KB on W1, the first workgroups' job)
+    typedef double vec2 __attribute__((ext_vector_type(2)));
+    const vec2 *__restrict__ src = reinterpret_cast<const vec2 *>(a.snap_src);
+    vec2 *__restrict__ dst = reinterpret_cast<vec2 *>(a.snap_dst);
+    for (long long k = (long long)bid * BLOCK + threadIdx.x; k < a.snap_n; k += (long long)nblk * BLOCK) dst[k] = src[k];
+  }
   {
     // sample (row j, thread t) = chunk base + j * BLOCK + t: every row is one coalesced load per wave.  A
     // sample's place in the chunk's ordered list = accepted samples of the rows before it + accepted samples of
