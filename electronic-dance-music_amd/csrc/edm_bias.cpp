@@ -64,11 +64,14 @@ class HillWriter {
       q_.emplace_back();
       q_.back().swap(events);
     }
-    cv_.notify_one();
+    // (no notify: waking a sleeping thread is a system call, ~3 us on the step's critical path every hill step; the
+    //  writer looks at the queue every millisecond by itself -- drain() and close() do wake it)
   }
   void drain() {
     if (!fp_) return;
     std::unique_lock<std::mutex> lk(m_);
+    if (q_.empty() && !busy_) return;
+    cv_.notify_one();
     idle_.wait(lk, [this] { return q_.empty() && !busy_; });
   }
   void close() {
@@ -87,7 +90,7 @@ class HillWriter {
   void run() {
     std::unique_lock<std::mutex> lk(m_);
     for (;;) {
-      cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+      cv_.wait_for(lk, std::chrono::milliseconds(1), [this] { return stop_ || !q_.empty(); });
       if (q_.empty()) {
         if (stop_) return;
         continue;
@@ -336,7 +339,20 @@ struct edm_hip_bias {
     long long local_off = 0, local_cnt = -1, local_cap = 0;
     const long long *range_dev = nullptr;
     bool terms_emitted = false;   // the batch's launch stored the hills' stencil terms in ord_terms (rows: ord_terms_rows)
+    const LimitResult *res_dev = nullptr;   // provisional entry (force pass queued before the host saw the limiter's result):
+                                            // nh is the launch bound, count and split index are read on the device
   } last_batch;
+  // reference-order array step, single rank: the force pass is queued from inside the hill batch's apply (ApplySpec::
+  // before_wait) -- behind the batch on the stream, ahead of the host's wait for the limiter
+  struct OrderedEarly {
+    bool armed = false, done = false;
+    long long n = 0;
+    const double *d_r = nullptr;
+    const int *d_first = nullptr;
+    double *d_force = nullptr;
+    unsigned long long tag = 0;
+    int nblk = 0, rc = 0;
+  } ord_early;
   bool ord_snap_pending = false;  // ordered_snapshot has been asked for, no launch has made the copy yet
   bool ord_step_active = false;   // between ordered_snapshot and the step's force pass: hill batches may emit their terms
   DevBuf<double> ord_terms;
@@ -836,6 +852,7 @@ static int exchange_hills(edm_hip_bias *b, long long nh_local, const double *d_x
 // the add_hill loop of one cycle (edm_bias.cpp:528-563 and :444-526) over device arrays
 static void ordered_snapshot_ride(edm_hip_bias *b, SelectArgs *a);
 static int ordered_snapshot_now(edm_hip_bias *b);
+static int ordered_forces_enqueue(edm_hip_bias *b);
 static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, int x_stride, const double *d_ru,
                              int apply_mask) {
   if (n <= 0 && !b->comm) return EDM_HIP_OK;  // with a communicator every rank must reach the exchange
@@ -1134,8 +1151,35 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     int rs = ordered_snapshot_now(b);
     if (rs) return rs;
   }
+  struct EarlyCtx {
+    edm_hip_bias *b;
+    double this_h;
+    const long long *d_sel;
+    long long bound;
+  } early_ctx{b, this_h, d_sel, nh};
+  if (b->ord_early.armed && deferred_bound && !packed_exchange && !b->comm) {
+    spec.before_wait_ctx = &early_ctx;
+    spec.before_wait = [](void *ctx, const double *d_base, const double *d_t1, const double *d_t2, const LimitResult *d_res,
+                          bool terms_emitted) {
+      EarlyCtx *c = static_cast<EarlyCtx *>(ctx);
+      edm_hip_bias *bb = c->b;
+      bb->last_batch = edm_hip_bias::LastBatch();
+      bb->last_batch.valid = true;
+      bb->last_batch.nh = c->bound;
+      bb->last_batch.heights = d_base;
+      bb->last_batch.h_const = c->this_h;
+      bb->last_batch.tail_h1 = d_t1;
+      bb->last_batch.tail_h2 = d_t2;
+      bb->last_batch.sel = c->d_sel;
+      bb->last_batch.terms_emitted = terms_emitted;
+      bb->last_batch.res_dev = d_res;
+      bb->ord_early.rc = ordered_forces_enqueue(bb);
+      bb->ord_early.done = true;
+    };
+  }
   int rc = apply_hills(b->bias, spec, &oc, false);
   if (rc == EDM_APPLY_BOUND_EXCEEDED) {
+    b->ord_early.done = false;   // (what the early force pass computed is void: the step's hill path is redone below)
     // (practically never) more hills than the launch bound -- on every rank alike, since the count is
     // global: nothing was applied; redo the step's hill path the synchronous way with exact counts
     b->force_sync = true;
@@ -1157,6 +1201,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   b->last_batch.sel = d_sel;
   b->last_batch.local_cnt = -1;
   b->last_batch.range_dev = nullptr;
+  b->last_batch.res_dev = nullptr;
   b->last_batch.terms_emitted = oc.terms_emitted;
   if (packed_exchange) {
     b->last_batch.sel = b->sel.p;
@@ -1462,6 +1507,7 @@ static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
   a.nh_cap = cap;
   a.hill_off = sliced ? b->last_batch.local_off : 0;
   a.range_dev = b->last_batch.range_dev;
+  a.res_dev = b->last_batch.res_dev;
   a.k = b->last_batch.k;
   a.heights = b->last_batch.heights;
   a.h_const = b->last_batch.h_const;
@@ -1514,6 +1560,48 @@ static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
   return EDM_HIP_OK;
 }
 
+// records of the batch's hills, then the force pass that reads them (b->last_batch, b->ord_early: the pairs)
+static int ordered_forces_enqueue(edm_hip_bias *b) {
+  edm_hip_gauss *g = b->bias;
+  hipStream_t s = g->stream;
+  OrderedForcesArgs a;
+  int rc = ordered_records_enqueue(b, &a);
+  if (rc) return rc;
+  a.n = b->ord_early.n;
+  a.r = b->ord_early.d_r;
+  a.first_sample = b->ord_early.d_first;
+  a.force = b->ord_early.d_force;
+  hipEvent_t e0, e1;
+  profile_slot(g, &e0, &e1);
+  // development aid (EDM_HIP_TRACE=k1o): stamps of the 100th force pass to stderr
+  static const bool tracing = getenv("EDM_HIP_TRACE") && !strcmp(getenv("EDM_HIP_TRACE"), "k1o");
+  const size_t trace_wgs = 65536;
+  if (tracing && b->ord_seq == 100) {
+    EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.trace), trace_wgs * 64));
+    EDM_HIP_TRY(hipMemset(a.trace, 0, trace_wgs * 64));
+  }
+  EDM_HIP_TRY(launch_pair_forces_ordered(g->g, a, g->d_partials, s, &b->ord_early.nblk, b->ord_early.tag, e0, e1));
+  if (a.trace) {
+    EDM_HIP_TRY(hipStreamSynchronize(s));
+    std::vector<unsigned long long> tr(trace_wgs * 8);
+    EDM_HIP_TRY(hipMemcpy(tr.data(), a.trace, trace_wgs * 64, hipMemcpyDeviceToHost));
+    (void)hipFree(a.trace);
+    a.trace = nullptr;
+    unsigned long long t0 = ~0ull;
+    for (size_t w = 0; w < trace_wgs; w++) if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
+    const char *names[5] = {"start", "hills staged", "rows staged", "first trip done", "last trip done"};
+    for (int k = 0; k < 5; k++) {
+      std::vector<double> v;
+      for (size_t w = 0; w < trace_wgs; w++) if (tr[w * 8 + k]) v.push_back((double)(tr[w * 8 + k] - t0) * 0.01);
+      if (v.empty()) continue;
+      std::sort(v.begin(), v.end());
+      fprintf(stderr, "[edm trace] k1o %-16s n=%4zu  min %6.2f  p25 %6.2f  med %6.2f  p75 %6.2f  max %6.2f us\n", names[k], v.size(),
+              v.front(), v[v.size() / 4], v[v.size() / 2], v[3 * v.size() / 4], v.back());
+    }
+  }
+  return EDM_HIP_OK;
+}
+
 static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *d_r, double *d_force,
                                     const int *d_first_sample, long long n_samples, const double *d_sample_r,
                                     const double *d_runiform, double *energy) {
@@ -1523,62 +1611,30 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   if (rc) return rc;
   b->pending = PendingForces();
   g->wait_polled = false;
+  const unsigned long long tag = forces_poll_enabled() ? ++g->force_seq : 0;
+  b->ord_early = edm_hip_bias::OrderedEarly();
+  b->ord_early.n = n;
+  b->ord_early.d_r = d_r;
+  b->ord_early.d_first = d_first_sample;
+  b->ord_early.d_force = d_force;
+  b->ord_early.tag = tag;
+  b->ord_early.armed = n > 0;
   rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
+  b->ord_early.armed = false;
   b->ord_step_active = false;
   b->ord_snap_pending = false;   // (no hill batch was applied: nobody needs the copy)
   if (rc) return rc;
   int nblk = 0;
-  const unsigned long long tag = forces_poll_enabled() ? ++g->force_seq : 0;
   bool tagged = false;
-  if (n > 0 && b->last_batch.valid && b->last_batch.nh > 0) {
-    OrderedForcesArgs a;
-    rc = ordered_records_enqueue(b, &a);
+  if (b->ord_early.done) {
+    // (the force pass went out behind the hill batch, before the host had the limiter's result)
+    if (b->ord_early.rc) return b->ord_early.rc;
+    nblk = b->ord_early.nblk;
+    tagged = tag != 0;
+  } else if (n > 0 && b->last_batch.valid && b->last_batch.nh > 0) {
+    rc = ordered_forces_enqueue(b);
     if (rc) return rc;
-    a.n = n;
-    a.r = d_r;
-    a.first_sample = d_first_sample;
-    a.force = d_force;
-    hipEvent_t e0, e1;
-    profile_slot(g, &e0, &e1);
-    // development aid (EDM_HIP_TRACE=k1o): stamps of the 100th force pass to stderr
-    static const bool tracing = getenv("EDM_HIP_TRACE") && !strcmp(getenv("EDM_HIP_TRACE"), "k1o");
-    const size_t trace_wgs = 65536;
-    if (tracing && b->ord_seq == 100) {
-      EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.trace), trace_wgs * 64));
-      EDM_HIP_TRY(hipMemset(a.trace, 0, trace_wgs * 64));
-    }
-    EDM_HIP_TRY(launch_pair_forces_ordered(g->g, a, g->d_partials, s, &nblk, tag, e0, e1));
-    if (a.trace) {
-      EDM_HIP_TRY(hipStreamSynchronize(s));
-      std::vector<unsigned long long> tr(trace_wgs * 8);
-      EDM_HIP_TRY(hipMemcpy(tr.data(), a.trace, trace_wgs * 64, hipMemcpyDeviceToHost));
-      (void)hipFree(a.trace);
-      a.trace = nullptr;
-      unsigned long long t0 = ~0ull;
-      for (size_t w = 0; w < trace_wgs; w++) if (tr[w * 8] && tr[w * 8] < t0) t0 = tr[w * 8];
-      const char *names[5] = {"start", "hills staged", "rows staged", "first trip done", "last trip done"};
-      for (int k = 0; k < 5; k++) {
-        std::vector<double> v;
-        for (size_t w = 0; w < trace_wgs; w++) if (tr[w * 8 + k]) v.push_back((double)(tr[w * 8 + k] - t0) * 0.01);
-        if (v.empty()) continue;
-        std::sort(v.begin(), v.end());
-        fprintf(stderr, "[edm trace] k1o %-16s n=%4zu  min %6.2f  p25 %6.2f  med %6.2f  p75 %6.2f  max %6.2f us\n", names[k], v.size(),
-                v.front(), v[v.size() / 4], v[v.size() / 2], v[3 * v.size() / 4], v.back());
-      }
-      std::vector<double> life, pro, trip;
-      for (size_t w = 0; w < trace_wgs; w++)
-        if (tr[w * 8]) {
-          life.push_back((double)(tr[w * 8 + 4] - tr[w * 8]) * 0.01);
-          pro.push_back((double)(tr[w * 8 + 2] - tr[w * 8]) * 0.01);
-          trip.push_back((double)(tr[w * 8 + 3] - tr[w * 8 + 2]) * 0.01);
-        }
-      std::sort(life.begin(), life.end());
-      std::sort(pro.begin(), pro.end());
-      std::sort(trip.begin(), trip.end());
-      if (!life.empty())
-        fprintf(stderr, "[edm trace] k1o per workgroup: life med %.2f max %.2f  prologue med %.2f max %.2f  first trip med %.2f max %.2f us\n",
-                life[life.size() / 2], life.back(), pro[pro.size() / 2], pro.back(), trip[trip.size() / 2], trip.back());
-    }
+    nblk = b->ord_early.nblk;
     tagged = tag != 0;
   } else if (n > 0) {
     // no new hill this step (none accepted, or edm_bias.cpp:534-535 skipped them): every pair sees the same bias

@@ -2008,6 +2008,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   LimitResult header_res;
   memset(&header_res, 0, sizeof(header_res));
   static const bool host_trace = getenv("EDM_HIP_TRACE") != nullptr;   // development aid: host-side stamps
+  if (spec.before_wait)
+    spec.before_wait(spec.before_wait_ctx, base_heights, ws.tail_h1.p, p_h2, dres, out ? out->terms_emitted : false);
   const auto ht_before_poll = std::chrono::steady_clock::now();
   ht_mark(g, 5);
   if (polled) {

@@ -220,6 +220,12 @@ struct ApplySpec {
   double *ord_terms = nullptr;
   unsigned *ord_dirty = nullptr;
   unsigned ord_seq = 0;
+  // ... and a call made once every launch of the batch is queued, BEFORE the host waits for the limiter's result: what
+  // depends on the batch only through device memory (the reference-order force pass) is queued here, behind the batch,
+  // instead of after the host's turn-around
+  void (*before_wait)(void *ctx, const double *d_base_heights, const double *d_tail_h1, const double *d_tail_h2,
+                      const LimitResult *d_res, bool terms_emitted) = nullptr;
+  void *before_wait_ctx = nullptr;
   bool fetch_heights = true;       // with d_h: copy the per-hill base heights back (a flush already has them)
   // optional: d_h is filled by the preparation kernel from this host-mapped array (nh doubles)
   const double *h_fetch_src = nullptr;

@@ -132,6 +132,7 @@ hipError_t launch_pair_forces(const Geom &g, const double *rec, long long n, con
 //       its source node at the same m once the first such hill (first_dirty, found by the record pass) lies before
 //       the pair.
 // 1-D grids only (fix_edm_pair.cpp:52), stencil not wider than a periodic grid, at most ordered_max_hills() hills.
+struct LimitResult;
 struct OrderedForcesArgs {
   long long nh;             // this rank's hills of the step's batch (true count; unused with range_dev)
   long long nh_cap;         // hills the record / count buffers were sized for (>= nh)
@@ -142,6 +143,9 @@ struct OrderedForcesArgs {
   long long hill_off;
   const long long *range_dev;
   long long k;              // hills [0, k): base height; hills >= k: the limiter's tail arrays (see HillHeights)
+  const LimitResult *res_dev;   // when set (single rank, launches queued before the host has seen the limiter's result):
+                                // nh and k are read from the limiter's device-side result, nh_cap bounds the count; a
+                                // batch the limiter refused (error != 0: nothing applied, the step is redone) counts 0 hills
   const double *heights;    // per-hill base heights or NULL (h_const)
   double h_const;
   const double *tail_h1, *tail_h2;

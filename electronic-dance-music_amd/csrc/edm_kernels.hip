@@ -4897,6 +4897,18 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
 // ---------------------------------------------------------------------------
 static constexpr int ORD_NODES = 32, ORD_PARTS = BLOCK / ORD_NODES, ORD_CHUNK = 64;   // (16-node tiles, twice the workgroups: no faster)
 static constexpr long long ORD_MAX_HILLS = 16384;   // (sample indices in LDS: 64 KB; list counts fit 16 bits)
+// this rank's hills of the batch and the limiter's split index, wherever they are known (see OrderedForcesArgs)
+__device__ __forceinline__ void ordered_batch_counts(const OrderedForcesArgs &a, long long &off, long long &nloc, long long &k) {
+  off = a.range_dev ? a.range_dev[0] : a.hill_off;
+  nloc = a.range_dev ? a.range_dev[1] : a.nh;
+  k = a.k;
+  if (a.res_dev) {
+    nloc = a.res_dev->error ? 0 : a.res_dev->nh;
+    k = a.res_dev->k;
+  }
+  if (nloc > a.nh_cap) nloc = a.nh_cap;
+  if (nloc < 0) nloc = 0;
+}
 long long ordered_max_hills() { return ORD_MAX_HILLS; }
 long long ordered_tiles(const Geom &g) { return (g.n[0] + ORD_NODES - 1) / ORD_NODES; }
 size_t ordered_record_doubles(const Geom &g, long long nh_cap) {
@@ -4963,9 +4975,8 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
   // this rank's hills: the whole batch, or (multi-GPU) its slice [off, off + nloc) of the rank-major global list --
   // the reference's ranks see their OWN hills of the step while they walk their pairs and replay the other ranks'
   // only in post_add_hill (edm_bias.cpp:565-583)
-  const long long off = a.range_dev ? a.range_dev[0] : a.hill_off;
-  long long nloc = a.range_dev ? a.range_dev[1] : a.nh;
-  if (nloc > a.nh_cap) nloc = a.nh_cap;
+  long long off, nloc, k_split;
+  ordered_batch_counts(a, off, nloc, k_split);
   for (long long base = 0; base < nloc; base += ORD_CHUNK) {
     const int cnt = (nloc - base < ORD_CHUNK) ? (int)(nloc - base) : ORD_CHUNK;
     if (threadIdx.x < 64) {   // wave 0: one hill of the chunk per lane
@@ -4981,9 +4992,9 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
           ht1 = a.ht[2 * cur + 1];
         }
         a1 = a.heights ? a.heights[cur] : a.h_const;
-        if (cur >= a.k) {
-          a1 = a.tail_h1[cur - a.k];
-          a2 = a.tail_h2[cur - a.k];
+        if (cur >= k_split) {
+          a1 = a.tail_h1[cur - k_split];
+          a2 = a.tail_h2[cur - k_split];
         }
         // (c == INT_MIN: a hill rejected at preparation -- outside a wall, gaussian_grid.h:214-216; both heights zero:
         //  a hill the limiter deferred whole)
@@ -5088,7 +5099,7 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
 }
 
 hipError_t launch_ordered_records(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s) {
-  if (!ordered_forces_supported(g) || (!a.range_dev && a.nh > a.nh_cap) || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
+  if (!ordered_forces_supported(g) || (!a.range_dev && !a.res_dev && a.nh > a.nh_cap) || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
   const unsigned nb = (unsigned)ordered_tiles(g);
   if (g.bper[0])
     hipLaunchKernelGGL(k_ordered_records<true>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
@@ -5108,8 +5119,8 @@ struct OrderedCommon {
 };
 __device__ __forceinline__ void ordered_common_init(const Geom &g, const OrderedForcesArgs &a, const DupPlan &dp, int *s_samples,
                                                     OrderedCommon &oc) {
-  long long nloc = a.range_dev ? a.range_dev[1] : a.nh;
-  if (nloc > a.nh_cap) nloc = a.nh_cap;
+  long long off, nloc, k_split;
+  ordered_batch_counts(a, off, nloc, k_split);
   oc.H = (int)nloc;
   for (int i = threadIdx.x; i < oc.H; i += blockDim.x) s_samples[i] = a.sel ? (int)a.sel[i] : i;
   __syncthreads();
@@ -5120,7 +5131,6 @@ __device__ __forceinline__ void ordered_common_init(const Geom &g, const Ordered
     __shared__ int s_fd;
     if (threadIdx.x == 0) s_fd = INT_MAX;
     __syncthreads();
-    const long long off = a.range_dev ? a.range_dev[0] : a.hill_off;
     for (int i = threadIdx.x; i < oc.H; i += blockDim.x)
       if (a.dirty_hill[off + i] == a.dirty_seq) atomicMin(&s_fd, i);
     __syncthreads();
@@ -5314,10 +5324,9 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
   }
   OrderedCommon oc;
   {
-    long long nloc = a.range_dev ? a.range_dev[1] : a.nh;
-    if (nloc > a.nh_cap) nloc = a.nh_cap;
+    long long off, nloc, k_split;
+    ordered_batch_counts(a, off, nloc, k_split);
     oc.H = (int)nloc;
-    const long long off = a.range_dev ? a.range_dev[0] : a.hill_off;
     int my_first = INT_MAX;   // the first of THIS RANK'S hills with a non-zero boundary correction (position in its slice)
     for (int k = threadIdx.x; k < oc.H; k += blockDim.x) {
       s_samples[k] = a.sel ? (int)a.sel[k] : k;
@@ -5458,7 +5467,7 @@ hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a,
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const size_t lds = sizeof(int) * (size_t)((a.range_dev ? a.nh_cap : a.nh) > 0 ? (a.range_dev ? a.nh_cap : a.nh) : 1);
+  const size_t lds = sizeof(int) * (size_t)(((a.range_dev || a.res_dev) ? a.nh_cap : a.nh) > 0 ? ((a.range_dev || a.res_dev) ? a.nh_cap : a.nh) : 1);
   EDM_LAUNCH_TIMED(k_pair_forces_ordered, dim3((unsigned)blocks), dim3(BLOCK), lds, s, ev0, ev1, g, a, dp, scratch, tag, per_block);
   if (blocks_out) *blocks_out = (int)blocks;
   return hipGetLastError();
@@ -5498,7 +5507,7 @@ hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl,
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const size_t lds = sizeof(int) * (size_t)((a.range_dev ? a.nh_cap : a.nh) > 0 ? (a.range_dev ? a.nh_cap : a.nh) : 1);
+  const size_t lds = sizeof(int) * (size_t)(((a.range_dev || a.res_dev) ? a.nh_cap : a.nh) > 0 ? ((a.range_dev || a.res_dev) ? a.nh_cap : a.nh) : 1);
   hipLaunchKernelGGL(k_pairlist_forces_ordered, dim3((unsigned)nb), dim3(BLOCK), lds, s, g, pl, a, dp, partials);
   if (blocks_out) *blocks_out = (int)nb;
   return hipGetLastError();
