@@ -4895,7 +4895,9 @@ hipError_t launch_limit(long long nh, const double *added, const double *heights
 // ---------------------------------------------------------------------------
 // fix edm_pair in the reference's order (see OrderedForcesArgs in edm_kernels.h)
 // ---------------------------------------------------------------------------
-static constexpr int ORD_NODES = 32, ORD_PARTS = BLOCK / ORD_NODES, ORD_CHUNK = 64;   // (16-node tiles, twice the workgroups: no faster)
+static constexpr int ORD_NODES = 32, ORD_PARTS = BLOCK / ORD_NODES, ORD_CHUNK = 128;   // (16-node tiles, twice the workgroups: no faster)
+// (chunks of 64 hills -- one wave lists -- made a W1 step's 125 hills two passes of list / fetch / run / store, each pass
+//  three dependent round trips: the densest tiles finished at 10 us; two waves list 128 hills in one pass)
 static constexpr long long ORD_MAX_HILLS = 16384;   // (sample indices in LDS: 64 KB; list counts fit 16 bits)
 // this rank's hills of the batch and the limiter's split index, wherever they are known (see OrderedForcesArgs)
 __device__ __forceinline__ void ordered_batch_counts(const OrderedForcesArgs &a, long long &off, long long &nloc, long long &k) {
@@ -4933,7 +4935,7 @@ __device__ __forceinline__ int ordered_offset(const Geom &g, int n, int c) {
 }
 
 // The running records of a step's hills, tile by tile.  A workgroup owns a tile of ORD_NODES nodes and walks the hill list
-// ORD_CHUNK hills at a time.  Wave 0 tests the chunk's hills against the tile and lists the ones that reach it IN ORDER
+// ORD_CHUNK hills at a time.  Waves 0 and 1 test the chunk's hills against the tile and list the ones that reach it IN ORDER
 // (ballot prefix; ~15 % of a W1 step's hills reach a given tile); the workgroup's ORD_PARTS parts compute the
 // unit-height stencil terms of the listed hills side by side (value and derivative of every (listed hill, node) into
 // LDS); part 0 then runs the heights over them in hill order -- rec += h1 term, then += h2 term where the limiter
@@ -4943,7 +4945,7 @@ __device__ __forceinline__ int ordered_offset(const Geom &g, int n, int c) {
 // records[tile][counts[m][tile] - 1][node] -- or the node's record before the batch when that count is zero.
 template <bool PERB>
 __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, OrderedForcesArgs a) {
-  static_assert(ORD_CHUNK == 64, "one wave tests and lists a chunk");
+  static_assert(ORD_CHUNK == 128 && BLOCK >= 128, "two waves test and list a chunk");
   const int tnode = threadIdx.x % ORD_NODES, part = threadIdx.x / ORD_NODES;
   const int tile = blockIdx.x, ntiles = gridDim.x;
   const int t0 = tile * ORD_NODES;
@@ -4967,7 +4969,7 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
     acc1 = r0.y;
   }
   double2 *R = reinterpret_cast<double2 *>(a.records) + (long long)tile * a.nh_cap * ORD_NODES;
-  __shared__ int s_c[ORD_CHUNK], s_upto[ORD_CHUNK], s_cnt, s_row[ORD_CHUNK];
+  __shared__ int s_c[ORD_CHUNK], s_cnt, s_row[ORD_CHUNK], s_wcnt[2];
   __shared__ double s_x[ORD_CHUNK], s_t[ORD_CHUNK][2], s_a1[ORD_CHUNK], s_a2[ORD_CHUNK];
   __shared__ double s_v[ORD_CHUNK][ORD_NODES], s_d[ORD_CHUNK][ORD_NODES];
   int listed = 0;       // hills of the earlier chunks the tile listed
@@ -4979,10 +4981,12 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
   ordered_batch_counts(a, off, nloc, k_split);
   for (long long base = 0; base < nloc; base += ORD_CHUNK) {
     const int cnt = (nloc - base < ORD_CHUNK) ? (int)(nloc - base) : ORD_CHUNK;
-    if (threadIdx.x < 64) {   // wave 0: one hill of the chunk per lane
-      bool take = false;
-      int c = INT_MIN;
-      double hx = 0, ht0 = 0, ht1 = 0, a1 = 0, a2 = 0;
+    // waves 0 and 1: one hill of the chunk per lane
+    bool take = false;
+    int c = INT_MIN, pos = 0;
+    double hx = 0, ht0 = 0, ht1 = 0, a1 = 0, a2 = 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < ORD_CHUNK) {
       if ((int)threadIdx.x < cnt) {
         const long long cur = off + base + threadIdx.x;   // (index in the batch's hill list)
         c = a.hc[cur];
@@ -5001,11 +5005,14 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
         take = c != INT_MIN && !(a1 == 0 && a2 == 0) && images(g, 0, c, t0, t1) != 0;
       }
       const unsigned long long bal = __ballot(take);
-      const int lane = threadIdx.x;
-      const int pos = __popcll(bal & ((1ull << lane) - 1ull));
-      s_upto[lane] = pos + (take ? 1 : 0);   // listed hills among the chunk's hills 0 .. lane
-      if ((int)threadIdx.x < cnt)            // row m = base + lane + 1: the first m hills
-        a.counts[(base + lane + 1) * ntiles + tile] = (unsigned short)(listed + pos + (take ? 1 : 0));
+      pos = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    }
+    __syncthreads();
+    if (threadIdx.x < ORD_CHUNK) {
+      if (wave == 1) pos += s_wcnt[0];   // (listed hills among the chunk's hills before this one)
+      if ((int)threadIdx.x < cnt)        // row m = base + thread + 1: the first m hills
+        a.counts[(base + threadIdx.x + 1) * ntiles + tile] = (unsigned short)(listed + pos + (take ? 1 : 0));
       if (take) {
         s_c[pos] = c;
         s_row[pos] = (int)(off + base + threadIdx.x);
@@ -5015,7 +5022,7 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
         s_a1[pos] = a1;
         s_a2[pos] = a2;
       }
-      if (lane == 0) s_cnt = __popcll(bal);
+      if (threadIdx.x == 0) s_cnt = s_wcnt[0] + s_wcnt[1];
     }
     __syncthreads();
     if (tr && threadIdx.x == 0 && base == 0) tr[2] = wall_clock64();
@@ -5054,28 +5061,32 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
     __syncthreads();
     if (tr && threadIdx.x == 0 && base == 0) tr[3] = wall_clock64();
     if (part == 0) {
-      // (four listed hills per trip: their LDS reads are requested together, the adds -- rec += h1 term, then += h2 term,
-      //  hill after hill -- stay one dependent chain; adding a zero term leaves the record as it is)
+      // (four listed hills per trip: their LDS reads are requested together and the products h * term computed off the
+      //  chain; the adds -- rec += h1 term, then += h2 term where the limiter added an undo hill (a branch the whole
+      //  wave takes or not), hill after hill -- stay one dependent chain.  No test for zero terms: a node the hill's
+      //  stencil does not reach adds h * 0, which leaves the record's value as it is -- a per-lane branch around it
+      //  cost more than the adds: ~100 ns per listed hill, 3.6 us for the densest tile's 37)
       for (int e0 = 0; e0 < nl; e0 += 4) {
-        double v[4], d[4], a1[4], a2[4];
+        double pv[4], pd[4], qv[4], qd[4];
+        bool undo[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int e = (e0 + q < nl) ? e0 + q : e0;
-          v[q] = s_v[e][tnode];
-          d[q] = s_d[e][tnode];
-          a1[q] = s_a1[e];
-          a2[q] = s_a2[e];
+          const double v = s_v[e][tnode], d = s_d[e][tnode], h1 = s_a1[e], h2 = s_a2[e];
+          pv[q] = h1 * v;
+          pd[q] = h1 * d;
+          qv[q] = h2 * v;
+          qd[q] = h2 * d;
+          undo[q] = h2 != 0;
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           if (e0 + q < nl) {
-            if (v[q] != 0 || d[q] != 0) {
-              acc0 += a1[q] * v[q];
-              acc1 += a1[q] * d[q];
-              if (a2[q] != 0) {
-                acc0 += a2[q] * v[q];
-                acc1 += a2[q] * d[q];
-              }
+            acc0 += pv[q];
+            acc1 += pd[q];
+            if (undo[q]) {
+              acc0 += qv[q];
+              acc1 += qd[q];
             }
             s_v[e0 + q][tnode] = acc0;
             s_d[e0 + q][tnode] = acc1;
