@@ -1050,6 +1050,59 @@ int edm_hip_gauss_wait(edm_hip_gauss *g) {
   return EDM_HIP_OK;
 }
 
+// The polled completion's ordering argument, put to the test: `iterations` launches of the protocol on a region of
+// `words` 8-byte words that all carry the launch's number; the host polls the flag exactly as apply_hills does and then
+// reads the region: a word that is not the launch's number is a flag that overtook its data.
+int edm_hip_debug_flag_order_stress(int iterations, long long words, long long *violations, long long *timeouts) {
+  if (violations) *violations = 0;
+  if (timeouts) *timeouts = 0;
+  if (iterations < 0 || words < 1 || words > (1 << 22)) return EDM_HIP_ERR_ARG;
+  char *h = nullptr;
+  const size_t bytes = (size_t)words * 8 + 128;
+  EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h), bytes, hipHostMallocMapped));
+  memset(h, 0, bytes);
+  char *d = nullptr;
+  hipError_t e = hipHostGetDevicePointer(reinterpret_cast<void **>(&d), h, 0);
+  hipStream_t s = nullptr;
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  long long bad = 0, late = 0;
+  volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(h + (size_t)words * 8 + 64);
+  volatile long long *payload = reinterpret_cast<volatile long long *>(h);
+  for (int it = 1; e == hipSuccess && it <= iterations; it++) {
+    e = launch_flag_order_stress(reinterpret_cast<long long *>(d), words, (unsigned long long)it,
+                                 reinterpret_cast<unsigned long long *>(d + (size_t)words * 8 + 64), s);
+    if (e != hipSuccess) break;
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
+    bool seen = false;
+    for (unsigned spin = 0;; spin++) {
+      if (flag[0] == (unsigned long long)it) { seen = true; break; }
+      __builtin_ia32_pause();
+      if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) {
+      late++;
+      e = hipStreamSynchronize(s);
+      continue;
+    }
+    // (last words first: they left the device last)
+    for (long long w = words - 1; w >= 0; w--)
+      if (payload[w] != (long long)it) bad++;
+  }
+  if (s) {
+    (void)hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
+  }
+  (void)hipHostFree(h);
+  if (e != hipSuccess) {
+    set_error(std::string("flag_order_stress: ") + hipGetErrorString(e));
+    return EDM_HIP_ERR_HIP;
+  }
+  if (violations) *violations = bad;
+  if (timeouts) *timeouts = late;
+  return EDM_HIP_OK;
+}
+
 int edm_hip_gauss_profile_enable(edm_hip_gauss *g, int enabled) {
   if (enabled && !g->prof_ev) {
     g->prof_ev = new hipEvent_t[2 * edm_hip_gauss::PROF_RING];

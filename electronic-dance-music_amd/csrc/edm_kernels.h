@@ -557,4 +557,8 @@ hipError_t launch_sum(long long n, const double *v, double *out, double *scratch
 // device array -> page-locked host memory by zero-copy stores (both 16-byte aligned), see edm_kernels.hip
 hipError_t launch_copy_to_host(const double *d_src, double *h_dst_mapped, long long n, hipStream_t s);
 
+// the completion protocol on a self-checking payload (edm_hip_debug_flag_order_stress)
+hipError_t launch_flag_order_stress(long long *dst_mapped, long long words, unsigned long long seq, unsigned long long *flag_mapped,
+                                    hipStream_t s);
+
 }  // namespace edm

@@ -2796,10 +2796,12 @@ __device__ __forceinline__ void limiter_stage(const HillList &h, const double *_
     // instead: every store into the region above was itself a system-scope (write-through, uncached) store to
     // host memory; s_waitcnt(0) + the barrier mean each wave has its acknowledgements; PCIe posted writes of one
     // requester are not reordered, so the flag cannot overtake the data on the way to host memory.  The host
-    // reads the flag (volatile) and then the data behind an acquire fence.  Guarded twice over: the polled word
-    // is checked against byte-identical results of the stream-wait path (EDM_HIP_POLL=0) in
-    // test_polled_completion_equals_stream_wait, and a poll that does not see its word within 2 ms falls back
-    // to hipStreamSynchronize.
+    // reads the flag (volatile) and then the data behind an acquire fence.  Put to the test by
+    // k_flag_order_stress / edm_hip_debug_flag_order_stress (this protocol on a region whose every word is the
+    // launch's number: tests/test_gpu_edge_cases.py runs 20 000 launches and requires zero words older than their
+    // flag); the polled word is also checked against byte-identical results of the stream-wait path (EDM_HIP_POLL=0)
+    // in test_polled_completion_equals_stream_wait, and a poll that does not see its word within 2 ms falls back to
+    // hipStreamSynchronize.
     if (threadIdx.x == 0 && la.done_flag)
       __hip_atomic_store(la.done_flag, la.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -5547,6 +5549,25 @@ hipError_t launch_copy_to_host(const double *d_src, double *h_dst_mapped, long l
   if (nb > 8) nb = 8;   // (8 ... 256 workgroups measured alike; the fewest leave the step's kernels alone)
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_copy_to_host, dim3((unsigned)nb), dim3(256), 0, s, d_src, h_dst_mapped, n);
+  return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// The completion protocol of limit_and_readback (relaxed system-scope stores into the host-mapped region, s_waitcnt(0),
+// barrier, relaxed system-scope flag) on a payload that makes an overtaking flag VISIBLE: every word of the region is
+// the launch's sequence number, so a host that sees the flag and then finds an older word has caught the flag ahead of
+// the data (edm_hip_debug_flag_order_stress, tests/test_gpu_edge_cases.py).
+__global__ void __launch_bounds__(BLOCK) k_flag_order_stress(long long *dst, long long words, unsigned long long seq,
+                                                             unsigned long long *flag) {
+  for (long long w = threadIdx.x; w < words; w += BLOCK)
+    __hip_atomic_store(&dst[w], (long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_s_waitcnt(0);   // every wave's stores into the host-mapped region have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_flag_order_stress(long long *dst_mapped, long long words, unsigned long long seq, unsigned long long *flag_mapped,
+                                    hipStream_t s) {
+  hipLaunchKernelGGL(k_flag_order_stress, dim3(1), dim3(BLOCK), 0, s, dst_mapped, words, seq, flag_mapped);
   return hipGetLastError();
 }
 

@@ -113,6 +113,7 @@ _PROTOS = {
     "edm_hip_bias_pair_step": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step_host": (C.c_int, [vp, C.c_longlong, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
     "edm_hip_gauss_wait": (C.c_int, [vp]),
+    "edm_hip_debug_flag_order_stress": (C.c_int, [C.c_int, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "edm_hip_bias_wait": (C.c_int, [vp]),
     "edm_hip_bias_step_host": (C.c_int, [vp, C.c_longlong, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_longlong, c_dp]),
     "edm_hip_bias_pair_step_ordered": (C.c_int, [vp, C.c_longlong, vp, vp, vp, C.c_longlong, vp, vp, C.c_longlong, c_dp]),
@@ -771,6 +772,13 @@ def _bias_step_host(self, x, f, mask=None, runiform=None, apply_mask=-1, hill_st
 Bias.step_host = _bias_step_host
 Bias.wait = lambda self: check(lib().edm_hip_bias_wait(self.h))
 Gauss.wait = lambda self: check(lib().edm_hip_gauss_wait(self.h))
+
+
+def flag_order_stress(iterations, words):
+    """edm_hip_debug_flag_order_stress: (words found older than their completion flag, launches whose flag timed out)"""
+    bad, late = C.c_longlong(0), C.c_longlong(0)
+    check(lib().edm_hip_debug_flag_order_stress(int(iterations), int(words), C.byref(bad), C.byref(late)))
+    return bad.value, late.value
 Bias.pair_step_ordered_device = _bias_pair_step_ordered_device
 Bias.pair_step_ordered_host = _bias_pair_step_ordered_host
 

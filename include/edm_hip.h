@@ -64,6 +64,12 @@ typedef struct edm_hip_bias edm_hip_bias;   /* EDMBias controller */
  * edm_hip_bias_wait() / edm_hip_gauss_wait() first: they wait for everything the object has queued. */
 
 int edm_hip_gauss_wait(edm_hip_gauss *g);
+/* Diagnostic: the completion protocol above (relaxed system-scope stores into host-mapped memory, s_waitcnt(0), a
+ * barrier, then the relaxed system-scope flag) run `iterations` times on a region of `words` 8-byte words that all carry
+ * the launch's number; the host polls the flag as the library does and then reads the region.  *violations = words
+ * found older than their flag (a flag that overtook its data; must be 0), *timeouts = launches whose flag did not
+ * arrive within 200 ms. */
+int edm_hip_debug_flag_order_stress(int iterations, long long words, long long *violations, long long *timeouts);
 int edm_hip_bias_wait(edm_hip_bias *b);
 
 /* ---- runtime ---------------------------------------------------------- */

@@ -304,3 +304,15 @@ def test_device_forces_read_from_a_non_blocking_stream_after_wait(oracle_lib, wo
         assert np.isfinite(e) and np.abs(out).max() > 0
     assert b.get("polled_forces") > polled0, "the calls did return on their polled energy sums"
     hip.hipStreamDestroy(stream)
+
+
+@pytest.mark.parametrize("words", [8, 1024, 8192, 65536])
+def test_completion_flag_never_overtakes_its_data(words):
+    """The polled completion publishes its flag with a RELAXED system-scope store behind s_waitcnt(0) + a barrier
+    (edm_kernels.hip, limit_and_readback): the same protocol on a region whose every word is the launch's number --
+    a host that sees the flag and then finds an older word has caught the flag ahead of its data.  64 B ... 512 KB
+    regions (the library's own are <= 64 KB), thousands of launches each, read back last word first."""
+    iterations = 20000 if words <= 8192 else 4000
+    bad, late = H.flag_order_stress(iterations, words)
+    assert late == 0, "a completion flag did not arrive within 200 ms"
+    assert bad == 0, "%d words were older than their completion flag" % bad
