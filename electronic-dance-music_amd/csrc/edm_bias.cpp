@@ -1156,8 +1156,10 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     double this_h;
     const long long *d_sel;
     long long bound;
-  } early_ctx{b, this_h, d_sel, nh};
-  if (b->ord_early.armed && deferred_bound && !packed_exchange && !b->comm) {
+    bool packed;
+    long long pack_bound;
+  } early_ctx{b, this_h, d_sel, nh, packed_exchange, pack_bound};
+  if (b->ord_early.armed && deferred_bound && (packed_exchange || !b->comm)) {
     spec.before_wait_ctx = &early_ctx;
     spec.before_wait = [](void *ctx, const double *d_base, const double *d_t1, const double *d_t2, const LimitResult *d_res,
                           bool terms_emitted) {
@@ -1173,6 +1175,11 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       bb->last_batch.sel = c->d_sel;
       bb->last_batch.terms_emitted = terms_emitted;
       bb->last_batch.res_dev = d_res;
+      if (c->packed) {   // (this rank's slice of the rank-major global list: where k_unpack_prep put it)
+        bb->last_batch.sel = bb->sel.p;
+        bb->last_batch.range_dev = bb->ord_range.p;
+        bb->last_batch.local_cap = c->pack_bound;
+      }
       bb->ord_early.rc = ordered_forces_enqueue(bb);
       bb->ord_early.done = true;
     };

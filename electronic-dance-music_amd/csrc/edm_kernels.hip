@@ -4907,7 +4907,8 @@ __device__ __forceinline__ void ordered_batch_counts(const OrderedForcesArgs &a,
   nloc = a.range_dev ? a.range_dev[1] : a.nh;
   k = a.k;
   if (a.res_dev) {
-    nloc = a.res_dev->error ? 0 : a.res_dev->nh;
+    if (!a.range_dev) nloc = a.res_dev->nh;
+    if (a.res_dev->error) nloc = 0;
     k = a.res_dev->k;
   }
   if (nloc > a.nh_cap) nloc = a.nh_cap;
