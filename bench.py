@@ -848,6 +848,26 @@ def main():
                        frac=a2 / HBM_PEAK_GBS, kernel_ms=ms2 / l2, kernel="k_pair_forces_fast<true> (LDS-staged window)",
                        bytes_per_launch=BYTES_PER_EVAL * n2, traffic=pmc_traffic("edm::k_pair_forces_fast<true"),
                        kernel_ms_rocprof=(rocprof_avg_us("edm::k_pair_forces_fast<true") or 0) / 1e3 or None)
+        # the same 38.8 M pairs through the REFERENCE-ORDER force pass (k_pair_forces_ordered, the headline's dominant
+        # kernel, out of its latency-bound regime): a hill step whose hills come from the W1 samples, pair k's first
+        # add_hill call spread evenly over them
+        if dist is None:
+            d_first2 = H.DeviceArray.from_host((np.arange(n2, dtype=np.int64) * npairs // n2).astype(np.int32))
+            for _ in range(2):
+                b.pair_step_ordered_device(d_r2, d_f2, d_first2, n2, d_r, d_u, npairs, est)
+            g.profile_enable(True)
+            g.profile_read(reset=True)
+            for _ in range(6):
+                b.pair_step_ordered_device(d_r2, d_f2, d_first2, n2, d_r, d_u, npairs, est)
+            ms3, l3 = g.profile_read(reset=True)
+            g.profile_enable(False)
+            if l3:
+                a3 = BYTES_PER_EVAL * n2 / (ms3 / l3 * 1e-3) / 1e9
+                roof_w2["reference_order"] = dict(
+                    kernel="k_pair_forces_ordered", kernel_ms=ms3 / l3, achieved=a3, frac=a3 / HBM_PEAK_GBS, unit="GB/s",
+                    bytes_per_launch=BYTES_PER_EVAL * n2,
+                    note="16 B per pair as above; the pass also reads a 4-byte sample index per pair and the hills' records")
+            del d_first2
 
     nd = None
     if not args.no_nd and rank == 0:

@@ -1182,6 +1182,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       }
       bb->ord_early.rc = ordered_forces_enqueue(bb);
       bb->ord_early.done = true;
+      ht_mark(bb->bias, 9);
     };
   }
   int rc = apply_hills(b->bias, spec, &oc, false);
@@ -1627,6 +1628,7 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   b->ord_early.tag = tag;
   b->ord_early.armed = n > 0;
   rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
+  ht_mark(g, 7);
   b->ord_early.armed = false;
   b->ord_step_active = false;
   b->ord_snap_pending = false;   // (no hill batch was applied: nobody needs the copy)
@@ -1681,15 +1683,33 @@ int edm_hip_bias_pair_step_ordered(edm_hip_bias *b, long long n, const double *d
   }
   if (n < 0) n = 0;
   if (n_samples < 0) n_samples = 0;
+  static const bool host_trace = getenv("EDM_HIP_TRACE") != nullptr;   // development aid: the call's host-side marks
+  static double last_exit_us = 0;
+  const double t_in = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  if (host_trace && b->bias) b->bias->ht_ref_us = t_in;
   int rc = do_pre_add_hill(b, est_hill_count < 0 ? n_samples : est_hill_count);
   if (rc) return rc;
   if (b->b_outofbounds) {
     if (n > 0) EDM_HIP_TRY(hipMemset(d_force, 0, sizeof(double) * (size_t)n));
     return do_post_add_hill(b);
   }
+  ht_mark(b->bias, 0);
   rc = pair_step_ordered_device(b, n, d_r, d_force, d_first_sample, n_samples, d_sample_r, d_runiform, energy);
   if (rc) return rc;
-  return do_post_add_hill(b);
+  ht_mark(b->bias, 8);
+  rc = do_post_add_hill(b);
+  if (host_trace) {
+    const double t_out = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (b->bias->ready_seq == 160) {
+      const double *m = b->bias->ht_marks;
+      fprintf(stderr, "[edm host] pair_step_ordered: %.2f us inside the call, %.2f us since the previous call returned\n"
+              "[edm host] marks (us after entry): pre_add_hill done %.2f | selection launch %.2f -> %.2f | hill batch launch %.2f -> %.2f | "
+              "force pass queued %.2f, poll %.2f -> %.2f | new hills processed %.2f | forces seen complete %.2f | exit %.2f\n",
+              t_out - t_in, t_in - last_exit_us, m[0], m[1], m[2], m[3], m[4], m[9], m[5], m[6], m[7], m[8], t_out - t_in);
+    }
+    last_exit_us = t_out;
+  }
+  return rc;
 }
 
 // ... for a caller whose arrays live in HOST memory (the host-list fix edm_pair): copies queued on the object's stream

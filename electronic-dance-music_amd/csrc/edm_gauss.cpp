@@ -1310,7 +1310,9 @@ int select_prep_enqueue(const edm_hip_gauss *g, const SelectArgs &a_in, const Hi
   }
   int rc = pending_forces_flush(g, pf);
   if (rc) return rc;
+  ht_mark(const_cast<edm_hip_gauss *>(g), 1);
   EDM_HIP_TRY(launch_select_prep(a, g->g, h, g->stream));
+  ht_mark(const_cast<edm_hip_gauss *>(g), 2);
   return EDM_HIP_OK;
 }
 // forces-only calls poll their workgroups' tagged sums unless EDM_HIP_POLL=0
@@ -1438,19 +1440,42 @@ static int save_pending_region(edm_hip_gauss *g) {
 }
 int apply_hills_fetch_deferred(edm_hip_gauss *g, long long nh_bound, long long nh, std::vector<double> &pos,
                                std::vector<double> &added) {
-  int rc = save_pending_region(g);
-  if (rc) return rc;
   const int dim = g->g.dim;
   const size_t off_flags = 64;
   const size_t off_h2 = off_flags + ((sizeof(int) * (size_t)nh_bound + 7) & ~(size_t)7);
   const size_t off_added = off_h2 + 2 * sizeof(double) * (size_t)nh_bound;
   const size_t off_pos = off_added + sizeof(double) * (size_t)nh_bound;
-  if (g->rb_saved.size() < off_pos + sizeof(double) * (size_t)nh_bound * dim || nh > nh_bound) {
-    set_error("apply_hills_fetch_deferred: no deferred read-back of that shape");
-    return EDM_HIP_ERR_STATE;
+  const size_t need = off_pos + sizeof(double) * (size_t)nh_bound * dim;
+  const char *region = nullptr;
+  if (g->rb_pending_seq) {
+    // still in the host-mapped region (nobody has queued a batch since): wait for its completion word and take the two
+    // slices that are wanted straight from there -- the region is laid out for the launch BOUND (23 KB on W1), the
+    // hills that exist fill a fifth of it, and this sits in front of the next step's first launch
+    if (g->rb_pending_bytes < need || nh > nh_bound) {
+      set_error("apply_hills_fetch_deferred: no deferred read-back of that shape");
+      return EDM_HIP_ERR_STATE;
+    }
+    volatile unsigned long long *w = reinterpret_cast<volatile unsigned long long *>(g->h_stage + g->h_stage_bytes - 128);
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+    bool seen = false;
+    for (unsigned spin = 0;; spin++) {
+      if (w[0] >= g->rb_pending_seq) { seen = true; break; }
+      __builtin_ia32_pause();
+      if ((spin & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
+    }
+    if (!seen) EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    g->rb_pending_seq = 0;
+    region = g->h_stage;
+  } else {
+    if (g->rb_saved.size() < need || nh > nh_bound) {
+      set_error("apply_hills_fetch_deferred: no deferred read-back of that shape");
+      return EDM_HIP_ERR_STATE;
+    }
+    region = g->rb_saved.data();
   }
-  const double *a = reinterpret_cast<const double *>(g->rb_saved.data() + off_added);
-  const double *p = reinterpret_cast<const double *>(g->rb_saved.data() + off_pos);
+  const double *a = reinterpret_cast<const double *>(region + off_added);
+  const double *p = reinterpret_cast<const double *>(region + off_pos);
   added.assign(a, a + nh);
   pos.assign(p, p + (size_t)nh * dim);
   return EDM_HIP_OK;

@@ -5249,8 +5249,8 @@ __device__ __forceinline__ void ordered_lookup(const Geom &g, const OrderedForce
 // arithmetic.  ~230 VALU instructions per pair in the general form, which the pass is bound by (16 waves per CU busy
 // through all four trips, in-kernel stamps), against ~63 in K1.
 struct OrderedLean {
-  const double2 *__restrict__ rec0;
-  const double2 *__restrict__ records;
+  const double2 *rec0;
+  long long records_minus_rec0;   // (records - rec0, in 16-byte records: both come from hipMalloc, 16-byte aligned at least)
   const unsigned short *rows;   // LDS
   int row0, ntiles, nh_cap;
   int lo_t, hi_t, first_dirty;   // outward copy nodes of the boundary duplication (-1: none), first hill that duplicates
@@ -5259,9 +5259,10 @@ struct OrderedLean {
 __device__ __forceinline__ double2 ordered_lean_record(const OrderedLean &L, int m, int node) {
   const int tile = node >> 5;   // ORD_NODES == 32
   const int u = L.rows[(m - L.row0) * L.ntiles + tile];
-  const unsigned off = (unsigned)((tile * L.nh_cap + (u - 1)) * ORD_NODES + (node & (ORD_NODES - 1)));
-  const double2 *p = u ? L.records + off : L.rec0 + node;
-  return *p;
+  // (one address, selected arithmetically: a pointer chosen by `u ? ... : ...` became a divergent branch per record)
+  const long long in_records = L.records_minus_rec0 + (long long)((tile * L.nh_cap + (u - 1)) * ORD_NODES + (node & (ORD_NODES - 1)));
+  const long long idx = u ? in_records : (long long)node;
+  return L.rec0[idx];
 }
 // in two halves, so that a thread can have two pairs' records in flight: the loads ...
 struct OrderedLeanLoaded {
@@ -5382,7 +5383,7 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
                     (long long)oc.ntiles * a.nh_cap * ORD_NODES < (1ll << 31);   // (32-bit record offsets)
   OrderedLean L;
   L.rec0 = reinterpret_cast<const double2 *>(a.rec0);
-  L.records = reinterpret_cast<const double2 *>(a.records);
+  L.records_minus_rec0 = reinterpret_cast<const double2 *>(a.records) - reinterpret_cast<const double2 *>(a.rec0);
   L.rows = s_rows;
   L.row0 = row0;
   L.ntiles = oc.ntiles;
@@ -5398,25 +5399,26 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
     // two pairs per trip: both pairs' records are requested before either is blended (a record comes from the L2 of
     // the XCD that wrote it or from memory: ~1.2 us under load, the trip's length); the next two pairs' distances and
     // sample indices travel meanwhile (the loads do not move above the force stores by themselves)
-    double x_next1 = 0.0;
-    int fs_next1 = 0;
-    if (i + BLOCK < end) {
-      x_next1 = a.r[i + BLOCK];
-      if (a.first_sample) fs_next1 = a.first_sample[i + BLOCK];
-    }
+    // (the prefetches are unconditional loads at clamped indices -- behind `if (j < end)` the compiler could not count
+    //  the loads in flight and waited for ALL of them, the just-issued ones included, at the top of every trip; without
+    //  sample indices the distances stand in as something valid to read, the value is not used)
+    const bool has_fs = a.first_sample != nullptr;
+    const int *fsp = has_fs ? a.first_sample : reinterpret_cast<const int *>(a.r);
+    const long long last = end - 1;
+    double x_next1 = a.r[(i + BLOCK < end) ? i + BLOCK : last];
+    int fs_next1 = fsp[(i + BLOCK < end) ? i + BLOCK : last];
     for (; i < end; i += 2 * BLOCK) {
       const long long i1 = i + BLOCK;
       const bool two = i1 < end;
       const double x0 = x_next, x1 = x_next1;
-      const long long f0 = a.first_sample ? (long long)fs_next : 2 * i;
-      const long long f1 = a.first_sample ? (long long)fs_next1 : 2 * i1;
-      if (i + 2 * BLOCK < end) {
-        x_next = a.r[i + 2 * BLOCK];
-        if (a.first_sample) fs_next = a.first_sample[i + 2 * BLOCK];
-      }
-      if (i + 3 * BLOCK < end) {
-        x_next1 = a.r[i + 3 * BLOCK];
-        if (a.first_sample) fs_next1 = a.first_sample[i + 3 * BLOCK];
+      const long long f0 = has_fs ? (long long)fs_next : 2 * i;
+      const long long f1 = has_fs ? (long long)fs_next1 : 2 * i1;
+      {
+        const long long j0 = (i + 2 * BLOCK < end) ? i + 2 * BLOCK : last, j1 = (i + 3 * BLOCK < end) ? i + 3 * BLOCK : last;
+        x_next = a.r[j0];
+        fs_next = fsp[j0];
+        x_next1 = a.r[j1];
+        fs_next1 = fsp[j1];
       }
       // (sample indices ascend with the pair index in the fix's list, so the count lies between the run's ends: a step
       //  or none of the search instead of log2(hills); any other order: the whole list, and the general form -- the
@@ -5469,6 +5471,7 @@ hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a,
   if (!ordered_forces_supported(g) || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
   // four pairs per thread: 17.8 us per 1 M pairs; two or one (more workgroups, each paying the prologue that stages the
   // hills' sample indices and its rows of the counts) 20.7 us; fewer, fatter workgroups (2 / 1 per CU) 22 / 33 us
+  // (after the lean form: 2 / 4 / 8 / 16 pairs per thread = 20.1 / 15.8 / 15.3 / 18.8 us per 1 M pairs)
   long long blocks = (a.n + 4 * BLOCK - 1) / (4 * BLOCK);
   if (blocks > MAX_BLOCKS) blocks = MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
