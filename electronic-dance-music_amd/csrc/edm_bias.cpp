@@ -1187,7 +1187,10 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   }
   int rc = apply_hills(b->bias, spec, &oc, false);
   if (rc == EDM_APPLY_BOUND_EXCEEDED) {
-    b->ord_early.done = false;   // (what the early force pass computed is void: the step's hill path is redone below)
+    // (what the early force pass computed is void: the step's hill path is redone below, and the force pass that follows
+    //  it tags its partial sums with a number of its own -- the void pass has written the old one)
+    b->ord_early.done = false;
+    if (b->ord_early.tag) b->ord_early.tag = ++b->bias->force_seq;
     // (practically never) more hills than the launch bound -- on every rank alike, since the count is
     // global: nothing was applied; redo the step's hill path the synchronous way with exact counts
     b->force_sync = true;
@@ -1619,13 +1622,13 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   if (rc) return rc;
   b->pending = PendingForces();
   g->wait_polled = false;
-  const unsigned long long tag = forces_poll_enabled() ? ++g->force_seq : 0;
+  const unsigned long long tag0 = forces_poll_enabled() ? ++g->force_seq : 0;
   b->ord_early = edm_hip_bias::OrderedEarly();
   b->ord_early.n = n;
   b->ord_early.d_r = d_r;
   b->ord_early.d_first = d_first_sample;
   b->ord_early.d_force = d_force;
-  b->ord_early.tag = tag;
+  b->ord_early.tag = tag0;
   b->ord_early.armed = n > 0;
   rc = process_new_hills(b, n_samples, d_sample_r, 1, d_runiform, -1);
   ht_mark(g, 7);
@@ -1635,6 +1638,7 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   if (rc) return rc;
   int nblk = 0;
   bool tagged = false;
+  const unsigned long long tag = b->ord_early.tag;   // (a redone step has taken a fresh one)
   if (b->ord_early.done) {
     // (the force pass went out behind the hill batch, before the host had the limiter's result)
     if (b->ord_early.rc) return b->ord_early.rc;

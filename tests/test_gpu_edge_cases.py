@@ -145,21 +145,23 @@ def test_skipped_round_when_buffer_not_drained(tmp_path, oracle_lib):
     assert np.array_equal(b.hist.values, o.hist.values)
 
 
-@pytest.mark.parametrize("entry", ["add_hills", "pair_step", "communicator"])
+@pytest.mark.parametrize("entry", ["add_hills", "pair_step", "communicator", "pair_step_ordered", "communicator_ordered"])
 def test_deferred_bound_exceeded_redo(entry, tmp_path, oracle_lib):
     """A stochastic step is queued against a launch bound (4 x the expected count + 128) before the accepted count
     is known; when the count exceeds the bound the limiter flags it (error 2), the chained gather / histogram /
     read-back / tile-flag clean-up must all stand down, and the controller redoes the hill path synchronously with
     the same device-RNG cycle.  Driven here by uniforms that accept EVERY sample (3000 against a bound of 256),
     through add_hills, the fused pair_step (forces ride in the aborted launch and must stay valid) and the packed
-    exchange of a one-rank communicator.  Bit for bit against a handle that never defers (debug_force_sync), at the
+    exchange of a one-rank communicator -- and the reference-order step, whose records and force pass are queued BEHIND
+    the aborted batch before the host knows (they count zero hills, and the redo launches them again).  Bit for bit
+    against a handle that never defers (debug_force_sync), at the
     parity tolerance against the oracle, and with ordinary steps before and after (tickets / flags left clean)."""
     text = BASE + "hill_prefactor 0.5\nhill_density 20\nbias_per_step 50\n"
     n = 3000
     runs = {}
     for tag in ("deferred", "sync"):
         b = _bias(tmp_path, entry + "_" + tag, text)
-        if entry == "communicator":
+        if entry.startswith("communicator"):
             b.comm_init(H.comm_unique_id(), 1, 0)
         if tag == "sync":
             b.set("debug_force_sync", 1)
@@ -172,6 +174,9 @@ def test_deferred_bound_exceeded_redo(entry, tmp_path, oracle_lib):
             d_f = H.DeviceArray.zeros((n,))
             if entry == "pair_step":
                 e = b.pair_step_device(d_r, d_f, n, d_r, d_u, n, est=n)
+            elif entry.endswith("_ordered"):
+                d_first = H.DeviceArray.from_host(np.arange(n, dtype=np.int32))
+                e = b.pair_step_ordered_device(d_r, d_f, d_first, n, d_r, d_u, n, est=n)
             else:
                 e = b.pair_forces_device(d_r, d_f, n)
                 b.add_hills_device(d_r, n, 1, d_u, -1, est=n)
@@ -196,15 +201,19 @@ def test_deferred_bound_exceeded_redo(entry, tmp_path, oracle_lib):
         r = W.pair_distances(n, 880 + step)
         u = np.zeros(n) if step == 1 else W.uniform(890 + step, n)
         fo = np.zeros((n, 1))
-        if entry == "pair_step":
-            o.pre_add_hill(n)
-            eo = o.update_forces(r.reshape(-1, 1).copy(), fo)
+        if entry.endswith("_ordered"):   # the reference fix's own loop: update_force, then add_hill, pair after pair
+            eo, f_loop, _ = o.pair_loop(r, np.zeros(n, dtype=np.int32), u, 1, n)
+            fo[:, 0] = f_loop
         else:
-            eo = o.update_forces(r.reshape(-1, 1).copy(), fo)
-            o.pre_add_hill(n)
-        for i in np.nonzero(u < 20.0 / n)[0]:
-            o.add_hill([r[i]], float(u[i]))
-        o.post_add_hill()
+            if entry == "pair_step":
+                o.pre_add_hill(n)
+                eo = o.update_forces(r.reshape(-1, 1).copy(), fo)
+            else:
+                eo = o.update_forces(r.reshape(-1, 1).copy(), fo)
+                o.pre_add_hill(n)
+            for i in np.nonzero(u < 20.0 / n)[0]:
+                o.add_hill([r[i]], float(u[i]))
+            o.post_add_hill()
         e1, f1, s1 = runs["deferred"][0][step]
         assert abs(e1 - eo) <= 1e-9 * max(abs(eo), 1e-300)
         assert np.allclose(f1, fo[:, 0], rtol=1e-8, atol=1e-11 * max(np.abs(fo).max(), 1e-300))
