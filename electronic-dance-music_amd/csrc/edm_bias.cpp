@@ -352,6 +352,8 @@ struct edm_hip_bias {
     double *d_force = nullptr;
     unsigned long long tag = 0;
     int nblk = 0, rc = 0;
+    bool list = false;     // the force pass over the device-resident neighbour list (pair_list_step) instead of arrays
+    PairListArgs pl;
   } ord_early;
   bool ord_snap_pending = false;  // ordered_snapshot has been asked for, no launch has made the copy yet
   bool ord_step_active = false;   // between ordered_snapshot and the step's force pass: hill batches may emit their terms
@@ -1578,6 +1580,12 @@ static int ordered_forces_enqueue(edm_hip_bias *b) {
   OrderedForcesArgs a;
   int rc = ordered_records_enqueue(b, &a);
   if (rc) return rc;
+  if (b->ord_early.list) {
+    PairListArgs pl = b->ord_early.pl;
+    pl.partial_tag = b->ord_early.tag;
+    EDM_HIP_TRY(launch_pairlist_forces_ordered(g->g, pl, a, g->d_partials, s, &b->ord_early.nblk));
+    return EDM_HIP_OK;
+  }
   a.n = b->ord_early.n;
   a.r = b->ord_early.d_r;
   a.first_sample = b->ord_early.d_first;
@@ -2178,7 +2186,15 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     }
     const int *saved_mask = b->d_mask;
     b->d_mask = b->vs_mask.p;
+    b->ord_early = edm_hip_bias::OrderedEarly();
+    if (ordered) {   // (records and force pass go out from inside the hill batch's apply, see pair_step_ordered_device)
+      b->ord_early.list = true;
+      b->ord_early.pl = a;
+      b->ord_early.tag = forces_poll_enabled() ? ++b->bias->force_seq : 0;
+      b->ord_early.armed = true;
+    }
     rc = process_new_hills(b, 2 * npairs, sample_r, 1, nullptr, 1);
+    b->ord_early.armed = false;
     b->ord_step_active = false;
     b->ord_snap_pending = false;
     b->d_mask = saved_mask;
@@ -2190,13 +2206,17 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   int nblk_ordered = 0;
   if (ordered) {
     if (rc) return rc;
-    if (forces_poll_enabled()) tag = ++b->bias->force_seq;
+    tag = b->ord_early.tag;   // (a step redone after an exceeded launch bound has taken a fresh one)
     a.partial_tag = tag;
-    if (b->last_batch.valid && b->last_batch.nh > 0) {
-      OrderedForcesArgs oa;
-      rc = ordered_records_enqueue(b, &oa);
+    if (b->ord_early.done) {
+      if (b->ord_early.rc) return b->ord_early.rc;
+      nblk_ordered = b->ord_early.nblk;
+    } else if (b->last_batch.valid && b->last_batch.nh > 0) {
+      b->ord_early.list = true;
+      b->ord_early.pl = a;
+      rc = ordered_forces_enqueue(b);
       if (rc) return rc;
-      EDM_HIP_TRY(launch_pairlist_forces_ordered(b->bias->g, a, oa, b->bias->d_partials, s, &nblk_ordered));
+      nblk_ordered = b->ord_early.nblk;
     } else {   // (no new hill: every entry sees the same bias)
       EDM_HIP_TRY(launch_pairlist_forces(b->bias->g, b->bias->rec, a, b->bias->d_partials, s, &nblk_ordered));
     }

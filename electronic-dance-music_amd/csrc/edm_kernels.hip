@@ -5496,8 +5496,50 @@ struct OrderedListLookup {
   const Geom &g;
   const OrderedForcesArgs &a;
   const OrderedCommon &oc;
-  __device__ __forceinline__ void lookup(double r, int entry, double &v, double &d) const {
-    ordered_lookup(g, a, oc, r, 2 * (long long)entry, v, d);
+  // the lean form of k_pair_forces_ordered with the counts read from memory (a list's entries come in atom order: their
+  // hill counts are all over the table, no rows to stage): one 16-bit count per corner tile -- one when both corners
+  // share a tile, 31 times out of 32 --, 32-bit record offsets, the address selected arithmetically
+  bool lean;
+  const double2 *rec0;
+  long long records_minus_rec0;
+  int ntiles, nh_cap;
+  double lo_ok, hi_open, eps;
+  __device__ __forceinline__ double2 record(int u, int tile, int node) const {
+    const long long in_records = records_minus_rec0 + (long long)((tile * nh_cap + (u - 1)) * ORD_NODES + (node & (ORD_NODES - 1)));
+    return rec0[u ? in_records : (long long)node];
+  }
+  __device__ __forceinline__ void lookup(double x, int entry, double &v, double &d) const {
+    const int m = ordered_hills_before(oc, 2 * (long long)entry);
+    if (lean) {
+      const bool in_range = (x >= lo_ok) & (x < hi_open);
+      const double q = (x - g.min[0]) * oc.inv_dx;
+      double fq = floor(q);
+      const double frac = q - fq;
+      const bool near = in_range & ((frac <= eps) | (frac >= 1.0 - eps));
+      if (near) fq = floor((x - g.min[0]) / g.dx[0]);
+      int idx = (int)fq;
+      idx = idx < 0 ? 0 : idx;
+      idx = idx > g.n[0] - 2 ? g.n[0] - 2 : idx;
+      const bool special = (m > oc.first_dirty) & ((idx == oc.lo_t) | (idx + 1 == oc.lo_t) | (idx == oc.hi_t) | (idx + 1 == oc.hi_t));
+      if (!special) {
+        const double where = x - g.min[0] - fq * g.dx[0];
+        const double X = where * oc.inv_dx;
+        const int t0 = idx >> 5, t1 = (idx + 1) >> 5;
+        const unsigned short *row = a.counts + (long long)m * ntiles;
+        const int u0 = row[t0];
+        const int u1 = (t1 == t0) ? u0 : (int)row[t1];
+        const double2 ra = record(u0, t0, idx), rb = record(u1, t1, idx + 1);
+        double vv, dd;
+        if ((X < 0.0) | (X > 1.0))   // `where` off by an ulp at a node: the reference's fabs() mirroring
+          hermite_1d_mirrored(ra.x, ra.y, rb.x, rb.y, X, g.dx[0], oc.inv_dx, vv, dd);
+        else
+          hermite_1d_horner(ra.x, scaled_slope(ra.x, ra.y, g.dx[0]), rb.x, scaled_slope(rb.x, rb.y, g.dx[0]), X, oc.inv_dx, vv, dd);
+        v = in_range ? vv : 0.0;
+        d = in_range ? dd : 0.0;
+        return;
+      }
+    }
+    ordered_lookup_m(g, a, oc, x, m, v, d);
   }
 };
 __global__ void __launch_bounds__(BLOCK) k_pairlist_forces_ordered(Geom g, PairListArgs pl, OrderedForcesArgs a, DupPlan dp,
@@ -5505,7 +5547,15 @@ __global__ void __launch_bounds__(BLOCK) k_pairlist_forces_ordered(Geom g, PairL
   extern __shared__ int s_samples[];
   OrderedCommon oc;
   ordered_common_init(g, a, dp, s_samples, oc);
-  const OrderedListLookup ord{g, a, oc};
+  OrderedListLookup ord{g, a, oc};
+  ord.ntiles = oc.ntiles;
+  ord.nh_cap = (int)a.nh_cap;
+  ord.lean = oc.fast && (long long)oc.ntiles * a.nh_cap * ORD_NODES < (1ll << 31);   // (32-bit record offsets)
+  ord.rec0 = reinterpret_cast<const double2 *>(a.rec0);
+  ord.records_minus_rec0 = reinterpret_cast<const double2 *>(a.records) - reinterpret_cast<const double2 *>(a.rec0);
+  ord.lo_ok = fmax(g.bmin[0], g.min[0]);
+  ord.hi_open = fmin(nextafter(g.bmax[0], 1.0e308), g.max[0] - g.dx[0]);
+  ord.eps = 1e-11 * fmax(1.0, (double)g.n[0]);
   pairlist_forces_body<false, OrderedListLookup>(g, a.rec0, pl, partials, 0.0, blockIdx.x, gridDim.x, &ord);
 }
 hipError_t launch_pairlist_forces_ordered(const Geom &g, const PairListArgs &pl, const OrderedForcesArgs &a, double *partials,

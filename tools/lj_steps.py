@@ -25,6 +25,8 @@ bl.setup(1.0, 1.0)
 bl.subdivide([0], [2.8], [0], [2.8], [0], [0.3])
 bl.set_hill_log(False)
 bl.set_device_rng(True, 777)
+if os.environ.get("LJ_ORDER", "0") == "1":   # the reference fix's order (the rewritten fix's default)
+    bl.set("reference_order", 1)
 bl.pair_list_upload(pr[:, 0], pr[:, 1], np.ones(na, dtype=np.int32))
 d_xa = H.DeviceArray.from_host(xa)
 d_fa = H.DeviceArray.zeros((na, 3))
