@@ -140,6 +140,35 @@ def test_device_entry_equals_host_entry(workdir):
         last = len(xs)
 
 
+@pytest.mark.parametrize("name", ["w1_density", "walls_inside", "all_samples"])
+def test_force_pass_does_not_depend_on_the_order_of_the_pair_array(name, workdir):
+    """A pair's force is a function of (distance, index of its first add_hill call) and the step's hills.  The force
+    pass takes a short cut for arrays whose sample indices ascend (the fix's list: a workgroup's run of pairs spans a
+    few rows of the counts, staged in LDS, and a lean per-pair form); a shuffled array sends every pair down the general
+    form (its row read from memory, the whole sample list searched) and must give every pair the same force."""
+    spec = PF.PAIRFIX[name]
+    a, _ = _make(H.Bias, spec, name, workdir, "asc")
+    b, _ = _make(H.Bias, spec, name, workdir, "shuf")
+    last = spec["nmax"]
+    rng = np.random.default_rng(5)
+    for step in range(2):
+        r, second, ru = PF.pairfix_inputs(name, step)
+        xs, us = PF.staged_samples(r, second, ru)
+        first = PF.first_calls(second)
+        perm = rng.permutation(len(r))
+        out = []
+        for bias, rr, ff in ((a, r, first), (b, np.ascontiguousarray(r[perm]), np.ascontiguousarray(first[perm]))):
+            d_r, d_f = H.DeviceArray.from_host(rr), H.DeviceArray.from_host(np.zeros(len(rr)))
+            d_first = H.DeviceArray.from_host(ff)
+            d_x, d_u = H.DeviceArray.from_host(xs), H.DeviceArray.from_host(us)
+            e = bias.pair_step_ordered_device(d_r, d_f, d_first, len(rr), d_x, d_u, len(xs), est=last)
+            out.append((e, d_f.to_host()))
+        (e1, f1), (e2, f2) = out
+        assert np.array_equal(f2, f1[perm]), "shuffled pairs must get the forces of the ascending array, bit for bit"
+        close(e2, e1, rtol=1e-12, atol=0, what="energy (another summation order)")
+        last = len(xs)
+
+
 def test_write_deviation_report():
     """(runs last in this module) the measured deviation of the fast mode, for INTEGRATION.md"""
     if not DEVIATION:

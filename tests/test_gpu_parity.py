@@ -756,21 +756,24 @@ def test_step_equals_separate_calls(workdir):
     assert state[0][0].max() > 0 and state[0][7] > 10 and np.abs(state[0][4]).max() > 0
 
 
+@pytest.mark.parametrize("layout", ["lammps_rows", "wide_rows_and_mask"])
 @pytest.mark.parametrize("dim", [2, 3])
-def test_step_host_helper_threads_and_pieces(dim, workdir):
+def test_step_host_helper_threads_and_pieces(dim, layout, workdir):
     """edm_hip_bias_step_host on enough atoms that the delta comes down in several pieces and helper threads share the
     add (odd atom count: the copy kernel's last double, the pieces' rounding): bit-identical to the device-array step,
-    with one adding thread and with five, on a force array that starts non-zero."""
+    with one adding thread and with five, on a force array that starts non-zero.  LAMMPS' own layout (rows of three)
+    and rows wider than that with a group mask (position rows of five doubles, force rows of four)."""
     n = 300001
     span = 16.0
+    xs, fs, masked = (3, 3, False) if layout == "lammps_rows" else (5, 4, True)
     text = ("tempering 0\nhill_prefactor 0.4\nhill_density 40\nbias_per_step 0.3\ndimension %d\nbox_low %s\n"
             "box_high %s\nbias_spacing %s\nbias_sigma %s\n" % (
                 dim, " ".join(["0"] * dim), " ".join(["16"] * dim), " ".join(["0.125"] * dim), " ".join(["0.4"] * dim)))
     results = []
     for tag, threads in (("device", 0), ("host1", 1), ("host5", 5)):
-        cfg = str(workdir / ("sh_%s_%d.edm" % (tag, dim)))
-        open(cfg, "w").write(text + "hills_filename %s/HILLS_sh_%s%d\nhistogram_filename %s/HIST_sh_%s%d\n" % (
-            workdir, tag, dim, workdir, tag, dim))
+        cfg = str(workdir / ("sh_%s_%d_%s.edm" % (tag, dim, layout)))
+        open(cfg, "w").write(text + "hills_filename %s/HILLS_sh_%s%d%s\nhistogram_filename %s/HIST_sh_%s%d%s\n" % (
+            workdir, tag, dim, layout, workdir, tag, dim, layout))
         b = H.Bias(cfg)
         b.setup(1.0, 1.0)
         b.subdivide([0] * dim, [span] * dim, [0] * dim, [span] * dim, [1] * dim, [0.0] * dim)
@@ -779,17 +782,20 @@ def test_step_host_helper_threads_and_pieces(dim, workdir):
             assert b.get("host_add_threads") == threads
         out = []
         for step in range(3):
-            x = np.ascontiguousarray(W.uniform(4100 + step, 3 * n).reshape(n, 3) * span)
+            x = np.ascontiguousarray(W.uniform(4100 + step, xs * n).reshape(n, xs) * span)
             u = W.uniform(4200 + step, n)
-            f0 = W.uniform(4300 + step, 3 * n).reshape(n, 3) - 0.5
+            f0 = W.uniform(4300 + step, fs * n).reshape(n, fs) - 0.5
+            mask = (W.splitmix64(4400 + step, n) % np.uint64(4)).astype(np.int32) if masked else None
             if threads:
                 f = f0.copy()
-                e = b.step_host(x, f, runiform=u, apply_mask=-1, hill_step=True, est=n)
+                e = b.step_host(x, f, mask=mask, runiform=u, apply_mask=1 if masked else -1, hill_step=True, est=n)
                 out.append((e, f))
             else:
                 d_x, d_u = H.DeviceArray.from_host(x), H.DeviceArray.from_host(u)
-                d_f = H.DeviceArray.zeros((n, 3))
-                e = b.step_device(d_x, 3, d_f, 3, n, d_u, -1, n)
+                d_f = H.DeviceArray.zeros((n, fs))
+                if masked:
+                    b.set_mask(mask)
+                e = b.step_device(d_x, xs, d_f, fs, n, d_u, 1 if masked else -1, n)
                 out.append((e, f0 + d_f.to_host()))
         results.append((out, b.gauss.download(), b.get("hills_added"), b.get("cum_bias")))
         del b
@@ -797,9 +803,9 @@ def test_step_host_helper_threads_and_pieces(dim, workdir):
         for (e0, f0), (e1, f1) in zip(results[0][0], other[0]):
             assert e0 == e1 and np.array_equal(f0, f1)
         assert np.array_equal(results[0][1][0], other[1][0]) and results[0][2:] == other[2:]
-    assert results[0][2] > 20
-    if dim < 3:   # columns beyond the dimension are the caller's own, untouched
-        assert np.array_equal(results[1][0][-1][1][:, dim:], (W.uniform(4302, 3 * n).reshape(n, 3) - 0.5)[:, dim:])
+    assert results[0][2] > 10
+    if dim < fs:   # columns beyond the dimension are the caller's own, untouched
+        assert np.array_equal(results[1][0][-1][1][:, dim:], (W.uniform(4302, fs * n).reshape(n, fs) - 0.5)[:, dim:])
 
 
 def test_large_selection_vs_oracle(oracle_lib, workdir):
