@@ -341,6 +341,10 @@ struct edm_hip_bias {
     bool terms_emitted = false;   // the batch's launch stored the hills' stencil terms in ord_terms (rows: ord_terms_rows)
     const LimitResult *res_dev = nullptr;   // provisional entry (force pass queued before the host saw the limiter's result):
                                             // nh is the launch bound, count and split index are read on the device
+    // ... or, beside the batch's launch on ord_stream: the limiter's word and the selection's count (OrderedForcesArgs)
+    const unsigned long long *wait_flag = nullptr;
+    unsigned long long wait_seq = 0;
+    const long long *d_nh = nullptr;
   } last_batch;
   // reference-order array step, single rank: the force pass is queued from inside the hill batch's apply (ApplySpec::
   // before_wait) -- behind the batch on the stream, ahead of the host's wait for the limiter
@@ -363,6 +367,14 @@ struct edm_hip_bias {
   DevBuf<double> ord_rec0, ord_records;   // OrderedForcesArgs::rec0 (taken before the batch) / ::records
   DevBuf<unsigned short> ord_counts;
   DevBuf<unsigned> ord_dirty;   // OrderedForcesArgs::dirty_hill (kept zero-initialised: step numbers start at 1)
+  // the record pass and the force pass of a single-rank reference-order step run on a stream of their own, BESIDE the
+  // hill batch's launch: the record pass waits in the kernel for the limiter's word and the emitters' flags
+  // (OrderedForcesArgs::wait_flag), not for the launch's end -- the gather tiles' half of it is nothing it needs
+  hipStream_t ord_stream = nullptr;
+  hipEvent_t ord_done_event = nullptr;
+  DevBuf<unsigned> ord_ready;   // LimitArgs::ord_ready (zero-initialised like ord_dirty)
+  DevBuf<int> ord_status;       // OrderedForcesArgs::status
+  bool ord_on_own_stream = false;   // this step's record / force passes went to ord_stream
   unsigned ord_seq = 0;
   DevBuf<int> ord_first;
   int reference_order = 0;     // edm_hip_bias_set("reference_order"): edm_hip_bias_pair_list_step evaluates its forces in
@@ -565,6 +577,12 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
     (void)hipStreamDestroy(b->copy_stream);
   }
   if (b->copy_event) (void)hipEventDestroy(b->copy_event);
+  if (b->ord_stream) {
+    (void)hipStreamSynchronize(b->ord_stream);
+    (void)hipStreamDestroy(b->ord_stream);
+  }
+  if (b->ord_done_event) (void)hipEventDestroy(b->ord_done_event);
+  b->ord_ready.release(); b->ord_status.release();
   b->hs_r.release(); b->hs_f.release(); b->hs_x.release(); b->hs_u.release(); b->hs_mask.release();
   if (b->h_delta) (void)hipHostFree(b->h_delta);
   for (int c = 0; c < 8; c++)
@@ -1161,10 +1179,22 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     bool packed;
     long long pack_bound;
   } early_ctx{b, this_h, d_sel, nh, packed_exchange, pack_bound};
+  b->ord_on_own_stream = false;
   if (b->ord_early.armed && deferred_bound && (packed_exchange || !b->comm)) {
+    if (!b->comm && spec.ord_terms && !b->bias->shared_device) {
+      // one rank with the device to itself: record and force pass on their own stream, beside the batch's launch
+      if (!b->ord_stream) {
+        EDM_HIP_TRY(hipStreamCreateWithFlags(&b->ord_stream, hipStreamNonBlocking));
+        EDM_HIP_TRY(hipEventCreateWithFlags(&b->ord_done_event, hipEventDisableTiming));
+      }
+      EDM_HIP_TRY(b->ord_ready.reserve_zeroed((size_t)2 * (size_t)(nh > 4096 ? nh : 4096)));
+      EDM_HIP_TRY(b->ord_status.reserve_zeroed(16));
+      spec.ord_ready = b->ord_ready.p;
+    }
     spec.before_wait_ctx = &early_ctx;
     spec.before_wait = [](void *ctx, const double *d_base, const double *d_t1, const double *d_t2, const LimitResult *d_res,
-                          bool terms_emitted) {
+                          bool terms_emitted, const unsigned long long *ready_flag, unsigned long long ready_seq,
+                          const long long *d_nh) {
       EarlyCtx *c = static_cast<EarlyCtx *>(ctx);
       edm_hip_bias *bb = c->b;
       bb->last_batch = edm_hip_bias::LastBatch();
@@ -1182,7 +1212,25 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
         bb->last_batch.range_dev = bb->ord_range.p;
         bb->last_batch.local_cap = c->pack_bound;
       }
+      if (!c->packed && terms_emitted && ready_flag && d_nh && bb->ord_stream && bb->ord_ready.p) {
+        // beside the batch's launch, behind nothing on the host's side: the record pass waits in the kernel for the
+        // limiter's word of THIS batch (an event behind the preparation cost the object's stream ~5 us between the
+        // selection and the batch, and the other stream ~10 us until the dependency had resolved)
+        bb->ord_on_own_stream = true;
+        bb->last_batch.wait_flag = ready_flag;
+        bb->last_batch.wait_seq = ready_seq;
+        bb->last_batch.d_nh = d_nh;
+      }
       bb->ord_early.rc = ordered_forces_enqueue(bb);
+      if (bb->ord_on_own_stream) {
+        // whatever comes next on the object's stream (and with it the null stream) is ordered behind the force pass, as it
+        // was when the pass ran on that stream: the forces it stores are the call's device output
+        if (hipEventRecord(bb->ord_done_event, bb->ord_stream) != hipSuccess ||
+            hipStreamWaitEvent(bb->bias->stream, bb->ord_done_event, 0) != hipSuccess) {
+          (void)hipGetLastError();
+          if (!bb->ord_early.rc) bb->ord_early.rc = EDM_HIP_ERR_HIP;
+        }
+      }
       bb->ord_early.done = true;
       ht_mark(bb->bias, 9);
     };
@@ -1193,6 +1241,10 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
     //  it tags its partial sums with a number of its own -- the void pass has written the old one)
     b->ord_early.done = false;
     if (b->ord_early.tag) b->ord_early.tag = ++b->bias->force_seq;
+    if (b->ord_on_own_stream) {   // (the void passes on their own stream: out of the way before the redo reuses their buffers)
+      EDM_HIP_TRY(hipStreamSynchronize(b->ord_stream));
+      b->ord_on_own_stream = false;
+    }
     // (practically never) more hills than the launch bound -- on every rank alike, since the count is
     // global: nothing was applied; redo the step's hill path the synchronous way with exact counts
     b->force_sync = true;
@@ -1215,6 +1267,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   b->last_batch.local_cnt = -1;
   b->last_batch.range_dev = nullptr;
   b->last_batch.res_dev = nullptr;
+  b->last_batch.wait_flag = nullptr;
   b->last_batch.terms_emitted = oc.terms_emitted;
   if (packed_exchange) {
     b->last_batch.sel = b->sel.p;
@@ -1521,6 +1574,14 @@ static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
   a.hill_off = sliced ? b->last_batch.local_off : 0;
   a.range_dev = b->last_batch.range_dev;
   a.res_dev = b->last_batch.res_dev;
+  if (b->last_batch.wait_flag) {
+    a.res_dev = nullptr;
+    a.wait_flag = b->last_batch.wait_flag;
+    a.wait_seq = b->last_batch.wait_seq;
+    a.nh_dev = b->last_batch.d_nh;
+    a.terms_ready = b->ord_ready.p;
+    a.status = b->ord_status.p;
+  }
   a.k = b->last_batch.k;
   a.heights = b->last_batch.heights;
   a.h_const = b->last_batch.h_const;
@@ -1548,9 +1609,9 @@ static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
     EDM_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a.trace), trace_wgs * 64));
     EDM_HIP_TRY(hipMemset(a.trace, 0, trace_wgs * 64));
   }
-  EDM_HIP_TRY(launch_ordered_records(g->g, g->tables(), a, g->stream));
+  EDM_HIP_TRY(launch_ordered_records(g->g, g->tables(), a, b->ord_on_own_stream ? b->ord_stream : g->stream));
   if (a.trace) {
-    EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+    EDM_HIP_TRY(hipStreamSynchronize(b->ord_on_own_stream ? b->ord_stream : g->stream));
     std::vector<unsigned long long> tr(trace_wgs * 8);
     EDM_HIP_TRY(hipMemcpy(tr.data(), a.trace, trace_wgs * 64, hipMemcpyDeviceToHost));
     (void)hipFree(a.trace);
@@ -1576,7 +1637,7 @@ static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
 // records of the batch's hills, then the force pass that reads them (b->last_batch, b->ord_early: the pairs)
 static int ordered_forces_enqueue(edm_hip_bias *b) {
   edm_hip_gauss *g = b->bias;
-  hipStream_t s = g->stream;
+  hipStream_t s = b->ord_on_own_stream ? b->ord_stream : g->stream;
   OrderedForcesArgs a;
   int rc = ordered_records_enqueue(b, &a);
   if (rc) return rc;
@@ -1643,7 +1704,10 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   b->ord_early.armed = false;
   b->ord_step_active = false;
   b->ord_snap_pending = false;   // (no hill batch was applied: nobody needs the copy)
-  if (rc) return rc;
+  if (rc) {
+    if (b->ord_on_own_stream) (void)hipStreamSynchronize(b->ord_stream);
+    return rc;
+  }
   int nblk = 0;
   bool tagged = false;
   const unsigned long long tag = b->ord_early.tag;   // (a redone step has taken a fresh one)
@@ -1671,6 +1735,7 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   }
   double e = 0;
   if (!(tagged && poll_tagged_partials(g, nblk, tag, &e))) {
+    if (b->ord_on_own_stream) EDM_HIP_TRY(hipStreamSynchronize(b->ord_stream));
     EDM_HIP_TRY(hipStreamSynchronize(s));
     e = 0;
     for (int k = 0; k < nblk; k++) e += g->h_partials[tagged ? 2 * k : k];
@@ -2205,7 +2270,10 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   unsigned long long tag = 0;
   int nblk_ordered = 0;
   if (ordered) {
-    if (rc) return rc;
+    if (rc) {
+      if (b->ord_on_own_stream) (void)hipStreamSynchronize(b->ord_stream);
+      return rc;
+    }
     tag = b->ord_early.tag;   // (a step redone after an exceeded launch bound has taken a fresh one)
     a.partial_tag = tag;
     if (b->ord_early.done) {
@@ -2233,6 +2301,7 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     b->bias->polled_forces++;
   } else {
     // (a polled hill batch has shown the stream past the force pass queued ahead of it)
+    if (ordered && b->ord_on_own_stream) EDM_HIP_TRY(hipStreamSynchronize(b->ord_stream));
     if (tag || !b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(s));
     e = 0;
     for (int k = 0; k < nblk; k++) e += b->bias->h_partials[tag ? 2 * k : k];
@@ -2395,6 +2464,7 @@ int edm_hip_bias_get_array(const edm_hip_bias *b, const char *name, double *out)
 int edm_hip_bias_wait(edm_hip_bias *b) {
   if (b && b->bias) EDM_HIP_TRY(hipStreamSynchronize(b->bias->stream));
   if (b && b->copy_stream) EDM_HIP_TRY(hipStreamSynchronize(b->copy_stream));
+  if (b && b->ord_stream) EDM_HIP_TRY(hipStreamSynchronize(b->ord_stream));
   return EDM_HIP_OK;
 }
 

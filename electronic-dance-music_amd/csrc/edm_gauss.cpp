@@ -1735,6 +1735,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
     int rcp = enqueue_preparation();
     if (rcp) return rcp;
   }
+  const unsigned long long *hook_ready_flag = nullptr;
+  unsigned long long hook_ready_seq = 0;
   if (sharded) {
     if (spec.shard_comm) {
       if (spec.shard_off < 0 || spec.shard_cnt < 0 || spec.shard_off + spec.shard_cnt > nh) {
@@ -1879,7 +1881,10 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
         la.ord_terms = spec.ord_terms;
         la.ord_dirty = spec.ord_dirty;
         la.ord_seq = spec.ord_seq;
+        la.ord_ready = spec.ord_ready;
         if (out) out->terms_emitted = true;
+        hook_ready_flag = la.ready_flag;
+        hook_ready_seq = la.ready_seq;
       }
       EDM_HIP_TRY(launch_integrals_gather(q, tabs, g->rec, hl, spec.d_h, spec.h_const, p_added, la, hh, plan, g->d_dirty, s,
                                           chain_post ? &ps : nullptr));
@@ -2087,7 +2092,8 @@ int apply_hills(edm_hip_gauss *g, const ApplySpec &spec, ApplyOutcome *out, bool
   memset(&header_res, 0, sizeof(header_res));
   static const bool host_trace = getenv("EDM_HIP_TRACE") != nullptr;   // development aid: host-side stamps
   if (spec.before_wait)
-    spec.before_wait(spec.before_wait_ctx, base_heights, ws.tail_h1.p, p_h2, dres, out ? out->terms_emitted : false);
+    spec.before_wait(spec.before_wait_ctx, base_heights, ws.tail_h1.p, p_h2, dres, out ? out->terms_emitted : false,
+                     hook_ready_flag, hook_ready_seq, spec.d_nh);
   const auto ht_before_poll = std::chrono::steady_clock::now();
   ht_mark(g, 5);
   if (polled) {

@@ -223,9 +223,14 @@ struct ApplySpec {
   // ... and a call made once every launch of the batch is queued, BEFORE the host waits for the limiter's result: what
   // depends on the batch only through device memory (the reference-order force pass) is queued here, behind the batch,
   // instead of after the host's turn-around
+  // (ready_flag / ready_seq: the word the batch's limiter publishes for the workgroups that wait for it, LimitArgs; NULL
+  //  when the batch did not go through the launch that has one.  d_nh: the batch's hill count on the device, or NULL)
   void (*before_wait)(void *ctx, const double *d_base_heights, const double *d_tail_h1, const double *d_tail_h2,
-                      const LimitResult *d_res, bool terms_emitted) = nullptr;
+                      const LimitResult *d_res, bool terms_emitted, const unsigned long long *ready_flag,
+                      unsigned long long ready_seq, const long long *d_nh) = nullptr;
   void *before_wait_ctx = nullptr;
+  // a record pass that will run BESIDE the batch's launch (LimitArgs::ord_ready)
+  unsigned *ord_ready = nullptr;
   bool fetch_heights = true;       // with d_h: copy the per-hill base heights back (a flush already has them)
   // optional: d_h is filled by the preparation kernel from this host-mapped array (nh doubles)
   const double *h_fetch_src = nullptr;

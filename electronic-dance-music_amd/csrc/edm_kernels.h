@@ -143,6 +143,15 @@ struct OrderedForcesArgs {
   long long hill_off;
   const long long *range_dev;
   long long k;              // hills [0, k): base height; hills >= k: the limiter's tail arrays (see HillHeights)
+  // the record pass BESIDE the hill batch's launch (another stream; see LimitArgs::ord_ready): it waits for the limiter's
+  // word `wait_seq` at `wait_flag` (the split index and the error state come with it), counts the hills in *nh_dev (the
+  // selection's count), waits for terms_ready[2 hill + part] == dirty_seq before it reads a hill's terms -- with
+  // agent-scope loads -- and leaves the batch's error state in *status for the force pass behind it
+  const unsigned long long *wait_flag;
+  unsigned long long wait_seq;
+  const long long *nh_dev;
+  const unsigned *terms_ready;
+  int *status;
   const LimitResult *res_dev;   // when set (single rank, launches queued before the host has seen the limiter's result):
                                 // nh and k are read from the limiter's device-side result, nh_cap bounds the count; a
                                 // batch the limiter refused (error != 0: nothing applied, the step is redone) counts 0 hills
@@ -491,6 +500,11 @@ struct LimitArgs {
   double *ord_terms;
   unsigned *ord_dirty;      // OrderedForcesArgs::dirty_hill
   unsigned ord_seq;
+  // ... and (ord_ready != NULL) for a record pass that runs BESIDE this launch, on another stream, instead of behind it:
+  // terms and notes leave as agent-scope stores, each emitter workgroup writes ord_seq to ord_ready[2 hill + part] once
+  // its stores are acknowledged, and the emitters are dispatched between the integrals and the gather tiles (which never
+  // go first then), so that the record pass finds them done when the limiter's word arrives
+  unsigned *ord_ready;
   // host-side, k_integrals_gather: another process runs kernels on this device (ranks sharing a GPU): the waiting
   // gather tiles are never dispatched ahead of the integrals; tiles_first_mode: -1 = the launcher's choice (memset
   // leaves 0 = integrals first, so callers set it), 0 / 1 = forced (tests)

@@ -3653,7 +3653,7 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MOD
 // follows such a hill): one word per hill holding the STEP'S NUMBER where it did -- no memset between steps, stale
 // numbers do not match.  Per hill, not one minimum: with several ranks a rank's pairs see its own slice of the list only.
 __device__ __forceinline__ void ordered_dirty_note(unsigned *dirty_hill, unsigned seq, long long hill) {
-  dirty_hill[hill] = seq;   // (every writer stores the same value)
+  publish(&dirty_hill[hill], seq);   // (every writer stores the same value; agent scope: the reader may be a launch on another stream)
 }
 // unit-height stencil terms of hill `hill` (LimitArgs::ord_terms): this workgroup's share `part` of `parts` of the
 // 2 msize + 1 stencil offsets, one (value, derivative) pair per offset -- zeros where the node lies outside the grid, a
@@ -3702,11 +3702,23 @@ __device__ __forceinline__ void ordered_emit_terms(const Geom &g, const Tables &
         }
       }
     }
-    row[o] = out;
+    if (la.ord_ready) {   // (read by a launch that runs beside this one: past this XCD's L2)
+      publish(&reinterpret_cast<double *>(row)[2 * o], out.x);
+      publish(&reinterpret_cast<double *>(row)[2 * o + 1], out.y);
+    } else {
+      row[o] = out;
+    }
   }
   if (any_nz) s_nz = 1;
+  if (la.ord_ready) __builtin_amdgcn_s_waitcnt(0);   // this wave's term stores have been acknowledged
   __syncthreads();
-  if (threadIdx.x == 0 && s_nz) ordered_dirty_note(la.ord_dirty, la.ord_seq, hill);
+  if (threadIdx.x == 0) {
+    if (s_nz) ordered_dirty_note(la.ord_dirty, la.ord_seq, hill);
+    if (la.ord_ready) {
+      __builtin_amdgcn_s_waitcnt(0);
+      publish(&la.ord_ready[ORD_EMIT_PARTS * hill + part], la.ord_seq);
+    }
+  }
 }
 
 template <bool PERB>
@@ -3717,8 +3729,15 @@ __global__ void __launch_bounds__(BLOCK) k_integrals_gather(Geom g, Tables t, do
                                                             unsigned nb_int, unsigned tiles_first, unsigned nb_emit) {
   // (the term emitters of a reference-order step: the last nb_emit workgroups of the launch, dispatched behind everybody
   //  else, waiting for nobody)
-  if (blockIdx.x >= gridDim.x - nb_emit) {
-    const unsigned e = blockIdx.x - (gridDim.x - nb_emit);
+  // (... or, with a record pass waiting for them beside this launch, LimitArgs::ord_ready: between the integrals and
+  //  the tiles -- the block index is rotated so that the rest of the kernel sees the usual order)
+  const unsigned bidx = (la.ord_ready && nb_emit)
+                            ? (blockIdx.x < nb_int ? blockIdx.x
+                                                   : (blockIdx.x < nb_int + nb_emit ? gridDim.x - nb_emit + (blockIdx.x - nb_int)
+                                                                                    : blockIdx.x - nb_emit))
+                            : blockIdx.x;
+  if (bidx >= gridDim.x - nb_emit) {
+    const unsigned e = bidx - (gridDim.x - nb_emit);
     ordered_emit_terms<PERB>(g, t, h, la, (long long)(e / ORD_EMIT_PARTS), (int)(e % ORD_EMIT_PARTS));
     return;
   }
@@ -3729,7 +3748,7 @@ __global__ void __launch_bounds__(BLOCK) k_integrals_gather(Geom g, Tables t, do
   // (host-checked against two resident workgroups per CU) they go first.
   // (`wg`: this workgroup's index in the order integrals | tiles, which the stamps and the rest of the code use)
   const unsigned ntile_all = gridDim.x - nb_emit - nb_int;
-  const unsigned wg = tiles_first ? (blockIdx.x < ntile_all ? nb_int + blockIdx.x : blockIdx.x - ntile_all) : blockIdx.x;
+  const unsigned wg = tiles_first ? (bidx < ntile_all ? nb_int + bidx : bidx - ntile_all) : bidx;
 #define EDM_STAMP(k) do { if (la.trace && threadIdx.x == 0) la.trace[(size_t)wg * 8 + (k)] = wall_clock64(); } while (0)
   EDM_STAMP(0);
   if (wg < nb_int) {
@@ -4018,6 +4037,7 @@ hipError_t launch_integrals_gather(const Geom &g, const Tables &t, double *rec, 
   const long long slots = (long long)per_cu * cu_count();
   unsigned tiles_first = ((long long)nb_tiles + 64 <= slots && (long long)nb_tiles + live + live / 4 <= slots) ? 1u : 0u;
   if (chain.shared_device) tiles_first = 0;             // integrals first: deadlock-free by construction
+  if (la.ord_ready) tiles_first = 0;                    // (a record pass on another stream shares the machine: likewise)
   if (chain.tiles_first_mode >= 0) tiles_first = chain.tiles_first_mode ? 1u : 0u;   // (tests)
   if (post.enabled) dup_ticket_tiles_1d(g, post, nb_tiles, BLOCK / 8);
   // (term emitters of a reference-order step, sized by the expected hill count like the rest of the launch)
@@ -4902,7 +4922,8 @@ static constexpr int ORD_NODES = 32, ORD_PARTS = BLOCK / ORD_NODES, ORD_CHUNK = 
 //  three dependent round trips: the densest tiles finished at 10 us; two waves list 128 hills in one pass)
 static constexpr long long ORD_MAX_HILLS = 16384;   // (sample indices in LDS: 64 KB; list counts fit 16 bits)
 // this rank's hills of the batch and the limiter's split index, wherever they are known (see OrderedForcesArgs)
-__device__ __forceinline__ void ordered_batch_counts(const OrderedForcesArgs &a, long long &off, long long &nloc, long long &k) {
+__device__ __forceinline__ void ordered_batch_counts(const OrderedForcesArgs &a, long long &off, long long &nloc, long long &k,
+                                                     bool force_pass = true) {
   off = a.range_dev ? a.range_dev[0] : a.hill_off;
   nloc = a.range_dev ? a.range_dev[1] : a.nh;
   k = a.k;
@@ -4910,6 +4931,11 @@ __device__ __forceinline__ void ordered_batch_counts(const OrderedForcesArgs &a,
     if (!a.range_dev) nloc = a.res_dev->nh;
     if (a.res_dev->error) nloc = 0;
     k = a.res_dev->k;
+  }
+  if (a.wait_flag) {   // (the record pass ran beside the hill batch: the selection's count; the split index came with the
+                       //  limiter's word, the record pass took it from there and left the error state for the force pass)
+    nloc = acquire(a.nh_dev);
+    if (force_pass && *a.status) nloc = 0;
   }
   if (nloc > a.nh_cap) nloc = a.nh_cap;
   if (nloc < 0) nloc = 0;
@@ -4966,7 +4992,7 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
   term_const<1>(g, tc);
   if (tr && threadIdx.x == 0) tr[1] = wall_clock64();
   double acc0 = 0, acc1 = 0;
-  if (in_grid && part == 0) {
+  if (in_grid && part == 0 && !a.wait_flag) {   // (beside the hill batch: the grid's step-start copy is read behind the wait below)
     const double2 r0 = reinterpret_cast<const double2 *>(a.rec0)[n];
     acc0 = r0.x;
     acc1 = r0.y;
@@ -4981,7 +5007,28 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
   // the reference's ranks see their OWN hills of the step while they walk their pairs and replay the other ranks'
   // only in post_add_hill (edm_bias.cpp:565-583)
   long long off, nloc, k_split;
-  ordered_batch_counts(a, off, nloc, k_split);
+  if (a.wait_flag) {
+    // this launch runs BESIDE the hill batch's (another stream, no event between them): everything above needed nothing
+    // of the step.  The limiter's word is waited for first -- it comes from the batch's launch, which its stream started
+    // behind the selection's: the prepared hills, their count and the grid's copy are complete, and read from here on
+    // with agent-scope loads (no line of this XCD's L2 from an earlier step); then the limiter's tail heights and the
+    // emitters' terms
+    __shared__ unsigned long long s_word;
+    if (threadIdx.x == 0) s_word = wait_for_word(a.wait_flag, a.wait_seq, false);
+    __syncthreads();
+    ordered_batch_counts(a, off, nloc, k_split, false);
+    const int state = ready_state_of(s_word);
+    const bool failed = state != EDM_READY_BELOW && (state & ~EDM_READY_FINAL) != 0;   // limiter overflow / launch bound exceeded
+    if (tile == 0 && threadIdx.x == 0) *a.status = failed ? 1 : 0;
+    if (failed) return;   // (nothing was applied and the host redoes the step: the force pass counts zero hills)
+    k_split = (state == EDM_READY_BELOW) ? nloc : (long long)ready_k_of(s_word);
+    if (in_grid && part == 0) {   // (the selection's launch wrote this step's copy)
+      acc0 = acquire(&a.rec0[2 * (long long)n]);
+      acc1 = acquire(&a.rec0[2 * (long long)n + 1]);
+    }
+  } else {
+    ordered_batch_counts(a, off, nloc, k_split, false);
+  }
   for (long long base = 0; base < nloc; base += ORD_CHUNK) {
     const int cnt = (nloc - base < ORD_CHUNK) ? (int)(nloc - base) : ORD_CHUNK;
     // waves 0 and 1: one hill of the chunk per lane
@@ -4992,20 +5039,38 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
     if (threadIdx.x < ORD_CHUNK) {
       if ((int)threadIdx.x < cnt) {
         const long long cur = off + base + threadIdx.x;   // (index in the batch's hill list)
-        c = a.hc[cur];
-        hx = a.hx[cur];
-        if (!PERB) {
-          ht0 = a.ht[2 * cur];
-          ht1 = a.ht[2 * cur + 1];
+        if (a.wait_flag) {
+          c = acquire(&a.hc[cur]);
+          hx = acquire(&a.hx[cur]);
+          if (!PERB) {
+            ht0 = acquire(&a.ht[2 * cur]);
+            ht1 = acquire(&a.ht[2 * cur + 1]);
+          }
+          a1 = a.heights ? acquire(&a.heights[cur]) : a.h_const;
+        } else {
+          c = a.hc[cur];
+          hx = a.hx[cur];
+          if (!PERB) {
+            ht0 = a.ht[2 * cur];
+            ht1 = a.ht[2 * cur + 1];
+          }
+          a1 = a.heights ? a.heights[cur] : a.h_const;
         }
-        a1 = a.heights ? a.heights[cur] : a.h_const;
         if (cur >= k_split) {
-          a1 = a.tail_h1[cur - k_split];
-          a2 = a.tail_h2[cur - k_split];
+          a1 = a.wait_flag ? acquire(&a.tail_h1[cur - k_split]) : a.tail_h1[cur - k_split];
+          a2 = a.wait_flag ? acquire(&a.tail_h2[cur - k_split]) : a.tail_h2[cur - k_split];
         }
         // (c == INT_MIN: a hill rejected at preparation -- outside a wall, gaussian_grid.h:214-216; both heights zero:
         //  a hill the limiter deferred whole)
         take = c != INT_MIN && !(a1 == 0 && a2 == 0) && images(g, 0, c, t0, t1) != 0;
+        if (take && a.terms_ready) {   // (the hill's two emitter workgroups, in the launch beside this one)
+          const unsigned long long t_spin = wall_clock64();
+          while (acquire(&a.terms_ready[ORD_EMIT_PARTS * cur]) != a.dirty_seq ||
+                 acquire(&a.terms_ready[ORD_EMIT_PARTS * cur + 1]) != a.dirty_seq) {
+            __builtin_amdgcn_s_sleep(7);
+            if (wall_clock64() - t_spin > 1000000000ull) __builtin_trap();   // 10 s at 100 MHz: never, short of a lost launch
+          }
+        }
       }
       const unsigned long long bal = __ballot(take);
       pos = __popcll(bal & ((1ull << lane) - 1ull));
@@ -5040,8 +5105,15 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
         double2 tv;
         tv.x = tv.y = 0.0;
         const int c = s_c[e];
-        if (in_grid && images(g, 0, c, n, n) != 0)
-          tv = reinterpret_cast<const double2 *>(a.terms)[(long long)s_row[e] * (2 * g.msize[0] + 1) + (ordered_offset(g, n, c) + g.msize[0])];
+        if (in_grid && images(g, 0, c, n, n) != 0) {
+          const long long at = (long long)s_row[e] * (2 * g.msize[0] + 1) + (ordered_offset(g, n, c) + g.msize[0]);
+          if (a.wait_flag) {   // (stored beside this launch: agent-scope loads, past this XCD's L2)
+            tv.x = acquire(&a.terms[2 * at]);
+            tv.y = acquire(&a.terms[2 * at + 1]);
+          } else {
+            tv = reinterpret_cast<const double2 *>(a.terms)[at];
+          }
+        }
         s_v[e][tnode] = tv.x;
         s_d[e][tnode] = tv.y;
       }
@@ -5112,9 +5184,17 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
   if (tr && threadIdx.x == 0) tr[6] = wall_clock64();
 }
 
+// One wave that waits for the limiter's word of a batch: queued ahead of a record pass that runs beside the batch's launch
+// (OrderedForcesArgs::wait_flag), it holds that pass's workgroups back -- they would wait as well, but with 70 KB of LDS
+// each on two thirds of the CUs, out of which the batch's own integrals and emitters had to stay -- until the word is
+// there (measured: the W1 step 67 us with the record pass dispatched at once, 62 behind this wave)
+__global__ void __launch_bounds__(64) k_wait_word(const unsigned long long *word, unsigned long long seq) {
+  if (threadIdx.x == 0) (void)wait_for_word(word, seq, false);
+}
 hipError_t launch_ordered_records(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s) {
   if (!ordered_forces_supported(g) || (!a.range_dev && !a.res_dev && a.nh > a.nh_cap) || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
   const unsigned nb = (unsigned)ordered_tiles(g);
+  if (a.wait_flag) hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, s, a.wait_flag, a.wait_seq);
   if (g.bper[0])
     hipLaunchKernelGGL(k_ordered_records<true>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
   else
