@@ -5184,17 +5184,35 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
   if (tr && threadIdx.x == 0) tr[6] = wall_clock64();
 }
 
-// One wave that waits for the limiter's word of a batch: queued ahead of a record pass that runs beside the batch's launch
-// (OrderedForcesArgs::wait_flag), it holds that pass's workgroups back -- they would wait as well, but with 70 KB of LDS
-// each on two thirds of the CUs, out of which the batch's own integrals and emitters had to stay -- until the word is
-// there (measured: the W1 step 67 us with the record pass dispatched at once, 62 behind this wave)
-__global__ void __launch_bounds__(64) k_wait_word(const unsigned long long *word, unsigned long long seq) {
-  if (threadIdx.x == 0) (void)wait_for_word(word, seq, false);
+// One wave that waits for the limiter's word of a batch and then for every emitter's flag: queued ahead of a record pass
+// that runs beside the batch's launch (OrderedForcesArgs::wait_flag), it holds that pass's workgroups back until
+// nothing they need is outstanding.  They would wait themselves -- but with 70 KB of LDS each on two thirds of the CUs,
+// out of which the batch's own integrals and emitters would have to stay (measured: the W1 step 67 us with the record
+// pass dispatched at once, 60 behind this wave); and a workgroup that holds LDS while it waits for workgroups that
+// still need a CU is how two tenants of one GPU can lock each other up: this wave holds nothing.
+__global__ void __launch_bounds__(64) k_wait_word(const unsigned long long *word, unsigned long long seq,
+                                                  const long long *nh_dev, long long nh_cap, const unsigned *terms_ready,
+                                                  unsigned ready_seq) {
+  __shared__ unsigned long long s_w;
+  if (threadIdx.x == 0) s_w = wait_for_word(word, seq, false);
+  __syncthreads();
+  const int state = ready_state_of(s_w);
+  if (state != EDM_READY_BELOW && (state & ~EDM_READY_FINAL) != 0) return;   // (the batch was refused: no terms are needed)
+  // (the word comes from the batch's launch, which started behind the selection's: the count is this step's)
+  long long n = acquire(nh_dev);
+  if (n > nh_cap) n = nh_cap;
+  const unsigned long long t0 = wall_clock64();
+  for (long long i = threadIdx.x; i < n * ORD_EMIT_PARTS; i += 64)
+    while (acquire(&terms_ready[i]) != ready_seq) {
+      __builtin_amdgcn_s_sleep(7);
+      if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();   // 10 s at 100 MHz: never, short of a lost launch
+    }
 }
 hipError_t launch_ordered_records(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s) {
   if (!ordered_forces_supported(g) || (!a.range_dev && !a.res_dev && a.nh > a.nh_cap) || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
   const unsigned nb = (unsigned)ordered_tiles(g);
-  if (a.wait_flag) hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, s, a.wait_flag, a.wait_seq);
+  if (a.wait_flag)
+    hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, s, a.wait_flag, a.wait_seq, a.nh_dev, a.nh_cap, a.terms_ready, a.dirty_seq);
   if (g.bper[0])
     hipLaunchKernelGGL(k_ordered_records<true>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
   else

@@ -206,3 +206,41 @@ def test_two_ranks_vs_reference_mpi_build(name, tmp_path):
         h2, n2 = _grid_file_numbers(gold)
         assert h1 == h2, "multi_write header must be byte-identical"
         close(n1, n2, rtol=0, atol=1.01e-8, what="multi_write body")
+
+
+def test_two_tenants_of_one_gpu(tmp_path):
+    """Two INDEPENDENT single-rank processes on one GPU, each running reference-order steps back to back: their record
+    passes run beside their hill batches on streams of their own and wait, in the kernel, for words and flags of their
+    own batch -- behind a one-wave gate, so that no workgroup holds LDS while it waits for workgroups that still need a
+    CU.  Neither may stall the other (no time-out, no polling fallback to the stream), and both must compute what a
+    process alone on the GPU computes, bit for bit."""
+    H.require_gpu()
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    worker = os.path.join(ROOT, "tests", "tenant_worker.py")
+    steps = 400
+
+    def run(tags):
+        procs = [subprocess.Popen([sys.executable, worker, t, str(tmp_path), str(steps)], stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True, env=env) for t in tags]
+        outs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=300)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            outs.append(o)
+        digests = []
+        for t, p, o in zip(tags, procs, outs):
+            assert p.returncode == 0, "tenant %s failed:\n%s" % (t, o[-3000:])
+            line = [ln for ln in o.splitlines() if ln.startswith("DIGEST")]
+            assert line, o[-2000:]
+            digests.append(line[-1].split()[1:])
+        return digests
+
+    alone = run(["alone"])[0]
+    pair = run(["a", "b"])
+    assert int(alone[1]) > 0
+    for d in pair:
+        assert d[0] == alone[0] and d[1] == alone[1], "a tenant computed something else than a process alone on the GPU"
