@@ -1181,8 +1181,8 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   } early_ctx{b, this_h, d_sel, nh, packed_exchange, pack_bound};
   b->ord_on_own_stream = false;
   if (b->ord_early.armed && deferred_bound && (packed_exchange || !b->comm)) {
-    if (!b->comm && spec.ord_terms && !b->bias->shared_device) {
-      // one rank with the device to itself: record and force pass on their own stream, beside the batch's launch
+    if (spec.ord_terms && !b->bias->shared_device) {
+      // a rank with the device to itself: record and force pass on their own stream, beside the batch's launch
       if (!b->ord_stream) {
         EDM_HIP_TRY(hipStreamCreateWithFlags(&b->ord_stream, hipStreamNonBlocking));
         EDM_HIP_TRY(hipEventCreateWithFlags(&b->ord_done_event, hipEventDisableTiming));
@@ -1212,7 +1212,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
         bb->last_batch.range_dev = bb->ord_range.p;
         bb->last_batch.local_cap = c->pack_bound;
       }
-      if (!c->packed && terms_emitted && ready_flag && d_nh && bb->ord_stream && bb->ord_ready.p) {
+      if (terms_emitted && ready_flag && d_nh && bb->ord_stream && bb->ord_ready.p) {
         // beside the batch's launch, behind nothing on the host's side: the record pass waits in the kernel for the
         // limiter's word of THIS batch (an event behind the preparation cost the object's stream ~5 us between the
         // selection and the batch, and the other stream ~10 us until the dependency had resolved)

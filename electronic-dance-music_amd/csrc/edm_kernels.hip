@@ -4934,7 +4934,12 @@ __device__ __forceinline__ void ordered_batch_counts(const OrderedForcesArgs &a,
   }
   if (a.wait_flag) {   // (the record pass ran beside the hill batch: the selection's count; the split index came with the
                        //  limiter's word, the record pass took it from there and left the error state for the force pass)
-    nloc = acquire(a.nh_dev);
+    if (a.range_dev) {   // (multi-GPU: this rank's slice of the global list, as k_unpack_prep left it)
+      off = acquire(&a.range_dev[0]);
+      nloc = acquire(&a.range_dev[1]);
+    } else {
+      nloc = acquire(a.nh_dev);
+    }
     if (force_pass && *a.status) nloc = 0;
   }
   if (nloc > a.nh_cap) nloc = a.nh_cap;
