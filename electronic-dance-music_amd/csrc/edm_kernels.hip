@@ -5026,7 +5026,7 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
     const bool failed = state != EDM_READY_BELOW && (state & ~EDM_READY_FINAL) != 0;   // limiter overflow / launch bound exceeded
     if (tile == 0 && threadIdx.x == 0) *a.status = failed ? 1 : 0;
     if (failed) return;   // (nothing was applied and the host redoes the step: the force pass counts zero hills)
-    k_split = (state == EDM_READY_BELOW) ? nloc : (long long)ready_k_of(s_word);
+    k_split = (state == EDM_READY_BELOW) ? off + nloc : (long long)ready_k_of(s_word);   // (indices of the batch's list: no tail)
     if (in_grid && part == 0) {   // (the selection's launch wrote this step's copy)
       acc0 = acquire(&a.rec0[2 * (long long)n]);
       acc1 = acquire(&a.rec0[2 * (long long)n + 1]);
@@ -5195,6 +5195,9 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
 // out of which the batch's own integrals and emitters would have to stay (measured: the W1 step 67 us with the record
 // pass dispatched at once, 60 behind this wave); and a workgroup that holds LDS while it waits for workgroups that
 // still need a CU is how two tenants of one GPU can lock each other up: this wave holds nothing.
+// (Letting the record pass out as soon as the emitters are done, to list and fetch terms before the word is there, was
+//  tried: the emitters finish about when the word arrives -- 10 us into the launch -- and until the parked gather tiles
+//  have run there is no LDS for a record workgroup anyway: no faster.)
 __global__ void __launch_bounds__(64) k_wait_word(const unsigned long long *word, unsigned long long seq,
                                                   const long long *nh_dev, long long nh_cap, const unsigned *terms_ready,
                                                   unsigned ready_seq) {
