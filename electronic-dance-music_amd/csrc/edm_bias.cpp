@@ -373,7 +373,11 @@ struct edm_hip_bias {
   hipStream_t ord_stream = nullptr;
   hipEvent_t ord_done_event = nullptr;
   DevBuf<unsigned> ord_ready;   // LimitArgs::ord_ready (zero-initialised like ord_dirty)
-  DevBuf<int> ord_status;       // OrderedForcesArgs::status
+  DevBuf<int> ord_status;       // OrderedForcesArgs::status: 0 fine, 1 batch refused, 2 the gate wave gave up (kernels of
+                                // different streams run one at a time) -- and the latter's host-mapped twin
+  int *h_ord_status = nullptr, *d_ord_status = nullptr;
+  bool ord_own_stream_off = false;   // ... after which the second stream is not used again by this object
+  long long ord_gate_giveups = 0;
   bool ord_on_own_stream = false;   // this step's record / force passes went to ord_stream
   unsigned ord_seq = 0;
   DevBuf<int> ord_first;
@@ -583,6 +587,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
   }
   if (b->ord_done_event) (void)hipEventDestroy(b->ord_done_event);
   b->ord_ready.release(); b->ord_status.release();
+  if (b->h_ord_status) (void)hipHostFree(b->h_ord_status);
   b->hs_r.release(); b->hs_f.release(); b->hs_x.release(); b->hs_u.release(); b->hs_mask.release();
   if (b->h_delta) (void)hipHostFree(b->h_delta);
   for (int c = 0; c < 8; c++)
@@ -1181,7 +1186,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
   } early_ctx{b, this_h, d_sel, nh, packed_exchange, pack_bound};
   b->ord_on_own_stream = false;
   if (b->ord_early.armed && deferred_bound && (packed_exchange || !b->comm)) {
-    if (spec.ord_terms && !b->bias->shared_device) {
+    if (spec.ord_terms && !b->bias->shared_device && !b->ord_own_stream_off) {
       // a rank with the device to itself: record and force pass on their own stream, beside the batch's launch
       if (!b->ord_stream) {
         EDM_HIP_TRY(hipStreamCreateWithFlags(&b->ord_stream, hipStreamNonBlocking));
@@ -1189,6 +1194,11 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
       }
       EDM_HIP_TRY(b->ord_ready.reserve_zeroed((size_t)2 * (size_t)(nh > 4096 ? nh : 4096)));
       EDM_HIP_TRY(b->ord_status.reserve_zeroed(16));
+      if (!b->h_ord_status) {
+        EDM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_ord_status), 64, hipHostMallocMapped));
+        EDM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_ord_status), b->h_ord_status, 0));
+        *reinterpret_cast<volatile int *>(b->h_ord_status) = 0;
+      }
       spec.ord_ready = b->ord_ready.p;
     }
     spec.before_wait_ctx = &early_ctx;
@@ -1212,7 +1222,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
         bb->last_batch.range_dev = bb->ord_range.p;
         bb->last_batch.local_cap = c->pack_bound;
       }
-      if (terms_emitted && ready_flag && d_nh && bb->ord_stream && bb->ord_ready.p) {
+      if (terms_emitted && ready_flag && d_nh && bb->ord_stream && bb->ord_ready.p && bb->d_ord_status && !bb->ord_own_stream_off) {
         // beside the batch's launch, behind nothing on the host's side: the record pass waits in the kernel for the
         // limiter's word of THIS batch (an event behind the preparation cost the object's stream ~5 us between the
         // selection and the batch, and the other stream ~10 us until the dependency had resolved)
@@ -1581,6 +1591,7 @@ static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
     a.nh_dev = b->last_batch.d_nh;
     a.terms_ready = b->ord_ready.p;
     a.status = b->ord_status.p;
+    a.status_host = b->d_ord_status;
   }
   a.k = b->last_batch.k;
   a.heights = b->last_batch.heights;
@@ -1682,6 +1693,28 @@ static int ordered_forces_enqueue(edm_hip_bias *b) {
   return EDM_HIP_OK;
 }
 
+// The passes on the second stream left without doing their work: their gate wave was let in ahead of the batch it waited
+// for and gave up (k_wait_word) -- something runs the process's kernels one at a time, a profiler collecting hardware
+// counters does.  The batch is through by now (the caller has waited for it): both passes again, behind it on the
+// object's stream, with a fresh tag; the second stream stays unused from here on.
+static int ordered_step_redo_after_gate(edm_hip_bias *b, int *nblk) {
+  edm_hip_gauss *g = b->bias;
+  EDM_HIP_TRY(hipStreamSynchronize(b->ord_stream));
+  EDM_HIP_TRY(hipStreamSynchronize(g->stream));
+  b->ord_on_own_stream = false;
+  b->ord_own_stream_off = true;
+  b->ord_gate_giveups++;
+  if (b->ord_early.tag) b->ord_early.tag = ++g->force_seq;
+  if (!(b->last_batch.valid && b->last_batch.nh > 0)) {
+    set_error("reference-order step: the force pass has to be queued again but the batch's record is gone");
+    return EDM_HIP_ERR_STATE;
+  }
+  int rc = ordered_forces_enqueue(b);
+  if (rc) return rc;
+  *nblk = b->ord_early.nblk;
+  return EDM_HIP_OK;
+}
+
 static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *d_r, double *d_force,
                                     const int *d_first_sample, long long n_samples, const double *d_sample_r,
                                     const double *d_runiform, double *energy) {
@@ -1737,6 +1770,11 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   if (!(tagged && poll_tagged_partials(g, nblk, tag, &e))) {
     if (b->ord_on_own_stream) EDM_HIP_TRY(hipStreamSynchronize(b->ord_stream));
     EDM_HIP_TRY(hipStreamSynchronize(s));
+    if (b->ord_on_own_stream && *reinterpret_cast<volatile int *>(b->h_ord_status) == 2) {
+      rc = ordered_step_redo_after_gate(b, &nblk);
+      if (rc) return rc;
+      EDM_HIP_TRY(hipStreamSynchronize(s));
+    }
     e = 0;
     for (int k = 0; k < nblk; k++) e += g->h_partials[tagged ? 2 * k : k];
   } else {
@@ -2295,7 +2333,8 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
   int rcf = pending_forces_flush(b->bias, &b->pending);   // (no hill launch carried it: nothing has touched the grid)
   if (rc) return rc;
   if (rcf) return rcf;
-  const int nblk = ordered ? nblk_ordered : b->pending.nblk;
+  int nblk = ordered ? nblk_ordered : b->pending.nblk;
+  int nblk_redo = -1;
   double e = 0;
   if (tag && poll_tagged_partials(b->bias, nblk, tag, &e)) {
     b->bias->polled_forces++;
@@ -2303,6 +2342,14 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     // (a polled hill batch has shown the stream past the force pass queued ahead of it)
     if (ordered && b->ord_on_own_stream) EDM_HIP_TRY(hipStreamSynchronize(b->ord_stream));
     if (tag || !b->bias->wait_polled) EDM_HIP_TRY(hipStreamSynchronize(s));
+    if (ordered && b->ord_on_own_stream && *reinterpret_cast<volatile int *>(b->h_ord_status) == 2) {
+      int nb2 = 0;
+      rc = ordered_step_redo_after_gate(b, &nb2);
+      if (rc) return rc;
+      EDM_HIP_TRY(hipStreamSynchronize(s));
+      nblk_redo = nb2;
+    }
+    if (nblk_redo >= 0) nblk = nblk_redo;
     e = 0;
     for (int k = 0; k < nblk; k++) e += b->bias->h_partials[tag ? 2 * k : k];
   }
@@ -2420,6 +2467,7 @@ int edm_hip_bias_get(const edm_hip_bias *b, const char *name, double *value) {
   G("lookup_prep_launches", b->bias ? b->bias->lookup_prep_launches : 0)
   G("bound_redos", b->bound_redos)
   G("reference_order", b->reference_order)
+  G("ord_gate_giveups", b->ord_gate_giveups)
   G("host_add_threads", b->host_add_threads)
 #undef G
   set_error(std::string("unknown EDMBias member ") + name);

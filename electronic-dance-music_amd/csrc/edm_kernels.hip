@@ -5018,13 +5018,16 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
     // behind the selection's: the prepared hills, their count and the grid's copy are complete, and read from here on
     // with agent-scope loads (no line of this XCD's L2 from an earlier step); then the limiter's tail heights and the
     // emitters' terms
+    // (the gate wave ahead of this launch gave up -- kernels of different streams are being run one at a time: leave, the
+    //  host queues this pass again behind the batch)
+    if (acquire(a.status) == 2) return;
     __shared__ unsigned long long s_word;
     if (threadIdx.x == 0) s_word = wait_for_word(a.wait_flag, a.wait_seq, false);
     __syncthreads();
     ordered_batch_counts(a, off, nloc, k_split, false);
     const int state = ready_state_of(s_word);
     const bool failed = state != EDM_READY_BELOW && (state & ~EDM_READY_FINAL) != 0;   // limiter overflow / launch bound exceeded
-    if (tile == 0 && threadIdx.x == 0) *a.status = failed ? 1 : 0;
+    if (tile == 0 && threadIdx.x == 0) publish(a.status, failed ? 1 : 0);
     if (failed) return;   // (nothing was applied and the host redoes the step: the force pass counts zero hills)
     k_split = (state == EDM_READY_BELOW) ? off + nloc : (long long)ready_k_of(s_word);   // (indices of the batch's list: no tail)
     if (in_grid && part == 0) {   // (the selection's launch wrote this step's copy)
@@ -5198,29 +5201,71 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
 // (Letting the record pass out as soon as the emitters are done, to list and fetch terms before the word is there, was
 //  tried: the emitters finish about when the word arrives -- 10 us into the launch -- and until the parked gather tiles
 //  have run there is no LDS for a record workgroup anyway: no faster.)
+// It does not wait for ever: where kernels of different streams are run one at a time (a profiler collecting hardware
+// counters serialises every queue of the process), this wave may be let in ahead of the batch it waits for, and the
+// batch then never starts.  After ORD_GATE_TICKS it writes 2 to *status and its host-mapped twin and leaves; the record and force
+// pass behind it see that and leave at once, and the host, once the batch is through, queues both again behind it
+// (edm_bias.cpp, ordered_step_finish) and stops using the second stream.
+static constexpr unsigned long long ORD_GATE_TICKS = 200000ull;   // 2 ms of the 100 MHz wall clock: 100x a healthy wait
 __global__ void __launch_bounds__(64) k_wait_word(const unsigned long long *word, unsigned long long seq,
                                                   const long long *nh_dev, long long nh_cap, const unsigned *terms_ready,
-                                                  unsigned ready_seq) {
+                                                  unsigned ready_seq, int *status, int *status_host) {
   __shared__ unsigned long long s_w;
-  if (threadIdx.x == 0) s_w = wait_for_word(word, seq, false);
+  __shared__ int s_gave_up;
+  if (threadIdx.x == 0) {
+    const unsigned long long want = seq & 0xFFFFFFFFFFull;
+    const unsigned long long t0 = wall_clock64();
+    s_gave_up = 0;
+    for (;;) {
+      const unsigned long long w = acquire(word);
+      if (ready_seq_of(w) == want) {
+        s_w = w;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(7);
+      if (wall_clock64() - t0 > ORD_GATE_TICKS) {
+        s_gave_up = 1;
+        break;
+      }
+    }
+  }
   __syncthreads();
+  if (s_gave_up) {
+    if (threadIdx.x == 0) {
+      publish(status, 2);
+      __hip_atomic_store(status_host, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
   const int state = ready_state_of(s_w);
   if (state != EDM_READY_BELOW && (state & ~EDM_READY_FINAL) != 0) return;   // (the batch was refused: no terms are needed)
   // (the word comes from the batch's launch, which started behind the selection's: the count is this step's)
   long long n = acquire(nh_dev);
   if (n > nh_cap) n = nh_cap;
   const unsigned long long t0 = wall_clock64();
-  for (long long i = threadIdx.x; i < n * ORD_EMIT_PARTS; i += 64)
+  bool late = false;
+  for (long long i = threadIdx.x; i < n * ORD_EMIT_PARTS && !late; i += 64)
     while (acquire(&terms_ready[i]) != ready_seq) {
       __builtin_amdgcn_s_sleep(7);
-      if (wall_clock64() - t0 > 1000000000ull) __builtin_trap();   // 10 s at 100 MHz: never, short of a lost launch
+      if (wall_clock64() - t0 > ORD_GATE_TICKS) {
+        late = true;
+        break;
+      }
     }
+  if (late) {
+    publish(status, 2);
+    __hip_atomic_store(status_host, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 hipError_t launch_ordered_records(const Geom &g, const Tables &t, const OrderedForcesArgs &a, hipStream_t s) {
   if (!ordered_forces_supported(g) || (!a.range_dev && !a.res_dev && a.nh > a.nh_cap) || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
   const unsigned nb = (unsigned)ordered_tiles(g);
-  if (a.wait_flag)
-    hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, s, a.wait_flag, a.wait_seq, a.nh_dev, a.nh_cap, a.terms_ready, a.dirty_seq);
+  if (a.wait_flag) {
+    // (tests: EDM_HIP_TEST_FORCE=ord_gate_giveup makes the gate wait for a word that never comes)
+    static const bool never = test_force("ord_gate_giveup");
+    hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, s, a.wait_flag, a.wait_seq + (never ? 777777ull : 0ull), a.nh_dev, a.nh_cap,
+                       a.terms_ready, a.dirty_seq, a.status, a.status_host);
+  }
   if (g.bper[0])
     hipLaunchKernelGGL(k_ordered_records<true>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
   else
@@ -5427,6 +5472,9 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
   if ((gridDim.x & 7u) == 0) run = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const long long beg = (long long)run * per_block;
   const long long end = (beg + per_block < a.n) ? beg + per_block : a.n;
+  // (the record pass ahead of this launch left without its records -- its gate gave up, see k_wait_word: leave too, without
+  //  a partial sum: the host's poll runs out, and it queues both passes again)
+  if (a.wait_flag && *a.status == 2) return;
   unsigned long long *tr = a.trace ? a.trace + (size_t)blockIdx.x * 8 : nullptr;   // (development aid: EDM_HIP_TRACE=k1o)
   if (tr && threadIdx.x == 0) tr[0] = wall_clock64();
   // ---- prologue: everything it reads from memory leaves at once (the hills' sample indices and correction flags, the
@@ -5651,6 +5699,7 @@ struct OrderedListLookup {
 __global__ void __launch_bounds__(BLOCK) k_pairlist_forces_ordered(Geom g, PairListArgs pl, OrderedForcesArgs a, DupPlan dp,
                                                                    double *__restrict__ partials) {
   extern __shared__ int s_samples[];
+  if (a.wait_flag && *a.status == 2) return;   // (as k_pair_forces_ordered)
   OrderedCommon oc;
   ordered_common_init(g, a, dp, s_samples, oc);
   OrderedListLookup ord{g, a, oc};

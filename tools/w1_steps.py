@@ -46,4 +46,4 @@ for _ in range(steps):
     step()
 H.synchronize()
 print("ordered" if ordered else "batch", "ms_per_step", (time.perf_counter() - t) / steps * 1e3,
-      "hills_added", b.get("hills_added"))
+      "hills_added", b.get("hills_added"), "gate give-ups", b.get("ord_gate_giveups"))
