@@ -712,7 +712,12 @@ def main():
     # Everything below is informational (component rates, the second quantity of the metric, the HBM-bound capture,
     # the CPU baseline).  The headline numbers are complete at this point: if an extra ever failed to finish -- the
     # multi-rank ones run collectives -- rank 0 still prints the line, marked, instead of losing the measurement.
+    gate_giveups = b.get("ord_gate_giveups")
     headline = headline_dict(args, world, npairs, elapsed, k_ms, k_launches, TIMED_EVERY, tail_us)
+    # (the reference-order step's record and force pass run on a second stream behind a gate wave that waits for the hill
+    #  batch's limiter; a gate that gave up -- kernels of different streams run one at a time, e.g. under rocprofv3 --pmc --
+    #  sends the object back to one stream for good: 0 in an ordinary run)
+    headline["second_stream_gate_giveups"] = gate_giveups
     # second quantity of the metric (BASELINE.json: "... + hill-adds/sec", target: strong scaling at 8 GPUs): the
     # all-samples hill mode, 1,048,576 hills per step in total split over the GPUs (a collective: every rank runs it);
     # part of the measured line, not of the guarded extras
