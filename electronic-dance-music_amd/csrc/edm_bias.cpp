@@ -1705,7 +1705,9 @@ static int ordered_step_redo_after_gate(edm_hip_bias *b, int *nblk) {
   b->ord_own_stream_off = true;
   b->ord_gate_giveups++;
   if (b->ord_early.tag) b->ord_early.tag = ++g->force_seq;
-  if (!(b->last_batch.valid && b->last_batch.nh > 0)) {
+  // (a batch that accepted no hill leaves a record of zero hills: the passes then read the grid's step-start copy, which
+  //  is the grid)
+  if (!b->last_batch.valid) {
     set_error("reference-order step: the force pass has to be queued again but the batch's record is gone");
     return EDM_HIP_ERR_STATE;
   }

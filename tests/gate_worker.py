@@ -13,9 +13,10 @@ import pairfix_cases as PF
 
 H.require_gpu()
 workdir = sys.argv[1]
+empty_first = len(sys.argv) > 2 and sys.argv[2] == "empty_first"   # the first step accepts no sample (uniforms of one)
 name = "w1_density"
 spec = PF.PAIRFIX[name]
-cfg = os.path.join(workdir, "gate_%s.edm" % (os.environ.get("EDM_HIP_TEST_FORCE") or "plain"))
+cfg = os.path.join(workdir, "gate_%s_%d.edm" % (os.environ.get("EDM_HIP_TEST_FORCE") or "plain", empty_first))
 with open(cfg, "w") as fh:
     fh.write(spec["cfg"] + "\nhills_filename %s.H\nhistogram_filename %s.hist\n" % (cfg, cfg))
 b = H.Bias(cfg)
@@ -26,6 +27,8 @@ last = spec["nmax"]
 for step in range(3):
     r, second, ru = PF.pairfix_inputs(name, step)
     xs, us = PF.staged_samples(r, second, ru)
+    if empty_first and step == 0:
+        us = np.ones_like(us)
     first = PF.first_calls(second)
     d_r, d_f = H.DeviceArray.from_host(r), H.DeviceArray.from_host(np.zeros(len(r)))
     d_first = H.DeviceArray.from_host(first)

@@ -169,12 +169,13 @@ def test_force_pass_does_not_depend_on_the_order_of_the_pair_array(name, workdir
         last = len(xs)
 
 
-def test_gate_wave_gives_up_and_the_step_is_finished_on_one_stream(workdir):
+@pytest.mark.parametrize("first_step", ["hills", "empty_first"])
+def test_gate_wave_gives_up_and_the_step_is_finished_on_one_stream(first_step, workdir):
     """The record pass of a single-rank step runs on a second stream behind a one-wave gate that waits, in the kernel,
     for the hill batch's limiter.  Where kernels of different streams are run one at a time (a profiler collecting
     hardware counters does that) the gate may be let in ahead of the batch and would wait for ever: it gives up after
     2 ms, the passes behind it leave, and the host queues them again behind the batch -- same numbers, and the second
-    stream stays unused from then on.  Forced here (EDM_HIP_TEST_FORCE=ord_gate_giveup, a worker process: the switch is
+    stream stays unused from then on (also when the step in question accepted no hill at all).  Forced here (EDM_HIP_TEST_FORCE=ord_gate_giveup, a worker process: the switch is
     read once per process)."""
     import subprocess
     import sys
@@ -185,8 +186,8 @@ def test_gate_wave_gives_up_and_the_step_is_finished_on_one_stream(workdir):
         env.pop("EDM_HIP_TEST_FORCE", None)
         if tag == "forced":
             env["EDM_HIP_TEST_FORCE"] = "ord_gate_giveup"
-        p = subprocess.run([sys.executable, os.path.join(root, "tests", "gate_worker.py"), str(workdir)], capture_output=True,
-                           text=True, env=env, timeout=300)
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "gate_worker.py"), str(workdir), first_step],
+                           capture_output=True, text=True, env=env, timeout=300)
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
         out[tag] = (line[1], int(line[2]))
