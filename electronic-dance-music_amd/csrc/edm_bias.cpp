@@ -1592,6 +1592,8 @@ static int ordered_records_enqueue(edm_hip_bias *b, OrderedForcesArgs *out) {
     a.terms_ready = b->ord_ready.p;
     a.status = b->ord_status.p;
     a.status_host = b->d_ord_status;
+    // (behind a collective the batch's launch starts when the slowest rank has arrived: 200 ms instead of 2)
+    a.gate_ticks = b->comm ? 20000000ull : 0ull;
   }
   a.k = b->last_batch.k;
   a.heights = b->last_batch.heights;

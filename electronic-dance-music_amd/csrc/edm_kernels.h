@@ -153,6 +153,7 @@ struct OrderedForcesArgs {
   const unsigned *terms_ready;
   int *status;
   int *status_host;   // host-mapped: the gate wave ahead of the record pass writes 2 here (and to *status) when it gives up
+  unsigned long long gate_ticks;   // ... after this many ticks of the 100 MHz wall clock (0: the default, 2 ms)
   const LimitResult *res_dev;   // when set (single rank, launches queued before the host has seen the limiter's result):
                                 // nh and k are read from the limiter's device-side result, nh_cap bounds the count; a
                                 // batch the limiter refused (error != 0: nothing applied, the step is redone) counts 0 hills

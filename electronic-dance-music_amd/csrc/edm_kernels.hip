@@ -5207,9 +5207,10 @@ __global__ void __launch_bounds__(BLOCK) k_ordered_records(Geom g, Tables t, Ord
 // pass behind it see that and leave at once, and the host, once the batch is through, queues both again behind it
 // (edm_bias.cpp, ordered_step_finish) and stops using the second stream.
 static constexpr unsigned long long ORD_GATE_TICKS = 200000ull;   // 2 ms of the 100 MHz wall clock: 100x a healthy wait
+// (with a communicator the batch sits behind a collective, which waits for the slowest rank: OrderedForcesArgs::gate_ticks)
 __global__ void __launch_bounds__(64) k_wait_word(const unsigned long long *word, unsigned long long seq,
                                                   const long long *nh_dev, long long nh_cap, const unsigned *terms_ready,
-                                                  unsigned ready_seq, int *status, int *status_host) {
+                                                  unsigned ready_seq, int *status, int *status_host, unsigned long long limit) {
   __shared__ unsigned long long s_w;
   __shared__ int s_gave_up;
   if (threadIdx.x == 0) {
@@ -5223,7 +5224,7 @@ __global__ void __launch_bounds__(64) k_wait_word(const unsigned long long *word
         break;
       }
       __builtin_amdgcn_s_sleep(7);
-      if (wall_clock64() - t0 > ORD_GATE_TICKS) {
+      if (wall_clock64() - t0 > limit) {
         s_gave_up = 1;
         break;
       }
@@ -5247,7 +5248,7 @@ __global__ void __launch_bounds__(64) k_wait_word(const unsigned long long *word
   for (long long i = threadIdx.x; i < n * ORD_EMIT_PARTS && !late; i += 64)
     while (acquire(&terms_ready[i]) != ready_seq) {
       __builtin_amdgcn_s_sleep(7);
-      if (wall_clock64() - t0 > ORD_GATE_TICKS) {
+      if (wall_clock64() - t0 > limit) {
         late = true;
         break;
       }
@@ -5264,7 +5265,7 @@ hipError_t launch_ordered_records(const Geom &g, const Tables &t, const OrderedF
     // (tests: EDM_HIP_TEST_FORCE=ord_gate_giveup makes the gate wait for a word that never comes)
     static const bool never = test_force("ord_gate_giveup");
     hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, s, a.wait_flag, a.wait_seq + (never ? 777777ull : 0ull), a.nh_dev, a.nh_cap,
-                       a.terms_ready, a.dirty_seq, a.status, a.status_host);
+                       a.terms_ready, a.dirty_seq, a.status, a.status_host, a.gate_ticks ? a.gate_ticks : ORD_GATE_TICKS);
   }
   if (g.bper[0])
     hipLaunchKernelGGL(k_ordered_records<true>, dim3(nb), dim3(BLOCK), 0, s, g, t, a);
