@@ -1749,6 +1749,13 @@ static int pair_step_ordered_device(edm_hip_bias *b, long long n, const double *
   bool tagged = false;
   const unsigned long long tag = b->ord_early.tag;   // (a redone step has taken a fresh one)
   if (b->ord_early.done) {
+    // (the batch's deferred log lines -- positions and per-hill bias from the read-back region -- are picked up NOW, while
+    //  the record and force pass run: at the start of the next cycle, where they would be fetched otherwise, they sit in
+    //  front of its first launch, ~2 us)
+    rc = resolve_deferred_log(b);
+    if (rc) return rc;
+  }
+  if (b->ord_early.done) {
     // (the force pass went out behind the hill batch, before the host had the limiter's result)
     if (b->ord_early.rc) return b->ord_early.rc;
     nblk = b->ord_early.nblk;
@@ -2318,6 +2325,10 @@ int edm_hip_bias_pair_list_step(edm_hip_bias *b, int nlocal, int itype, int jtyp
     }
     tag = b->ord_early.tag;   // (a step redone after an exceeded launch bound has taken a fresh one)
     a.partial_tag = tag;
+    if (b->ord_early.done) {
+      int rcl = resolve_deferred_log(b);   // (while the force pass runs, see pair_step_ordered_device)
+      if (rcl) return rcl;
+    }
     if (b->ord_early.done) {
       if (b->ord_early.rc) return b->ord_early.rc;
       nblk_ordered = b->ord_early.nblk;
