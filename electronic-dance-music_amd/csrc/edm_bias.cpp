@@ -557,7 +557,13 @@ static int resolve_deferred_log(edm_hip_bias *b) {
     e.added = added[(size_t)i];
     e.cum_over_volume = b->deferred_log.cum_over_volume;
   }
-  b->hills.submit(ev);
+  // (called between two cycles there is nothing ahead of these lines; called inside the cycle that deferred them -- the
+  //  reference-order step does, while its force pass runs -- the cycle's earlier events, an overflow flush's lines, are
+  //  still waiting for post_add_hill and go first)
+  if (b->hill_events.empty())
+    b->hills.submit(ev);
+  else
+    b->hill_events.insert(b->hill_events.end(), ev.begin(), ev.end());
   return EDM_HIP_OK;
 }
 
