@@ -61,7 +61,9 @@ typedef struct edm_hip_bias edm_hip_bias;   /* EDMBias controller */
  * the handle's own stream and on the null stream (blocking streams: hipMemcpy, edm_hip_memcpy_*, kernels launched on
  * stream 0), which is what every consumer in this repository is.  A consumer on a stream of its own created with
  * hipStreamNonBlocking (Kokkos-style), a peer GPU, or the host reading through a mapping must call
- * edm_hip_bias_wait() / edm_hip_gauss_wait() first: they wait for everything the object has queued. */
+ * edm_hip_bias_wait() / edm_hip_gauss_wait() first: they wait for everything the object has queued.
+ * (The reference-order pair step computes its forces on a second stream of the object, beside the hill batch; the
+ * object's own stream is made to wait for that pass before the call returns control of it, so the same holds.) */
 
 int edm_hip_gauss_wait(edm_hip_gauss *g);
 /* Diagnostic: the completion protocol above (relaxed system-scope stores into host-mapped memory, s_waitcnt(0), a
