@@ -5621,9 +5621,261 @@ __global__ void __launch_bounds__(BLOCK) k_pair_forces_ordered(Geom g, OrderedFo
   }
 }
 
+// The force pass for LONG pair arrays (>= PAIR_LDS_THRESHOLD pairs), K1's own layout: one workgroup of 1024 threads per CU,
+// a window of the grid in LDS -- here the window holds the node records as they stood behind the first m hills, m = the
+// hill count of the pairs being looked up.  A workgroup owns a contiguous run of pairs; sample indices ascend with the
+// pair index in the fix's list, so the run's hill counts are a handful of consecutive values m = row0 .. row1 and the
+// pairs of one value are contiguous: per value the window is staged once (from the running records, through the
+// counts: ~125 KB of L2 reads) and every thread walks on through its own pairs -- pair t, t + 1024, ... -- until it
+// meets one of a later value, where it waits for that pass.  Pairs the scheme does not cover -- a sample index outside the
+// run's ends (an array that does not ascend), a corner outside the window, the reference's mirrored blend -- take the
+// general form with the records read from memory, like the short-array kernel's rare cases.  With two random 128-byte
+// lines per pair out of a 2.5 MB table the short-array kernel is bound by L1 line fills at this size: 402 us for the
+// 38.8 M pairs of W2, 0.19 of the HBM roofline.
+static constexpr int ORD_WIN_HILLS = 2048;                                              // sample indices staged in LDS
+static constexpr int ORD_WIN_NODES = (163840 - 256 - ORD_WIN_HILLS * 4 - 64) / 16;      // 9708 nodes
+// one pair of the window form: from the window if its hill count is the staged one and its cell lies inside, else the
+// general form
+struct OrderedWin {
+  const double2 *win;   // LDS
+  int w0, wn, m;
+  double lo_ok, hi_open, eps;
+};
+__device__ __forceinline__ bool ordered_win_pair(const Geom &g, const OrderedCommon &oc, const OrderedWin &W, double x, bool staged,
+                                                 double &v, double &d) {
+  // straight-line (predicated) like K1's pair_one, so that a thread's two lookups interleave.  Returns whether the pair
+  // has to take the general form instead: a hill count that is not the staged one, a cell outside the window, `where`
+  // off by an ulp at a node (the reference's mirrored blend)
+  const bool in_range = (x >= W.lo_ok) & (x < W.hi_open);
+  const double q = (x - g.min[0]) * oc.inv_dx;
+  double fq = floor(q);
+  const double frac = q - fq;
+  const bool near = in_range & ((frac <= W.eps) | (frac >= 1.0 - W.eps));
+  if (wave_any(near)) {
+    if (near) fq = floor((x - g.min[0]) / g.dx[0]);
+  }
+  int idx = (int)fq;
+  idx = idx < 0 ? 0 : idx;
+  idx = idx > g.n[0] - 2 ? g.n[0] - 2 : idx;
+  const double where = x - g.min[0] - fq * g.dx[0];
+  const double X = where * oc.inv_dx;
+  const int li = idx - W.w0;
+  const bool inw = (unsigned)li < (unsigned)(W.wn - 1);   // 0 <= li and idx + 1 inside the window, in one comparison
+  const int lc = inw ? li : 0;
+  const double2 ra = W.win[lc], rb = W.win[lc + 1];
+  double vv, dd;
+  hermite_1d_horner(ra.x, ra.y, rb.x, rb.y, X, oc.inv_dx, vv, dd);
+  v = in_range ? vv : 0.0;
+  d = in_range ? dd : 0.0;
+  return !staged | (in_range & (!inw | (X < 0.0) | (X > 1.0)));
+}
+__global__ void __launch_bounds__(FAST_BLOCK) k_pair_forces_ordered_win(Geom g, OrderedForcesArgs a, DupPlan dp,
+                                                                        double *__restrict__ block_energy,
+                                                                        unsigned long long tag, long long per_block, int w0,
+                                                                        int wn) {
+  extern __shared__ double2 lds_win[];
+  if (a.wait_flag && *a.status == 2) return;   // (as k_pair_forces_ordered)
+  double *red = reinterpret_cast<double *>(lds_win);   // first 256 B: reduction scratch
+  double2 *win = lds_win + 16;
+  int *s_samples = reinterpret_cast<int *>(lds_win + 16 + wn);
+  __shared__ int s_fd;
+  // (per_block is even: a thread takes two neighbouring pairs per trip, 16 bytes of distances in, 16 bytes of forces out)
+  const long long beg = (long long)blockIdx.x * per_block;
+  const long long end = (beg + per_block < a.n) ? beg + per_block : a.n;
+  const long long end2 = beg < end ? beg + ((end - beg) & ~1LL) : beg;   // the run's whole twos end here; an odd last pair goes alone
+  const bool has_fs = a.first_sample != nullptr;
+  typedef double vd2 __attribute__((ext_vector_type(2)));
+  typedef int vi2 __attribute__((ext_vector_type(2)));
+  const vd2 *r2 = reinterpret_cast<const vd2 *>(a.r);
+  const vi2 *f2 = reinterpret_cast<const vi2 *>(has_fs ? a.first_sample : reinterpret_cast<const int *>(a.r));
+  vd2 *o2 = reinterpret_cast<vd2 *>(a.force);
+  long long i = beg + 2 * (long long)threadIdx.x;     // first pair of this thread's next two
+  const long long last2 = end2 > beg ? end2 - 2 : beg;
+  vd2 x_next = {0.0, 0.0};
+  vi2 fs_next = {0, 0};
+  if (beg < end2) {
+    const long long j = (i < end2 ? i : last2) >> 1;
+    x_next = r2[j];
+    fs_next = f2[j];
+  }
+  long long fs0 = 0, fs1 = -1;
+  if (beg < end) {
+    fs0 = has_fs ? (long long)a.first_sample[beg] : 2 * beg;
+    fs1 = has_fs ? (long long)a.first_sample[end - 1] : 2 * (end - 1);
+  }
+  OrderedCommon oc;
+  {
+    long long off, nloc, k_split;
+    ordered_batch_counts(a, off, nloc, k_split);
+    oc.H = (int)nloc;
+    int my_first = INT_MAX;
+    for (int k = threadIdx.x; k < oc.H; k += FAST_BLOCK) {
+      s_samples[k] = a.sel ? (int)a.sel[k] : k;
+      if (a.dirty_hill[off + k] == a.dirty_seq && k < my_first) my_first = k;
+    }
+    if (threadIdx.x == 0) s_fd = INT_MAX;
+    __syncthreads();
+    if (my_first != INT_MAX) atomicMin(&s_fd, my_first);
+    oc.samples = s_samples;
+    oc.ntiles = (g.n[0] + ORD_NODES - 1) / ORD_NODES;
+    oc.lo_t = oc.lo_s = oc.hi_t = oc.hi_s = -1;
+    if (!g.bper[0]) {   // duplicate_boundary_lanes' cases 0 and 3 in one dimension
+      if (dp.lo[0] > 0 && dp.lo[0] < (unsigned long long)g.n[0]) {
+        oc.lo_t = (int)dp.lo[0] - 1;
+        oc.lo_s = (int)dp.lo[0];
+      }
+      if (dp.hi[0] + 1 < (unsigned long long)g.n[0]) {
+        oc.hi_t = (int)dp.hi[0] + 1;
+        oc.hi_s = (int)dp.hi[0];
+      }
+    }
+    oc.fast = true;   // (the launcher took this kernel for an interpolating, non-periodic 1-D grid)
+    oc.inv_dx = 1.0 / g.dx[0];
+    __syncthreads();
+    oc.first_dirty = s_fd;
+  }
+  int row0 = 0, row1 = -1;
+  if (beg < end) {
+    row0 = ordered_hills_before(oc, fs0);
+    row1 = ordered_hills_before(oc, fs1, row0);
+  }
+  OrderedWin W;
+  W.win = win;
+  W.w0 = w0;
+  W.wn = wn;
+  W.lo_ok = fmax(g.bmin[0], g.min[0]);
+  W.hi_open = fmin(nextafter(g.bmax[0], 1.0e308), g.max[0] - g.dx[0]);
+  W.eps = 1e-11 * fmax(1.0, (double)g.n[0]);
+  double e_acc = 0;
+  for (int m = row0; m <= row1; m++) {
+    // the window behind the first m hills: (value, scaled slope) per node, the boundary duplication applied
+    {
+      // (a node is count -> record, two dependent loads: all of a thread's counts are requested before its first
+      //  record, all records before the first is used -- one node after the other this took ~19 us per window)
+      constexpr int PER = 5;   // (nodes per thread and batch: ten at once cost 40 registers the loop below needs)
+      const unsigned short *row = a.counts + (long long)m * oc.ntiles;
+      const double2 *rec0 = reinterpret_cast<const double2 *>(a.rec0);
+      const double2 *recs = reinterpret_cast<const double2 *>(a.records);
+      for (int k0 = 0; k0 < wn; k0 += PER * FAST_BLOCK) {
+        int u[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+          const int k = k0 + threadIdx.x + q * FAST_BLOCK;
+          u[q] = k < wn ? (int)row[(w0 + k) >> 5] : 0;
+        }
+        double2 r[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+          const int k = k0 + threadIdx.x + q * FAST_BLOCK;
+          const int node = w0 + (k < wn ? k : 0);
+          const int tile = node >> 5;
+          r[q] = u[q] ? recs[((long long)tile * a.nh_cap + (u[q] - 1)) * ORD_NODES + (node & (ORD_NODES - 1))] : rec0[node];
+        }
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+          const int k = k0 + threadIdx.x + q * FAST_BLOCK;
+          if (k < wn) {
+            r[q].y = scaled_slope(r[q].x, r[q].y, g.dx[0]);
+            win[k] = r[q];
+          }
+        }
+      }
+      __syncthreads();
+      // (outward copy nodes of the boundary duplication: their value is their source's from the first hill with a
+      //  non-zero correction on -- two nodes, through the general source)
+      if (threadIdx.x < 2) {
+        const int node = threadIdx.x == 0 ? oc.lo_t : oc.hi_t;
+        if (node >= w0 && node < w0 + wn) {
+          const OrderedSource src{a, oc, m};
+          double2 t = src.get(node);
+          t.y = scaled_slope(t.x, t.y, g.dx[0]);
+          win[node - w0] = t;
+        }
+      }
+    }
+    __syncthreads();
+    W.m = m;
+    while (i < end2) {
+      const vd2 x = x_next;
+      const long long fa = has_fs ? (long long)fs_next.x : 2 * i, fb = has_fs ? (long long)fs_next.y : 2 * (i + 1);
+      const bool in_a = (fa >= fs0) & (fa <= fs1), in_b = (fb >= fs0) & (fb <= fs1);
+      const int ma = ordered_hills_before(oc, fa, in_a ? row0 : 0, in_a ? row1 : oc.H);
+      if (in_a && ma > m) break;   // (a later pass's pairs: their window is not staged yet)
+      const int mb = ordered_hills_before(oc, fb, in_b ? row0 : 0, in_b ? row1 : oc.H);
+      {
+        const long long j = ((i + 2 * FAST_BLOCK < end2) ? i + 2 * FAST_BLOCK : last2) >> 1;
+        x_next = r2[j];
+        fs_next = f2[j];
+      }
+      double va, da, vb, db;
+      const bool ga = ordered_win_pair(g, oc, W, x.x, in_a && ma == m, va, da);
+      // (the second of the two may already be behind the next hill -- one such two per hill and run: the general form)
+      const bool gb = ordered_win_pair(g, oc, W, x.y, in_b && mb == m, vb, db);
+      if (wave_any(ga | gb)) {
+        if (ga) ordered_lookup_m(g, a, oc, x.x, ma, va, da);
+        if (gb) ordered_lookup_m(g, a, oc, x.y, mb, vb, db);
+      }
+      e_acc += va;
+      e_acc += vb;
+      vd2 out;
+      out.x = 0.0 - da;
+      out.y = 0.0 - db;
+      o2[i >> 1] = out;
+      i += 2 * FAST_BLOCK;
+    }
+    __syncthreads();   // (everybody is through with this window before it is overwritten)
+  }
+  // (twos no pass took -- none, unless the array does not ascend -- and the run's odd last pair)
+  for (; i < end2; i += 2 * FAST_BLOCK)
+    for (int q = 0; q < 2; q++) {
+      const long long p = i + q;
+      const long long fs = has_fs ? (long long)a.first_sample[p] : 2 * p;
+      double v, d;
+      ordered_lookup_m(g, a, oc, a.r[p], ordered_hills_before(oc, fs), v, d);
+      e_acc += v;
+      a.force[p] = 0.0 - d;
+    }
+  if (beg < end && end2 < end && threadIdx.x == 0) {
+    const long long p = end - 1;
+    const long long fs = has_fs ? (long long)a.first_sample[p] : 2 * p;
+    double v, d;
+    ordered_lookup_m(g, a, oc, a.r[p], ordered_hills_before(oc, fs), v, d);
+    e_acc += v;
+    a.force[p] = 0.0 - d;
+  }
+  const double sum = block_sum(e_acc, red);
+  if (threadIdx.x == 0) {
+    if (tag) store_partial_tagged(block_energy, blockIdx.x, sum, tag);
+    else block_energy[blockIdx.x] = sum;
+  }
+}
+
 hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a, double *scratch, hipStream_t s,
                                       int *blocks_out, unsigned long long tag, hipEvent_t ev0, hipEvent_t ev1) {
   if (!ordered_forces_supported(g) || a.nh_cap > ORD_MAX_HILLS) return hipErrorInvalidValue;
+  // long arrays: the LDS-window form (see k_pair_forces_ordered_win), where a workgroup's run of pairs spans few hills
+  static const bool win_env = !test_force("no_k1o_window");   // (tests: the short-array kernel on long arrays too)
+  // (hills per workgroup's run: a pass and ~125 KB of window each -- 2048 hills over 256 runs are nine passes of a few
+  //  microseconds beside a run's 100+ us of lookups)
+  if (win_env && a.n >= PAIR_LDS_THRESHOLD && pair_fast_path(g) && a.nh_cap <= ORD_WIN_HILLS) {
+    const int blocks = cu_count();
+    const long long per_block = (((a.n + blocks - 1) / blocks) + 1) & ~1LL;   // (even: two pairs per thread and trip)
+    const int wn = g.n[0] < ORD_WIN_NODES ? g.n[0] : ORD_WIN_NODES;
+    const int w0 = g.n[0] - wn;   // top-aligned: pair distances populate the upper range
+    const size_t lds = 256 + (size_t)wn * 16 + (size_t)ORD_WIN_HILLS * 4;
+    static bool attr_win = false;
+    if (!attr_win) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair_forces_ordered_win),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 256 + ORD_WIN_NODES * 16 + ORD_WIN_HILLS * 4);
+      if (e != hipSuccess) return e;
+      attr_win = true;
+    }
+    const DupPlan dpw = make_dup_plan(g);
+    EDM_LAUNCH_TIMED(k_pair_forces_ordered_win, dim3((unsigned)blocks), dim3(FAST_BLOCK), lds, s, ev0, ev1, g, a, dpw, scratch, tag,
+                     per_block, w0, wn);
+    if (blocks_out) *blocks_out = blocks;
+    return hipGetLastError();
+  }
   // four pairs per thread: 17.8 us per 1 M pairs; two or one (more workgroups, each paying the prologue that stages the
   // hills' sample indices and its rows of the counts) 20.7 us; fewer, fatter workgroups (2 / 1 per CU) 22 / 33 us
   // (after the lean form: 2 / 4 / 8 / 16 pairs per thread = 20.1 / 15.8 / 15.3 / 18.8 us per 1 M pairs)

@@ -195,6 +195,32 @@ def test_gate_wave_gives_up_and_the_step_is_finished_on_one_stream(first_step, w
     assert out["plain"][0] == out["forced"][0], "the step finished on one stream must give the same energies and forces"
 
 
+def test_long_pair_arrays_take_the_lds_window_form(workdir):
+    """Two million pairs: the force pass keeps a window of the running records in LDS (k_pair_forces_ordered_win, K1's
+    layout for long arrays).  Same forces, bit for bit, as the short-array kernel on the same array (forced by
+    EDM_HIP_TEST_FORCE=no_k1o_window in a worker process), with walls inside the grid, pairs outside the window and
+    outside the walls -- and as the same pairs in shuffled order, which the window form hands to the general form one
+    by one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, token, extra in (("window", None, []), ("short", "no_k1o_window", []), ("shuffled", None, ["shuffled"])):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("EDM_HIP_TEST_FORCE", None)
+        if token:
+            env["EDM_HIP_TEST_FORCE"] = token
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "k1o_window_worker.py"), str(workdir)] + extra,
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+        out[tag] = (line[1], [float(v) for v in line[2:4]], int(line[4]))
+    assert out["window"][2] > 100
+    for other in ("short", "shuffled"):
+        assert out[other][0] == out["window"][0], "forces of the %s run differ from the window form's" % other
+        close(out[other][1], out["window"][1], rtol=1e-12, atol=0, what="energies (another summation order)")
+
+
 def test_write_deviation_report():
     """(runs last in this module) the measured deviation of the fast mode, for INTEGRATION.md"""
     if not DEVIATION:
