@@ -5857,6 +5857,7 @@ hipError_t launch_pair_forces_ordered(const Geom &g, const OrderedForcesArgs &a,
   static const bool win_env = !test_force("no_k1o_window");   // (tests: the short-array kernel on long arrays too)
   // (hills per workgroup's run: a pass and ~125 KB of window each -- 2048 hills over 256 runs are nine passes of a few
   //  microseconds beside a run's 100+ us of lookups)
+  // (at W1's 1 M pairs the window form is slower: the step 71 against 59 us -- K1's own break-even is ~1.5 M pairs too)
   if (win_env && a.n >= PAIR_LDS_THRESHOLD && pair_fast_path(g) && a.nh_cap <= ORD_WIN_HILLS) {
     const int blocks = cu_count();
     const long long per_block = (((a.n + blocks - 1) / blocks) + 1) & ~1LL;   // (even: two pairs per thread and trip)
