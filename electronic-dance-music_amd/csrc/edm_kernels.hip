@@ -5691,12 +5691,15 @@ __global__ void __launch_bounds__(FAST_BLOCK) k_pair_forces_ordered_win(Geom g, 
   vd2 *o2 = reinterpret_cast<vd2 *>(a.force);
   long long i = beg + 2 * (long long)threadIdx.x;     // first pair of this thread's next two
   const long long last2 = end2 > beg ? end2 - 2 : beg;
-  vd2 x_next = {0.0, 0.0};
-  vi2 fs_next = {0, 0};
+  constexpr long long S = 2 * FAST_BLOCK;   // a thread's next two pairs lie S pairs on
+  vd2 x_next = {0.0, 0.0}, xb_next = {0.0, 0.0};
+  vi2 fs_next = {0, 0}, fb_next = {0, 0};
   if (beg < end2) {
-    const long long j = (i < end2 ? i : last2) >> 1;
-    x_next = r2[j];
-    fs_next = f2[j];
+    const long long j = (i < end2 ? i : last2) >> 1, jb = (i + S < end2 ? i + S : last2) >> 1;
+    x_next = __builtin_nontemporal_load(&r2[j]);
+    fs_next = __builtin_nontemporal_load(&f2[j]);
+    xb_next = __builtin_nontemporal_load(&r2[jb]);
+    fb_next = __builtin_nontemporal_load(&f2[jb]);
   }
   long long fs0 = 0, fs1 = -1;
   if (beg < end) {
@@ -5757,11 +5760,16 @@ __global__ void __launch_bounds__(FAST_BLOCK) k_pair_forces_ordered_win(Geom g, 
       const double2 *rec0 = reinterpret_cast<const double2 *>(a.rec0);
       const double2 *recs = reinterpret_cast<const double2 *>(a.records);
       for (int k0 = 0; k0 < wn; k0 += PER * FAST_BLOCK) {
+        // (behind the run's first hill count only the tiles the next hill reached change -- a tenth of them: the others'
+        //  counts are what they were, and so are their nodes in the window)
         int u[PER];
+        bool changed[PER];
 #pragma unroll
         for (int q = 0; q < PER; q++) {
           const int k = k0 + threadIdx.x + q * FAST_BLOCK;
-          u[q] = k < wn ? (int)row[(w0 + k) >> 5] : 0;
+          const int tile = (w0 + (k < wn ? k : 0)) >> 5;
+          u[q] = k < wn ? (int)row[tile] : 0;
+          changed[q] = k < wn && (m == row0 || u[q] != (int)row[tile - oc.ntiles]);
         }
         double2 r[PER];
 #pragma unroll
@@ -5769,12 +5777,14 @@ __global__ void __launch_bounds__(FAST_BLOCK) k_pair_forces_ordered_win(Geom g, 
           const int k = k0 + threadIdx.x + q * FAST_BLOCK;
           const int node = w0 + (k < wn ? k : 0);
           const int tile = node >> 5;
-          r[q] = u[q] ? recs[((long long)tile * a.nh_cap + (u[q] - 1)) * ORD_NODES + (node & (ORD_NODES - 1))] : rec0[node];
+          r[q].x = r[q].y = 0.0;
+          if (changed[q])
+            r[q] = u[q] ? recs[((long long)tile * a.nh_cap + (u[q] - 1)) * ORD_NODES + (node & (ORD_NODES - 1))] : rec0[node];
         }
 #pragma unroll
         for (int q = 0; q < PER; q++) {
           const int k = k0 + threadIdx.x + q * FAST_BLOCK;
-          if (k < wn) {
+          if (changed[q]) {
             r[q].y = scaled_slope(r[q].x, r[q].y, g.dx[0]);
             win[k] = r[q];
           }
@@ -5795,38 +5805,77 @@ __global__ void __launch_bounds__(FAST_BLOCK) k_pair_forces_ordered_win(Geom g, 
     }
     __syncthreads();
     W.m = m;
+    const long long lo_s = m > 0 ? (long long)oc.samples[m - 1] : LLONG_MIN, hi_s = m < oc.H ? (long long)oc.samples[m] : LLONG_MAX;
+    // two twos per trip -- pairs (i, i + 1) and (i + S, i + S + 1), four lookups in flight like K1 -- with the next two
+    // twos' distances and sample indices requested a trip ahead
     while (i < end2) {
-      const vd2 x = x_next;
-      const long long fa = has_fs ? (long long)fs_next.x : 2 * i, fb = has_fs ? (long long)fs_next.y : 2 * (i + 1);
-      const bool in_a = (fa >= fs0) & (fa <= fs1), in_b = (fb >= fs0) & (fb <= fs1);
-      const int ma = ordered_hills_before(oc, fa, in_a ? row0 : 0, in_a ? row1 : oc.H);
-      if (in_a && ma > m) break;   // (a later pass's pairs: their window is not staged yet)
-      const int mb = ordered_hills_before(oc, fb, in_b ? row0 : 0, in_b ? row1 : oc.H);
+      const bool has_b = i + S < end2;
+      const vd2 xa = x_next, xb = xb_next;
+      const vi2 ia = fs_next, ib = fb_next;
+      const long long fa0 = has_fs ? (long long)ia.x : 2 * i, fa1 = has_fs ? (long long)ia.y : 2 * (i + 1);
+      const long long fb0 = has_fs ? (long long)ib.x : 2 * (i + S), fb1 = has_fs ? (long long)ib.y : 2 * (i + S + 1);
+      // a pair's hill count is the staged m iff its sample index lies in (sample index of hill m - 1, that of hill m]:
+      // two comparisons, no search; beyond the upper end it belongs to a later pass, below the lower one (an array
+      // that does not ascend) it takes the general form, which searches the whole list
+      if (fa0 > hi_s) break;   // (a later pass's pairs: their window is not staged yet)
+      const bool st_a0 = (fa0 > lo_s) & (fa0 <= hi_s), st_a1 = (fa1 > lo_s) & (fa1 <= hi_s);
+      const bool st_b0 = (fb0 > lo_s) & (fb0 <= hi_s), st_b1 = (fb1 > lo_s) & (fb1 <= hi_s);
+      const bool b_now = has_b && !(fb0 > hi_s);   // (the second two may have to wait for a later pass)
+      vd2 nxa, nxb;
+      vi2 nfa, nfb;
       {
-        const long long j = ((i + 2 * FAST_BLOCK < end2) ? i + 2 * FAST_BLOCK : last2) >> 1;
-        x_next = r2[j];
-        fs_next = f2[j];
+        const long long ja = ((i + 2 * S < end2) ? i + 2 * S : last2) >> 1, jb = ((i + 3 * S < end2) ? i + 3 * S : last2) >> 1;
+        nxa = __builtin_nontemporal_load(&r2[ja]);   // (streamed once, like K1's)
+        nfa = __builtin_nontemporal_load(&f2[ja]);
+        nxb = __builtin_nontemporal_load(&r2[jb]);
+        nfb = __builtin_nontemporal_load(&f2[jb]);
       }
-      double va, da, vb, db;
-      const bool ga = ordered_win_pair(g, oc, W, x.x, in_a && ma == m, va, da);
-      // (the second of the two may already be behind the next hill -- one such two per hill and run: the general form)
-      const bool gb = ordered_win_pair(g, oc, W, x.y, in_b && mb == m, vb, db);
-      if (wave_any(ga | gb)) {
-        if (ga) ordered_lookup_m(g, a, oc, x.x, ma, va, da);
-        if (gb) ordered_lookup_m(g, a, oc, x.y, mb, vb, db);
+      double va0, da0, va1, da1, vb0 = 0.0, db0 = 0.0, vb1 = 0.0, db1 = 0.0;
+      const bool ga0 = ordered_win_pair(g, oc, W, xa.x, st_a0, va0, da0);
+      // (the second of a two may already be behind the next hill -- one such two per hill and run: the general form)
+      const bool ga1 = ordered_win_pair(g, oc, W, xa.y, st_a1, va1, da1);
+      bool gb0 = false, gb1 = false;
+      if (b_now) {
+        gb0 = ordered_win_pair(g, oc, W, xb.x, st_b0, vb0, db0);
+        gb1 = ordered_win_pair(g, oc, W, xb.y, st_b1, vb1, db1);
       }
-      e_acc += va;
-      e_acc += vb;
+      if (wave_any(ga0 | ga1 | gb0 | gb1)) {
+        // (the general form searches the hills' sample indices itself: the pair's count may be any)
+        if (ga0) ordered_lookup(g, a, oc, xa.x, fa0, va0, da0);
+        if (ga1) ordered_lookup(g, a, oc, xa.y, fa1, va1, da1);
+        if (gb0) ordered_lookup(g, a, oc, xb.x, fb0, vb0, db0);
+        if (gb1) ordered_lookup(g, a, oc, xb.y, fb1, vb1, db1);
+      }
+      e_acc += va0;
+      e_acc += va1;
       vd2 out;
-      out.x = 0.0 - da;
-      out.y = 0.0 - db;
-      o2[i >> 1] = out;
-      i += 2 * FAST_BLOCK;
+      out.x = 0.0 - da0;
+      out.y = 0.0 - da1;
+      __builtin_nontemporal_store(out, &o2[i >> 1]);
+      if (b_now) {
+        e_acc += vb0;
+        e_acc += vb1;
+        out.x = 0.0 - db0;
+        out.y = 0.0 - db1;
+        __builtin_nontemporal_store(out, &o2[(i + S) >> 1]);
+        i += 2 * S;
+        x_next = nxa;
+        fs_next = nfa;
+        xb_next = nxb;
+        fb_next = nfb;
+      } else {
+        i += S;           // (the second two becomes the next trip's first: now, or in the pass it waits for)
+        x_next = xb;
+        fs_next = ib;
+        xb_next = nxa;
+        fb_next = nfa;
+        if (has_b) break;
+      }
     }
     __syncthreads();   // (everybody is through with this window before it is overwritten)
   }
   // (twos no pass took -- none, unless the array does not ascend -- and the run's odd last pair)
-  for (; i < end2; i += 2 * FAST_BLOCK)
+  for (; i < end2; i += S)
     for (int q = 0; q < 2; q++) {
       const long long p = i + q;
       const long long fs = has_fs ? (long long)a.first_sample[p] : 2 * p;
