@@ -869,7 +869,8 @@ def main():
             if l3:
                 a3 = BYTES_PER_EVAL * n2 / (ms3 / l3 * 1e-3) / 1e9
                 roof_w2["reference_order"] = dict(
-                    kernel="k_pair_forces_ordered", kernel_ms=ms3 / l3, achieved=a3, frac=a3 / HBM_PEAK_GBS, unit="GB/s",
+                    kernel="k_pair_forces_ordered_win (the LDS-window form long arrays take)", kernel_ms=ms3 / l3, achieved=a3,
+                    frac=a3 / HBM_PEAK_GBS, unit="GB/s",
                     bytes_per_launch=BYTES_PER_EVAL * n2,
                     note="16 B per pair as above; the pass also reads a 4-byte sample index per pair and the hills' records")
             del d_first2
