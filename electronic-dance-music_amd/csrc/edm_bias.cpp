@@ -372,6 +372,10 @@ struct edm_hip_bias {
   // (OrderedForcesArgs::wait_flag), not for the launch's end -- the gather tiles' half of it is nothing it needs
   hipStream_t ord_stream = nullptr;
   hipEvent_t ord_done_event = nullptr;
+  // (host-array entry: recorded behind the uploads it queued on the object's stream; the second stream's gate wave is
+  //  held back until they are through -- its 2 ms are for the step's kernels, not for 29 MB over PCIe ahead of them)
+  hipEvent_t ord_up_event = nullptr;
+  bool ord_wait_uploads = false;
   DevBuf<unsigned> ord_ready;   // LimitArgs::ord_ready (zero-initialised like ord_dirty)
   DevBuf<int> ord_status;       // OrderedForcesArgs::status: 0 fine, 1 batch refused, 2 the gate wave gave up (kernels of
                                 // different streams run one at a time) -- and the latter's host-mapped twin
@@ -592,6 +596,7 @@ int edm_hip_bias_destroy(edm_hip_bias *b) {
     (void)hipStreamDestroy(b->ord_stream);
   }
   if (b->ord_done_event) (void)hipEventDestroy(b->ord_done_event);
+  if (b->ord_up_event) (void)hipEventDestroy(b->ord_up_event);
   b->ord_ready.release(); b->ord_status.release();
   if (b->h_ord_status) (void)hipHostFree(b->h_ord_status);
   b->hs_r.release(); b->hs_f.release(); b->hs_x.release(); b->hs_u.release(); b->hs_mask.release();
@@ -1232,6 +1237,7 @@ static int process_new_hills(edm_hip_bias *b, long long n, const double *d_x, in
         // beside the batch's launch, behind nothing on the host's side: the record pass waits in the kernel for the
         // limiter's word of THIS batch (an event behind the preparation cost the object's stream ~5 us between the
         // selection and the batch, and the other stream ~10 us until the dependency had resolved)
+        if (bb->ord_wait_uploads && bb->ord_up_event) (void)hipStreamWaitEvent(bb->ord_stream, bb->ord_up_event, 0);
         bb->ord_on_own_stream = true;
         bb->last_batch.wait_flag = ready_flag;
         bb->last_batch.wait_seq = ready_seq;
@@ -1887,8 +1893,12 @@ int edm_hip_bias_pair_step_ordered_host(edm_hip_bias *b, long long n, const doub
     if (h_runiform)
       EDM_HIP_TRY(hipMemcpyAsync(b->hs_u.p, h_runiform, sizeof(double) * (size_t)n_samples, hipMemcpyHostToDevice, s));
   }
+  if (!b->ord_up_event) EDM_HIP_TRY(hipEventCreateWithFlags(&b->ord_up_event, hipEventDisableTiming));
+  EDM_HIP_TRY(hipEventRecord(b->ord_up_event, s));
+  b->ord_wait_uploads = true;
   rc = pair_step_ordered_device(b, n, b->hs_r.p, b->hs_f.p, h_first_sample ? b->ord_first.p : nullptr, n_samples,
                                 b->hs_x.p, h_runiform ? b->hs_u.p : nullptr, energy);
+  b->ord_wait_uploads = false;
   if (rc) return rc;
   if (n > 0) EDM_HIP_TRY(hipMemcpyAsync(h_force, b->hs_f.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
   EDM_HIP_TRY(hipStreamSynchronize(s));
