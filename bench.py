@@ -497,8 +497,17 @@ def coordinate_cv_measure(H, W, tmpdir):
         t_copy = (time.perf_counter() - t7) / 20
         if rc_copy:
             raise RuntimeError("plain hipMemcpy probe failed: %d" % rc_copy)
+        # ... and against 24 B per atom in EACH direction (what a fix that ships atom->x up and atom->f down moves)
+        t8 = time.perf_counter()
+        for _ in range(20):
+            rc_copy |= hip.hipMemcpy(C.c_void_p(d_tmp.ptr), C.c_void_p(xh.ctypes.data), C.c_size_t(xh.nbytes), 4)
+            rc_copy |= hip.hipMemcpy(C.c_void_p(fh.ctypes.data), C.c_void_p(d_tmp.ptr), C.c_size_t(24 * natoms), 4)
+        t_copy48 = (time.perf_counter() - t8) / 20
+        if rc_copy:
+            raise RuntimeError("plain hipMemcpy probe failed: %d" % rc_copy)
         pcie = dict(ms_per_step=t_host * 1e3, bytes_up_per_atom=24 + 8, bytes_down_per_atom=8 * dim,
                     plain_copies_of_the_same_bytes_ms=t_copy * 1e3, ratio_to_plain_copies=t_host / t_copy,
+                    plain_copies_of_2x24B_per_atom_ms=t_copy48 * 1e3, ratio_to_copies_of_2x24B_per_atom=t_host / t_copy48,
                     note="edm_hip_bias_step_host on pageable numpy arrays (the position block is page-locked in place by the "
                          "library): positions + uniforms up, bias-force delta down, added to the force array on the host")
         del bb
